@@ -1,0 +1,218 @@
+/*
+ * relgnn.h — C ABI of librelgnn.so: the MI355X (gfx950) sparse relational
+ * message-passing hot path of microsoft/tf-gnn-samples.
+ *
+ * The reference has NO FFI boundary of its own for this path: below the Python
+ * functions gnns.sparse_*_layer() it calls stock TensorFlow-1 ops.  Each entry
+ * point below therefore replaces one TF op *call site family* of the reference
+ * (cited as reference file:line, relative to the reference root) and is what a
+ * maintainer would bind from Python (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller unless the
+ *     parameter name starts with `h_` (host pointer).  Nothing is allocated,
+ *     freed or retained by the library; workspaces are caller-allocated and
+ *     sized by the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     work is enqueued asynchronously on it; no entry point synchronises.
+ *   - Every entry point returns an int status (RELGNN_OK == 0) and never
+ *     throws.  Index-range errors found ON DEVICE are reported through the
+ *     caller-provided `err_flag` word (see relgnn_relational_keys), because
+ *     reporting them through the return value would need a device sync.
+ *   - float == IEEE binary32, index == int32_t, row-major everywhere.
+ *   - Functions are re-entrant w.r.t. distinct streams/devices; there is no
+ *     global mutable state.
+ */
+#ifndef RELGNN_H_
+#define RELGNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELGNN_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define RELGNN_OK 0
+#define RELGNN_EINVAL 1 /* bad argument (null pointer, negative size, bad enum, misalignment) */
+#define RELGNN_ENOSPC 2 /* workspace too small */
+#define RELGNN_EHIP 3   /* a HIP runtime call / kernel launch failed */
+#define RELGNN_EUNSUPPORTED 4
+
+/* bits OR-ed into *err_flag by device-side validation */
+#define RELGNN_ERRFLAG_INDEX_OUT_OF_RANGE 1u /* TF: InvalidArgumentError for gather / segment ids */
+
+/* ---- aggregation modes: utils/utils.py:23-33 (get_aggregation_function) -- */
+#define RELGNN_AGG_SUM 0    /* tf.unsorted_segment_sum                      */
+#define RELGNN_AGG_MEAN 1   /* tf.unsorted_segment_mean   : sum / max(n,1)   */
+#define RELGNN_AGG_SQRT_N 2 /* tf.unsorted_segment_sqrt_n : sum / sqrt(max(n,1)) */
+#define RELGNN_AGG_MAX 3    /* tf.unsorted_segment_max    : empty -> -FLT_MAX */
+
+/* ---- activations: utils/utils.py:36-58 (get_activation) ------------------ */
+#define RELGNN_ACT_LINEAR 0
+#define RELGNN_ACT_TANH 1
+#define RELGNN_ACT_RELU 2
+#define RELGNN_ACT_LEAKY_RELU 3 /* tf.nn.leaky_relu default alpha = 0.2 */
+#define RELGNN_ACT_ELU 4
+#define RELGNN_ACT_SELU 5
+#define RELGNN_ACT_GELU 6 /* erf form, utils/utils.py:53-55 */
+
+int relgnn_abi_version(void);
+const char* relgnn_status_string(int status);
+
+/* ========================================================================== *
+ * 1. Index bookkeeping (bit-exact integer work)
+ * ========================================================================== */
+
+/*
+ * relgnn_relational_keys — flatten one adjacency list into the type-major
+ * message list the reference builds with tf.concat.
+ *
+ * Replaces: the `adjacency_list_for_edge_type[:, 0] / [:, 1]` slicing and
+ * `tf.concat(edge_type_to_message_targets, axis=0)` at gnns/rgcn.py:68-78
+ * (identically ggnn.py:59-69, rgat.py:68-80, rgin.py:90-101,
+ * gnn_film.py:68-83, gnn_edge_mlp.py:72-82).
+ *
+ * adj        : [num_edges, 2] int32, adj[e] = {source, target}
+ *              (messages flow column 0 -> column 1, gnns/rgcn.py:85-86)
+ * msg_base   : offset of this edge type's first message in the type-major
+ *              message list (= sum of num_edges of lower edge types)
+ * For message m = msg_base + e it writes
+ *   key_by_target[m] = target * num_edge_types + edge_type
+ *   key_by_source[m] = source * num_edge_types + edge_type
+ * and ORs RELGNN_ERRFLAG_INDEX_OUT_OF_RANGE into *err_flag (if non-null) when
+ * source or target is outside [0, num_nodes); the keys of an invalid edge are
+ * clamped into range so that later stages stay in bounds (the caller is expected
+ * to check the flag and raise, as TF-CPU does with InvalidArgumentError).
+ */
+int relgnn_relational_keys(const int32_t* adj, int64_t num_edges, int32_t edge_type,
+                           int32_t num_edge_types, int32_t num_nodes, int64_t msg_base,
+                           int32_t* key_by_target, int32_t* key_by_source,
+                           uint32_t* err_flag, void* stream);
+
+/*
+ * relgnn_segment_plan — stable bucketing of messages by segment id.
+ *
+ * Replaces: the implicit scatter order of tf.unsorted_segment_* (utils/utils.py:23-33):
+ * a STABLE sort by segment id makes every segment's messages contiguous while
+ * keeping the reference's message order inside the segment, so a sequential
+ * in-register accumulation reproduces the sequential CPU kernel's summation
+ * order without atomics.
+ *
+ * keys    : [num_messages] int32 in [0, num_segments) (negative ids are dropped by
+ *           TF; here they are NOT allowed: validate first)
+ * rowptr  : [num_segments + 1] out; messages of segment s are sorted positions
+ *           rowptr[s] .. rowptr[s+1]-1
+ * perm    : [num_messages] out; perm[p] = original message index at sorted position p
+ *           (ascending inside a segment: stability)
+ * sorted_keys : [num_messages] out (may be NULL if the caller does not need it)
+ */
+size_t relgnn_segment_plan_workspace_bytes(int64_t num_messages, int64_t num_segments);
+int relgnn_segment_plan(const int32_t* keys, int64_t num_messages, int64_t num_segments,
+                        int32_t* rowptr, int32_t* perm, int32_t* sorted_keys,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i] = table[index[i]]  (int32).  Index plumbing between the two CSR orders. */
+int relgnn_gather_i32(const int32_t* table, const int32_t* index, int64_t n, int32_t* out,
+                      void* stream);
+/* out[i] = table[index[i]] / divisor  (int32; recovers node id from node*L+type keys). */
+int relgnn_gather_div_i32(const int32_t* table, const int32_t* index, int64_t n,
+                          int32_t divisor, int32_t* out, void* stream);
+/* out[i] = table[index[i]]  (float32). */
+int relgnn_gather_f32(const float* table, const int32_t* index, int64_t n, float* out,
+                      void* stream);
+/* inv[perm[p]] = p. */
+int relgnn_invert_perm(const int32_t* perm, int64_t n, int32_t* inv, void* stream);
+
+/*
+ * relgnn_degree_scale — per-message 1/(c + eps) normalisation weights.
+ *
+ * Replaces: gnns/rgcn.py:100-104 (identically gnn_film.py:96-100,
+ * gnn_edge_mlp.py:104-108): embedding_lookup of type_to_num_incoming_edges[l, :]
+ * by edge target, `1.0 / (x + SMALL_NUMBER)` in float32.
+ *
+ * degree_table : [num_edge_types, num_nodes] float32 exactly as fed by the task
+ *                (tasks/sparse_graph_task.py:144-145)
+ * rowptr       : [num_nodes*num_edge_types + 1] by-(target,type) CSR row pointer
+ * scale        : [num_messages] out, in by-target sorted order:
+ *                scale[p] = 1.0f / (degree_table[l, v] + eps) for p in sub-segment (v, l)
+ */
+int relgnn_degree_scale(const float* degree_table, const int32_t* rowptr, int32_t num_edge_types,
+                        int32_t num_nodes, float eps, float* scale, void* stream);
+
+/*
+ * relgnn_segment_counts_scale — backward helper for mean / sqrt_n:
+ * scale[p] = (w ? w[p] : 1) * f(n_seg(p)),  f = 1/max(n,1) (MEAN) or 1/sqrt(max(n,1)) (SQRT_N),
+ * where n_seg is the length of the (merged) segment that holds sorted position p.
+ */
+int relgnn_segment_counts_scale(const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                                int32_t mode, const float* w, float* scale, void* stream);
+
+/* ========================================================================== *
+ * 2. The hot kernel: fused gather + (scale) + segment reduce
+ * ========================================================================== */
+
+/*
+ * relgnn_seg_reduce_fwd
+ *
+ *   out[s, :] = finalize_mode( REDUCE_{p = rowptr[s*seg_stride]}^{rowptr[(s+1)*seg_stride]-1}
+ *                                  (w ? w[p] : 1) * X[col[p], :] )          s in [0, num_segments)
+ *
+ * accumulated SEQUENTIALLY in p (one rounding for the product, one for the add:
+ * no FMA contraction), which is the order of TF-CPU's UnsortedSegmentSum on the
+ * reference's concatenated message tensor.
+ *
+ * Replaces, fused into one pass: tf.nn.embedding_lookup (gnns/rgcn.py:87-89), the
+ * 1/in-degree multiply (rgcn.py:100-104), tf.concat (rgcn.py:108) and
+ * tf.unsorted_segment_{sum,mean,sqrt_n,max} (rgcn.py:109-112 via utils/utils.py:23-33);
+ * same call-site family in ggnn.py:76-89, rgin.py:110-133, gnn_film.py:92-116,
+ * gnn_edge_mlp.py:91-116 and the task head tasks/qm9_task.py:185-187.
+ *
+ * X       : [num_rows_x, ldx] float32, only the first D columns of a row are read
+ * rowptr  : [num_segments*seg_stride + 1]; seg_stride > 1 merges that many consecutive
+ *           sub-segments (the per-edge-type buckets of one target node) into one output row
+ * col     : [num_messages] row of X gathered by each sorted message
+ * w       : [num_messages] or NULL
+ * out     : [num_segments, ldo] float32, first D columns written
+ * act     : RELGNN_ACT_* applied to the finalized row before the store (epilogue
+ *           fusion of rgcn.py:114); RELGNN_ACT_LINEAR for none
+ * D, ldx, ldo in floats.  Fast path needs D%4==0, ldx%4==0, ldo%4==0 and 16-byte
+ * aligned X/out; anything else takes the scalar-lane kernel.
+ */
+int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                          const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                          const int32_t* col, const float* w, int32_t act, float* out,
+                          int64_t ldo, void* stream);
+
+/*
+ * unsorted_segment_max gradient w.r.t. the gathered table, TF semantics
+ * (math_grad.py _UnsortedSegmentMinOrMaxGrad [TF-internal]): the gradient of out[s,d] is
+ * split EQUALLY among all messages p of segment s with w[p]*X[col[p],d] == out[s,d].
+ *
+ * relgnn_seg_max_count (forward plan):
+ *   gsel[s,d] = gout[s,d] / #{p in s : w[p]*X[col[p],d] == out[s,d]}      (0 for empty s)
+ * relgnn_seg_max_bwd (TRANSPOSED plan: segments = rows r of X, entries q = the output
+ * segment seg_b[q] each message of r went to):
+ *   gX[r,d] = sum_q [ w_b[q]*X[r,d] == out[seg_b[q],d] ] * w_b[q] * gsel[seg_b[q],d]
+ */
+int relgnn_seg_max_count(const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
+                         int64_t num_segments, int32_t seg_stride, const int32_t* col,
+                         const float* w, const float* out, const float* gout, int64_t ldo,
+                         float* gsel, void* stream);
+int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* rowptr_b,
+                       int64_t num_rows_x, int32_t seg_stride_b, const int32_t* seg_b,
+                       const float* w_b, const float* out, const float* gsel, int64_t ldo,
+                       float* gX, int64_t ldgx, void* stream);
+
+/* elementwise epilogue gradient: gin = gout * act'(.) evaluated from the activation OUTPUT y
+ * (valid for LINEAR/TANH/RELU/LEAKY_RELU/ELU/SELU).  n = number of floats. */
+int relgnn_act_bwd_from_output(int32_t act, const float* y, const float* gout, int64_t n,
+                               float* gin, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELGNN_H_ */

@@ -1,0 +1,103 @@
+"""ctypes binding of librelgnn.so (C ABI: include/relgnn.h).
+
+This is the ONLY compute backend of the package.  There is no CPU / eager-PyTorch fallback:
+if the HIP library is missing, or a tensor is not a float32/int32 CUDA(HIP) tensor, the
+call fails loudly.  (The NumPy oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+import ctypes
+import os
+from pathlib import Path
+
+import torch  # imported first on purpose: makes torch's libamdhip64.so.7 the process-wide HIP runtime
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "librelgnn.so"
+
+OK, EINVAL, ENOSPC, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
+ERRFLAG_INDEX_OUT_OF_RANGE = 1
+
+AGG_SUM, AGG_MEAN, AGG_SQRT_N, AGG_MAX = 0, 1, 2, 3
+ACT_LINEAR, ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU, ACT_SELU, ACT_GELU = range(7)
+
+_c_i32, _c_i64, _c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every function declared in include/relgnn.h
+_SIGNATURES = {
+    "relgnn_abi_version": (ctypes.c_int, []),
+    "relgnn_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "relgnn_relational_keys": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i64, _ptr, _ptr, _ptr, _ptr]),
+    "relgnn_segment_plan_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i64]),
+    "relgnn_segment_plan": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    "relgnn_gather_i32": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_gather_div_i32": (ctypes.c_int, [_ptr, _ptr, _c_i64, _c_i32, _ptr, _ptr]),
+    "relgnn_gather_f32": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_invert_perm": (ctypes.c_int, [_ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_degree_scale": (ctypes.c_int, [_ptr, _ptr, _c_i32, _c_i32, _c_f32, _ptr, _ptr]),
+    "relgnn_segment_counts_scale": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
+    "relgnn_seg_reduce_fwd": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
+    "relgnn_seg_max_count": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_seg_max_bwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_act_bwd_from_output": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr]),
+}
+
+_lib = None
+
+
+class RelGnnLibraryError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen librelgnn.so and type every entry point.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RelGnnLibraryError(
+            "%s not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). There is no CPU fallback for this path." % LIB_PATH)
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.relgnn_abi_version() != 1:
+        raise RelGnnLibraryError("librelgnn.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def exported_signatures():
+    return dict(_SIGNATURES)
+
+
+def status_string(code: int) -> str:
+    return load_library().relgnn_status_string(code).decode()
+
+
+def check(code: int, what: str):
+    if code == OK:
+        return
+    msg = "%s failed: %s (status %d)" % (what, status_string(code), code)
+    if code in (EINVAL, EUNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses anything but HIP device memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RelGnnLibraryError(
+            "librelgnn kernels only run on MI355X device tensors; got a %s tensor. "
+            "There is no CPU fallback for this path." % t.device)
+    if not t.is_contiguous():
+        raise ValueError("librelgnn expects contiguous tensors")
+    return t.data_ptr()
+
+
+def current_stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,416 @@
+// Fused gather + per-message scale + segment reduce: THE hot kernel of the path.
+//
+// Replaces, in one pass over a (target, edge type)-bucketed CSR:
+//   tf.nn.embedding_lookup            gnns/rgcn.py:87-89
+//   1/(num_incoming + 1e-7) multiply  gnns/rgcn.py:100-104
+//   tf.concat(messages_per_type)      gnns/rgcn.py:108
+//   tf.unsorted_segment_{sum,mean,sqrt_n,max}   gnns/rgcn.py:109-112 (utils/utils.py:23-33)
+// and the same call-site family in ggnn.py / rgin.py / gnn_film.py / gnn_edge_mlp.py.
+//
+// Mapping (CDNA4, wave = 64):
+//   * lanes run across the FEATURE dimension (float4 per lane: one 1 KiB coalesced
+//     global_load_dwordx4 per wave for a 256-float row), so one wave owns one output row
+//     and accumulates the segment's messages SEQUENTIALLY in registers, in the
+//     reference's message order (type-major, then edge order).  No atomics, no LDS, and
+//     the fp32 summation order of TF-CPU's UnsortedSegmentSum is preserved.
+//   * the gathered row index is wave-uniform: it is fetched with one coalesced load per
+//     64 messages and broadcast with v_readlane into an SGPR, so every row load is
+//     `scalar base + lane offset` (no per-lane 64-bit address arithmetic).
+//   * UNROLL independent row loads are in flight per wave before the first add.
+//   * for D <= 128 a wave is split into 64/GROUP lane groups, one segment each.
+//   * blockIdx is remapped so that each XCD (own 4 MiB L2) walks a contiguous range of
+//     targets: a batch is a disjoint union of graphs, so neighbouring targets gather
+//     from the same ~2 MiB slab of source rows.
+//
+// Bound: HBM / Infinity-Cache bandwidth.  Algorithmic bytes per launch:
+//   M*(4*D + 8) + S_out*4*D (+ 4*(S_out*stride+1) for rowptr)      
+#include "common.h"
+
+using namespace relgnn;
+
+namespace {
+
+constexpr int kUnroll = 8;
+
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case RELGNN_ACT_TANH: return act_fwd<RELGNN_ACT_TANH>(x);
+    case RELGNN_ACT_RELU: return act_fwd<RELGNN_ACT_RELU>(x);
+    case RELGNN_ACT_LEAKY_RELU: return act_fwd<RELGNN_ACT_LEAKY_RELU>(x);
+    case RELGNN_ACT_ELU: return act_fwd<RELGNN_ACT_ELU>(x);
+    case RELGNN_ACT_SELU: return act_fwd<RELGNN_ACT_SELU>(x);
+    case RELGNN_ACT_GELU: return act_fwd<RELGNN_ACT_GELU>(x);
+    default: return x;
+  }
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ void combine(float4& acc, float w, const float4& v) {
+  // product and add are rounded separately (file is built with -ffp-contract=off):
+  // messages = scale * gathered_row; acc = acc + messages, as the reference's op chain.
+  float4 m = make_float4(w * v.x, w * v.y, w * v.z, w * v.w);
+  if constexpr (IS_MAX) {
+    acc.x = fmaxf(acc.x, m.x); acc.y = fmaxf(acc.y, m.y);
+    acc.z = fmaxf(acc.z, m.z); acc.w = fmaxf(acc.w, m.w);
+  } else {
+    acc.x += m.x; acc.y += m.y; acc.z += m.z; acc.w += m.w;
+  }
+}
+
+__device__ __forceinline__ float4 finalize(int mode, int act, float4 a, int n) {
+  if (mode == RELGNN_AGG_MEAN) {
+    float d = (float)max(n, 1);
+    a.x /= d; a.y /= d; a.z /= d; a.w /= d;
+  } else if (mode == RELGNN_AGG_SQRT_N) {
+    float d = sqrtf((float)max(n, 1));
+    a.x /= d; a.y /= d; a.z /= d; a.w /= d;
+  }
+  if (act != RELGNN_ACT_LINEAR) {
+    a.x = act_apply(act, a.x); a.y = act_apply(act, a.y);
+    a.z = act_apply(act, a.z); a.w = act_apply(act, a.w);
+  }
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------
+// One wave per output row.  NCH = float4 chunks per lane (row width up to NCH*256 floats).
+// ---------------------------------------------------------------------------------------
+template <int NCH, bool IS_MAX, bool HAS_W>
+__global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
+    const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr,
+    int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
+    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4,
+    int64_t n_logical_blocks, int32_t col_block0) {
+  const int64_t lb = xcd_logical_block(n_logical_blocks);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t s = lb * 4 + (threadIdx.x >> 6);
+  if (s >= num_segments) return;
+
+  // wave-uniform segment bounds -> SGPRs
+  const int beg = __builtin_amdgcn_readfirstlane(rowptr[s * stride]);
+  const int end = __builtin_amdgcn_readfirstlane(rowptr[(s + 1) * stride]);
+
+  const int c0 = (col_block0 + (int)blockIdx.y * NCH) * 64 + lane;  // this lane's first float4 column
+  float4 acc[NCH];
+  bool on[NCH];
+  uint32_t cc[NCH];  // column used for LOADS: clamped into the row so that lanes past the
+                     // row end read a valid (ignored) address instead of branching
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float init = IS_MAX ? -FLT_MAX : 0.f;
+    acc[c] = make_float4(init, init, init, init);
+    on[c] = (c0 + 64 * c) < D4;
+    cc[c] = (uint32_t)min(c0 + 64 * c, D4 - 1);
+  }
+  const uint32_t ld = (uint32_t)ldx4;  // host guarantees num_rows_x * ldx4 < 2^32
+
+  for (int p = beg; p < end; p += 64) {
+    const int n = min(64, end - p);
+    // one coalesced index (and weight) load per 64 messages
+    const int my_col = (lane < n) ? col[p + lane] : 0;
+    float my_w = 1.f;
+    if constexpr (HAS_W) my_w = (lane < n) ? w[p + lane] : 0.f;
+
+    int k = 0;
+    for (; k + kUnroll <= n; k += kUnroll) {
+      float4 v[kUnroll][NCH];
+      float ww[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k + u);
+        ww[u] = HAS_W ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), k + u)) : 1.f;
+        const float4* row = X + (size_t)(r * ld);  // scalar (SGPR) row base
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[u][c] = row[cc[c]];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) combine<IS_MAX>(acc[c], ww[u], v[u][c]);
+    }
+    for (; k < n; ++k) {
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k);
+      const float wk = HAS_W ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), k)) : 1.f;
+      const float4* row = X + (size_t)(r * ld);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float4 v = row[cc[c]];
+        combine<IS_MAX>(acc[c], wk, v);
+      }
+    }
+  }
+
+  float4* orow = out + s * ldo4 + c0;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (on[c]) orow[64 * c] = finalize(mode, act, acc[c], end - beg);
+}
+
+// ---------------------------------------------------------------------------------------
+// 64/GROUP segments per wave (rows of at most GROUP float4 = GROUP*4 floats).
+// ---------------------------------------------------------------------------------------
+template <int GROUP, bool IS_MAX, bool HAS_W>
+__global__ __launch_bounds__(256) void seg_reduce_group_kernel(
+    const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr,
+    int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
+    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4,
+    int64_t n_logical_blocks) {
+  constexpr int SEGS_PER_WAVE = 64 / GROUP;
+  constexpr int U = 4;
+  const int64_t lb = xcd_logical_block(n_logical_blocks);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / GROUP, gl = lane % GROUP;
+  const int64_t s = (lb * 4 + (threadIdx.x >> 6)) * SEGS_PER_WAVE + g;
+  const bool valid = s < num_segments;
+  const int beg = valid ? rowptr[s * stride] : 0;
+  const int end = valid ? rowptr[(s + 1) * stride] : 0;
+  const int len = end - beg;
+  // wave-uniform trip count: longest segment of the wave
+  int maxlen = len;
+#pragma unroll
+  for (int off = 32; off >= GROUP; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+
+  const bool on = gl < D4;
+  const float init = IS_MAX ? -FLT_MAX : 0.f;
+  float4 acc = make_float4(init, init, init, init);
+  // loads are unconditional (clamped column, row 0 for padding messages) and the combine is
+  // predicated with a select: no divergent branches inside the wave
+  const float4* Xl = X + min(gl, D4 - 1);
+  const uint32_t ld = (uint32_t)ldx4;
+
+  for (int p0 = 0; p0 < maxlen; p0 += GROUP) {
+    const int idx = p0 + gl;
+    const int my_col = (idx < len) ? col[beg + idx] : 0;
+    float my_w = 1.f;
+    if constexpr (HAS_W) my_w = (idx < len) ? w[beg + idx] : 0.f;
+    const int nn = min(GROUP, maxlen - p0);
+    for (int k = 0; k < nn; k += U) {
+      float4 v[U];
+      float ww[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t r = (uint32_t)__shfl(my_col, (k + u) & (GROUP - 1), GROUP);
+        ww[u] = HAS_W ? __shfl(my_w, (k + u) & (GROUP - 1), GROUP) : 1.f;
+        v[u] = Xl[(size_t)(r * ld)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float4 t = acc;
+        combine<IS_MAX>(t, ww[u], v[u]);
+        if (p0 + k + u < len) acc = t;
+      }
+    }
+  }
+  if (valid && on) out[s * ldo4 + gl] = finalize(mode, act, acc, len);
+}
+
+// ---------------------------------------------------------------------------------------
+// Scalar-lane fallback: any D / ld / alignment.  One wave per output row, lanes stride D.
+// ---------------------------------------------------------------------------------------
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void seg_reduce_scalar_kernel(
+    const float* __restrict__ X, int64_t ldx, int32_t D, const int32_t* __restrict__ rowptr,
+    int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
+    const float* __restrict__ w, int32_t mode, int32_t act, float* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= num_segments) return;
+  const int beg = rowptr[s * stride], end = rowptr[(s + 1) * stride];
+  for (int d = lane; d < D; d += 64) {
+    float acc = IS_MAX ? -FLT_MAX : 0.f;
+    for (int p = beg; p < end; ++p) {
+      float m = (w ? w[p] : 1.f) * X[(int64_t)col[p] * ldx + d];
+      acc = IS_MAX ? fmaxf(acc, m) : acc + m;
+    }
+    float nrm = (float)max(end - beg, 1);
+    if (mode == RELGNN_AGG_MEAN) acc /= nrm;
+    if (mode == RELGNN_AGG_SQRT_N) acc /= sqrtf(nrm);
+    out[s * ldo + d] = act_apply(act, acc);
+  }
+}
+
+// ---- unsorted_segment_max backward helpers (not on the default path; generic lanes) ----
+// gsel[s,d] = gout[s,d] / #{p in s : w[p]*X[col[p],d] == out[s,d]}
+__global__ __launch_bounds__(256) void seg_max_count_kernel(
+    const float* __restrict__ X, int64_t ldx, int32_t D, const int32_t* __restrict__ rowptr,
+    int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
+    const float* __restrict__ w, const float* __restrict__ out, const float* __restrict__ gout,
+    int64_t ldo, float* __restrict__ gsel) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= num_segments) return;
+  const int beg = rowptr[s * stride], end = rowptr[(s + 1) * stride];
+  for (int d = lane; d < D; d += 64) {
+    const float o = out[s * ldo + d];
+    float cnt = 0.f;
+    for (int p = beg; p < end; ++p) {
+      float m = (w ? w[p] : 1.f) * X[(int64_t)col[p] * ldx + d];
+      cnt += (m == o) ? 1.f : 0.f;
+    }
+    gsel[s * ldo + d] = cnt > 0.f ? gout[s * ldo + d] / cnt : 0.f;
+  }
+}
+
+// transposed plan: gX[r,d] = sum_q [w_b[q]*X[r,d] == out[seg_b[q],d]] * w_b[q] * gsel[seg_b[q],d]
+__global__ __launch_bounds__(256) void seg_max_bwd_kernel(
+    const float* __restrict__ X, int64_t ldx, int32_t D, const int32_t* __restrict__ rowptr_b,
+    int64_t num_rows, int32_t stride_b, const int32_t* __restrict__ seg_b,
+    const float* __restrict__ w_b, const float* __restrict__ out, const float* __restrict__ gsel,
+    int64_t ldo, float* __restrict__ gX, int64_t ldgx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= num_rows) return;
+  const int beg = rowptr_b[r * stride_b], end = rowptr_b[(r + 1) * stride_b];
+  for (int d = lane; d < D; d += 64) {
+    const float x = X[r * ldx + d];
+    float acc = 0.f;
+    for (int q = beg; q < end; ++q) {
+      const float wq = w_b ? w_b[q] : 1.f;
+      const int64_t s = seg_b[q];
+      if (wq * x == out[s * ldo + d]) acc += wq * gsel[s * ldo + d];
+    }
+    gX[r * ldgx + d] = acc;
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_from_output_kernel(const float* __restrict__ y,
+                                                                  const float* __restrict__ gout,
+                                                                  int64_t n, float* __restrict__ gin) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float yy = y[i], g = gout[i];
+    float d = 1.f;
+    if constexpr (ACT == RELGNN_ACT_TANH) d = 1.f - yy * yy;
+    if constexpr (ACT == RELGNN_ACT_RELU) d = yy > 0.f ? 1.f : 0.f;
+    if constexpr (ACT == RELGNN_ACT_LEAKY_RELU) d = yy > 0.f ? 1.f : 0.2f;
+    if constexpr (ACT == RELGNN_ACT_ELU) d = yy > 0.f ? 1.f : yy + 1.f;
+    if constexpr (ACT == RELGNN_ACT_SELU) {
+      const float scale = 1.0507009873554804934193349852946f;
+      const float scale_alpha = 1.7580993408473768599402175208123f;
+      d = yy > 0.f ? scale : yy + scale_alpha;
+    }
+    gin[i] = g * d;
+  }
+}
+
+template <int NCH, bool IS_MAX>
+int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
+                int64_t S, int32_t stride, const int32_t* col, const float* w, int32_t mode,
+                int32_t act, float* out, int64_t ldo, hipStream_t st) {
+  const int D4 = D / 4;
+  const int64_t nlb = (S + 3) / 4;
+  const int col_blocks = (D4 + 64 * NCH - 1) / (64 * NCH);
+  dim3 grid((unsigned)(((nlb + 7) / 8) * 8), (unsigned)col_blocks);
+  if (has_w)
+    seg_reduce_wave_kernel<NCH, IS_MAX, true><<<grid, 256, 0, st>>>(
+        reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0);
+  else
+    seg_reduce_wave_kernel<NCH, IS_MAX, false><<<grid, 256, 0, st>>>(
+        reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0);
+  return launch_status();
+}
+
+template <int GROUP, bool IS_MAX>
+int launch_group(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
+                 int64_t S, int32_t stride, const int32_t* col, const float* w, int32_t mode,
+                 int32_t act, float* out, int64_t ldo, hipStream_t st) {
+  constexpr int SEGS_PER_BLOCK = 4 * (64 / GROUP);
+  const int64_t nlb = (S + SEGS_PER_BLOCK - 1) / SEGS_PER_BLOCK;
+  dim3 grid((unsigned)(((nlb + 7) / 8) * 8));
+  if (has_w)
+    seg_reduce_group_kernel<GROUP, IS_MAX, true><<<grid, 256, 0, st>>>(
+        reinterpret_cast<const float4*>(X), ldx / 4, D / 4, rowptr, S, stride, col, w, mode, act,
+        reinterpret_cast<float4*>(out), ldo / 4, nlb);
+  else
+    seg_reduce_group_kernel<GROUP, IS_MAX, false><<<grid, 256, 0, st>>>(
+        reinterpret_cast<const float4*>(X), ldx / 4, D / 4, rowptr, S, stride, col, w, mode, act,
+        reinterpret_cast<float4*>(out), ldo / 4, nlb);
+  return launch_status();
+}
+
+template <bool IS_MAX>
+int dispatch_fwd(const float* X, int64_t num_rows_x, int64_t ldx, int32_t D, const int32_t* rowptr, int64_t S,
+                 int32_t stride, const int32_t* col, const float* w, int32_t mode, int32_t act,
+                 float* out, int64_t ldo, hipStream_t st) {
+  const bool vec_ok = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(X) &&
+                      aligned16(out) && (num_rows_x * (ldx / 4) < ((int64_t)1 << 32));
+  if (!vec_ok) {
+    seg_reduce_scalar_kernel<IS_MAX><<<(unsigned)((S + 3) / 4), 256, 0, st>>>(
+        X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo);
+    return launch_status();
+  }
+  const bool has_w = w != nullptr;
+  const int D4 = D / 4;
+  if (D4 <= 8) return launch_group<8, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
+  if (D4 <= 16) return launch_group<16, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
+  if (D4 <= 32) return launch_group<32, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
+  if (D4 <= 64) return launch_wave<1, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
+  if (D4 <= 128) return launch_wave<2, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
+  return launch_wave<4, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                          const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                          const int32_t* col, const float* w, int32_t act, float* out, int64_t ldo,
+                          void* stream) {
+  if (mode < RELGNN_AGG_SUM || mode > RELGNN_AGG_MAX) return RELGNN_EINVAL;
+  if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (D < 0 || num_segments < 0 || seg_stride <= 0 || num_rows_x < 0 || ldx < D || ldo < D)
+    return RELGNN_EINVAL;
+  if (num_segments == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !out) return RELGNN_EINVAL;
+  // X / col may be null only when there is not a single message; the kernel never touches them then.
+  if (num_segments > (int64_t)INT32_MAX * 4) return RELGNN_EUNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  if (mode == RELGNN_AGG_MAX)
+    return dispatch_fwd<true>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st);
+  return dispatch_fwd<false>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st);
+}
+
+int relgnn_seg_max_count(const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
+                         int64_t num_segments, int32_t seg_stride, const int32_t* col,
+                         const float* w, const float* out, const float* gout, int64_t ldo,
+                         float* gsel, void* stream) {
+  if (D < 0 || num_segments < 0 || seg_stride <= 0) return RELGNN_EINVAL;
+  if (num_segments == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !out || !gout || !gsel) return RELGNN_EINVAL;
+  seg_max_count_kernel<<<(unsigned)((num_segments + 3) / 4), 256, 0, as_stream(stream)>>>(
+      X, ldx, D, rowptr, num_segments, seg_stride, col, w, out, gout, ldo, gsel);
+  return launch_status();
+}
+
+int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* rowptr_b,
+                       int64_t num_rows_x, int32_t seg_stride_b, const int32_t* seg_b,
+                       const float* w_b, const float* out, const float* gsel, int64_t ldo,
+                       float* gX, int64_t ldgx, void* stream) {
+  if (D < 0 || num_rows_x < 0 || seg_stride_b <= 0) return RELGNN_EINVAL;
+  if (num_rows_x == 0 || D == 0) return RELGNN_OK;
+  if (!X || !rowptr_b || !gX) return RELGNN_EINVAL;
+  seg_max_bwd_kernel<<<(unsigned)((num_rows_x + 3) / 4), 256, 0, as_stream(stream)>>>(
+      X, ldx, D, rowptr_b, num_rows_x, seg_stride_b, seg_b, w_b, out, gsel, ldo, gX, ldgx);
+  return launch_status();
+}
+
+int relgnn_act_bwd_from_output(int32_t act, const float* y, const float* gout, int64_t n, float* gin,
+                               void* stream) {
+  if (n < 0) return RELGNN_EINVAL;
+  if (act == RELGNN_ACT_GELU) return RELGNN_EUNSUPPORTED;  // not monotone: needs the pre-activation
+  if (n == 0) return RELGNN_OK;
+  if (!y || !gout || !gin) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  RELGNN_DISPATCH_ACT(act, A,
+                      (act_bwd_from_output_kernel<A><<<flat_grid(n, 256), 256, 0, st>>>(y, gout, n, gin)));
+  return launch_status();
+}
+
+}  // extern "C"

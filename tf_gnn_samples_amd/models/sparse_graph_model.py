@@ -1,0 +1,339 @@
+"""Model driver mirror (models/sparse_graph_model.py of the reference).
+
+Hot-path scope: the per-layer loop of __build_graph_propagation_model
+(:162-202) and the abstract hook _apply_gnn_layer (:204-225), same names and argument meaning.
+The training-step plumbing around it (optimizer with per-variable clip_by_norm :227-260, epoch
+loop with throughput counters :263-311) is restated minimally so that the reference's own
+"edges/sec" number (README.md:34-35) can be measured end to end.
+
+TF1 builds a static graph once and feeds numpy batches through sess.run; here the variables
+live in a VariableStore under the reference's TF names, batches live in HBM (DeviceBatch), and a
+step is eager PyTorch-ROCm around the librelgnn HIP kernels.
+"""
+import os
+import pickle
+import time
+from abc import ABC, abstractmethod
+from typing import Any, Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from ..graph import as_rel_graph
+from ..tasks import DataFold, DeviceBatch, Sparse_Graph_Task
+from ..utils import apply_activation, get_activation, layer_norm
+from ..variables import VariableStore
+
+
+class TFStyleOptimizer:
+    """compute_gradients -> per-variable tf.clip_by_norm -> apply_gradients
+    (models/sparse_graph_model.py:227-260) with TF1 update rules [TF-internal]:
+      Adam    : lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; var -= lr_t*m/(sqrt(v)+eps), eps=1e-8
+      RMSProp : ms = d*ms+(1-d)*g^2; mom = momentum*mom + lr*g/sqrt(ms+eps); var -= mom, eps=1e-10, ms0=1
+      SGD     : var -= lr*g
+    """
+
+    def __init__(self, params: List[torch.nn.Parameter], name: str, learning_rate: float, clamp_gradient_norm: float,
+                 decay: float = 0.98, momentum: float = 0.85):
+        self.params = [p for p in params if p.requires_grad]
+        self.name = name.lower()
+        if self.name not in ('sgd', 'rmsprop', 'adam'):
+            raise Exception('Unknown optimizer "%s".' % name)
+        self.lr, self.clip, self.decay, self.momentum = learning_rate, clamp_gradient_norm, decay, momentum
+        self.t = 0
+        if self.name == 'adam':
+            self.m = [torch.zeros_like(p) for p in self.params]
+            self.v = [torch.zeros_like(p) for p in self.params]
+        elif self.name == 'rmsprop':
+            self.ms = [torch.ones_like(p) for p in self.params]
+            self.mom = [torch.zeros_like(p) for p in self.params]
+
+    @torch.no_grad()
+    def clip_gradients(self):
+        """tf.clip_by_norm per variable: g * clip / max(||g||, clip)."""
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        norms = torch._foreach_norm(grads)
+        scales = [self.clip / torch.clamp(n, min=self.clip) for n in norms]
+        torch._foreach_mul_(grads, scales)
+
+    @torch.no_grad()
+    def step(self, lr_scale: float = 1.0):
+        ps = [p for p in self.params if p.grad is not None]
+        gs = [p.grad for p in ps]
+        if not ps:
+            return
+        lr = self.lr * lr_scale
+        self.t += 1
+        if self.name == 'sgd':
+            torch._foreach_add_(ps, gs, alpha=-lr)
+        elif self.name == 'adam':
+            b1, b2, eps = 0.9, 0.999, 1e-8
+            idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+            m = [self.m[i] for i in idx]
+            v = [self.v[i] for i in idx]
+            torch._foreach_mul_(m, b1)
+            torch._foreach_add_(m, gs, alpha=1 - b1)
+            torch._foreach_mul_(v, b2)
+            torch._foreach_addcmul_(v, gs, gs, value=1 - b2)
+            lr_t = lr * (1 - b2 ** self.t) ** 0.5 / (1 - b1 ** self.t)
+            denom = torch._foreach_sqrt(v)
+            torch._foreach_add_(denom, eps)
+            torch._foreach_addcdiv_(ps, m, denom, value=-lr_t)
+        else:
+            eps = 1e-10
+            idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+            ms = [self.ms[i] for i in idx]
+            mom = [self.mom[i] for i in idx]
+            torch._foreach_mul_(ms, self.decay)
+            torch._foreach_addcmul_(ms, gs, gs, value=1 - self.decay)
+            denom = torch._foreach_add(ms, eps)
+            torch._foreach_sqrt_(denom)
+            torch._foreach_mul_(mom, self.momentum)
+            torch._foreach_addcdiv_(mom, gs, denom, value=lr)
+            torch._foreach_sub_(ps, mom)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+class Sparse_Graph_Model(ABC):
+    """Abstract superclass of all graph models (reference docstring: models/sparse_graph_model.py:16-20)."""
+
+    @classmethod
+    def default_params(cls):
+        # models/sparse_graph_model.py:22-45
+        return {
+            'max_nodes_in_batch': 50000,
+            'graph_num_layers': 8,
+            'graph_num_timesteps_per_layer': 1,
+            'graph_layer_input_dropout_keep_prob': 0.8,
+            'graph_dense_between_every_num_gnn_layers': 1,
+            'graph_model_activation_function': 'tanh',
+            'graph_residual_connection_every_num_layers': 2,
+            'graph_inter_layer_norm': False,
+            'max_epochs': 10000,
+            'patience': 25,
+            'optimizer': 'Adam',
+            'learning_rate': 0.001,
+            'learning_rate_decay': 0.98,
+            'lr_for_num_graphs_per_batch': None,
+            'momentum': 0.85,
+            'clamp_gradient_norm': 1.0,
+            'random_seed': 0,
+        }
+
+    @staticmethod
+    @abstractmethod
+    def name(params: Dict[str, Any]) -> str:
+        raise NotImplementedError()
+
+    def __init__(self, params: Dict[str, Any], task: Sparse_Graph_Task, run_id: str = "run",
+                 result_dir: str = ".", device: Optional[str] = None) -> None:
+        self.params = params
+        self.task = task
+        self.run_id = run_id
+        self.result_dir = result_dir
+        self.device = torch.device(device if device is not None else "cuda")
+        self.training = False
+        torch.manual_seed(params['random_seed'])
+        np.random.seed(params['random_seed'])
+        self.variables = VariableStore(seed=params['random_seed'])
+        self.__make_model()
+        self.variables.to(self.device)
+        self.__make_train_step()
+
+    @property
+    def log_file(self):
+        return os.path.join(self.result_dir, "%s.log" % self.run_id)
+
+    @property
+    def best_model_file(self):
+        return os.path.join(self.result_dir, "%s_best_model.pickle" % self.run_id)
+
+    def log_line(self, msg):
+        try:
+            with open(self.log_file, 'a') as log_fh:
+                log_fh.write(msg + '\n')
+        except OSError:
+            pass
+        print(msg)
+
+    # -------------------- Model Saving/Loading (reference pickle layout :91-126) --------------------
+    def save_model(self, path: str) -> None:
+        data_to_save = {
+            "model_class": self.name(self.params),
+            "task_class": self.task.name(),
+            "model_params": self.params,
+            "task_params": self.task.params,
+            "task_metadata": self.task.get_metadata(),
+            "weights": self.variables.tf_weights(),
+        }
+        with open(path, 'wb') as out_file:
+            pickle.dump(data_to_save, out_file, pickle.HIGHEST_PROTOCOL)
+
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        self.variables.load_tf_weights(weights)
+
+    # -------------------- Model Construction --------------------
+    @abstractmethod
+    def _gnn_layer_variables(self, in_dim: int) -> Dict[str, Any]:
+        """TF-relative variable specs of ONE gnn layer (what the reference's layer function would
+        create under variable_scope('gnn_layer_%i'))."""
+        raise NotImplementedError()
+
+    def __make_model(self):
+        p = self.params
+        h_dim = p['hidden_size']
+        vs = self.variables
+        if self.task.initial_node_feature_size != h_dim:          # :165-170, unnamed Keras Dense
+            vs.create("graph_model/dense/kernel", (self.task.initial_node_feature_size, h_dim))
+        self._inter_norm_name = []
+        for layer_idx in range(p['graph_num_layers']):            # :176-200
+            scope = "graph_model/gnn_layer_%i" % layer_idx
+            specs = dict(self._gnn_layer_variables(h_dim))
+            if p['graph_inter_layer_norm']:
+                ln = "LayerNorm_1" if "LayerNorm/gamma" in specs else "LayerNorm"   # TF uniquifies the 2nd scope
+                specs[ln + "/beta"] = ((h_dim,), "zeros")
+                specs[ln + "/gamma"] = ((h_dim,), "ones")
+                self._inter_norm_name.append(ln)
+            else:
+                self._inter_norm_name.append(None)
+            if layer_idx % p['graph_dense_between_every_num_gnn_layers'] == 0:
+                specs["Dense/kernel"] = ((h_dim, h_dim), "glorot_uniform")
+            vs.create_all(scope, specs)
+        out_scope = "dense_1" if self.task.initial_node_feature_size != h_dim else "dense"
+        self._task_scope = out_scope
+        vs.create_all(out_scope, self.task.output_variables(h_dim))
+        self.log_line("Model has %i parameters." % vs.num_parameters())
+
+    def compute_final_node_representations(self, initial_node_features: torch.Tensor,
+                                           adjacency_lists, type_to_num_incoming_edges: torch.Tensor,
+                                           dropout_keep_prob: float = 1.0) -> torch.Tensor:
+        """__build_graph_propagation_model, models/sparse_graph_model.py:162-202."""
+        p = self.params
+        activation_fn = get_activation(p['graph_model_activation_function'])
+        w = self.variables.scope("graph_model")
+        num_nodes = initial_node_features.shape[0]
+        graph = as_rel_graph(adjacency_lists, num_nodes)   # bucketed once, shared by every layer
+        if self.task.initial_node_feature_size != p['hidden_size']:
+            cur_node_representations = apply_activation(activation_fn, initial_node_features @ w["dense/kernel"])
+        else:
+            cur_node_representations = initial_node_features
+        last_residual_representations = torch.zeros_like(cur_node_representations)
+        for layer_idx in range(p['graph_num_layers']):
+            self._layer_weights = w.scope('gnn_layer_%i' % layer_idx)
+            if dropout_keep_prob < 1.0:
+                cur_node_representations = torch.nn.functional.dropout(
+                    cur_node_representations, p=1.0 - dropout_keep_prob, training=True)
+            if layer_idx % p['graph_residual_connection_every_num_layers'] == 0:
+                t = cur_node_representations
+                if layer_idx > 0:
+                    cur_node_representations = (cur_node_representations + last_residual_representations) / 2
+                last_residual_representations = t
+            cur_node_representations = self._apply_gnn_layer(
+                cur_node_representations, graph, type_to_num_incoming_edges, p['graph_num_timesteps_per_layer'])
+            if p['graph_inter_layer_norm']:
+                ln = self._inter_norm_name[layer_idx]
+                cur_node_representations = layer_norm(cur_node_representations,
+                                                      self._layer_weights[ln + "/gamma"], self._layer_weights[ln + "/beta"])
+            if layer_idx % p['graph_dense_between_every_num_gnn_layers'] == 0:
+                cur_node_representations = apply_activation(
+                    activation_fn, cur_node_representations @ self._layer_weights["Dense/kernel"])
+        return cur_node_representations
+
+    @abstractmethod
+    def _apply_gnn_layer(self,
+                         node_representations: torch.Tensor,
+                         adjacency_lists: List[torch.Tensor],
+                         type_to_num_incoming_edges: torch.Tensor,
+                         num_timesteps: int) -> torch.Tensor:
+        """Run a GNN layer on a graph (models/sparse_graph_model.py:204-225; same arguments).
+        The current layer's variables are available as self._layer_weights."""
+        raise Exception("Models have to implement _apply_gnn_layer!")
+
+    def __make_train_step(self):
+        p = self.params
+        self.optimizer = TFStyleOptimizer(list(self.variables.parameters()), p['optimizer'], p['learning_rate'],
+                                          p['clamp_gradient_norm'], decay=p['learning_rate_decay'],
+                                          momentum=p['momentum'])
+
+    # -------------------- Training Loop --------------------
+    def forward_batch(self, batch: DeviceBatch, training: bool):
+        keep = self.params['graph_layer_input_dropout_keep_prob'] if training else 1.0
+        final = self.compute_final_node_representations(
+            batch.initial_node_features, batch.adjacency_lists, batch.type_to_num_incoming_edges, keep)
+        return self.task.compute_task_metrics(final, batch, self.variables.scope(self._task_scope))
+
+    def train_step(self, batch: DeviceBatch, grad_hook=None) -> Dict[str, torch.Tensor]:
+        """forward + backward + per-variable clip + optimizer update == one sess.run with train_step (:287-293)."""
+        self.optimizer.zero_grad()
+        metrics = self.forward_batch(batch, training=True)
+        metrics['loss'].backward()
+        if grad_hook is not None:  # data-parallel gradient all-reduce goes here (before clipping)
+            grad_hook(self.optimizer.params)
+        self.optimizer.clip_gradients()
+        lr_scale = 1.0
+        lr_n = self.params.get('lr_for_num_graphs_per_batch')
+        if lr_n is not None:
+            lr_scale = float(batch.num_graphs) / float(lr_n)
+        self.optimizer.step(lr_scale)
+        return metrics
+
+    def _run_epoch(self, epoch_name: str, data: Iterable[Any], data_fold: DataFold, quiet: bool = False):
+        """__run_epoch, :263-311: returns (avg loss, task metric results, graphs, graphs/s, nodes/s, edges/s)."""
+        batch_iterator = self.task.make_minibatch_iterator(data, data_fold, self.params['max_nodes_in_batch'])
+        start_time = time.time()
+        processed_graphs = processed_nodes = processed_edges = 0
+        epoch_loss = 0.0
+        task_metric_results = []
+        for step, mb in enumerate(batch_iterator):
+            batch = DeviceBatch(mb, self.device)
+            if data_fold == DataFold.TRAIN:
+                m = self.train_step(batch)
+            else:
+                with torch.no_grad():
+                    m = self.forward_batch(batch, training=False)
+            m = {k: float(v) for k, v in m.items()}   # one sync per step, like sess.run's fetch
+            processed_graphs += mb.num_graphs
+            processed_nodes += mb.num_nodes
+            processed_edges += mb.num_edges
+            epoch_loss += m['loss'] * mb.num_graphs
+            task_metric_results.append(m)
+            if not quiet:
+                print("Running %s, batch %i (has %i graphs). Loss so far: %.4f"
+                      % (epoch_name, step, mb.num_graphs, epoch_loss / processed_graphs), end='\r')
+        epoch_time = time.time() - start_time
+        per_graph_loss = epoch_loss / max(processed_graphs, 1)
+        return (per_graph_loss, task_metric_results, processed_graphs, processed_graphs / epoch_time,
+                processed_nodes / epoch_time, processed_edges / epoch_time)
+
+    def train(self, quiet: bool = False, max_epochs: Optional[int] = None):
+        """:318-371 without TensorBoard: early stopping on the task's validation metric."""
+        total_time_start = time.time()
+        train_data = self.task._loaded_data[DataFold.TRAIN]
+        valid_data = self.task._loaded_data[DataFold.VALIDATION]
+        best_valid_metric, best_epoch = float("+inf"), 0
+        for epoch in range(1, (max_epochs or self.params['max_epochs']) + 1):
+            self.log_line("== Epoch %i" % epoch)
+            loss, res, n, gs, ns, es = self._run_epoch("epoch %i (training)" % epoch, train_data, DataFold.TRAIN, quiet)
+            self.log_line(" Train: loss: %.5f || %s || graphs/sec: %.2f | nodes/sec: %.0f | edges/sec: %.0f"
+                          % (loss, self.task.pretty_print_epoch_task_metrics(res, n), gs, ns, es))
+            loss, res, n, gs, ns, es = self._run_epoch("epoch %i (validation)" % epoch, valid_data, DataFold.VALIDATION, quiet)
+            metric = self.task.early_stopping_metric(res, n)
+            self.log_line(" Valid: loss: %.5f || %s || graphs/sec: %.2f | nodes/sec: %.0f | edges/sec: %.0f"
+                          % (loss, self.task.pretty_print_epoch_task_metrics(res, n), gs, ns, es))
+            if metric < best_valid_metric:
+                self.save_model(self.best_model_file)
+                best_valid_metric, best_epoch = metric, epoch
+            elif epoch - best_epoch >= self.params['patience']:
+                self.log_line("Stopping training after %i epochs without improvement." % self.params['patience'])
+                break
+        self.log_line("Training took %is." % (time.time() - total_time_start))
+
+    def test(self, data, quiet: bool = False):
+        loss, res, n, gs, ns, es = self._run_epoch("Test", list(data), DataFold.TEST, quiet)
+        self.log_line("Loss %.5f on %i graphs" % (loss, n))
+        self.log_line("Metrics: %s" % self.task.pretty_print_epoch_task_metrics(res, n))

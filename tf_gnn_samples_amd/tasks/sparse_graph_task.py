@@ -1,0 +1,80 @@
+"""Input contract of the hot path (mirror of tasks/sparse_graph_task.py:10-20,139-149).
+
+A minibatch is ONE disjoint-union graph:
+  initial_node_features       float32 [V, F]
+  adjacency_lists             L x int32 [E_l, 2], rows = [source, target]
+  type_to_num_incoming_edges  float32 [L, V]   (float despite the reference docstring, :144-145)
+"""
+from enum import Enum
+from typing import Any, Dict, List, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+
+class DataFold(Enum):
+    TRAIN = 0
+    VALIDATION = 1
+    TEST = 2
+
+
+class MinibatchData(NamedTuple):
+    feed_dict: Dict[str, Any]
+    num_graphs: int
+    num_nodes: int
+    num_edges: int
+
+
+class DeviceBatch:
+    """The feed dict of one minibatch, resident in HBM (the reference copies host->device on every
+    sess.run, models/sparse_graph_model.py:293; here it is done once, explicitly)."""
+
+    def __init__(self, mb: MinibatchData, device, pin: bool = False):
+        fd = mb.feed_dict
+        self.num_graphs, self.num_nodes, self.num_edges = mb.num_graphs, mb.num_nodes, mb.num_edges
+
+        def put(a, dtype):
+            t = torch.as_tensor(np.ascontiguousarray(a), dtype=dtype)
+            if pin and device != "cpu":
+                t = t.pin_memory()
+            return t.to(device, non_blocking=pin)
+
+        self.initial_node_features = put(fd['initial_node_features'], torch.float32)
+        self.adjacency_lists = [put(np.asarray(a).reshape(-1, 2), torch.int32) for a in fd['adjacency_lists']]
+        self.type_to_num_incoming_edges = put(fd['type_to_num_incoming_edges'], torch.float32)
+        self.graph_nodes_list = put(fd['graph_nodes_list'], torch.int32) if fd.get('graph_nodes_list') is not None else None
+        self.extra = {k: v for k, v in fd.items() if k not in (
+            'initial_node_features', 'adjacency_lists', 'type_to_num_incoming_edges', 'graph_nodes_list')}
+        for k, v in list(self.extra.items()):
+            if isinstance(v, np.ndarray):
+                self.extra[k] = put(v, torch.float32 if v.dtype.kind == 'f' else torch.int64)
+
+
+class Sparse_Graph_Task:
+    """Minimal task interface used by Sparse_Graph_Model (tasks/sparse_graph_task.py:23-254)."""
+
+    @classmethod
+    def default_params(cls):
+        return {}
+
+    @staticmethod
+    def name() -> str:
+        raise NotImplementedError()
+
+    def __init__(self, params: Dict[str, Any]):
+        self.params = params
+        self._loaded_data = {}  # type: Dict[DataFold, Any]
+
+    @property
+    def num_edge_types(self) -> int:
+        raise NotImplementedError()
+
+    @property
+    def initial_node_feature_size(self) -> int:
+        raise NotImplementedError()
+
+    def get_metadata(self) -> Dict[str, Any]:
+        return {}
+
+    def restore_from_metadata(self, metadata: Dict[str, Any]) -> None:
+        pass

@@ -1,0 +1,221 @@
+"""Host-side mirror of the reference's utils/utils.py (same names, argument meaning and
+error behaviour) on PyTorch-ROCm tensors.
+
+  get_aggregation_function  utils/utils.py:23-33   -> HIP segment kernels (ops.py)
+  get_activation            utils/utils.py:36-58
+  get_gated_unit            utils/utils.py:10-20   (Keras SimpleRNNCell / GRUCell semantics, TF 1.13)
+  MLP                       utils/utils.py:77-126
+  micro_f1                  utils/utils.py:61-74
+  SMALL_NUMBER, BIG_NUMBER  utils/utils.py:6-7
+
+Node-wise dense work (Dense, GRU, layer norm) is plain PyTorch-ROCm (hipBLASLt / elementwise);
+it is not the gather/segment hot path.
+"""
+import math
+from typing import Callable, List, Mapping, Optional, Union
+
+import torch
+
+from . import ops
+
+BIG_NUMBER = 1e7
+SMALL_NUMBER = 1e-7
+
+
+def get_aggregation_function(aggregation_fun: Optional[str]):
+    if aggregation_fun in ['sum', 'unsorted_segment_sum']:
+        return ops.unsorted_segment_sum
+    if aggregation_fun in ['max', 'unsorted_segment_max']:
+        return ops.unsorted_segment_max
+    if aggregation_fun in ['mean', 'unsorted_segment_mean']:
+        return ops.unsorted_segment_mean
+    if aggregation_fun in ['sqrt_n', 'unsorted_segment_sqrt_n']:
+        return ops.unsorted_segment_sqrt_n
+    else:
+        raise ValueError("Unknown aggregation function '%s'!" % aggregation_fun)
+
+
+def _gelu(x):
+    # erf form of the reference (utils/utils.py:53-55)
+    cdf = 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    return x * cdf
+
+
+def _leaky_relu(x):
+    return torch.nn.functional.leaky_relu(x, 0.2)  # tf.nn.leaky_relu default alpha
+
+
+def get_activation(activation_fun: Optional[str]):
+    if activation_fun is None:
+        return None
+    activation_fun = activation_fun.lower()
+    if activation_fun == 'linear':
+        return None
+    if activation_fun == 'tanh':
+        return torch.tanh
+    if activation_fun == 'relu':
+        return torch.relu
+    if activation_fun == 'leaky_relu':
+        return _leaky_relu
+    if activation_fun == 'elu':
+        return torch.nn.functional.elu
+    if activation_fun == 'selu':
+        return torch.selu
+    if activation_fun == 'gelu':
+        return _gelu
+    else:
+        raise ValueError("Unknown activation function '%s'!" % activation_fun)
+
+
+def apply_activation(fn, x):
+    return x if fn is None else fn(x)
+
+
+def hard_sigmoid(x):
+    """Keras hard_sigmoid (GRUCell's default recurrent_activation in TF 1.13): clip(0.2x+0.5, 0, 1)."""
+    return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
+
+
+def layer_norm(x, gamma, beta, eps: float = 1e-12):
+    """tf.contrib.layers.layer_norm on a [V, D] tensor: moments over the last axis (biased
+    variance), variance_epsilon 1e-12, learnable gamma/beta over the last axis."""
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
+
+
+class _GatedUnit:
+    """Callable cell(inputs, [state]) -> (output, [new_state]) like a Keras RNN cell."""
+
+    def __init__(self, units: int, kind: str, activation_fn, weights: Mapping[str, torch.Tensor]):
+        self.units, self.kind, self.activation_fn, self.w = units, kind, activation_fn, weights
+
+    def __call__(self, inputs, states):
+        h = states[0]
+        u = self.units
+        act = self.activation_fn
+        K, U, b = self.w["kernel"], self.w["recurrent_kernel"], self.w["bias"]
+        if self.kind == 'rnn':
+            out = torch.addmm(b, inputs, K) + h @ U
+            out = apply_activation(act, out)
+            return out, [out]
+        # GRU, reset_after=False, gate order z, r, h (Keras GRUCell, TF 1.13)
+        xk = torch.addmm(b, inputs, K)                       # [V, 3u]
+        rec = h @ U[:, :2 * u]                               # [V, 2u]
+        z = hard_sigmoid(xk[:, :u] + rec[:, :u])
+        r = hard_sigmoid(xk[:, u:2 * u] + rec[:, u:])
+        hh = apply_activation(act, xk[:, 2 * u:] + (r * h) @ U[:, 2 * u:])
+        out = z * h + (1.0 - z) * hh
+        return out, [out]
+
+
+GATED_UNIT_SCOPES = {'rnn': 'simple_rnn_cell', 'gru': 'gru_cell', 'lstm': 'lstm_cell'}
+
+
+def gated_unit_variable_shapes(units: int, input_dim: int, gated_unit: str):
+    """TF variable names (relative to the layer scope) and shapes of the cell's weights."""
+    name = gated_unit.lower()
+    if name == 'rnn':
+        g = 1
+    elif name == 'gru':
+        g = 3
+    elif name == 'lstm':
+        g = 4
+    else:
+        raise Exception("Unknown RNN cell type '%s'." % gated_unit)
+    scope = GATED_UNIT_SCOPES[name]
+    return {
+        scope + "/kernel": ((input_dim, g * units), "glorot_uniform"),
+        scope + "/recurrent_kernel": ((units, g * units), "orthogonal"),
+        scope + "/bias": ((g * units,), "zeros"),
+    }
+
+
+def get_gated_unit(units: int, gated_unit: str, activation_function: str, weights: Mapping[str, torch.Tensor]):
+    """Mirror of get_gated_unit(units, gated_unit, activation_function); `weights` carries the
+    cell variables (kernel [D_in, g*units], recurrent_kernel [units, g*units], bias [g*units])."""
+    activation_fn = get_activation(activation_function)
+    gated_unit_name = gated_unit.lower()
+    if gated_unit_name == 'rnn':
+        return _GatedUnit(units, 'rnn', activation_fn, weights)
+    if gated_unit_name == 'gru':
+        return _GatedUnit(units, 'gru', activation_fn, weights)
+    if gated_unit_name == 'lstm':
+        # The reference passes a single state to LSTMCell (gnns/ggnn.py:92), which fails inside
+        # Keras (LSTM needs [h, c]); there is no behaviour to reproduce.
+        raise NotImplementedError("LSTM cells cannot work in the reference's GGNN layer (single state)")
+    else:
+        raise Exception("Unknown RNN cell type '%s'." % gated_unit)
+
+
+def micro_f1(logits, labels):
+    predicted = torch.round(torch.sigmoid(logits)).to(torch.int32)
+    labels = labels.to(torch.int32)
+    true_pos = torch.count_nonzero(predicted * labels)
+    false_pos = torch.count_nonzero(predicted * (labels - 1))
+    false_neg = torch.count_nonzero((predicted - 1) * labels)
+    precision = true_pos / (true_pos + false_pos)
+    recall = true_pos / (true_pos + false_neg)
+    fmeasure = (2 * precision * recall) / (precision + recall)
+    return fmeasure.to(torch.float32)
+
+
+class MLP(object):
+    """utils/utils.py:77-126.  `weights` maps "dense/kernel", "dense_1/kernel", ... (and
+    ".../bias" when use_biases) to tensors in TF layout [in, out]."""
+
+    def __init__(self,
+                 out_size: int,
+                 hidden_layers: Union[List[int], int] = 1,
+                 use_biases: bool = False,
+                 activation_fun: Optional[Callable[[torch.Tensor], torch.Tensor]] = torch.relu,
+                 dropout_rate: float = 0.0,
+                 name: Optional[str] = "MLP",
+                 weights: Optional[Mapping[str, torch.Tensor]] = None,
+                 training: bool = False,
+                 ):
+        if isinstance(hidden_layers, int):
+            hidden_layer_sizes = [out_size] * hidden_layers
+        else:
+            hidden_layer_sizes = hidden_layers
+        if len(hidden_layer_sizes) > 1:
+            assert activation_fun is not None, "Multiple linear layers without an activation"
+        self.hidden_layer_sizes = list(hidden_layer_sizes)
+        self.out_size = out_size
+        self.use_biases = use_biases
+        self.activation_fun = activation_fun
+        self.dropout_rate = dropout_rate
+        self.name = name
+        self.weights = weights
+        self.training = training
+
+    @staticmethod
+    def layer_names(num_layers: int):
+        return ["dense" if i == 0 else "dense_%i" % i for i in range(num_layers)]
+
+    @classmethod
+    def variable_shapes(cls, in_size: int, out_size: int, hidden_layers: Union[List[int], int] = 1,
+                        use_biases: bool = False, name: str = "MLP"):
+        sizes = [out_size] * hidden_layers if isinstance(hidden_layers, int) else list(hidden_layers)
+        dims = [in_size] + sizes + [out_size]
+        res = {}
+        for i, lname in enumerate(cls.layer_names(len(dims) - 1)):
+            res["%s/%s/kernel" % (name, lname)] = ((dims[i], dims[i + 1]), "glorot_uniform")
+            if use_biases:
+                res["%s/%s/bias" % (name, lname)] = ((dims[i + 1],), "zeros")
+        return res
+
+    def _dense(self, i, x):
+        lname = self.layer_names(len(self.hidden_layer_sizes) + 1)[i]
+        k = self.weights["%s/%s/kernel" % (self.name, lname)]
+        y = x @ k
+        if self.use_biases:
+            y = y + self.weights["%s/%s/bias" % (self.name, lname)]
+        return y
+
+    def __call__(self, input: torch.Tensor) -> torch.Tensor:
+        activations = input
+        n_hidden = len(self.hidden_layer_sizes)
+        for i in range(n_hidden):
+            if self.dropout_rate > 0.0 and self.training:
+                activations = torch.nn.functional.dropout(activations, self.dropout_rate, True)
+            activations = apply_activation(self.activation_fun, self._dense(i, activations))
+        return self._dense(n_hidden, activations)
