@@ -1,0 +1,90 @@
+"""Index bookkeeping on the device == NumPy oracle, bit for bit (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bookkeeping
+from helpers import degree_table, random_relational_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_graph(adj, V, dev):
+    from tf_gnn_samples_amd.graph import RelGraph
+    g = RelGraph([torch.as_tensor(a, device=dev) for a in adj], V)
+    ref = bookkeeping.relational_buckets(adj, V)
+    for name in ("key_by_target", "key_by_source", "rowptr_t", "perm_t", "col_t", "src_t", "rowptr_s", "perm_s",
+                 "tgt_s", "frow_s", "pos_t_of_s", "inv_perm_t"):
+        got = getattr(g, name).cpu().numpy()
+        assert got.dtype == np.int32
+        np.testing.assert_array_equal(got, ref[name], err_msg=name)
+    return g, ref
+
+
+@pytest.mark.parametrize("V,L,E,empty", [(1, 1, 1, ()), (7, 3, 20, (1,)), (300, 5, 2000, ()), (5000, 23, 3000, (3, 4, 22))])
+def test_relgraph_matches_oracle(gpu_device, V, L, E, empty):
+    rng = np.random.default_rng(V + L)
+    adj = random_relational_graph(rng, V, L, E, empty_types=empty)
+    _check_graph(adj, V, gpu_device)
+
+
+def test_relgraph_all_types_empty(gpu_device):
+    adj = [np.zeros((0, 2), np.int32) for _ in range(3)]
+    g, ref = _check_graph(adj, 4, gpu_device)
+    assert g.M == 0 and g.rowptr_t.cpu().tolist() == [0] * 13
+
+
+def test_csr_round_trip_reconstructs_adjacency(gpu_device):
+    """bucketed CSR o inverse permutation == original adjacency lists."""
+    from tf_gnn_samples_amd.graph import RelGraph
+    rng = np.random.default_rng(9)
+    V, L = 400, 4
+    adj = random_relational_graph(rng, V, L, [900, 0, 50, 1200])
+    g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)
+    rowptr, perm, col = g.rowptr_t.cpu().numpy(), g.perm_t.cpu().numpy(), g.col_t.cpu().numpy()
+    M = sum(len(a) for a in adj)
+    seg = np.repeat(np.arange(V * L), np.diff(rowptr))       # (target, type) of every sorted position
+    src = np.empty(M, np.int64); tgt = np.empty(M, np.int64); typ = np.empty(M, np.int64)
+    src[perm], tgt[perm], typ[perm] = col // L, seg // L, seg % L
+    off = 0
+    for l, a in enumerate(adj):
+        np.testing.assert_array_equal(np.stack([src[off:off + len(a)], tgt[off:off + len(a)]], 1), a)
+        assert (typ[off:off + len(a)] == l).all()
+        off += len(a)
+    # recomputed in-degrees == type_to_num_incoming_edges
+    deg = np.diff(rowptr).reshape(V, L).T
+    np.testing.assert_array_equal(deg, degree_table(adj, V).astype(np.int64))
+
+
+def test_out_of_range_node_id_raises(gpu_device):
+    from tf_gnn_samples_amd.graph import RelGraph
+    adj = [torch.tensor([[0, 1], [2, 5]], dtype=torch.int32, device=gpu_device)]
+    with pytest.raises(ValueError, match="outside"):
+        RelGraph(adj, 4)
+    adj = [torch.tensor([[0, 1], [-1, 2]], dtype=torch.int32, device=gpu_device)]
+    with pytest.raises(ValueError, match="outside"):
+        RelGraph(adj, 4)
+
+
+def test_degree_scale_bit_exact(gpu_device):
+    from tf_gnn_samples_amd.graph import RelGraph
+    rng = np.random.default_rng(11)
+    V, L = 200, 3
+    adj = random_relational_graph(rng, V, L, 1500)
+    deg = degree_table(adj, V)
+    g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)
+    w = g.degree_scale(torch.as_tensor(deg, device=gpu_device)).cpu().numpy()
+    ref = bookkeeping.relational_buckets(adj, V)
+    key = ref["key_by_target"][ref["perm_t"]]
+    expect = np.float32(1.0) / (deg[key % L, key // L] + np.float32(1e-7))
+    np.testing.assert_array_equal(w, expect.astype(np.float32))
+
+
+def test_segment_plan_generic_stable(gpu_device):
+    from tf_gnn_samples_amd.graph import build_segment_plan
+    rng = np.random.default_rng(12)
+    keys = rng.integers(0, 1000, size=50000).astype(np.int32)
+    rowptr, perm, sk = build_segment_plan(torch.as_tensor(keys, device=gpu_device), 1000, want_sorted_keys=True)
+    np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(keys, kind='stable').astype(np.int32))
+    np.testing.assert_array_equal(rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=1000))]))
+    np.testing.assert_array_equal(sk.cpu().numpy(), np.sort(keys))

@@ -1,0 +1,87 @@
+"""Data parallelism BY GRAPH across the GPUs of one node.
+
+A minibatch of the reference is a disjoint union of graphs (tasks/ppi_task.py:220-233): no edge
+crosses graphs, so message passing never communicates.  Whole graphs are assigned to ranks
+(balanced by edge count), every rank builds its own local disjoint-union batch exactly as the
+single-GPU batcher would, and the ONLY collective is one all-reduce(SUM) of the flat fp32
+gradient per step over RCCL/xGMI (one process per GPU, torch.distributed backend "nccl" == RCCL).
+
+Objective equivalence with the single-batch reference loss (tasks/ppi_task.py:183-191,
+loss = total_loss / num_nodes_in_batch): rank r holds g_r = d(total_r / n_r); the global gradient
+is sum_r n_r * g_r / sum_r n_r.  The weight n_r rides in the last slot of the same flat buffer, so
+there is exactly one collective.  Per-variable clip_by_norm (models/sparse_graph_model.py:253-260)
+is applied AFTER the all-reduce.
+"""
+import os
+from typing import List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_graphs_by_edges(edge_counts: Sequence[int], world_size: int) -> List[List[int]]:
+    """Greedy longest-processing-time assignment of whole graphs to ranks, balancing sum_l E_l.
+    Deterministic (ties broken by graph index / lowest rank); each shard keeps ascending graph order."""
+    order = sorted(range(len(edge_counts)), key=lambda i: (-int(edge_counts[i]), i))
+    loads = [0] * world_size
+    shards: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += int(edge_counts[i])
+    return [sorted(s) for s in shards]
+
+
+def init_distributed(backend: str = None):
+    """One process per GPU; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradientAllReducer:
+    """Weighted gradient average across ranks with ONE all-reduce of one flat fp32 buffer."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.views = []
+        off = 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+    @torch.no_grad()
+    def __call__(self, local_weight: float):
+        """grad <- sum_r w_r * grad_r / sum_r w_r  (w_r = local_weight, e.g. nodes in the local batch)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(self.views, grads)
+        self.flat[:-1].mul_(float(local_weight))
+        self.flat[-1] = float(local_weight)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat[:-1].div_(self.flat[-1])
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
