@@ -212,6 +212,114 @@ int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* ro
 int relgnn_act_bwd_from_output(int32_t act, const float* y, const float* gout, int64_t n,
                                float* gin, void* stream);
 
+/* ========================================================================== *
+ * 3. GNN-FiLM fused message kernels  (gnns/gnn_film.py:86-116)
+ * ========================================================================== */
+
+/*
+ *   out[v,:] = AGG_l AGG_{p in (v,l)}  act( gamma[v,l,:] * (w[p] * T[col[p],:]) + beta[v,l,:] )
+ * with [gamma | beta] = film[v*L + l, 0:2D]  (film = H @ F_l on nodes, gnn_film.py:102-106).
+ * Replaces gnn_film.py:92-116: gather (:92), degree scale (:96-100), FiLM-weight gather (:103-106),
+ * modulate (:108), concat (:111), activation (:112), segment reduce (:113-116).  The two Dense
+ * layers (:94, :102) run node-side in the caller (one GEMM each).
+ *   T    : [num_nodes*L, ldt]    per-node per-type messages h_u W_l, row = src*L + l
+ *   film : [num_nodes*L, ldf >= 2D]
+ *   rowptr/col/w : by-(target,type) plan (relgnn_segment_plan over key_by_target)
+ * D % 4 == 0, D <= 1024, 16-byte aligned rows (RELGNN_EUNSUPPORTED otherwise).
+ */
+int relgnn_film_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const float* film,
+                    int64_t ldf, int32_t D, const int32_t* rowptr, int32_t num_nodes,
+                    int32_t num_edge_types, const int32_t* col, const float* w, float* out,
+                    int64_t ldo, void* stream);
+/* backward, pass A (by-target plan): with g_p = gagg[v,:] * act'(pre_p),
+ *   gfilm[v*L+l, 0:D]  = sum_p g_p * (w[p] T[col[p]])      (d gamma)
+ *   gfilm[v*L+l, D:2D] = sum_p g_p                          (d beta)
+ * every (v,l) row is written.  gagg = d loss / d (un-finalised aggregate), i.e. the caller has
+ * already folded the mean / sqrt_n factor in.  Sum-like modes only (max: use the unfused path). */
+int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
+                         int32_t D, const int32_t* rowptr, int32_t num_nodes,
+                         int32_t num_edge_types, const int32_t* col, const float* w,
+                         const float* gagg, int64_t ldg, float* gfilm, int64_t ldgf, void* stream);
+/* backward, pass B (by-(source,type) plan; row r of T owns its outgoing messages q):
+ *   gT[r,:] = sum_q w_b[q] * gamma[frow_b[q],:] * g_q,
+ *   g_q = gagg[tgt_b[q],:] * act'(gamma[frow_b[q]] * (w_b[q] * T[r,:]) + beta[frow_b[q]]) */
+int relgnn_film_bwd_msg(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
+                        int32_t D, const int32_t* rowptr_b, int64_t num_rows_t,
+                        const int32_t* tgt_b, const int32_t* frow_b, const float* w_b,
+                        const float* gagg, int64_t ldg, float* gT, int64_t ldgt, void* stream);
+
+/* ========================================================================== *
+ * 4. RGAT segmented-softmax attention  (gnns/rgat.py:86-138)
+ * ========================================================================== */
+
+/*
+ * For target v, head k (K = num_heads, Dh = D/K, Dh % 4 == 0), messages p of v over ALL edge types:
+ *   z[p,k]   = s_src[col[p], k] + s_tgt[v*L + l(p), k]
+ *   e[p,k]   = leaky_relu_{slope}(z[p,k])                                (rgat.py:112-115)
+ *   a[p,k]   = exp( (e - max_p e) - log(sum_p exp(e - max_p e)) )        (rgat.py:126-130,
+ *              dpu_utils.tfutils.unsorted_segment_log_softmax + tf.exp)
+ *   out[v, k*Dh:(k+1)*Dh] = sum_p a[p,k] * T[col[p], k*Dh:(k+1)*Dh]     (rgat.py:131-136)
+ * s_src[r,k] = <T[r, head k], a_l[k, 0:Dh]> and s_tgt[r,k] = <T[r, head k], a_l[k, Dh:2Dh]> for
+ * r = node*L + l are [num_nodes*L, K] tables computed node-side by the caller (they replace the
+ * [E, K, 2Dh] concat + einsum of rgat.py:106-115).  alpha (nullable, [num_messages, K], by-target
+ * order) is saved for the backward.
+ */
+int relgnn_rgat_fwd(const float* T, int64_t ldt, int32_t D, int32_t num_heads, const float* s_src,
+                    const float* s_tgt, const int32_t* rowptr, int32_t num_nodes,
+                    int32_t num_edge_types, const int32_t* col, float slope, float* out,
+                    int64_t ldo, float* alpha, void* stream);
+/* backward pass A (by-target plan):
+ *   dz[p,k] = a[p,k] * (<gout_vk, T[col[p]]_k> - <gout_vk, out_vk>) * lrelu'(z[p,k])    ([M,K], by-target order)
+ *   gs_tgt[v*L+l, k] = sum_{p in (v,l)} dz[p,k]                                            (every row written) */
+int relgnn_rgat_bwd_logits(const float* T, int64_t ldt, int32_t D, int32_t num_heads,
+                           const float* s_src, const float* s_tgt, const int32_t* rowptr,
+                           int32_t num_nodes, int32_t num_edge_types, const int32_t* col,
+                           float slope, const float* alpha, const float* out, const float* gout,
+                           int64_t ldo, float* dz, float* gs_tgt, void* stream);
+/* backward pass B (by-(source,type) plan): pos_b[q] = by-target position of message q
+ *   gT[r, head k] = sum_q alpha[pos_b[q],k] * gout[tgt_b[q], head k];   gs_src[r,k] = sum_q dz[pos_b[q],k] */
+int relgnn_rgat_bwd_msg(int32_t D, int32_t num_heads, const int32_t* rowptr_b, int64_t num_rows_t,
+                        const int32_t* tgt_b, const int32_t* pos_b, const float* alpha,
+                        const float* dz, const float* gout, int64_t ldo, float* gT, int64_t ldgt,
+                        float* gs_src, void* stream);
+
+/* ========================================================================== *
+ * 5. Messages from BOTH endpoint states  (gnns/gnn_edge_mlp.py:91-116, rgin.py:110-129,
+ *    rgcn.py:91-104 use_both_source_and_target)
+ * ========================================================================== */
+
+/*
+ * The first Dense layer on [h_u || h_v] splits into node-side P = H @ W[:D_in] (row src*L+l) and
+ * Q = H @ W[D_in:] (row tgt*L+l).
+ *   single Dense (no hidden layer), fused:  out[v,:] = AGG_p act( w[p] * (P[col[p],:] + Q[v*L + l(p),:]) )
+ *   backward: relgnn_pair_bwd_q (by-target) gQ[v*L+l] = sum_p w[p]*g_p ; relgnn_pair_bwd_p (by-source)
+ *   gP[r] = sum_q w_b[q]*g_q, g = gagg[target] * act'(w*(P+Q)).
+ */
+int relgnn_pair_fwd(int32_t mode, int32_t act, const float* P, int64_t ldp, const float* Q,
+                    int64_t ldq, int32_t D, const int32_t* rowptr, int32_t num_nodes,
+                    int32_t num_edge_types, const int32_t* col, const float* w, float* out,
+                    int64_t ldo, void* stream);
+int relgnn_pair_bwd_q(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                      int32_t D, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
+                      const int32_t* col, const float* w, const float* gagg, int64_t ldg, float* gQ,
+                      int64_t ldgq, void* stream);
+int relgnn_pair_bwd_p(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                      int32_t D, const int32_t* rowptr_b, int64_t num_rows_p, const int32_t* tgt_b,
+                      const int32_t* frow_b, const float* w_b, const float* gagg, int64_t ldg,
+                      float* gP, int64_t ldgp, void* stream);
+/*
+ * Deeper edge MLPs (utils/utils.py:120-126): materialise the first layer's activations in the
+ * ORIGINAL type-major message order so the caller can run the remaining per-type Dense layers on
+ * contiguous [E_l, D] blocks (genuinely per-edge GEMMs):
+ *   ghidden == NULL : out[m,:] = act( P[row_src[m],:] + (Q ? Q[row_tgt[m],:] : 0) )
+ *   ghidden != NULL : out[m,:] = ghidden[m,:] * act'( P[row_src[m],:] + (Q ? Q[row_tgt[m],:] : 0) )
+ * row_src = key_by_source, row_tgt = key_by_target of relgnn_relational_keys.
+ */
+int relgnn_pair_materialize(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                            int32_t D, const int32_t* row_src, const int32_t* row_tgt,
+                            int64_t num_messages, const float* ghidden, float* out, int64_t ldo,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

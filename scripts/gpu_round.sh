@@ -14,9 +14,9 @@ timeout 600 python bench.py --steps 20 --warmup 5 2>gpurun_out/bench.err | tee g
 tail -5 gpurun_out/bench.err
 if [ "${PROFILE:-1}" = "1" ]; then
   echo "== rocprofv3 kernel trace"
-  cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- \
+  cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- \
       python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
   cd $GRAFT_REPO_ROOT
-  find gpurun_out/prof -name "*stats*" | head; 
+  find gpurun_out/prof -type f | head -20; 
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
 fi

@@ -40,6 +40,16 @@ _SIGNATURES = {
     "relgnn_seg_max_count": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_seg_max_bwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_act_bwd_from_output": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
+    "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_film_bwd_msg": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_rgat_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_rgat_bwd_logits": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
+    "relgnn_rgat_bwd_msg": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_pair_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
+    "relgnn_pair_bwd_q": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_pair_bwd_p": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_pair_materialize": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr]),
 }
 
 _lib = None
@@ -86,8 +96,10 @@ def check(code: int, what: str):
     raise RuntimeError(msg)
 
 
-def ptr(t):
-    """Device pointer of a tensor (None -> NULL).  Refuses anything but HIP device memory."""
+def ptr(t, rows_strided: bool = False):
+    """Device pointer of a tensor (None -> NULL).  Refuses anything but HIP device memory.
+    rows_strided=True accepts a 2-D tensor whose rows are dense (stride(1) == 1) but whose row
+    stride exceeds its width (the C ABI takes the leading dimension separately)."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -95,7 +107,8 @@ def ptr(t):
             "librelgnn kernels only run on MI355X device tensors; got a %s tensor. "
             "There is no CPU fallback for this path." % t.device)
     if not t.is_contiguous():
-        raise ValueError("librelgnn expects contiguous tensors")
+        if not (rows_strided and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+            raise ValueError("librelgnn expects contiguous tensors")
     return t.data_ptr()
 
 

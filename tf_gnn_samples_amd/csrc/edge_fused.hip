@@ -1,0 +1,491 @@
+// Fused edge-wise message kernels over the (target, type)-bucketed CSR:
+//   FiLM   gnns/gnn_film.py:92-116      msg = act( gamma[v,l] * (w * T[src,l]) + beta[v,l] )
+//   PAIR   gnns/gnn_edge_mlp.py:91-112, gnns/rgin.py:110-129, gnns/rgcn.py:91-104
+//                                        msg = act( w * (P[src,l] + Q[v,l]) )
+// Each replaces the reference's chain  embedding_lookup (x2) -> elementwise -> concat ->
+// unsorted_segment_*  by ONE pass: a lane group owns one target node, walks its per-type
+// sub-segments, loads the per-(target,type) row(s) once per sub-segment and the gathered source
+// row once per message, and accumulates sequentially in registers (reference message order,
+// no atomics).  Backward = one by-target pass (gradients of the per-(target,type) rows) plus one
+// by-(source,type) pass (gradients of the gathered rows), both atomics-free as well.
+//
+// Lanes run across features (float4 per lane).  G lanes per node: 64 (D > 128) or 32/16/8,
+// NCH float4 chunks per lane (D <= 1024).  Bound: HBM / Infinity-Cache bandwidth;
+// algorithmic bytes: M*(4D+8) + S_nonempty*rowbytes + V*4D.
+#include "common.h"
+
+using namespace relgnn;
+
+namespace {
+
+constexpr int KIND_FILM = 0;
+constexpr int KIND_PAIR = 1;
+constexpr int PU = 4;  // messages in flight per lane group
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+
+// The activation id is a wave-uniform RUNTIME value (one uniform branch per message; the kernels are
+// memory-bound) so that the kernel count stays at geometry x kind instead of x 7 activations.
+template <int ACT>
+__device__ __forceinline__ float4 act4_t(float4 x) {
+  return make_float4(act_fwd<ACT>(x.x), act_fwd<ACT>(x.y), act_fwd<ACT>(x.z), act_fwd<ACT>(x.w));
+}
+template <int ACT>
+__device__ __forceinline__ float4 actg4_t(float4 x) {
+  return make_float4(act_grad<ACT>(x.x), act_grad<ACT>(x.y), act_grad<ACT>(x.z), act_grad<ACT>(x.w));
+}
+__device__ __forceinline__ float4 act4(int act, float4 x) {
+  switch (act) {
+    case RELGNN_ACT_TANH: return act4_t<RELGNN_ACT_TANH>(x);
+    case RELGNN_ACT_RELU: return act4_t<RELGNN_ACT_RELU>(x);
+    case RELGNN_ACT_LEAKY_RELU: return act4_t<RELGNN_ACT_LEAKY_RELU>(x);
+    case RELGNN_ACT_ELU: return act4_t<RELGNN_ACT_ELU>(x);
+    case RELGNN_ACT_SELU: return act4_t<RELGNN_ACT_SELU>(x);
+    case RELGNN_ACT_GELU: return act4_t<RELGNN_ACT_GELU>(x);
+    default: return x;
+  }
+}
+__device__ __forceinline__ float4 actg4(int act, float4 x) {
+  switch (act) {
+    case RELGNN_ACT_TANH: return actg4_t<RELGNN_ACT_TANH>(x);
+    case RELGNN_ACT_RELU: return actg4_t<RELGNN_ACT_RELU>(x);
+    case RELGNN_ACT_LEAKY_RELU: return actg4_t<RELGNN_ACT_LEAKY_RELU>(x);
+    case RELGNN_ACT_ELU: return actg4_t<RELGNN_ACT_ELU>(x);
+    case RELGNN_ACT_SELU: return actg4_t<RELGNN_ACT_SELU>(x);
+    case RELGNN_ACT_GELU: return actg4_t<RELGNN_ACT_GELU>(x);
+    default: return make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+}
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator*(float a, float4 b) { return make_float4(a * b.x, a * b.y, a * b.z, a * b.w); }
+__device__ __forceinline__ float4 max4(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+
+// pre-activation of one message.  rowA/rowB: gamma/beta (FiLM) or q/unused (PAIR)
+template <int KIND>
+__device__ __forceinline__ float4 pre_act(float w, float4 t, float4 rowA, float4 rowB) {
+  if constexpr (KIND == KIND_FILM) return rowA * (w * t) + rowB;  // gnn_film.py:100,108
+  else return w * (t + rowA);                                      // gnn_edge_mlp.py:102-108
+}
+
+struct GroupGeom {
+  int g, gl;          // lane group within the wave, lane within the group
+  int64_t node;       // node / row owned by this group
+  bool valid;
+};
+
+template <int G>
+__device__ __forceinline__ GroupGeom geom(int64_t n_rows, int64_t n_logical_blocks) {
+  GroupGeom r;
+  const int64_t lb = xcd_logical_block(n_logical_blocks);
+  const int lane = threadIdx.x & 63;
+  r.g = lane / G;
+  r.gl = lane % G;
+  r.node = lb < 0 ? n_rows : (lb * 4 + (threadIdx.x >> 6)) * (64 / G) + r.g;
+  r.valid = r.node < n_rows;
+  return r;
+}
+
+// -----------------------------------------------------------------------------------------
+// forward:  out[v] = finalize( AGG_l AGG_{p in (v,l)} act(pre_act(w[p], T[col[p]], rows(v,l))) )
+// -----------------------------------------------------------------------------------------
+template <int G, int NCH, int KIND, bool IS_MAX>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(
+    const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
+    const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
+    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4, int64_t nlb) {
+  const GroupGeom gg = geom<G>(V, nlb);
+  if (!gg.valid) return;
+  const int64_t v = gg.node;
+  bool on[NCH];
+  int cc[NCH];
+  float4 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    on[c] = gg.gl + G * c < D4;
+    cc[c] = min(gg.gl + G * c, D4 - 1);
+    acc[c] = f4(IS_MAX ? -FLT_MAX : 0.f);
+  }
+  const int seg_b = rowptr[v * L], seg_e = rowptr[(v + 1) * L];
+  int b = seg_b;
+  for (int l = 0; l < L; ++l) {
+    const int e = rowptr[v * L + l + 1];
+    if (b < e) {
+      float4 ra[NCH], rb[NCH];
+      const float4* arow = A + (v * L + l) * lda4;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        ra[c] = arow[cc[c]];
+        rb[c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+      }
+      for (int p = b; p < e; p += PU) {
+        int r[PU];
+        float ww[PU];
+        float4 t[PU][NCH];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+          const int idx = min(p + u, e - 1);
+          r[u] = col[idx];
+          ww[u] = w ? w[idx] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) t[u][c] = T[(int64_t)r[u] * ldt4 + cc[c]];
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          if (p + u < e) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const float4 m = act4(act, pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+              acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
+            }
+          }
+      }
+    }
+    b = e;
+  }
+  const float n = (float)max(seg_e - seg_b, 1);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (on[c]) {
+      float4 a = acc[c];
+      if (mode == RELGNN_AGG_MEAN) a = make_float4(a.x / n, a.y / n, a.z / n, a.w / n);
+      if (mode == RELGNN_AGG_SQRT_N) { const float s = sqrtf(n); a = make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+      out[v * ldo4 + gg.gl + G * c] = a;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// backward A (by-target): gradient of the per-(target,type) rows.
+//   g_p = gagg[v] * act'(pre_p)
+//   FiLM: gA[(v,l)] = [ sum_p g_p * (w_p T[col p]) | sum_p g_p ]       (d gamma | d beta)
+//   PAIR: gA[(v,l)] =   sum_p g_p * w_p                                  (d q)
+// Every (v,l) row is written (zeros for empty sub-segments).
+// -----------------------------------------------------------------------------------------
+template <int G, int NCH, int KIND>
+__global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
+    const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
+    const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
+    const float* __restrict__ w, const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gA,
+    int64_t ldga4, int32_t act, int64_t nlb) {
+  const GroupGeom gg = geom<G>(V, nlb);
+  if (!gg.valid) return;
+  const int64_t v = gg.node;
+  bool on[NCH];
+  int cc[NCH];
+  float4 g[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    on[c] = gg.gl + G * c < D4;
+    cc[c] = min(gg.gl + G * c, D4 - 1);
+    g[c] = gagg[v * ldg4 + cc[c]];
+  }
+  int b = rowptr[v * L];
+  for (int l = 0; l < L; ++l) {
+    const int e = rowptr[v * L + l + 1];
+    float4 s1[NCH], s2[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) s1[c] = s2[c] = f4(0.f);
+    if (b < e) {
+      float4 ra[NCH], rb[NCH];
+      const float4* arow = A + (v * L + l) * lda4;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        ra[c] = arow[cc[c]];
+        rb[c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+      }
+      for (int p = b; p < e; p += PU) {
+        int r[PU];
+        float ww[PU];
+        float4 t[PU][NCH];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+          const int idx = min(p + u, e - 1);
+          r[u] = col[idx];
+          ww[u] = w ? w[idx] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) t[u][c] = T[(int64_t)r[u] * ldt4 + cc[c]];
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          if (p + u < e) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const float4 gp = g[c] * actg4(act, pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+              if constexpr (KIND == KIND_FILM) {
+                s1[c] = s1[c] + gp * (ww[u] * t[u][c]);
+                s2[c] = s2[c] + gp;
+              } else {
+                s1[c] = s1[c] + ww[u] * gp;
+              }
+            }
+          }
+      }
+    }
+    float4* grow = gA + (v * L + l) * ldga4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (on[c]) {
+        grow[gg.gl + G * c] = s1[c];
+        if constexpr (KIND == KIND_FILM) grow[D4 + gg.gl + G * c] = s2[c];
+      }
+    b = e;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// backward B (by-(source,type) rows r of T): gradient of the gathered rows.
+//   gT[r] = sum_q dmsg_q,  g_q = gagg[tgt_b[q]] * act'(pre_q)
+//   FiLM: dmsg = w_q * gamma[frow_b[q]] * g_q ;  PAIR: dmsg = w_q * g_q
+// -----------------------------------------------------------------------------------------
+template <int G, int NCH, int KIND>
+__global__ __launch_bounds__(256) void edge_bwd_msgs_kernel(
+    const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
+    const int32_t* __restrict__ rowptr_b, int64_t n_rows, const int32_t* __restrict__ tgt_b,
+    const int32_t* __restrict__ frow_b, const float* __restrict__ w_b, const float4* __restrict__ gagg,
+    int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int32_t act, int64_t nlb) {
+  const GroupGeom gg = geom<G>(n_rows, nlb);
+  if (!gg.valid) return;
+  const int64_t r = gg.node;
+  bool on[NCH];
+  int cc[NCH];
+  float4 t[NCH], acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    on[c] = gg.gl + G * c < D4;
+    cc[c] = min(gg.gl + G * c, D4 - 1);
+    t[c] = T[r * ldt4 + cc[c]];
+    acc[c] = f4(0.f);
+  }
+  const int b = rowptr_b[r], e = rowptr_b[r + 1];
+  for (int q = b; q < e; q += PU) {
+    int fr[PU], tg[PU];
+    float ww[PU];
+    float4 ra[PU][NCH], rb[PU][NCH], g[PU][NCH];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int idx = min(q + u, e - 1);
+      fr[u] = frow_b[idx];
+      tg[u] = tgt_b[idx];
+      ww[u] = w_b ? w_b[idx] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float4* arow = A + (int64_t)fr[u] * lda4;
+        ra[u][c] = arow[cc[c]];
+        rb[u][c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+        g[u][c] = gagg[(int64_t)tg[u] * ldg4 + cc[c]];
+      }
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+      if (q + u < e) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const float4 gp = g[u][c] * actg4(act, pre_act<KIND>(ww[u], t[c], ra[u][c], rb[u][c]));
+          if constexpr (KIND == KIND_FILM) acc[c] = acc[c] + ww[u] * (ra[u][c] * gp);
+          else acc[c] = acc[c] + ww[u] * gp;
+        }
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (on[c]) gT[r * ldgt4 + gg.gl + G * c] = acc[c];
+}
+
+// -----------------------------------------------------------------------------------------
+// materialise per-message hidden states in the ORIGINAL type-major message order:
+//   hidden[m] = act( P[row_src[m]] + Q[row_tgt[m]] )     (rows = node*L + type)
+// (first Dense of an edge MLP on [h_u || h_v], utils/utils.py:120-126; the per-type dense layers
+//  that follow are genuinely per-edge GEMMs on contiguous [E_l, D] blocks.)
+// and its gradient w.r.t. the pre-activation: gpre[m] = ghidden[m] * act'(P[..] + Q[..]).
+// -----------------------------------------------------------------------------------------
+template <bool GRAD>
+__global__ __launch_bounds__(256) void pair_materialize_kernel(int32_t act, 
+    const float4* __restrict__ P, int64_t ldp4, const float4* __restrict__ Q, int64_t ldq4, int32_t D4,
+    const int32_t* __restrict__ row_src, const int32_t* __restrict__ row_tgt, int64_t M,
+    const float4* __restrict__ ghidden, float4* __restrict__ out, int64_t ldo4) {
+  const int64_t total = M * D4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D4;
+    const int c = (int)(i - m * D4);
+    float4 pre = P[(int64_t)row_src[m] * ldp4 + c];
+    if (Q) pre = pre + Q[(int64_t)row_tgt[m] * ldq4 + c];
+    if constexpr (GRAD) out[m * ldo4 + c] = ghidden[m * ldo4 + c] * actg4(act, pre);
+    else out[m * ldo4 + c] = act4(act, pre);
+  }
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------
+struct Geo { int G, NCH; };
+inline bool pick_geo(int D, Geo* g) {
+  if (D <= 0 || D % 4 != 0 || D > 1024) return false;
+  const int D4 = D / 4;
+  if (D4 <= 8) *g = {8, 1};
+  else if (D4 <= 16) *g = {16, 1};
+  else if (D4 <= 32) *g = {32, 1};
+  else if (D4 <= 64) *g = {64, 1};
+  else if (D4 <= 128) *g = {64, 2};
+  else *g = {64, 4};
+  return true;
+}
+inline int64_t logical_blocks(int64_t rows, int G) { return (rows + 4 * (64 / G) - 1) / (4 * (64 / G)); }
+inline unsigned padded_grid(int64_t nlb) { return (unsigned)(((nlb + 7) / 8) * 8); }
+
+#define RELGNN_DISPATCH_GEO(geo, GG, NN, ...)                                        \
+  if (geo.G == 8) { constexpr int GG = 8, NN = 1; __VA_ARGS__; }                      \
+  else if (geo.G == 16) { constexpr int GG = 16, NN = 1; __VA_ARGS__; }               \
+  else if (geo.G == 32) { constexpr int GG = 32, NN = 1; __VA_ARGS__; }               \
+  else if (geo.NCH == 1) { constexpr int GG = 64, NN = 1; __VA_ARGS__; }              \
+  else if (geo.NCH == 2) { constexpr int GG = 64, NN = 2; __VA_ARGS__; }              \
+  else { constexpr int GG = 64, NN = 4; __VA_ARGS__; }
+
+inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && ld % 4 == 0; }
+
+template <int KIND>
+int launch_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda,
+               int32_t D, const int32_t* rowptr, int32_t V, int32_t L, const int32_t* col,
+               const float* w, float* out, int64_t ldo, hipStream_t st) {
+  Geo geo;
+  if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(out, ldo)) return RELGNN_EUNSUPPORTED;
+  const int64_t nlb = logical_blocks(V, geo.G);
+  const unsigned grid = padded_grid(nlb);
+  const bool is_max = mode == RELGNN_AGG_MAX;
+  if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  RELGNN_DISPATCH_GEO(geo, GG, NN, {
+    if (is_max)
+      edge_fwd_kernel<GG, NN, KIND, true><<<grid, 256, 0, st>>>(
+          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, mode, act, (float4*)out, ldo / 4, nlb);
+    else
+      edge_fwd_kernel<GG, NN, KIND, false><<<grid, 256, 0, st>>>(
+          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, mode, act, (float4*)out, ldo / 4, nlb);
+  });
+  return launch_status();
+}
+
+template <int KIND>
+int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda, int32_t D,
+                    const int32_t* rowptr, int32_t V, int32_t L, const int32_t* col, const float* w,
+                    const float* gagg, int64_t ldg, float* gA, int64_t ldga, hipStream_t st) {
+  Geo geo;
+  if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(gagg, ldg) || !vec_ok(gA, ldga))
+    return RELGNN_EUNSUPPORTED;
+  const int64_t nlb = logical_blocks(V, geo.G);
+  const unsigned grid = padded_grid(nlb);
+  if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  RELGNN_DISPATCH_GEO(geo, GG, NN, {
+    edge_bwd_rows_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
+        (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4,
+        (float4*)gA, ldga / 4, act, nlb);
+  });
+  return launch_status();
+}
+
+template <int KIND>
+int launch_bwd_msgs(int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda, int32_t D,
+                    const int32_t* rowptr_b, int64_t n_rows, const int32_t* tgt_b, const int32_t* frow_b,
+                    const float* w_b, const float* gagg, int64_t ldg, float* gT, int64_t ldgt, hipStream_t st) {
+  Geo geo;
+  if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(gagg, ldg) || !vec_ok(gT, ldgt))
+    return RELGNN_EUNSUPPORTED;
+  const int64_t nlb = logical_blocks(n_rows, geo.G);
+  const unsigned grid = padded_grid(nlb);
+  if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  RELGNN_DISPATCH_GEO(geo, GG, NN, {
+    edge_bwd_msgs_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
+        (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,
+        (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, nlb);
+  });
+  return launch_status();
+}
+
+inline bool bad_common(int32_t D, int32_t V, int32_t L) { return D < 0 || V < 0 || L <= 0; }
+
+}  // namespace
+
+extern "C" {
+
+int relgnn_film_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const float* film,
+                    int64_t ldf, int32_t D, const int32_t* rowptr, int32_t num_nodes,
+                    int32_t num_edge_types, const int32_t* col, const float* w, float* out, int64_t ldo,
+                    void* stream) {
+  if (bad_common(D, num_nodes, num_edge_types) || mode < RELGNN_AGG_SUM || mode > RELGNN_AGG_MAX || ldf < 2 * D)
+    return RELGNN_EINVAL;
+  if (num_nodes == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !out) return RELGNN_EINVAL;
+  return launch_fwd<KIND_FILM>(mode, act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, out, ldo, as_stream(stream));
+}
+
+int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
+                         int32_t D, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
+                         const int32_t* col, const float* w, const float* gagg, int64_t ldg, float* gfilm,
+                         int64_t ldgf, void* stream) {
+  if (bad_common(D, num_nodes, num_edge_types) || ldf < 2 * D || ldgf < 2 * D) return RELGNN_EINVAL;
+  if (num_nodes == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !gagg || !gfilm) return RELGNN_EINVAL;
+  return launch_bwd_rows<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gfilm, ldgf, as_stream(stream));
+}
+
+int relgnn_film_bwd_msg(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
+                        int32_t D, const int32_t* rowptr_b, int64_t num_rows_t, const int32_t* tgt_b,
+                        const int32_t* frow_b, const float* w_b, const float* gagg, int64_t ldg, float* gT,
+                        int64_t ldgt, void* stream) {
+  if (D < 0 || num_rows_t < 0 || ldf < 2 * D) return RELGNN_EINVAL;
+  if (num_rows_t == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr_b || !T || !gT) return RELGNN_EINVAL;
+  return launch_bwd_msgs<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr_b, num_rows_t, tgt_b, frow_b, w_b, gagg, ldg, gT, ldgt, as_stream(stream));
+}
+
+int relgnn_pair_fwd(int32_t mode, int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                    int32_t D, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
+                    const int32_t* col, const float* w, float* out, int64_t ldo, void* stream) {
+  if (bad_common(D, num_nodes, num_edge_types) || mode < RELGNN_AGG_SUM || mode > RELGNN_AGG_MAX) return RELGNN_EINVAL;
+  if (num_nodes == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !out) return RELGNN_EINVAL;
+  return launch_fwd<KIND_PAIR>(mode, act, P, ldp, Q, ldq, D, rowptr, num_nodes, num_edge_types, col, w, out, ldo, as_stream(stream));
+}
+
+int relgnn_pair_bwd_q(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq, int32_t D,
+                      const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types, const int32_t* col,
+                      const float* w, const float* gagg, int64_t ldg, float* gQ, int64_t ldgq, void* stream) {
+  if (bad_common(D, num_nodes, num_edge_types)) return RELGNN_EINVAL;
+  if (num_nodes == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !gagg || !gQ) return RELGNN_EINVAL;
+  return launch_bwd_rows<KIND_PAIR>(act, P, ldp, Q, ldq, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gQ, ldgq, as_stream(stream));
+}
+
+int relgnn_pair_bwd_p(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq, int32_t D,
+                      const int32_t* rowptr_b, int64_t num_rows_p, const int32_t* tgt_b, const int32_t* frow_b,
+                      const float* w_b, const float* gagg, int64_t ldg, float* gP, int64_t ldgp, void* stream) {
+  if (D < 0 || num_rows_p < 0) return RELGNN_EINVAL;
+  if (num_rows_p == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr_b || !P || !gP) return RELGNN_EINVAL;
+  return launch_bwd_msgs<KIND_PAIR>(act, P, ldp, Q, ldq, D, rowptr_b, num_rows_p, tgt_b, frow_b, w_b, gagg, ldg, gP, ldgp, as_stream(stream));
+}
+
+int relgnn_pair_materialize(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq, int32_t D,
+                            const int32_t* row_src, const int32_t* row_tgt, int64_t num_messages,
+                            const float* ghidden, float* out, int64_t ldo, void* stream) {
+  if (D < 0 || num_messages < 0) return RELGNN_EINVAL;
+  if (num_messages == 0 || D == 0) return RELGNN_OK;
+  if (!P || !row_src || !out || (Q && !row_tgt)) return RELGNN_EINVAL;
+  if (D % 4 != 0 || !vec_ok(P, ldp) || (Q && !vec_ok(Q, ldq)) || !vec_ok(out, ldo) || (ghidden && !aligned16(ghidden)))
+    return RELGNN_EUNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = flat_grid(num_messages * (D / 4), 256);
+  if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (ghidden)
+    pair_materialize_kernel<true><<<grid, 256, 0, st>>>(act, (const float4*)P, ldp / 4, (const float4*)Q, ldq / 4, D / 4, row_src,
+                                                        row_tgt, num_messages, (const float4*)ghidden, (float4*)out, ldo / 4);
+  else
+    pair_materialize_kernel<false><<<grid, 256, 0, st>>>(act, (const float4*)P, ldp / 4, (const float4*)Q, ldq / 4, D / 4, row_src,
+                                                         row_tgt, num_messages, nullptr, (float4*)out, ldo / 4);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+"""sparse_rgat_layer — MI355X mirror of gnns/rgat.py:9-141.
+
+    e_{u,l,v,k} = leaky_relu( a_{l,k} . [ (W_l h_u)_k || (W_l h_v)_k ] )
+    alpha       = softmax over ALL messages into v (all edge types), per head k
+    h'_v        = sigma( concat_k  sum alpha_{u,l,v,k} (W_l h_u)_k )
+
+The attention logit is linear in the two transformed endpoint states, so it decomposes into the
+per-node scalars s_src[u,l,k] = a_{l,k}[:Dh] . (W_l h_u)_k and s_tgt[v,l,k] = a_{l,k}[Dh:] . (W_l h_v)_k
+(two [V*L, K] tables).  The segmented softmax + weighted sum then needs 4*K bytes per message for the
+softmax passes and ONE gather of the source row (csrc/rgat.hip) — instead of the reference's two
+[E, D] gathers, [E, K, 2D/K] concat, einsum and K x (5-op log-softmax + segment-sum).
+"""
+from typing import List, Mapping, Optional
+
+import torch
+
+from .. import ops
+from ..graph import as_rel_graph
+from ..utils import apply_activation, get_activation
+from ._common import concat_edge_kernels, require_weights
+
+
+def rgat_layer_variables(num_edge_types: int, in_dim: int, state_dim: int):
+    specs = {}
+    for l in range(num_edge_types):
+        specs["Edge_%i_Weight/kernel" % l] = ((in_dim, state_dim), "glorot_uniform")
+        # tf.get_variable(shape=(2*state_dim)) without initializer: glorot_uniform (TF1 default) [TF-internal]
+        specs["Edge_%i_Attention_Parameters" % l] = ((2 * state_dim,), "glorot_uniform")
+    return specs
+
+
+def sparse_rgat_layer(node_embeddings: torch.Tensor,
+                      adjacency_lists: List[torch.Tensor],
+                      state_dim: Optional[int],
+                      num_heads: int = 4,
+                      num_timesteps: int = 1,
+                      activation_function: Optional[str] = "tanh",
+                      *,
+                      weights: Mapping[str, torch.Tensor] = None,
+                      ) -> torch.Tensor:
+    """See gnns/rgat.py:16-57.  `weights`: "Edge_%i_Weight/kernel" [D, state_dim] and
+    "Edge_%i_Attention_Parameters" [2*state_dim] (reshaped (K, 2*state_dim/K): the first state_dim/K entries
+    of each head act on the SOURCE half, rgat.py:106-111)."""
+    weights = require_weights(weights, "sparse_rgat_layer")
+    num_nodes, in_dim = node_embeddings.shape
+    if state_dim is None:
+        state_dim = in_dim
+    per_head_dim = state_dim // num_heads
+    if per_head_dim * num_heads != state_dim:
+        raise ValueError("state_dim must be divisible by num_heads")
+    graph = as_rel_graph(adjacency_lists, num_nodes)
+    L = graph.L
+    activation_fn = get_activation(activation_function)
+    w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")                        # [D, L*state_dim]
+    att = torch.stack([weights["Edge_%i_Attention_Parameters" % l] for l in range(L)], dim=0)
+    att = att.view(L, num_heads, 2 * per_head_dim)
+    att_src, att_tgt = att[:, :, :per_head_dim], att[:, :, per_head_dim:]                   # [L, K, Dh] each
+
+    cur_node_states = node_embeddings
+    for _ in range(num_timesteps):
+        transformed = cur_node_states @ w_cat                                               # [V, L*state_dim]
+        t4 = transformed.view(num_nodes, L, num_heads, per_head_dim)
+        s_src = (t4 * att_src.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)       # [V*L, K]
+        s_tgt = (t4 * att_tgt.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)
+        aggregated = ops.rgat_attention(transformed.view(num_nodes * L, state_dim), s_src, s_tgt, graph, num_heads, 0.2)
+        cur_node_states = apply_activation(activation_fn, aggregated)
+    return cur_node_states

@@ -177,6 +177,50 @@ class RelGraph:
             self._scales.popitem(last=False)
         return w
 
+    def w_by_source(self, w: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """per-message weights re-ordered from by-target positions to by-(source,type) positions."""
+        if w is None:
+            return None
+        key = ("w_s", w.data_ptr())
+        if key not in self._plans:
+            lib = _lib.load_library()
+            ws = torch.empty_like(w)
+            _lib.check(lib.relgnn_gather_f32(_lib.ptr(w), _lib.ptr(self.pos_t_of_s), self.M, _lib.ptr(ws),
+                                             _lib.current_stream()), "relgnn_gather_f32")
+            self._plans[key] = (w, ws)
+        return self._plans[key][1]
+
+    def w_original_order(self, w: torch.Tensor) -> torch.Tensor:
+        """per-message weights in the reference's type-major message order."""
+        key = ("w_o", w.data_ptr())
+        if key not in self._plans:
+            lib = _lib.load_library()
+            wo = torch.empty_like(w)
+            _lib.check(lib.relgnn_gather_f32(_lib.ptr(w), _lib.ptr(self.inv_perm_t), self.M, _lib.ptr(wo),
+                                             _lib.current_stream()), "relgnn_gather_f32")
+            self._plans[key] = (w, wo)
+        return self._plans[key][1]
+
+    def messages_per_target(self) -> torch.Tensor:
+        """n_v = number of incoming messages of node v over all edge types, float32 [V], clamped to >= 1
+        (the N of tf.unsorted_segment_mean / sqrt_n)."""
+        if "n_v" not in self._plans:
+            rp = self.rowptr_t
+            n = (rp[self.L::self.L] - rp[:-1:self.L]).clamp(min=1).to(torch.float32)
+            self._plans["n_v"] = n
+        return self._plans["n_v"]
+
+    @property
+    def tgt_t(self):
+        """target NODE of each by-target position."""
+        if "tgt_t" not in self._plans:
+            lib = _lib.load_library()
+            t = _i32(self.M, self.device)
+            _lib.check(lib.relgnn_gather_div_i32(_lib.ptr(self.key_by_target), _lib.ptr(self.perm_t), self.M, self.L,
+                                                 _lib.ptr(t), _lib.current_stream()), "relgnn_gather_div_i32")
+            self._plans["tgt_t"] = t
+        return self._plans["tgt_t"]
+
     # ---- plans ----------------------------------------------------------------------------
     def plan_transformed(self, w: Optional[torch.Tensor] = None) -> GatherReducePlan:
         """Messages gathered from a per-(node, type) table T [V*L, D] (row = src*L + l), reduced
@@ -198,6 +242,45 @@ class RelGraph:
                 num_rows_x=self.V, rowptr_b=self.rowptr_s, stride_b=self.L, col_b=self.tgt_s,
                 pos_b=self.pos_t_of_s, num_messages=self.M))
         return self._plans[key][1]
+
+
+    def plan_messages(self) -> GatherReducePlan:
+        """Messages materialised as an [M, D] tensor in the reference's type-major order (the operand of
+        tf.unsorted_segment_* in the reference), reduced into their target nodes."""
+        key = ("MSG",)
+        if key not in self._plans:
+            dev = self.device
+            if "tgt_orig" not in self._plans:
+                lib = _lib.load_library()
+                t = _i32(self.M, dev)
+                ident = torch.arange(self.M, dtype=torch.int32, device=dev)
+                _lib.check(lib.relgnn_gather_div_i32(_lib.ptr(self.key_by_target), _lib.ptr(ident), self.M, self.L,
+                                                     _lib.ptr(t), _lib.current_stream()), "relgnn_gather_div_i32")
+                self._plans["tgt_orig"] = t
+            self._plans[key] = (None, GatherReducePlan(
+                rowptr=self.rowptr_t, stride=self.L, col=self.perm_t, w=None, num_out=self.V, num_rows_x=self.M,
+                rowptr_b=torch.arange(self.M + 1, dtype=torch.int32, device=dev), stride_b=1,
+                col_b=self._plans["tgt_orig"], pos_b=self.inv_perm_t, num_messages=self.M))
+        return self._plans[key][1]
+
+    def plan_target_rows(self) -> GatherReducePlan:
+        """Every message carries its TARGET node's own row (the h_v half of [h_u || h_v] when no edge MLP
+        follows, gnns/rgin.py:114-125): out[v] = AGG over v's messages of X[v]."""
+        key = ("TGT",)
+        if key not in self._plans:
+            self._plans[key] = (None, GatherReducePlan(
+                rowptr=self.rowptr_t, stride=self.L, col=self.tgt_t, w=None, num_out=self.V, num_rows_x=self.V,
+                rowptr_b=self.rowptr_t, stride_b=self.L, col_b=self.tgt_t,
+                pos_b=torch.arange(self.M, dtype=torch.int32, device=self.device), num_messages=self.M))
+        return self._plans[key][1]
+
+    @property
+    def type_offsets(self):
+        """start of every edge type in the type-major message list (python ints), length L+1."""
+        offs = [0]
+        for e in self.edge_counts:
+            offs.append(offs[-1] + e)
+        return offs
 
 
 # ---- cache: the layer functions receive raw adjacency lists on every call ------------------

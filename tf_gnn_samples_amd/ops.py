@@ -54,7 +54,7 @@ def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEA
     D = X.shape[1]
     out = torch.empty((num_out, D), dtype=torch.float32, device=X.device)
     _lib.check(lib.relgnn_seg_reduce_fwd(
-        mode, _lib.ptr(X), X.shape[0], X.stride(0), D, _lib.ptr(rowptr), num_out, stride,
+        mode, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), D, _lib.ptr(rowptr), num_out, stride,
         _lib.ptr(col), _lib.ptr(w), act, _lib.ptr(out), D, _lib.current_stream()),
         "relgnn_seg_reduce_fwd")
     return out
@@ -66,7 +66,7 @@ class _SegGatherReduce(torch.autograd.Function):
         _check_f32(X, "X")
         if X.dim() != 2 or X.shape[0] != plan.num_rows_x:
             raise ValueError("X must be [%d, D], got %s" % (plan.num_rows_x, tuple(X.shape)))
-        if X.stride(1) != 1:
+        if X.stride(1) != 1 or (mode == _lib.AGG_MAX and not X.is_contiguous()):
             X = X.contiguous()
         out = _seg_reduce_raw(mode, X, plan.rowptr, plan.stride, plan.col, plan.w, plan.num_out, act)
         ctx.plan, ctx.mode, ctx.act = plan, mode, act
@@ -186,3 +186,159 @@ def unsorted_segment_sqrt_n(data, segment_ids, num_segments):
 def unsorted_segment_max(data, segment_ids, num_segments):
     """Empty segments yield float32 lowest (-3.4028235e38), as TF does."""
     return _unsorted_segment("max", data, segment_ids, num_segments)
+
+
+# ---- fused edge-wise message kernels (csrc/edge_fused.hip) ----------------------------------
+def _mode_factor(graph, mode: int):
+    """d(finalised aggregate)/d(raw sum) per target node: 1, 1/max(n,1) or 1/sqrt(max(n,1))."""
+    if mode == _lib.AGG_SUM:
+        return None
+    n = graph.messages_per_target()
+    return (1.0 / n) if mode == _lib.AGG_MEAN else (1.0 / torch.sqrt(n))
+
+
+class _FusedEdgeMessages(torch.autograd.Function):
+    """kind 'film': out[v] = AGG act(gamma[v,l] * (w * T[src,l]) + beta[v,l]),  A = film [V*L, 2D]
+       kind 'pair': out[v] = AGG act(w * (T[src,l] + A[v,l])),                  A = Q    [V*L, D]"""
+
+    @staticmethod
+    def forward(ctx, T, A, graph, w, mode: int, act: int, kind: str):
+        lib = _lib.load_library()
+        _check_f32(T, "T"); _check_f32(A, "A")
+        T, A = T.contiguous(), A.contiguous()
+        V, L = graph.V, graph.L
+        D = T.shape[1]
+        if T.shape[0] != V * L or A.shape[0] != V * L or A.shape[1] != (2 * D if kind == "film" else D):
+            raise ValueError("bad operand shapes for fused %s messages" % kind)
+        out = torch.empty((V, D), dtype=torch.float32, device=T.device)
+        fn = lib.relgnn_film_fwd if kind == "film" else lib.relgnn_pair_fwd
+        _lib.check(fn(mode, act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t), V, L,
+                      _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(out), D, _lib.current_stream()),
+                   "relgnn_%s_fwd" % kind)
+        ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.kind = graph, w, mode, act, kind
+        ctx.save_for_backward(T, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        graph, w, mode, act, kind = ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.kind
+        if mode == _lib.AGG_MAX:
+            raise RuntimeError("fused %s messages have no max-aggregation backward; the layer uses the unfused path" % kind)
+        T, A = ctx.saved_tensors
+        V, L = graph.V, graph.L
+        D = T.shape[1]
+        f = _mode_factor(graph, mode)
+        gagg = (gout * f.unsqueeze(1)).contiguous() if f is not None else gout.contiguous()
+        gA = torch.empty_like(A)
+        gT = torch.empty_like(T)
+        if kind == "film":
+            _lib.check(lib.relgnn_film_bwd_film(act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t),
+                                                V, L, _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(gagg), D,
+                                                _lib.ptr(gA), A.shape[1], st), "relgnn_film_bwd_film")
+            _lib.check(lib.relgnn_film_bwd_msg(act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_s),
+                                               V * L, _lib.ptr(graph.tgt_s), _lib.ptr(graph.frow_s),
+                                               _lib.ptr(graph.w_by_source(w)), _lib.ptr(gagg), D, _lib.ptr(gT), D, st),
+                       "relgnn_film_bwd_msg")
+        else:
+            _lib.check(lib.relgnn_pair_bwd_q(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_t), V, L,
+                                             _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(gagg), D, _lib.ptr(gA), D, st),
+                       "relgnn_pair_bwd_q")
+            _lib.check(lib.relgnn_pair_bwd_p(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_s), V * L,
+                                             _lib.ptr(graph.tgt_s), _lib.ptr(graph.frow_s), _lib.ptr(graph.w_by_source(w)),
+                                             _lib.ptr(gagg), D, _lib.ptr(gT), D, st), "relgnn_pair_bwd_p")
+        return gT, gA, None, None, None, None, None
+
+
+def film_messages_reduce(T, film, graph, w, aggregation: str, activation: Optional[str]):
+    """gnns/gnn_film.py:92-116 in one kernel (sum / mean / sqrt_n; max forward only)."""
+    return _FusedEdgeMessages.apply(T, film, graph, w, aggregation_mode_id(aggregation), activation_id(activation), "film")
+
+
+def pair_messages_reduce_fused(P, Q, graph, w, aggregation: str, activation: Optional[str]):
+    return _FusedEdgeMessages.apply(P, Q, graph, w, aggregation_mode_id(aggregation), activation_id(activation), "pair")
+
+
+class _PairMaterialize(torch.autograd.Function):
+    """hidden[m] = act(P[src_m*L+l_m] + Q[tgt_m*L+l_m]) in the reference's type-major message order."""
+
+    @staticmethod
+    def forward(ctx, P, Q, graph, act: int):
+        lib = _lib.load_library()
+        P = P.contiguous()
+        Q = Q.contiguous() if Q is not None else None
+        M, D = graph.M, P.shape[1]
+        out = torch.empty((M, D), dtype=torch.float32, device=P.device)
+        _lib.check(lib.relgnn_pair_materialize(act, _lib.ptr(P), D, _lib.ptr(Q), D, D, _lib.ptr(graph.key_by_source),
+                                               _lib.ptr(graph.key_by_target), M, None, _lib.ptr(out), D,
+                                               _lib.current_stream()), "relgnn_pair_materialize")
+        ctx.graph, ctx.act, ctx.has_q = graph, act, Q is not None
+        ctx.save_for_backward(P, Q)
+        return out
+
+    @staticmethod
+    def backward(ctx, ghidden):
+        lib = _lib.load_library()
+        graph, act = ctx.graph, ctx.act
+        P, Q = ctx.saved_tensors
+        M, D = graph.M, P.shape[1]
+        ghidden = ghidden.contiguous()
+        gpre = torch.empty_like(ghidden)
+        _lib.check(lib.relgnn_pair_materialize(act, _lib.ptr(P), D, _lib.ptr(Q), D, D, _lib.ptr(graph.key_by_source),
+                                               _lib.ptr(graph.key_by_target), M, _lib.ptr(ghidden), _lib.ptr(gpre), D,
+                                               _lib.current_stream()), "relgnn_pair_materialize")
+        S = graph.V * graph.L
+        # gP[r] = sum of gpre over the messages whose source row is r; gQ[f] likewise by target row
+        gP = _seg_reduce_raw(_lib.AGG_SUM, gpre, graph.rowptr_s, 1, graph.perm_s, None, S)
+        gQ = _seg_reduce_raw(_lib.AGG_SUM, gpre, graph.rowptr_t, 1, graph.perm_t, None, S) if ctx.has_q else None
+        return gP, gQ, None, None
+
+
+def pair_materialize(P, Q, graph, activation: Optional[str]):
+    return _PairMaterialize.apply(P, Q, graph, activation_id(activation))
+
+
+# ---- RGAT (csrc/rgat.hip) -----------------------------------------------------------------------
+class _RgatAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, T, s_src, s_tgt, graph, num_heads: int, slope: float):
+        lib = _lib.load_library()
+        T, s_src, s_tgt = T.contiguous(), s_src.contiguous(), s_tgt.contiguous()
+        V, L, M = graph.V, graph.L, graph.M
+        D = T.shape[1]
+        out = torch.empty((V, D), dtype=torch.float32, device=T.device)
+        alpha = torch.empty((M, num_heads), dtype=torch.float32, device=T.device)
+        _lib.check(lib.relgnn_rgat_fwd(_lib.ptr(T), D, D, num_heads, _lib.ptr(s_src), _lib.ptr(s_tgt),
+                                       _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope, _lib.ptr(out), D,
+                                       _lib.ptr(alpha), _lib.current_stream()), "relgnn_rgat_fwd")
+        ctx.graph, ctx.K, ctx.slope = graph, num_heads, slope
+        ctx.save_for_backward(T, s_src, s_tgt, alpha, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        graph, K, slope = ctx.graph, ctx.K, ctx.slope
+        T, s_src, s_tgt, alpha, out = ctx.saved_tensors
+        V, L, M = graph.V, graph.L, graph.M
+        D = T.shape[1]
+        gout = gout.contiguous()
+        dz = torch.empty((M, K), dtype=torch.float32, device=T.device)
+        gs_tgt = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
+        _lib.check(lib.relgnn_rgat_bwd_logits(_lib.ptr(T), D, D, K, _lib.ptr(s_src), _lib.ptr(s_tgt),
+                                              _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope,
+                                              _lib.ptr(alpha), _lib.ptr(out), _lib.ptr(gout), D, _lib.ptr(dz),
+                                              _lib.ptr(gs_tgt), st), "relgnn_rgat_bwd_logits")
+        gT = torch.empty_like(T)
+        gs_src = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
+        _lib.check(lib.relgnn_rgat_bwd_msg(D, K, _lib.ptr(graph.rowptr_s), V * L, _lib.ptr(graph.tgt_s),
+                                           _lib.ptr(graph.pos_t_of_s), _lib.ptr(alpha), _lib.ptr(dz), _lib.ptr(gout), D,
+                                           _lib.ptr(gT), D, _lib.ptr(gs_src), st), "relgnn_rgat_bwd_msg")
+        return gT, gs_src, gs_tgt, None, None, None
+
+
+def rgat_attention(T, s_src, s_tgt, graph, num_heads: int, slope: float = 0.2):
+    """gnns/rgat.py:98-136: segmented softmax over all incoming messages + attention-weighted sum."""
+    return _RgatAttention.apply(T, s_src, s_tgt, graph, int(num_heads), float(slope))
