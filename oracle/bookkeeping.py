@@ -101,3 +101,24 @@ def in_degree_table(adjacency_lists, num_nodes: int) -> np.ndarray:
     as it is fed (tasks/sparse_graph_task.py:144-145)."""
     return np.stack([np.bincount(np.asarray(a).reshape(-1, 2)[:, 1], minlength=num_nodes)
                      for a in adjacency_lists]).astype(np.float32)
+
+
+def qm9_graph_to_adjacency_lists(graph, num_nodes, num_edge_types, add_self_loop_edges=True, tie_fwd_bkwd_edges=True):
+    """Restatement of tasks/qm9_task.py:114-147 (raw triples (src, e, dst), e in 1..4):
+    list-append in triple order, both directions when tied, self loops appended last on type 0,
+    every list sorted lexicographically (:135).  Returns (adjacency lists, in-degree table [L, V])."""
+    lists = [[] for _ in range(num_edge_types)]
+    deg = np.zeros(shape=(num_edge_types, num_nodes))
+    for src, e, dest in graph:
+        fwd = e if add_self_loop_edges else e - 1
+        lists[fwd].append((src, dest))
+        deg[fwd, dest] += 1
+        if tie_fwd_bkwd_edges:
+            lists[fwd].append((dest, src))
+            deg[fwd, src] += 1
+    if add_self_loop_edges:
+        for node in range(num_nodes):
+            deg[0, node] = 1
+            lists[0].append((node, node))
+    adj = [np.array(sorted(a), dtype=np.int32) if len(a) > 0 else np.zeros(shape=(0, 2), dtype=np.int32) for a in lists]
+    return adj, deg

@@ -1,0 +1,101 @@
+"""N > 1 path on CPU: world_size-2 gloo processes.  Data parallelism by graph must reproduce the
+single-batch objective: the all-reduced, node-weighted gradient of the two shards equals the gradient of
+the union batch.  The compute here is the oracle's torch-CPU mirror (the HIP path needs a GPU); what is
+under test is the package's sharding + GradientAllReducer logic and its loss scaling."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_problem():
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    from tf_gnn_samples_amd.tasks.synthetic import make_ppi_shaped_graphs
+    graphs = make_ppi_shaped_graphs(6, seed=7, mean_nodes=60, std_nodes=20, min_nodes=20, max_nodes=120,
+                                    fwd_edges_per_node=4.0, feature_size=12, num_labels=5)
+    gen = torch.Generator().manual_seed(0)
+    D = 16
+    weights = {"in": torch.randn(12, D, generator=gen) * 0.3, "out": torch.randn(D, 5, generator=gen) * 0.3}
+    for l in range(3):
+        weights["Edge_%i_Weight/kernel" % l] = torch.randn(D, D, generator=gen) * 0.3
+    return graphs, weights, D
+
+
+def _loss_and_grads(graphs, weights, D):
+    """PPI objective on one disjoint-union batch: total_loss / num_nodes (tasks/ppi_task.py:183-191)."""
+    from oracle import torch_ref as R
+    from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    mb = next(task.make_minibatch_iterator(list(graphs), DataFold.VALIDATION, 10 ** 9))
+    fd = mb.feed_dict
+    ws = {k: v.clone().requires_grad_(True) for k, v in weights.items()}
+    x = torch.as_tensor(fd["initial_node_features"])
+    adj = [torch.as_tensor(a) for a in fd["adjacency_lists"]]
+    deg = torch.as_tensor(fd["type_to_num_incoming_edges"], dtype=torch.float32)
+    h = torch.tanh(x @ ws["in"])
+    h = R.sparse_rgcn_layer(h, adj, deg, D, 1, "tanh", "sum", weights=ws)
+    logits = h @ ws["out"]
+    y = torch.as_tensor(fd["target_labels"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y, reduction="sum") / y.shape[0]
+    loss.backward()
+    return mb.num_nodes, ws
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    from tf_gnn_samples_amd.parallel import GradientAllReducer, init_distributed, shard_graphs_by_edges
+    r, _, w = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    graphs, weights, D = _make_problem()
+    counts = [sum(len(a) for a in g.adjacency_lists) for g in graphs]
+    shard = shard_graphs_by_edges(counts, world)[rank]
+    n_local, ws = _loss_and_grads([graphs[i] for i in shard], weights, D)
+    params = [torch.nn.Parameter(v.detach().clone()) for v in ws.values()]
+    for p, v in zip(params, ws.values()):
+        p.grad = v.grad.clone()
+    reducer = GradientAllReducer(params)
+    reducer(float(n_local))
+    q.put((rank, shard, [p.grad.numpy().copy() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_gradient_equals_union_batch():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    graphs, weights, D = _make_problem()
+    _, ws = _loss_and_grads(graphs, weights, D)
+    full = [v.grad.numpy() for v in ws.values()]
+    shards = sorted(i for _, s, _ in results for i in s)
+    assert shards == list(range(len(graphs)))
+    for _, _, grads in results:
+        for a, b in zip(grads, full):
+            assert np.abs(a - b).max() < 1e-5 * max(1.0, np.abs(b).max())

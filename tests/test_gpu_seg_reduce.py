@@ -136,7 +136,8 @@ def test_seg_reduce_gradient_matches_autograd_reference(gpu_device, agg):
         msgs = wm.unsqueeze(1) * msgs
     ref = R.unsorted_segment(agg, msgs, torch.as_tensor(tg), V)
     ref.backward(torch.as_tensor(gout, dtype=torch.float64))
-    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 1e-5
+    nonempty = np.bincount(tg, minlength=V) > 0   # an empty max-segment is dtype-lowest: differs between fp32 and fp64
+    assert np.abs(out.detach().cpu().numpy()[nonempty] - ref.detach().numpy()[nonempty]).max() < 1e-5
     scale = max(1.0, float(Xr.grad.abs().max()))
     assert np.abs(Xd.grad.cpu().numpy() - Xr.grad.numpy()).max() < 1e-5 * scale
 
