@@ -8,6 +8,7 @@ from typing import List, Mapping, Optional
 import torch
 
 from .. import ops
+from ..dense import dense
 from ..graph import as_rel_graph
 from ..utils import gated_unit_variable_shapes, get_gated_unit
 from ._common import concat_edge_kernels, require_weights
@@ -49,7 +50,7 @@ def sparse_ggnn_layer(node_embeddings: torch.Tensor,
     w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
-        transformed = (cur_node_states @ w_cat).view(num_nodes * L, state_dim)
+        transformed = dense(cur_node_states, w_cat).view(num_nodes * L, state_dim)
         aggregated_messages = ops.seg_gather_reduce(transformed, plan, message_aggregation_function, None)
         cur_node_states = gated_cell(aggregated_messages, [cur_node_states])[0]
     return cur_node_states

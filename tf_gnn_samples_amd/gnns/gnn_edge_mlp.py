@@ -12,6 +12,7 @@ from typing import List, Mapping, Optional
 import torch
 
 from .. import ops
+from ..dense import dense
 from ..graph import as_rel_graph
 from ..utils import MLP, apply_activation, get_activation, layer_norm
 from ._common import require_weights
@@ -58,9 +59,9 @@ def sparse_gnn_edge_mlp_layer(node_embeddings: torch.Tensor,
         d = cur_node_states.shape[1]
         if num_edge_hidden_layers == 0:
             k = [weights["Edge_%i_MLP/dense/kernel" % l] for l in range(L)]
-            p = (cur_node_states @ torch.cat([x[:d] for x in k], dim=1)).view(num_nodes * L, state_dim)
+            p = dense(cur_node_states, torch.cat([x[:d] for x in k], dim=1)).view(num_nodes * L, state_dim)
             if use_target_state_as_input:
-                q = (cur_node_states @ torch.cat([x[d:] for x in k], dim=1)).view(num_nodes * L, state_dim)
+                q = dense(cur_node_states, torch.cat([x[d:] for x in k], dim=1)).view(num_nodes * L, state_dim)
             else:
                 q = torch.zeros_like(p)
             aggregated = pair_messages_reduce(p, q, graph, w, message_aggregation_function,

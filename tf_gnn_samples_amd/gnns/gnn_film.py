@@ -13,6 +13,7 @@ from typing import List, Mapping, Optional
 import torch
 
 from .. import _lib, ops
+from ..dense import dense
 from ..graph import as_rel_graph
 from ..utils import apply_activation, get_activation, layer_norm
 from ._common import concat_edge_kernels, require_weights
@@ -55,8 +56,8 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
 
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
-        transformed = (cur_node_states @ w_msg).view(num_nodes * L, state_dim)      # row v*L+l = h_v W_l
-        film = (cur_node_states @ w_film).view(num_nodes * L, 2 * state_dim)        # row v*L+l = [gamma | beta]
+        transformed = dense(cur_node_states, w_msg).view(num_nodes * L, state_dim)      # row v*L+l = h_v W_l
+        film = dense(cur_node_states, w_film).view(num_nodes * L, 2 * state_dim)        # row v*L+l = [gamma | beta]
         if mode == _lib.AGG_MAX:
             # max backward needs the materialised messages (tie handling); not a shipped configuration
             msgs = transformed.index_select(0, graph.key_by_source.long())

@@ -11,6 +11,7 @@ from typing import Mapping, Optional, Sequence
 import torch
 
 from .. import _lib, ops
+from ..dense import dense
 from ..utils import apply_activation, get_activation
 
 
@@ -48,11 +49,11 @@ def edge_mlp_messages(cur: torch.Tensor, graph, weights: Mapping[str, torch.Tens
     k0 = [weights["%s/%s/kernel" % (mlp_name_pattern % l, names[0])] for l in range(L)]
     w_src = torch.cat([k[:d_in] for k in k0], dim=1)                                  # [D, L*Dh]
     dh = k0[0].shape[1]
-    p = (cur @ w_src).view(V * L, dh)
+    p = dense(cur, w_src).view(V * L, dh)
     q = None
     if use_target_state_as_input:
         w_tgt = torch.cat([k[d_in:] for k in k0], dim=1)
-        q = (cur @ w_tgt).view(V * L, dh)
+        q = dense(cur, w_tgt).view(V * L, dh)
     hidden = ops.pair_materialize(p, q, graph, hidden_activation)                     # [M, Dh]
     act_fn = get_activation(hidden_activation)
     offs = graph.type_offsets
@@ -60,7 +61,7 @@ def edge_mlp_messages(cur: torch.Tensor, graph, weights: Mapping[str, torch.Tens
     for l in range(L):
         h = hidden[offs[l]:offs[l + 1]]
         for i in range(1, num_hidden_layers + 1):
-            h = h @ weights["%s/%s/kernel" % (mlp_name_pattern % l, names[i])]
+            h = dense(h, weights["%s/%s/kernel" % (mlp_name_pattern % l, names[i])])
             if i < num_hidden_layers:
                 h = apply_activation(act_fn, h)
         outs.append(h)

@@ -15,6 +15,7 @@ from typing import List, Mapping, Optional
 import torch
 
 from .. import ops
+from ..dense import dense
 from ..graph import as_rel_graph
 from ..utils import apply_activation, get_activation
 from ._common import concat_edge_kernels, require_weights
@@ -58,7 +59,7 @@ def sparse_rgat_layer(node_embeddings: torch.Tensor,
 
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
-        transformed = cur_node_states @ w_cat                                               # [V, L*state_dim]
+        transformed = dense(cur_node_states, w_cat)                                               # [V, L*state_dim]
         t4 = transformed.view(num_nodes, L, num_heads, per_head_dim)
         s_src = (t4 * att_src.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)       # [V*L, K]
         s_tgt = (t4 * att_tgt.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)

@@ -15,6 +15,7 @@ from typing import List, Mapping, Optional
 
 import torch
 
+from ..dense import dense
 from ..graph import as_rel_graph
 from ._common import concat_edge_kernels, reduce_and_activate, require_weights
 from .pair import pair_messages_reduce
@@ -55,7 +56,7 @@ def sparse_rgcn_layer(node_embeddings: torch.Tensor,
         plan = graph.plan_transformed(w)
         w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")          # [D, L*state_dim]
         for _ in range(num_timesteps):
-            transformed = (cur_node_states @ w_cat).view(num_nodes * L, state_dim)  # row v*L+l = h_v W_l
+            transformed = dense(cur_node_states, w_cat).view(num_nodes * L, state_dim)  # row v*L+l = h_v W_l
             cur_node_states = reduce_and_activate(transformed, plan, message_aggregation_function,
                                                   activation_function)
         return cur_node_states
@@ -66,8 +67,8 @@ def sparse_rgcn_layer(node_embeddings: torch.Tensor,
         d = cur_node_states.shape[1]
         w_src = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel", rows=slice(0, d))
         w_tgt = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel", rows=slice(d, 2 * d))
-        p = (cur_node_states @ w_src).view(num_nodes * L, state_dim)
-        q = (cur_node_states @ w_tgt).view(num_nodes * L, state_dim)
+        p = dense(cur_node_states, w_src).view(num_nodes * L, state_dim)
+        q = dense(cur_node_states, w_tgt).view(num_nodes * L, state_dim)
         cur_node_states = pair_messages_reduce(p, q, graph, w, message_aggregation_function,
                                                message_activation=None,
                                                output_activation=activation_function)

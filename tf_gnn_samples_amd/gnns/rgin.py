@@ -13,6 +13,7 @@ from typing import List, Mapping, Optional
 import torch
 
 from .. import ops
+from ..dense import dense
 from ..graph import as_rel_graph
 from ..utils import MLP, apply_activation, get_activation, layer_norm
 from ._common import require_weights
@@ -83,8 +84,8 @@ def sparse_rgin_layer(node_embeddings: torch.Tensor,
             aggregated = ops.seg_gather_reduce(transformed, graph.plan_transformed(None), message_aggregation_function, None)
         elif num_edge_MLP_hidden_layers == 0:
             k = [weights["Edge_%i_MLP/dense/kernel" % l] for l in range(L)]
-            p = (cur_node_states @ torch.cat([x[:d] for x in k], dim=1)).view(num_nodes * L, state_dim)
-            q = (cur_node_states @ torch.cat([x[d:] for x in k], dim=1)).view(num_nodes * L, state_dim)
+            p = dense(cur_node_states, torch.cat([x[:d] for x in k], dim=1)).view(num_nodes * L, state_dim)
+            q = dense(cur_node_states, torch.cat([x[d:] for x in k], dim=1)).view(num_nodes * L, state_dim)
             aggregated = pair_messages_reduce(p, q, graph, None, message_aggregation_function,
                                               message_activation=activation_function, output_activation=None)
         else:

@@ -19,6 +19,7 @@ from typing import Any, Dict, Iterable, List, Optional
 import numpy as np
 import torch
 
+from ..dense import dense
 from ..graph import as_rel_graph
 from ..tasks import DataFold, DeviceBatch, Sparse_Graph_Task
 from ..utils import apply_activation, get_activation, layer_norm
@@ -54,9 +55,9 @@ class TFStyleOptimizer:
         grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:
             return
-        norms = torch._foreach_norm(grads)
-        scales = [self.clip / torch.clamp(n, min=self.clip) for n in norms]
-        torch._foreach_mul_(grads, scales)
+        norms = torch.stack(torch._foreach_norm(grads))
+        scales = self.clip / torch.clamp(norms, min=self.clip)       # == 1 where ||g|| <= clip
+        torch._foreach_mul_(grads, list(scales.unbind(0)))
 
     @torch.no_grad()
     def step(self, lr_scale: float = 1.0):
@@ -219,7 +220,7 @@ class Sparse_Graph_Model(ABC):
         num_nodes = initial_node_features.shape[0]
         graph = as_rel_graph(adjacency_lists, num_nodes)   # bucketed once, shared by every layer
         if self.task.initial_node_feature_size != p['hidden_size']:
-            cur_node_representations = apply_activation(activation_fn, initial_node_features @ w["dense/kernel"])
+            cur_node_representations = apply_activation(activation_fn, dense(initial_node_features, w["dense/kernel"]))
         else:
             cur_node_representations = initial_node_features
         last_residual_representations = torch.zeros_like(cur_node_representations)
@@ -241,7 +242,7 @@ class Sparse_Graph_Model(ABC):
                                                       self._layer_weights[ln + "/gamma"], self._layer_weights[ln + "/beta"])
             if layer_idx % p['graph_dense_between_every_num_gnn_layers'] == 0:
                 cur_node_representations = apply_activation(
-                    activation_fn, cur_node_representations @ self._layer_weights["Dense/kernel"])
+                    activation_fn, dense(cur_node_representations, self._layer_weights["Dense/kernel"]))
         return cur_node_representations
 
     @abstractmethod

@@ -12,7 +12,8 @@ from typing import Any, Dict, Iterator, List, Optional
 import numpy as np
 import torch
 
-from ..utils import micro_f1
+from ..dense import dense
+from ..utils import micro_f1, micro_f1_label_masks
 from .sparse_graph_task import DataFold, MinibatchData, Sparse_Graph_Task
 from .synthetic import GraphSample, make_ppi_shaped_graphs
 
@@ -141,12 +142,14 @@ class PPI_Task(Sparse_Graph_Task):
 
     def compute_task_metrics(self, final_node_representations: torch.Tensor, batch, weights) -> Dict[str, torch.Tensor]:
         labels = batch.extra['target_labels']
-        per_node_logits = torch.addmm(weights["bias"], final_node_representations, weights["kernel"])
-        losses = torch.nn.functional.binary_cross_entropy_with_logits(per_node_logits, labels, reduction='none')
-        total_loss = losses.sum()
+        per_node_logits = dense(final_node_representations, weights["kernel"], weights["bias"])
+        total_loss = torch.nn.functional.binary_cross_entropy_with_logits(per_node_logits, labels, reduction='sum')
         num_nodes_in_batch = labels.shape[0]
+        masks = batch.extra.get('_f1_label_masks')
+        if masks is None:   # labels are constant per batch: build the two predicates once
+            masks = batch.extra['_f1_label_masks'] = micro_f1_label_masks(labels)
         return {'loss': total_loss / float(num_nodes_in_batch), 'total_loss': total_loss,
-                'f1_score': micro_f1(per_node_logits.detach(), labels)}
+                'f1_score': micro_f1(per_node_logits.detach(), labels, masks)}
 
     # -------------------- Minibatching (tasks/ppi_task.py:197-256) --------------------
     def make_minibatch_iterator(self, data: List[GraphSample], data_fold: DataFold,

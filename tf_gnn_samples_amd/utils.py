@@ -17,6 +17,7 @@ from typing import Callable, List, Mapping, Optional, Union
 import torch
 
 from . import ops
+from .dense import dense
 
 BIG_NUMBER = 1e7
 SMALL_NUMBER = 1e-7
@@ -94,15 +95,15 @@ class _GatedUnit:
         act = self.activation_fn
         K, U, b = self.w["kernel"], self.w["recurrent_kernel"], self.w["bias"]
         if self.kind == 'rnn':
-            out = torch.addmm(b, inputs, K) + h @ U
+            out = dense(inputs, K, b) + dense(h, U)
             out = apply_activation(act, out)
             return out, [out]
         # GRU, reset_after=False, gate order z, r, h (Keras GRUCell, TF 1.13)
-        xk = torch.addmm(b, inputs, K)                       # [V, 3u]
-        rec = h @ U[:, :2 * u]                               # [V, 2u]
+        xk = dense(inputs, K, b)                             # [V, 3u]
+        rec = dense(h, U[:, :2 * u])                         # [V, 2u]
         z = hard_sigmoid(xk[:, :u] + rec[:, :u])
         r = hard_sigmoid(xk[:, u:2 * u] + rec[:, u:])
-        hh = apply_activation(act, xk[:, 2 * u:] + (r * h) @ U[:, 2 * u:])
+        hh = apply_activation(act, xk[:, 2 * u:] + dense(r * h, U[:, 2 * u:]))
         out = z * h + (1.0 - z) * hh
         return out, [out]
 
@@ -146,12 +147,22 @@ def get_gated_unit(units: int, gated_unit: str, activation_function: str, weight
         raise Exception("Unknown RNN cell type '%s'." % gated_unit)
 
 
-def micro_f1(logits, labels):
-    predicted = torch.round(torch.sigmoid(logits)).to(torch.int32)
-    labels = labels.to(torch.int32)
-    true_pos = torch.count_nonzero(predicted * labels)
-    false_pos = torch.count_nonzero(predicted * (labels - 1))
-    false_neg = torch.count_nonzero((predicted - 1) * labels)
+def micro_f1_label_masks(labels):
+    """(int(label) != 0, int(label) != 1): the two label predicates micro_f1 needs; constant per batch."""
+    li = labels.to(torch.int32)
+    return li != 0, li != 1
+
+
+def micro_f1(logits, labels, label_masks=None):
+    """utils/utils.py:61-74 on integers, restated with boolean masks (identical counts):
+      predicted = round(sigmoid(logits))  ==  sigmoid(logits) > 0.5   (round-half-even sends exactly 0.5 to 0)
+      true_pos  = #(predicted * labels != 0);  false_pos = #(predicted * (labels - 1) != 0)
+      false_neg = #((predicted - 1) * labels != 0)"""
+    predicted = torch.sigmoid(logits) > 0.5
+    lab_nz, lab_n1 = label_masks if label_masks is not None else micro_f1_label_masks(labels)
+    true_pos = (predicted & lab_nz).sum()
+    false_pos = (predicted & lab_n1).sum()
+    false_neg = (~predicted & lab_nz).sum()
     precision = true_pos / (true_pos + false_pos)
     recall = true_pos / (true_pos + false_neg)
     fmeasure = (2 * precision * recall) / (precision + recall)
@@ -206,10 +217,8 @@ class MLP(object):
     def _dense(self, i, x):
         lname = self.layer_names(len(self.hidden_layer_sizes) + 1)[i]
         k = self.weights["%s/%s/kernel" % (self.name, lname)]
-        y = x @ k
-        if self.use_biases:
-            y = y + self.weights["%s/%s/bias" % (self.name, lname)]
-        return y
+        b = self.weights["%s/%s/bias" % (self.name, lname)] if self.use_biases else None
+        return dense(x, k, b)
 
     def __call__(self, input: torch.Tensor) -> torch.Tensor:
         activations = input
