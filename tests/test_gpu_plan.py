@@ -88,3 +88,15 @@ def test_segment_plan_generic_stable(gpu_device):
     np.testing.assert_array_equal(perm.cpu().numpy(), np.argsort(keys, kind='stable').astype(np.int32))
     np.testing.assert_array_equal(rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=1000))]))
     np.testing.assert_array_equal(sk.cpu().numpy(), np.sort(keys))
+
+
+def test_deferred_validation_raises_at_check(gpu_device):
+    from tf_gnn_samples_amd.graph import RelGraph, check_pending_graph_errors
+    check_pending_graph_errors()
+    bad = [torch.tensor([[0, 9]], dtype=torch.int32, device=gpu_device)]
+    g = RelGraph(bad, 4, validate="deferred")      # no sync, no raise yet
+    with pytest.raises(ValueError, match="outside"):
+        check_pending_graph_errors()
+    check_pending_graph_errors()                      # cleared
+    ok = RelGraph([torch.tensor([[0, 3]], dtype=torch.int32, device=gpu_device)], 4, validate="deferred")
+    check_pending_graph_errors()

@@ -85,7 +85,12 @@ def build_segment_plan(keys: torch.Tensor, num_segments: int, want_sorted_keys: 
 class RelGraph:
     """(edge type, target)- and (edge type, source)-bucketed view of one batched graph."""
 
-    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int, validate: bool = True):
+    def __init__(self, adjacency_lists: Sequence[torch.Tensor], num_nodes: int, validate=True):
+        """validate=True : read the device-side range-check flag now (one host sync) and raise ValueError
+                            for node ids outside [0, num_nodes), as TF-CPU raises InvalidArgumentError;
+           validate="deferred": keep the flag on the device; call .check() (or check_pending_graph_errors())
+                            at the next natural sync point — lets the host run ahead of the GPU;
+           validate=False: never read it."""
         lib = _lib.load_library()
         if len(adjacency_lists) == 0:
             raise ValueError("need at least one edge type")
@@ -141,9 +146,20 @@ class RelGraph:
         self._src_t = None
         self._plans = {}
         self._scales = OrderedDict()
-        if validate and int(err.item()) != 0:
-            # TF-CPU raises InvalidArgumentError for out-of-range gather / segment ids.
-            raise ValueError("adjacency list holds a node id outside [0, %d)" % V)
+        self._err_flag = err
+        self._checked = False
+        if validate is True:
+            self.check()
+        elif validate == "deferred":
+            _PENDING_CHECKS.append(self)
+
+    def check(self):
+        """Host sync: raise if the device-side validation saw a node id outside [0, V)."""
+        if not self._checked:
+            self._checked = True
+            if int(self._err_flag.item()) != 0:
+                # TF-CPU raises InvalidArgumentError for out-of-range gather / segment ids.
+                raise ValueError("adjacency list holds a node id outside [0, %d)" % self.V)
 
     # ---- derived index arrays -----------------------------------------------------------
     @property
@@ -288,7 +304,17 @@ _GRAPH_CACHE: "OrderedDict[tuple, RelGraph]" = OrderedDict()
 _GRAPH_CACHE_SIZE = 8
 
 
-def as_rel_graph(adjacency_lists, num_nodes: int) -> RelGraph:
+_PENDING_CHECKS: List["RelGraph"] = []
+
+
+def check_pending_graph_errors():
+    """Validate every RelGraph built with validate="deferred" since the last call (one host sync each)."""
+    pending, _PENDING_CHECKS[:] = list(_PENDING_CHECKS), []
+    for g in pending:
+        g.check()
+
+
+def as_rel_graph(adjacency_lists, num_nodes: int, validate=True) -> RelGraph:
     """RelGraph for these adjacency tensors (built once per batch, reused by every layer)."""
     if isinstance(adjacency_lists, RelGraph):
         if adjacency_lists.V != num_nodes:
@@ -299,7 +325,7 @@ def as_rel_graph(adjacency_lists, num_nodes: int) -> RelGraph:
     if g is not None:
         _GRAPH_CACHE.move_to_end(key)
         return g
-    g = RelGraph(adjacency_lists, num_nodes)
+    g = RelGraph(adjacency_lists, num_nodes, validate=validate)
     g._cache_refs = list(adjacency_lists)  # keep the keyed storage alive while cached
     _GRAPH_CACHE[key] = g
     while len(_GRAPH_CACHE) > _GRAPH_CACHE_SIZE:

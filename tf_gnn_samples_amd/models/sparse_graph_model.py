@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from ..dense import dense
-from ..graph import as_rel_graph
+from ..graph import as_rel_graph, check_pending_graph_errors
 from ..tasks import DataFold, DeviceBatch, Sparse_Graph_Task
 from ..utils import apply_activation, get_activation, layer_norm
 from ..variables import VariableStore
@@ -218,7 +218,8 @@ class Sparse_Graph_Model(ABC):
         activation_fn = get_activation(p['graph_model_activation_function'])
         w = self.variables.scope("graph_model")
         num_nodes = initial_node_features.shape[0]
-        graph = as_rel_graph(adjacency_lists, num_nodes)   # bucketed once, shared by every layer
+        # bucketed once, shared by every layer; the index range check is read back at the next fetch
+        graph = as_rel_graph(adjacency_lists, num_nodes, validate="deferred")
         if self.task.initial_node_feature_size != p['hidden_size']:
             cur_node_representations = apply_activation(activation_fn, dense(initial_node_features, w["dense/kernel"]))
         else:
@@ -298,6 +299,7 @@ class Sparse_Graph_Model(ABC):
                 with torch.no_grad():
                     m = self.forward_batch(batch, training=False)
             m = {k: float(v) for k, v in m.items()}   # one sync per step, like sess.run's fetch
+            check_pending_graph_errors()
             processed_graphs += mb.num_graphs
             processed_nodes += mb.num_nodes
             processed_edges += mb.num_edges
