@@ -94,6 +94,36 @@ def time_segment_kernel(batch, hidden, iters):
     return ms, alg_bytes, M
 
 
+def pmc_traffic_bytes():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_b_seg_reduce_pmc.csv; collected by scripts/gpu_profile.sh, separate --pmc runs):
+    2 * FETCH_SIZE * 1024 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md section HBM)
+    + WRITE_SIZE * 1024.  None if the summary is not there."""
+    f = ROOT / "profiles" / "r01_b_seg_reduce_pmc.csv"
+    if not f.exists():
+        return None
+    vals = {}
+    for line in f.read_text().splitlines()[1:]:
+        parts = line.split(",")
+        vals[parts[1]] = float(parts[3])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0
+
+
+def time_h2d(mb, device, iters=5):
+    """Host->device time of one batch's feed (pinned staging buffers), the copy the reference pays inside every
+    sess.run (models/sparse_graph_model.py:293).  Reported next to the HBM-resident number, never inside it."""
+    from tf_gnn_samples_amd.tasks import DeviceBatch
+    DeviceBatch(mb, device, pin=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        DeviceBatch(mb, device, pin=True)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
 def cpu_baseline(sample_graphs, params):
     """Reference-order CPU restatement (oracle/torch_ref.py: gather -> per-edge [E,D]@[D,D] -> 1/deg scale
     -> concat -> index_add -> ReLU), full training step (fwd + bwd through autograd) on a bounded
@@ -265,10 +295,19 @@ def main():
         "roofline": {
             "kernel": "seg_reduce_wave_kernel<1,false,true> (gather + 1/deg scale + segment-sum + ReLU, one RGCN layer fwd)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            "traffic": pmc_traffic_bytes(), "traffic_source": "profiles/r01_b_seg_reduce_pmc.csv (rocprofv3 --pmc FETCH_SIZE / "
+            "WRITE_SIZE, separate passes; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)",
+            "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
             "messages_per_launch": M, "edge_layers_per_sec": M / (k_ms * 1e-3),
         },
     }
+    if rank == 0:
+        try:
+            h2d_ms = time_h2d(mb, device)
+            result["h2d_ms_per_batch_pinned"] = h2d_ms
+            result["value_incl_serial_h2d"] = total_edges / world / ((elapsed / args.steps) + h2d_ms * 1e-3) * world
+        except Exception as e:
+            result["h2d_ms_per_batch_pinned"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(local_graphs[:args.cpu_sample_graphs], params)

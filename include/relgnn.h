@@ -320,6 +320,18 @@ int relgnn_pair_materialize(int32_t act, const float* P, int64_t ldp, const floa
                             int64_t num_messages, const float* ghidden, float* out, int64_t ldo,
                             void* stream);
 
+/* ========================================================================== *
+ * 6. Dense-layer helper (task-head plumbing around the path)
+ * ========================================================================== */
+
+/*
+ * out[c] = sum_r X[r, c]: the bias gradient of a Keras Dense over V node rows (tasks/ppi_task.py:176-179
+ * backward), deterministic two-stage reduction.  workspace: relgnn_column_sum_workspace_bytes().
+ */
+size_t relgnn_column_sum_workspace_bytes(int64_t rows, int32_t cols);
+int relgnn_column_sum(const float* X, int64_t rows, int32_t cols, int64_t ld, float* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """Where does the HOST time of one training step go? (cProfile over 30 steps, no per-step sync)"""
 import cProfile, pstats, sys, time, io
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from tf_gnn_samples_amd.graph import clear_graph_cache

@@ -175,3 +175,24 @@ def test_full_size_properties_c2_shape(gpu_device):
         b, e = rowptr[v * L], rowptr[(v + 1) * L]
         ref = (wn[b:e, None] * An[col[b:e]]).sum(0)
         assert np.abs(oan[v] - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("V,N", [(1, 1), (1000, 121), (32203, 121), (5000, 300), (257, 64)])
+def test_dense_bias_gradient_column_sum(gpu_device, V, N):
+    from tf_gnn_samples_amd.dense import column_sum, dense
+    rng = np.random.default_rng(V + N)
+    g = rng.standard_normal((V, N)).astype(np.float32)
+    out = column_sum(torch.as_tensor(g, device=gpu_device)).cpu().numpy()
+    ref = g.astype(np.float64).sum(0)
+    assert np.abs(out - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()) * 4
+    # whole Dense (split-K weight gradient + bias gradient) against torch autograd in fp64
+    x = rng.standard_normal((V, 48)).astype(np.float32)
+    k = rng.standard_normal((48, N)).astype(np.float32) * 0.1
+    b = rng.standard_normal(N).astype(np.float32)
+    xd, kd, bd = [torch.as_tensor(a, device=gpu_device).requires_grad_(True) for a in (x, k, b)]
+    dense(xd, kd, bd).backward(torch.as_tensor(g, device=gpu_device))
+    xr, kr, br = [torch.as_tensor(a, dtype=torch.float64).requires_grad_(True) for a in (x, k, b)]
+    (xr @ kr + br).backward(torch.as_tensor(g, dtype=torch.float64))
+    for a, r in ((xd, xr), (kd, kr), (bd, br)):
+        scale = max(1.0, float(r.grad.abs().max()))
+        assert float((a.grad.cpu().double() - r.grad).abs().max()) < 2e-5 * scale

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "relgnn_pair_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
     "relgnn_pair_bwd_q": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_pair_bwd_p": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_column_sum_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i32]),
+    "relgnn_column_sum": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i64, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     "relgnn_pair_materialize": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr]),
 }
 

@@ -26,6 +26,8 @@
 //   M*(4*D + 8) + S_out*4*D (+ 4*(S_out*stride+1) for rowptr)      
 #include "common.h"
 
+#include <stdlib.h>
+
 using namespace relgnn;
 
 namespace {
@@ -75,13 +77,14 @@ __device__ __forceinline__ float4 finalize(int mode, int act, float4 a, int n) {
 // ---------------------------------------------------------------------------------------
 // One wave per output row.  NCH = float4 chunks per lane (row width up to NCH*256 floats).
 // ---------------------------------------------------------------------------------------
-template <int NCH, bool IS_MAX, bool HAS_W>
+template <int NCH, bool IS_MAX, bool HAS_W, int UNROLL = kUnroll, bool NT = false, bool XCD = true>
 __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
     const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
     const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4,
     int64_t n_logical_blocks, int32_t col_block0) {
-  const int64_t lb = xcd_logical_block(n_logical_blocks);
+  const int64_t lb = XCD ? xcd_logical_block(n_logical_blocks)
+                         : ((int64_t)blockIdx.x < n_logical_blocks ? (int64_t)blockIdx.x : -1);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
   const int64_t s = lb * 4 + (threadIdx.x >> 6);
@@ -108,16 +111,17 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
   for (int p = beg; p < end; p += 64) {
     const int n = min(64, end - p);
     // one coalesced index (and weight) load per 64 messages
-    const int my_col = (lane < n) ? col[p + lane] : 0;
+    // index / weight streams are read once: keep them out of the way of the gathered rows (NT)
+    const int my_col = (lane < n) ? (NT ? __builtin_nontemporal_load(col + p + lane) : col[p + lane]) : 0;
     float my_w = 1.f;
-    if constexpr (HAS_W) my_w = (lane < n) ? w[p + lane] : 0.f;
+    if constexpr (HAS_W) my_w = (lane < n) ? (NT ? __builtin_nontemporal_load(w + p + lane) : w[p + lane]) : 0.f;
 
     int k = 0;
-    for (; k + kUnroll <= n; k += kUnroll) {
-      float4 v[kUnroll][NCH];
-      float ww[kUnroll];
+    for (; k + UNROLL <= n; k += UNROLL) {
+      float4 v[UNROLL][NCH];
+      float ww[UNROLL];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
+      for (int u = 0; u < UNROLL; ++u) {
         const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k + u);
         ww[u] = HAS_W ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), k + u)) : 1.f;
         const float4* row = X + (size_t)(r * ld);  // scalar (SGPR) row base
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
         for (int c = 0; c < NCH; ++c) v[u][c] = row[cc[c]];
       }
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u)
+      for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) combine<IS_MAX>(acc[c], ww[u], v[u][c]);
     }
@@ -144,7 +148,16 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
   float4* orow = out + s * ldo4 + c0;
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
-    if (on[c]) orow[64 * c] = finalize(mode, act, acc[c], end - beg);
+    if (on[c]) {
+      const float4 r = finalize(mode, act, acc[c], end - beg);
+      if constexpr (NT) {  // streamed output: do not displace gathered rows from L2
+        float* o = reinterpret_cast<float*>(orow + 64 * c);
+        __builtin_nontemporal_store(r.x, o); __builtin_nontemporal_store(r.y, o + 1);
+        __builtin_nontemporal_store(r.z, o + 2); __builtin_nontemporal_store(r.w, o + 3);
+      } else {
+        orow[64 * c] = r;
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -297,6 +310,17 @@ __global__ __launch_bounds__(256) void act_bwd_from_output_kernel(const float* _
   }
 }
 
+// Tuning knob (experiments only): RELGNN_SEG_VARIANT bit0 = unroll 16, bit1 = non-temporal streams,
+// bit2 = no XCD swizzle.  Read once.
+inline int seg_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RELGNN_SEG_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 template <int NCH, bool IS_MAX>
 int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
                 int64_t S, int32_t stride, const int32_t* col, const float* w, int32_t mode,
@@ -305,6 +329,29 @@ int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_
   const int64_t nlb = (S + 3) / 4;
   const int col_blocks = (D4 + 64 * NCH - 1) / (64 * NCH);
   dim3 grid((unsigned)(((nlb + 7) / 8) * 8), (unsigned)col_blocks);
+  if constexpr (NCH == 1 && !IS_MAX) {
+    const int var = seg_variant();
+    if (var != 0 && has_w) {
+#define RELGNN_VARIANT_CASE(ID, U, N, X_)                                                              \
+  case ID:                                                                                             \
+    seg_reduce_wave_kernel<1, false, true, U, N, X_><<<grid, 256, 0, st>>>(                            \
+        reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,         \
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0);                                              \
+    return launch_status();
+      switch (var) {
+        RELGNN_VARIANT_CASE(1, 16, false, true)
+        RELGNN_VARIANT_CASE(2, 8, true, true)
+        RELGNN_VARIANT_CASE(3, 16, true, true)
+        RELGNN_VARIANT_CASE(4, 8, false, false)
+        RELGNN_VARIANT_CASE(5, 16, false, false)
+        RELGNN_VARIANT_CASE(6, 8, true, false)
+        RELGNN_VARIANT_CASE(7, 16, true, false)
+        RELGNN_VARIANT_CASE(8, 4, false, true)
+        default: break;
+      }
+#undef RELGNN_VARIANT_CASE
+    }
+  }
   if (has_w)
     seg_reduce_wave_kernel<NCH, IS_MAX, true><<<grid, 256, 0, st>>>(
         reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,

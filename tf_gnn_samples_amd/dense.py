@@ -31,6 +31,22 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def column_sum(g: torch.Tensor) -> torch.Tensor:
+    """sum over rows of a [V, N] tensor (bias gradient).  torch's strided reduction took 330 us and rocBLAS gemv
+    230 us for [32k, 121] on MI355X; the two-stage HIP kernel (csrc/dense_utils.hip) is bandwidth-bound."""
+    if not g.is_cuda:
+        return g.sum(0)
+    from . import _lib
+    lib = _lib.load_library()
+    V, N = g.shape
+    out = torch.empty(N, dtype=torch.float32, device=g.device)
+    nbytes = lib.relgnn_column_sum_workspace_bytes(V, N)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device)
+    _lib.check(lib.relgnn_column_sum(_lib.ptr(g), V, N, g.stride(0), _lib.ptr(out), _lib.ptr(ws), nbytes,
+                                     _lib.current_stream()), "relgnn_column_sum")
+    return out
+
+
 class _DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, bias):
@@ -48,7 +64,7 @@ class _DenseFn(torch.autograd.Function):
         gk = matmul_tn_splitk(x.contiguous(), g) if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.mv(g.t(), torch.ones(g.shape[0], dtype=g.dtype, device=g.device))
+            gb = column_sum(g)
         return gx, gk, gb
 
 
