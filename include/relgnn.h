@@ -332,6 +332,37 @@ size_t relgnn_column_sum_workspace_bytes(int64_t rows, int32_t cols);
 int relgnn_column_sum(const float* X, int64_t rows, int32_t cols, int64_t ld, float* out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ========================================================================== *
+ * 7. Training-step plumbing around the path
+ * ========================================================================== */
+
+#define RELGNN_MT_MAX 48 /* tensors per multi-tensor launch */
+
+/*
+ * Per-variable gradient norms and the fused update of models/sparse_graph_model.py:227-260:
+ *   g' = g * clip / max(||g||_2, clip)            (tf.clip_by_norm per variable, :253-260; clip <= 0: no clipping)
+ *   m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;  p -= lr_t * m / (sqrt(v) + eps)      (tf.train.AdamOptimizer,
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller) [TF-internal update rule]
+ * h_* are HOST arrays of n <= RELGNN_MT_MAX device pointers / element counts; norms is a device [n] array.
+ */
+int relgnn_mt_l2norm(const float* const* h_grads, const int64_t* h_sizes, int32_t n, float* norms,
+                     void* stream);
+int relgnn_mt_adam_clip(float* const* h_params, const float* const* h_grads, float* const* h_m,
+                        float* const* h_v, const int64_t* h_sizes, int32_t n, const float* norms,
+                        float clip, float lr_t, float beta1, float beta2, float eps, void* stream);
+
+/*
+ * PPI output head in one pass (tasks/ppi_task.py:181-191 + utils/utils.py:61-74):
+ *   stats[0] = sum_i sigmoid_cross_entropy_with_logits(logits_i, labels_i)
+ *   stats[1..3] = true_pos, false_pos, false_neg of round(sigmoid(logits)) vs int(labels);  stats[4] = micro-F1
+ * and the loss gradient  glogits = gscale[0] * (sigmoid(logits) - labels).  n = number of elements.
+ */
+size_t relgnn_sigmoid_ce_stats_workspace_bytes(void);
+int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n, float* stats,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* gscale,
+                          float* glogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,57 @@
+"""Fused training-step plumbing (csrc/train_utils.hip) vs the un-fused restatements."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_clip_adam_matches_unfused_tf_rules(gpu_device):
+    from tf_gnn_samples_amd.models.sparse_graph_model import TFStyleOptimizer
+    torch.manual_seed(0)
+    shapes = [(50, 256), (256, 768), (256, 256), (121,), (1,), (256, 121), (3, 5, 7)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s, device=gpu_device)) for s in shapes]
+    pa = mk()
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = TFStyleOptimizer(pa, "Adam", 1e-3, 1.0)
+    ob = TFStyleOptimizer(pb, "Adam", 1e-3, 1.0)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = torch.randn_like(a) * (5.0 if i % 2 == 0 else 0.01)   # some clipped, some not
+            a.grad, b.grad = g.clone(), g.clone()
+        pb[4].grad = None
+        pa[4].grad = None                                              # variable without gradient: untouched
+        oa.clip_and_step(lr_scale=0.5)                                 # fused
+        ob.clip_gradients(); ob.step(lr_scale=0.5)                     # foreach reference
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    assert oa.t == ob.t == 4
+
+
+def test_sigmoid_ce_stats_and_gradient(gpu_device):
+    from tf_gnn_samples_amd.tasks.ppi_task import _SigmoidCEStats
+    from tf_gnn_samples_amd.utils import micro_f1
+    rng = np.random.default_rng(0)
+    V, N = 3000, 121
+    x = (rng.standard_normal((V, N)) * 3).astype(np.float32)
+    x[0, 0] = 0.0
+    x[0, 1] = 40.0
+    x[0, 2] = -40.0
+    z = (rng.random((V, N)) < 0.3).astype(np.float32)
+    xd = torch.as_tensor(x, device=gpu_device).requires_grad_(True)
+    zd = torch.as_tensor(z, device=gpu_device)
+    stats = _SigmoidCEStats.apply(xd, zd)
+    (stats[0] / V).backward()
+    ref = OM.sigmoid_cross_entropy_with_logits(x.astype(np.float64), z.astype(np.float64))
+    assert abs(float(stats[0]) - ref.sum()) < 1e-5 * ref.sum()
+    pred = np.round(1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.int32)
+    zi = z.astype(np.int32)
+    tp, fp, fn = np.count_nonzero(pred * zi), np.count_nonzero(pred * (zi - 1)), np.count_nonzero((pred - 1) * zi)
+    assert [int(stats[1]), int(stats[2]), int(stats[3])] == [tp, fp, fn]
+    p, r = tp / (tp + fp), tp / (tp + fn)
+    assert abs(float(stats[4]) - 2 * p * r / (p + r)) < 1e-6
+    assert abs(float(stats[4]) - float(micro_f1(xd.detach(), zd))) < 1e-6
+    gref = (1.0 / (1.0 + np.exp(-x.astype(np.float64))) - z) / V
+    assert np.abs(xd.grad.cpu().numpy() - gref).max() < 1e-7

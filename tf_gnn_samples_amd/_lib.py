@@ -18,6 +18,7 @@ OK, EINVAL, ENOSPC, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
 ERRFLAG_INDEX_OUT_OF_RANGE = 1
 
 AGG_SUM, AGG_MEAN, AGG_SQRT_N, AGG_MAX = 0, 1, 2, 3
+MT_MAX = 48
 ACT_LINEAR, ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU, ACT_SELU, ACT_GELU = range(7)
 
 _c_i32, _c_i64, _c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
@@ -51,6 +52,11 @@ _SIGNATURES = {
     "relgnn_pair_bwd_p": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_column_sum_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i32]),
     "relgnn_column_sum": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i64, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    "relgnn_mt_l2norm": (ctypes.c_int, [_ptr, _ptr, _c_i32, _ptr, _ptr]),
+    "relgnn_mt_adam_clip": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _ptr]),
+    "relgnn_sigmoid_ce_stats_workspace_bytes": (ctypes.c_size_t, []),
+    "relgnn_sigmoid_ce_stats": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    "relgnn_sigmoid_ce_bwd": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_pair_materialize": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr]),
 }
 

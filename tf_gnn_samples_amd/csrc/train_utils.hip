@@ -1,0 +1,200 @@
+// Training-step plumbing AROUND the hot path, fused so that the step is not
+// launch-bound once the gather/segment kernels and GEMMs are fast:
+//   * multi-tensor per-variable clip_by_norm + TF-style Adam   models/sparse_graph_model.py:227-260
+//   * PPI output head loss + micro-F1 counts in one pass        tasks/ppi_task.py:181-191, utils/utils.py:61-74
+// Deterministic (no float atomics): fixed-shape tree reductions only.
+#include "common.h"
+
+using namespace relgnn;
+
+namespace {
+
+struct MtArgs {
+  float* p[RELGNN_MT_MAX];
+  const float* g[RELGNN_MT_MAX];
+  float* m[RELGNN_MT_MAX];
+  float* v[RELGNN_MT_MAX];
+  long long n[RELGNN_MT_MAX];
+};
+
+struct NormArgs {
+  const float* g[RELGNN_MT_MAX];
+  long long n[RELGNN_MT_MAX];
+};
+
+__device__ __forceinline__ double block_sum_1024(double x, double* red) {
+  // wave reduce (64 lanes) then across the 16 waves of a 1024-thread block, fixed order
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) red[wave] = x;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+  __syncthreads();
+  return t;  // valid in thread 0
+}
+
+// one 1024-thread block per tensor: norms[t] = sqrt(sum g^2)
+__global__ __launch_bounds__(1024) void mt_l2norm_kernel(NormArgs a, float* __restrict__ norms) {
+  __shared__ double red[16];
+  const int t = blockIdx.x;
+  const float* g = a.g[t];
+  const long long n = a.n[t];
+  double acc = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = g[i];
+    acc += x * x;
+  }
+  const double s = block_sum_1024(acc, red);
+  if (threadIdx.x == 0) norms[t] = (float)sqrt(s);
+}
+
+// grid (chunks, tensors): g' = g * clip / max(||g||, clip)  (tf.clip_by_norm), then TF1 Adam:
+//   m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr_t * m / (sqrt(v) + eps),  lr_t = lr sqrt(1-b2^t)/(1-b1^t)
+__global__ __launch_bounds__(256) void mt_adam_clip_kernel(MtArgs a, const float* __restrict__ norms, float clip,
+                                                           float lr_t, float b1, float b2, float eps) {
+  const int t = blockIdx.y;
+  const long long n = a.n[t];
+  const long long chunk = 4096;
+  const long long beg = (long long)blockIdx.x * chunk;
+  if (beg >= n) return;
+  const long long end = min(n, beg + chunk);
+  float scale = 1.f;
+  if (clip > 0.f) {
+    const float nrm = norms[t];
+    scale = clip / fmaxf(nrm, clip);
+  }
+  float* p = a.p[t];
+  const float* g = a.g[t];
+  float* m = a.m[t];
+  float* v = a.v[t];
+  for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * (gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// ---- PPI head: sigmoid cross-entropy sum + micro-F1 counts -------------------------------------
+// stats = {sum of losses, true_pos, false_pos, false_neg, micro-F1}
+__global__ __launch_bounds__(1024) void sigmoid_ce_stats_kernel(const float* __restrict__ logits,
+                                                                const float* __restrict__ labels, long long n,
+                                                                double* __restrict__ partial) {
+  __shared__ double red[16];
+  double loss = 0.0, tp = 0.0, fp = 0.0, fn = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float x = logits[i], z = labels[i];
+    // tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
+    loss += (double)(fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))));
+    const bool pred = (1.f / (1.f + expf(-x))) > 0.5f;  // round(sigmoid(x)) with round-half-even
+    const int zi = (int)z;
+    tp += (pred && zi != 0) ? 1.0 : 0.0;
+    fp += (pred && zi != 1) ? 1.0 : 0.0;
+    fn += (!pred && zi != 0) ? 1.0 : 0.0;
+  }
+  double s;
+  s = block_sum_1024(loss, red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = s;
+  s = block_sum_1024(tp, red);   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = s;
+  s = block_sum_1024(fp, red);   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = s;
+  s = block_sum_1024(fn, red);   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = s;
+}
+
+__global__ void sigmoid_ce_stats_final_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ stats) {
+  __shared__ double tot[4];
+  const int k = threadIdx.x;
+  if (k < 4) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[b * 4 + k];
+    stats[k] = (float)s;
+    tot[k] = s;
+  }
+  __syncthreads();
+  if (k == 0) {
+    // utils/utils.py:70-74: int64 counts, float64 true division, cast to float32
+    const double precision = tot[1] / (tot[1] + tot[2]);
+    const double recall = tot[1] / (tot[1] + tot[3]);
+    stats[4] = (float)((2.0 * precision * recall) / (precision + recall));
+  }
+}
+
+// glogits = gscale[0] * (sigmoid(x) - z)
+__global__ __launch_bounds__(256) void sigmoid_ce_bwd_kernel(const float* __restrict__ logits,
+                                                             const float* __restrict__ labels, long long n,
+                                                             const float* __restrict__ gscale, float* __restrict__ gl) {
+  const float gs = gscale[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float x = logits[i];
+    gl[i] = gs * (1.f / (1.f + expf(-x)) - labels[i]);
+  }
+}
+
+constexpr int kStatsBlocks = 256;
+
+}  // namespace
+
+extern "C" {
+
+int relgnn_mt_l2norm(const float* const* h_grads, const int64_t* h_sizes, int32_t n, float* norms, void* stream) {
+  if (n < 0 || n > RELGNN_MT_MAX) return RELGNN_EINVAL;
+  if (n == 0) return RELGNN_OK;
+  if (!h_grads || !h_sizes || !norms) return RELGNN_EINVAL;
+  NormArgs a;
+  for (int i = 0; i < n; ++i) {
+    if (h_sizes[i] < 0 || (h_sizes[i] > 0 && !h_grads[i])) return RELGNN_EINVAL;
+    a.g[i] = h_grads[i];
+    a.n[i] = h_sizes[i];
+  }
+  mt_l2norm_kernel<<<n, 1024, 0, as_stream(stream)>>>(a, norms);
+  return launch_status();
+}
+
+int relgnn_mt_adam_clip(float* const* h_params, const float* const* h_grads, float* const* h_m, float* const* h_v,
+                        const int64_t* h_sizes, int32_t n, const float* norms, float clip, float lr_t, float beta1,
+                        float beta2, float eps, void* stream) {
+  if (n < 0 || n > RELGNN_MT_MAX) return RELGNN_EINVAL;
+  if (n == 0) return RELGNN_OK;
+  if (!h_params || !h_grads || !h_m || !h_v || !h_sizes || (clip > 0.f && !norms)) return RELGNN_EINVAL;
+  MtArgs a;
+  long long maxn = 0;
+  for (int i = 0; i < n; ++i) {
+    if (h_sizes[i] < 0) return RELGNN_EINVAL;
+    a.p[i] = h_params[i]; a.g[i] = h_grads[i]; a.m[i] = h_m[i]; a.v[i] = h_v[i]; a.n[i] = h_sizes[i];
+    if (h_sizes[i] > maxn) maxn = h_sizes[i];
+  }
+  if (maxn == 0) return RELGNN_OK;
+  dim3 grid((unsigned)((maxn + 4095) / 4096), (unsigned)n);
+  mt_adam_clip_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, norms, clip, lr_t, beta1, beta2, eps);
+  return launch_status();
+}
+
+size_t relgnn_sigmoid_ce_stats_workspace_bytes(void) { return (size_t)kStatsBlocks * 4 * sizeof(double); }
+
+int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n, float* stats, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (n < 0 || !stats) return RELGNN_EINVAL;
+  if (!workspace || workspace_bytes < relgnn_sigmoid_ce_stats_workspace_bytes()) return RELGNN_ENOSPC;
+  if (n > 0 && (!logits || !labels)) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int nblk = (int)((n + 1023) / 1024);
+  if (nblk < 1) nblk = 1;
+  if (nblk > kStatsBlocks) nblk = kStatsBlocks;
+  sigmoid_ce_stats_kernel<<<nblk, 1024, 0, st>>>(logits, labels, n, static_cast<double*>(workspace));
+  sigmoid_ce_stats_final_kernel<<<1, 64, 0, st>>>(static_cast<const double*>(workspace), nblk, stats);
+  return launch_status();
+}
+
+int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* gscale, float* glogits,
+                          void* stream) {
+  if (n < 0) return RELGNN_EINVAL;
+  if (n == 0) return RELGNN_OK;
+  if (!logits || !labels || !gscale || !glogits) return RELGNN_EINVAL;
+  sigmoid_ce_bwd_kernel<<<flat_grid(n, 256), 256, 0, as_stream(stream)>>>(logits, labels, n, gscale, glogits);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -18,6 +18,35 @@ from .sparse_graph_task import DataFold, MinibatchData, Sparse_Graph_Task
 from .synthetic import GraphSample, make_ppi_shaped_graphs
 
 
+class _SigmoidCEStats(torch.autograd.Function):
+    """stats = [sum of sigmoid-CE losses, true_pos, false_pos, false_neg, micro-F1] in one pass over the logits
+    (csrc/train_utils.hip); only stats[0] is differentiable."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        from .. import _lib
+        lib = _lib.load_library()
+        logits, labels = logits.contiguous(), labels.contiguous()
+        stats = torch.empty(5, dtype=torch.float32, device=logits.device)
+        nbytes = lib.relgnn_sigmoid_ce_stats_workspace_bytes()
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=logits.device)
+        _lib.check(lib.relgnn_sigmoid_ce_stats(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), _lib.ptr(stats),
+                                               _lib.ptr(ws), nbytes, _lib.current_stream()), "relgnn_sigmoid_ce_stats")
+        ctx.save_for_backward(logits, labels)
+        return stats
+
+    @staticmethod
+    def backward(ctx, gstats):
+        from .. import _lib
+        lib = _lib.load_library()
+        logits, labels = ctx.saved_tensors
+        gscale = gstats[0:1].contiguous()
+        gl = torch.empty_like(logits)
+        _lib.check(lib.relgnn_sigmoid_ce_bwd(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), _lib.ptr(gscale),
+                                             _lib.ptr(gl), _lib.current_stream()), "relgnn_sigmoid_ce_bwd")
+        return gl, None
+
+
 class PPI_Task(Sparse_Graph_Task):
     @classmethod
     def default_params(cls):
@@ -143,13 +172,14 @@ class PPI_Task(Sparse_Graph_Task):
     def compute_task_metrics(self, final_node_representations: torch.Tensor, batch, weights) -> Dict[str, torch.Tensor]:
         labels = batch.extra['target_labels']
         per_node_logits = dense(final_node_representations, weights["kernel"], weights["bias"])
-        total_loss = torch.nn.functional.binary_cross_entropy_with_logits(per_node_logits, labels, reduction='sum')
         num_nodes_in_batch = labels.shape[0]
-        masks = batch.extra.get('_f1_label_masks')
-        if masks is None:   # labels are constant per batch: build the two predicates once
-            masks = batch.extra['_f1_label_masks'] = micro_f1_label_masks(labels)
-        return {'loss': total_loss / float(num_nodes_in_batch), 'total_loss': total_loss,
-                'f1_score': micro_f1(per_node_logits.detach(), labels, masks)}
+        if per_node_logits.is_cuda:
+            stats = _SigmoidCEStats.apply(per_node_logits, labels)   # loss sum + F1 counts + F1: one pass
+            total_loss, f1 = stats[0], stats[4].detach()
+        else:
+            total_loss = torch.nn.functional.binary_cross_entropy_with_logits(per_node_logits, labels, reduction='sum')
+            f1 = micro_f1(per_node_logits.detach(), labels)
+        return {'loss': total_loss / float(num_nodes_in_batch), 'total_loss': total_loss, 'f1_score': f1}
 
     # -------------------- Minibatching (tasks/ppi_task.py:197-256) --------------------
     def make_minibatch_iterator(self, data: List[GraphSample], data_fold: DataFold,
