@@ -197,8 +197,17 @@ def cpu_baseline(sample_graphs, params):
 
 def main():
     args = parse_args()
+    # stdout must carry exactly ONE line (the JSON): park the real fd 1 and point fd 1 at stderr so that neither
+    # Python prints nor C-level chatter of libraries (gloo/RCCL/hipBLASLt) can land on it.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from tf_gnn_samples_amd.parallel import GradientAllReducer, init_distributed
-    rank, local_rank, world = init_distributed()
+    # debug knobs (single-GPU dry run of the N>1 path): RELGNN_DIST_BACKEND=gloo RELGNN_FORCE_DEVICE=0
+    force_dev = os.environ.get("RELGNN_FORCE_DEVICE")
+    if force_dev is not None:
+        os.environ["LOCAL_RANK"] = force_dev
+    rank, local_rank, world = init_distributed(os.environ.get("RELGNN_DIST_BACKEND"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -314,9 +323,11 @@ def main():
         except Exception as e:  # the baseline is reporting only; never lose the GPU number over it
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
-        sys.stdout = real_stdout
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
