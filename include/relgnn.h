@@ -283,6 +283,29 @@ int relgnn_rgat_bwd_msg(int32_t D, int32_t num_heads, const int32_t* rowptr_b, i
                         const float* dz, const float* gout, int64_t ldo, float* gT, int64_t ldgt,
                         float* gs_src, void* stream);
 
+/*
+ * Fast path of the same computation (rgat_fast.hip), used when num_heads in {1,2,4,8} and (D/num_heads) % 4 == 0;
+ * RELGNN_EUNSUPPORTED otherwise (callers fall back to relgnn_rgat_fwd / _bwd_logits / _bwd_msg):
+ *   relgnn_rgat_alpha    alpha[p,k] (the segmented softmax, rgat.py:112-130) with lanes across MESSAGES: the two
+ *                        softmax passes read 4K bytes per message and never touch the gathered rows
+ *   relgnn_headw_reduce  out[s, head h] = sum_{p in segment s} W[(wpos ? wpos[p] : p), h] * X[col[p], head h]
+ *                        = rgat.py:131-136 with W = alpha (forward), and the gradient w.r.t. T on the transposed plan
+ *                        (X = gout, col = tgt_b, wpos = pos_b)
+ *   relgnn_rgat_dz       dz[p,k] as in relgnn_rgat_bwd_logits (needs D <= 256 and D/num_heads/4 a power of two);
+ *                        gs_tgt / gs_src are then plain relgnn_seg_reduce_fwd calls over dz [M, K]
+ */
+int relgnn_rgat_alpha(const float* s_src, const float* s_tgt, int32_t num_heads, const int32_t* rowptr,
+                      int32_t num_nodes, int32_t num_edge_types, const int32_t* col, float slope,
+                      float* alpha, void* stream);
+int relgnn_headw_reduce(const float* X, int64_t num_rows_x, int64_t ldx, int32_t D, int32_t num_heads,
+                        const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                        const int32_t* col, const float* W, const int32_t* wpos, float* out, int64_t ldo,
+                        void* stream);
+int relgnn_rgat_dz(const float* T, int64_t num_rows_t, int64_t ldt, int32_t D, int32_t num_heads,
+                   const float* s_src, const float* s_tgt, const int32_t* rowptr, int32_t num_nodes,
+                   int32_t num_edge_types, const int32_t* col, float slope, const float* alpha,
+                   const float* out, const float* gout, int64_t ldo, float* dz, void* stream);
+
 /* ========================================================================== *
  * 5. Messages from BOTH endpoint states  (gnns/gnn_edge_mlp.py:91-116, rgin.py:110-129,
  *    rgcn.py:91-104 use_both_source_and_target)

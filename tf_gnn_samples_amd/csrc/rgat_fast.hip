@@ -1,0 +1,346 @@
+// RGAT fast path (wave-uniform addressing, same loop structure as seg_reduce.hip):
+//   relgnn_rgat_alpha      segmented softmax over all incoming messages of a target; LANES RUN ACROSS MESSAGES
+//                          (K floats per message: the two softmax passes never touch the 4*D-byte rows)
+//   relgnn_headw_reduce    out[s, head h] = sum_p W[wpos[p], h] * X[col[p], head h]   (per-head weighted gather-reduce;
+//                          forward pass 3 with W = alpha, and the gradient w.r.t. T on the transposed buckets)
+//   relgnn_rgat_dz         dz[p,h] = a[p,h] * (<gout_vh, T[col p]_h> - <gout_vh, out_vh>) * lrelu'(z[p,h])
+// Replaces gnns/rgat.py:98-136 like rgat.hip does; these kernels are used when K in {1,2,4,8} and Dh % 4 == 0.
+#include "common.h"
+
+using namespace relgnn;
+
+namespace {
+
+constexpr int kU = 8;
+
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+  return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+  return x;
+}
+__device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---- alpha: one wave per target, lanes across messages -----------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void rgat_alpha_kernel(const float* __restrict__ s_src, const float* __restrict__ s_tgt,
+                                                         const int32_t* __restrict__ rowptr, int32_t V, int32_t L,
+                                                         const int32_t* __restrict__ col, float slope,
+                                                         float* __restrict__ alpha, int64_t nlb) {
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t v = lb * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int beg = __builtin_amdgcn_readfirstlane(rowptr[v * L]);
+  const int end = __builtin_amdgcn_readfirstlane(rowptr[(v + 1) * L]);
+  if (beg == end) return;
+
+  auto logits = [&](int idx, float (&e)[K]) {
+    // edge type of sorted position idx: number of bucket boundaries <= idx (buckets of v are consecutive)
+    int l = 0;
+    for (int j = 1; j < L; ++j) l += (idx >= rowptr[v * L + j]) ? 1 : 0;
+    const int64_t r = col[idx];
+    const float* ss = s_src + r * K;
+    const float* st = s_tgt + (v * L + l) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) e[k] = lrelu(ss[k] + st[k], slope);
+  };
+
+  float mx[K], sm[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { mx[k] = -FLT_MAX; sm[k] = 0.f; }
+  const bool single = (end - beg) <= 64;
+  float e0[K];
+  if (single) {  // the common case: all logits of the target stay in registers
+    const int idx = beg + lane;
+    const bool ok = idx < end;
+    if (ok) logits(idx, e0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) mx[k] = wave_max(ok ? e0[k] : -FLT_MAX);
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[k] = wave_sum(ok ? expf(e0[k] - mx[k]) : 0.f);
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) alpha[(int64_t)idx * K + k] = expf((e0[k] - mx[k]) - logf(sm[k]));
+    }
+    return;
+  }
+  for (int p = beg; p < end; p += 64) {
+    const int idx = p + lane;
+    const bool ok = idx < end;
+    float e[K];
+    if (ok) logits(idx, e);
+#pragma unroll
+    for (int k = 0; k < K; ++k) mx[k] = fmaxf(mx[k], wave_max(ok ? e[k] : -FLT_MAX));
+  }
+  for (int p = beg; p < end; p += 64) {
+    const int idx = p + lane;
+    const bool ok = idx < end;
+    float e[K];
+    if (ok) logits(idx, e);
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[k] += wave_sum(ok ? expf(e[k] - mx[k]) : 0.f);
+  }
+  for (int p = beg; p < end; p += 64) {
+    const int idx = p + lane;
+    if (idx < end) {
+      float e[K];
+      logits(idx, e);
+#pragma unroll
+      for (int k = 0; k < K; ++k) alpha[(int64_t)idx * K + k] = expf((e[k] - mx[k]) - logf(sm[k]));
+    }
+  }
+}
+
+// ---- per-head weighted gather-reduce --------------------------------------------------------------
+template <int NCH, int K>
+__global__ __launch_bounds__(256) void headw_reduce_kernel(
+    const float4* __restrict__ X, int64_t ldx4, int32_t D4, int32_t Dh4, const int32_t* __restrict__ rowptr,
+    int64_t num_segments, int32_t stride, const int32_t* __restrict__ col, const float* __restrict__ W,
+    const int32_t* __restrict__ wpos, float4* __restrict__ out, int64_t ldo4, int64_t nlb) {
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t s = lb * 4 + (threadIdx.x >> 6);
+  if (s >= num_segments) return;
+  const int beg = __builtin_amdgcn_readfirstlane(rowptr[s * stride]);
+  const int end = __builtin_amdgcn_readfirstlane(rowptr[(s + 1) * stride]);
+  float4 acc[NCH];
+  bool on[NCH];
+  uint32_t cc[NCH];
+  int head[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    on[c] = lane + 64 * c < D4;
+    cc[c] = (uint32_t)min(lane + 64 * c, D4 - 1);
+    head[c] = (int)cc[c] / Dh4;
+  }
+  const uint32_t ld = (uint32_t)ldx4;
+  for (int p = beg; p < end; p += 64) {
+    const int n = min(64, end - p);
+    const bool ok = lane < n;
+    const int my_col = ok ? col[p + lane] : 0;
+    const int64_t wrow = ok ? (wpos ? (int64_t)wpos[p + lane] : (int64_t)(p + lane)) : 0;
+    float my_w[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) my_w[k] = ok ? W[wrow * K + k] : 0.f;
+    int k0 = 0;
+    for (; k0 + kU <= n; k0 += kU) {
+      float4 v[kU][NCH];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k0 + u);
+        const float4* row = X + (size_t)(r * ld);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[u][c] = row[cc[c]];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        float wl[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) wl[c] = 0.f;
+#pragma unroll
+        for (int h = 0; h < K; ++h) {
+          const float sh = rl(my_w[h], k0 + u);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) wl[c] = (head[c] == h) ? sh : wl[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          acc[c].x += wl[c] * v[u][c].x; acc[c].y += wl[c] * v[u][c].y;
+          acc[c].z += wl[c] * v[u][c].z; acc[c].w += wl[c] * v[u][c].w;
+        }
+      }
+    }
+    for (; k0 < n; ++k0) {
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k0);
+      const float4* row = X + (size_t)(r * ld);
+      float wl[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) wl[c] = 0.f;
+#pragma unroll
+      for (int h = 0; h < K; ++h) {
+        const float sh = rl(my_w[h], k0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) wl[c] = (head[c] == h) ? sh : wl[c];
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float4 t = row[cc[c]];
+        acc[c].x += wl[c] * t.x; acc[c].y += wl[c] * t.y; acc[c].z += wl[c] * t.z; acc[c].w += wl[c] * t.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (on[c]) out[s * ldo4 + lane + 64 * c] = acc[c];
+}
+
+// ---- dz: one wave per target, lanes across features ---------------------------------------------
+// requires NCH == 1 and Dh4 a power of two (lanes of a head are one aligned group): the per-message
+// per-head dot product is a log2(Dh4)-step butterfly.
+template <int K>
+__global__ __launch_bounds__(256) void rgat_dz_kernel(
+    const float4* __restrict__ T, int64_t ldt4, int32_t D4, int32_t Dh4, const float* __restrict__ s_src,
+    const float* __restrict__ s_tgt, const int32_t* __restrict__ rowptr, int32_t V, int32_t L,
+    const int32_t* __restrict__ col, float slope, const float* __restrict__ alpha, const float4* __restrict__ out,
+    const float4* __restrict__ gout, int64_t ldo4, float* __restrict__ dz, int64_t nlb) {
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t v = lb * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int beg = __builtin_amdgcn_readfirstlane(rowptr[v * L]);
+  const int end = __builtin_amdgcn_readfirstlane(rowptr[(v + 1) * L]);
+  if (beg == end) return;
+  const bool on = lane < D4;
+  const uint32_t cc = (uint32_t)min(lane, D4 - 1);
+  const int head = (int)cc / Dh4;
+  const float4 go = on ? gout[v * ldo4 + cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+  auto head_sum = [&](float x) {
+    for (int off = Dh4 >> 1; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    return x;  // total of this lane's head
+  };
+  const float cdot = head_sum(on ? dot4(go, out[v * ldo4 + cc]) : 0.f);
+  const uint32_t ld = (uint32_t)ldt4;
+  for (int p = beg; p < end; p += 64) {
+    const int n = min(64, end - p);
+    const int idx = p + lane;
+    const bool ok = lane < n;
+    const int my_col = ok ? col[idx] : 0;
+    // this lane's message: logits derivative factors and alpha, K heads
+    float my_a[K], my_d[K], my_dz[K];
+    if (ok) {
+      int l = 0;
+      for (int j = 1; j < L; ++j) l += (idx >= rowptr[v * L + j]) ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float z = s_src[(int64_t)my_col * K + k] + s_tgt[(v * L + l) * K + k];
+        my_d[k] = z > 0.f ? 1.f : slope;
+        my_a[k] = alpha[(int64_t)idx * K + k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) my_dz[k] = 0.f;
+    int k0 = 0;
+    for (; k0 + kU <= n; k0 += kU) {
+      float4 t[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k0 + u);
+        t[u] = T[(size_t)(r * ld) + cc];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const float dal = head_sum(on ? dot4(go, t[u]) : 0.f) - cdot;   // (dalpha - <gout,out>) of my head
+        // hand the value of head h to the lane that owns message k0+u
+#pragma unroll
+        for (int h = 0; h < K; ++h) {
+          const float val = rl(dal, h * Dh4);                           // any lane of head h holds it
+          my_dz[h] = (lane == k0 + u) ? val : my_dz[h];
+        }
+      }
+    }
+    for (; k0 < n; ++k0) {
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k0);
+      const float4 t = T[(size_t)(r * ld) + cc];
+      const float dal = head_sum(on ? dot4(go, t) : 0.f) - cdot;
+#pragma unroll
+      for (int h = 0; h < K; ++h) {
+        const float val = rl(dal, h * Dh4);
+        my_dz[h] = (lane == k0) ? val : my_dz[h];
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) dz[(int64_t)idx * K + k] = my_a[k] * my_dz[k] * my_d[k];
+    }
+  }
+}
+
+inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && ld % 4 == 0; }
+inline unsigned padded_grid(int64_t nlb) { return (unsigned)(((nlb + 7) / 8) * 8); }
+
+#define RGAT_DISPATCH_K(K_, KK, ...)                      \
+  switch (K_) {                                           \
+    case 1: { constexpr int KK = 1; __VA_ARGS__; break; } \
+    case 2: { constexpr int KK = 2; __VA_ARGS__; break; } \
+    case 4: { constexpr int KK = 4; __VA_ARGS__; break; } \
+    case 8: { constexpr int KK = 8; __VA_ARGS__; break; } \
+    default: return RELGNN_EUNSUPPORTED;                  \
+  }
+
+}  // namespace
+
+extern "C" {
+
+int relgnn_rgat_alpha(const float* s_src, const float* s_tgt, int32_t num_heads, const int32_t* rowptr,
+                      int32_t num_nodes, int32_t num_edge_types, const int32_t* col, float slope, float* alpha,
+                      void* stream) {
+  if (num_nodes < 0 || num_edge_types <= 0 || num_heads <= 0) return RELGNN_EINVAL;
+  if (num_nodes == 0) return RELGNN_OK;
+  if (!s_src || !s_tgt || !rowptr || !alpha) return RELGNN_EINVAL;
+  const int64_t nlb = ((int64_t)num_nodes + 3) / 4;
+  RGAT_DISPATCH_K(num_heads, KK, (rgat_alpha_kernel<KK><<<padded_grid(nlb), 256, 0, as_stream(stream)>>>(
+                                     s_src, s_tgt, rowptr, num_nodes, num_edge_types, col, slope, alpha, nlb)));
+  return launch_status();
+}
+
+int relgnn_headw_reduce(const float* X, int64_t num_rows_x, int64_t ldx, int32_t D, int32_t num_heads,
+                        const int32_t* rowptr, int64_t num_segments, int32_t seg_stride, const int32_t* col,
+                        const float* W, const int32_t* wpos, float* out, int64_t ldo, void* stream) {
+  if (D < 0 || num_segments < 0 || seg_stride <= 0 || num_heads <= 0 || num_rows_x < 0) return RELGNN_EINVAL;
+  if (num_segments == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !out || !W) return RELGNN_EINVAL;
+  if (D % num_heads != 0 || (D / num_heads) % 4 != 0 || D > 1024 || !vec_ok(X, ldx) || !vec_ok(out, ldo) ||
+      num_rows_x * (ldx / 4) >= ((int64_t)1 << 32))
+    return RELGNN_EUNSUPPORTED;
+  const int D4 = D / 4, Dh4 = D / num_heads / 4;
+  const int64_t nlb = (num_segments + 3) / 4;
+  const int nch = D4 <= 64 ? 1 : (D4 <= 128 ? 2 : 4);
+  hipStream_t st = as_stream(stream);
+#define HEADW_LAUNCH(NN, KK)                                                                                       \
+  headw_reduce_kernel<NN, KK><<<padded_grid(nlb), 256, 0, st>>>((const float4*)X, ldx / 4, D4, Dh4, rowptr,        \
+                                                                 num_segments, seg_stride, col, W, wpos, (float4*)out, \
+                                                                 ldo / 4, nlb)
+  RGAT_DISPATCH_K(num_heads, KK, {
+    if (nch == 1) HEADW_LAUNCH(1, KK);
+    else if (nch == 2) HEADW_LAUNCH(2, KK);
+    else HEADW_LAUNCH(4, KK);
+  });
+#undef HEADW_LAUNCH
+  return launch_status();
+}
+
+int relgnn_rgat_dz(const float* T, int64_t num_rows_t, int64_t ldt, int32_t D, int32_t num_heads, const float* s_src,
+                   const float* s_tgt, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
+                   const int32_t* col, float slope, const float* alpha, const float* out, const float* gout,
+                   int64_t ldo, float* dz, void* stream) {
+  if (D < 0 || num_nodes < 0 || num_edge_types <= 0 || num_heads <= 0) return RELGNN_EINVAL;
+  if (num_nodes == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr || !out || !gout || !s_src || !s_tgt || !alpha || !dz) return RELGNN_EINVAL;
+  const int D4 = D / 4;
+  if (D % 4 != 0 || D % num_heads != 0 || (D / num_heads) % 4 != 0) return RELGNN_EUNSUPPORTED;
+  const int Dh4 = D / num_heads / 4;
+  if (D4 > 64 || !is_pow2(Dh4) || !vec_ok(T, ldt) || !vec_ok(out, ldo) || !aligned16(gout) ||
+      num_rows_t * (ldt / 4) >= ((int64_t)1 << 32))
+    return RELGNN_EUNSUPPORTED;
+  const int64_t nlb = ((int64_t)num_nodes + 3) / 4;
+  RGAT_DISPATCH_K(num_heads, KK, (rgat_dz_kernel<KK><<<padded_grid(nlb), 256, 0, as_stream(stream)>>>(
+                                     (const float4*)T, ldt / 4, D4, Dh4, s_src, s_tgt, rowptr, num_nodes, num_edge_types,
+                                     col, slope, alpha, (const float4*)out, (const float4*)gout, ldo / 4, dz, nlb)));
+  return launch_status();
+}
+
+}  // extern "C"

@@ -227,6 +227,13 @@ class RelGraph:
         return self._plans["n_v"]
 
     @property
+    def iota(self):
+        """[0, 1, ..., M-1] int32 (identity gather for per-message tables already in by-target order)."""
+        if "iota" not in self._plans:
+            self._plans["iota"] = torch.arange(self.M, dtype=torch.int32, device=self.device)
+        return self._plans["iota"]
+
+    @property
     def tgt_t(self):
         """target NODE of each by-target position."""
         if "tgt_t" not in self._plans:

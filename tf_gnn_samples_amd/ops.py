@@ -299,20 +299,38 @@ def pair_materialize(P, Q, graph, activation: Optional[str]):
     return _PairMaterialize.apply(P, Q, graph, activation_id(activation))
 
 
-# ---- RGAT (csrc/rgat.hip) -----------------------------------------------------------------------
+# ---- RGAT (csrc/rgat_fast.hip, generic fallback csrc/rgat.hip) -------------------------------------
+def _rgat_fast_ok(D: int, K: int) -> bool:
+    return K in (1, 2, 4, 8) and D % K == 0 and (D // K) % 4 == 0 and D <= 1024
+
+
+def _rgat_dz_fast_ok(D: int, K: int) -> bool:
+    dh4 = D // K // 4 if K and D % (4 * K) == 0 else 0
+    return _rgat_fast_ok(D, K) and D <= 256 and dh4 > 0 and (dh4 & (dh4 - 1)) == 0
+
+
 class _RgatAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, T, s_src, s_tgt, graph, num_heads: int, slope: float):
         lib = _lib.load_library()
+        st = _lib.current_stream()
         T, s_src, s_tgt = T.contiguous(), s_src.contiguous(), s_tgt.contiguous()
         V, L, M = graph.V, graph.L, graph.M
         D = T.shape[1]
         out = torch.empty((V, D), dtype=torch.float32, device=T.device)
         alpha = torch.empty((M, num_heads), dtype=torch.float32, device=T.device)
-        _lib.check(lib.relgnn_rgat_fwd(_lib.ptr(T), D, D, num_heads, _lib.ptr(s_src), _lib.ptr(s_tgt),
-                                       _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope, _lib.ptr(out), D,
-                                       _lib.ptr(alpha), _lib.current_stream()), "relgnn_rgat_fwd")
-        ctx.graph, ctx.K, ctx.slope = graph, num_heads, slope
+        fast = _rgat_fast_ok(D, num_heads)
+        if fast:
+            _lib.check(lib.relgnn_rgat_alpha(_lib.ptr(s_src), _lib.ptr(s_tgt), num_heads, _lib.ptr(graph.rowptr_t), V, L,
+                                             _lib.ptr(graph.col_t), slope, _lib.ptr(alpha), st), "relgnn_rgat_alpha")
+            _lib.check(lib.relgnn_headw_reduce(_lib.ptr(T), V * L, D, D, num_heads, _lib.ptr(graph.rowptr_t), V, L,
+                                               _lib.ptr(graph.col_t), _lib.ptr(alpha), None, _lib.ptr(out), D, st),
+                       "relgnn_headw_reduce")
+        else:
+            _lib.check(lib.relgnn_rgat_fwd(_lib.ptr(T), D, D, num_heads, _lib.ptr(s_src), _lib.ptr(s_tgt),
+                                           _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope, _lib.ptr(out), D,
+                                           _lib.ptr(alpha), st), "relgnn_rgat_fwd")
+        ctx.graph, ctx.K, ctx.slope, ctx.fast = graph, num_heads, slope, fast
         ctx.save_for_backward(T, s_src, s_tgt, alpha, out)
         return out
 
@@ -326,16 +344,29 @@ class _RgatAttention(torch.autograd.Function):
         D = T.shape[1]
         gout = gout.contiguous()
         dz = torch.empty((M, K), dtype=torch.float32, device=T.device)
-        gs_tgt = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
-        _lib.check(lib.relgnn_rgat_bwd_logits(_lib.ptr(T), D, D, K, _lib.ptr(s_src), _lib.ptr(s_tgt),
-                                              _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope,
-                                              _lib.ptr(alpha), _lib.ptr(out), _lib.ptr(gout), D, _lib.ptr(dz),
-                                              _lib.ptr(gs_tgt), st), "relgnn_rgat_bwd_logits")
-        gT = torch.empty_like(T)
-        gs_src = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
-        _lib.check(lib.relgnn_rgat_bwd_msg(D, K, _lib.ptr(graph.rowptr_s), V * L, _lib.ptr(graph.tgt_s),
-                                           _lib.ptr(graph.pos_t_of_s), _lib.ptr(alpha), _lib.ptr(dz), _lib.ptr(gout), D,
-                                           _lib.ptr(gT), D, _lib.ptr(gs_src), st), "relgnn_rgat_bwd_msg")
+        if ctx.fast and _rgat_dz_fast_ok(D, K):
+            _lib.check(lib.relgnn_rgat_dz(_lib.ptr(T), V * L, D, D, K, _lib.ptr(s_src), _lib.ptr(s_tgt),
+                                          _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope, _lib.ptr(alpha),
+                                          _lib.ptr(out), _lib.ptr(gout), D, _lib.ptr(dz), st), "relgnn_rgat_dz")
+            gs_tgt = _seg_reduce_raw(_lib.AGG_SUM, dz, graph.rowptr_t, 1, graph.iota, None, V * L)
+        else:
+            gs_tgt = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
+            _lib.check(lib.relgnn_rgat_bwd_logits(_lib.ptr(T), D, D, K, _lib.ptr(s_src), _lib.ptr(s_tgt),
+                                                  _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope,
+                                                  _lib.ptr(alpha), _lib.ptr(out), _lib.ptr(gout), D, _lib.ptr(dz),
+                                                  _lib.ptr(gs_tgt), st), "relgnn_rgat_bwd_logits")
+        if ctx.fast:
+            gT = torch.empty_like(T)
+            _lib.check(lib.relgnn_headw_reduce(_lib.ptr(gout), V, D, D, K, _lib.ptr(graph.rowptr_s), V * L, 1,
+                                               _lib.ptr(graph.tgt_s), _lib.ptr(alpha), _lib.ptr(graph.pos_t_of_s),
+                                               _lib.ptr(gT), D, st), "relgnn_headw_reduce")
+            gs_src = _seg_reduce_raw(_lib.AGG_SUM, dz, graph.rowptr_s, 1, graph.pos_t_of_s, None, V * L)
+        else:
+            gT = torch.empty_like(T)
+            gs_src = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
+            _lib.check(lib.relgnn_rgat_bwd_msg(D, K, _lib.ptr(graph.rowptr_s), V * L, _lib.ptr(graph.tgt_s),
+                                               _lib.ptr(graph.pos_t_of_s), _lib.ptr(alpha), _lib.ptr(dz), _lib.ptr(gout), D,
+                                               _lib.ptr(gT), D, _lib.ptr(gs_src), st), "relgnn_rgat_bwd_msg")
         return gT, gs_src, gs_tgt, None, None, None
 
 
