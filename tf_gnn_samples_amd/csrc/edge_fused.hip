@@ -297,6 +297,248 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_kernel(
     if (on[c]) gT[r * ldgt4 + gg.gl + G * c] = acc[c];
 }
 
+// =========================================================================================
+// Wave-per-node variants (D > 128, L <= 63): same structure as seg_reduce_wave_kernel — the bucket
+// bounds of the node live in ONE vector register (lane j holds rowptr[v*L + j]) and are broadcast with
+// v_readlane; row indices of a 64-message chunk are fetched with one coalesced load and broadcast into
+// SGPRs, so every gathered-row load is scalar base + lane offset, WU loads in flight.
+// =========================================================================================
+constexpr int WU = 8;
+
+__device__ __forceinline__ float rlf(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int NCH, int KIND, bool IS_MAX>
+__global__ __launch_bounds__(256) void edge_fwd_wave_kernel(
+    const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
+    const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
+    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4, int64_t nlb) {
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t v = lb * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int my_b = rowptr[v * L + min(lane, L)];
+  bool on[NCH];
+  uint32_t cc[NCH];
+  float4 acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    on[c] = lane + 64 * c < D4;
+    cc[c] = (uint32_t)min(lane + 64 * c, D4 - 1);
+    acc[c] = f4(IS_MAX ? -FLT_MAX : 0.f);
+  }
+  const uint32_t ld = (uint32_t)ldt4;
+  const int seg_b = __builtin_amdgcn_readlane(my_b, 0);
+  int b = seg_b;
+  for (int l = 0; l < L; ++l) {
+    const int e = __builtin_amdgcn_readlane(my_b, l + 1);
+    if (b < e) {
+      float4 ra[NCH], rb[NCH];
+      const float4* arow = A + (v * L + l) * lda4;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        ra[c] = arow[cc[c]];
+        rb[c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+      }
+      for (int p = b; p < e; p += 64) {
+        const int n = min(64, e - p);
+        const int my_col = (lane < n) ? col[p + lane] : 0;
+        const float my_w = (w && lane < n) ? w[p + lane] : 1.f;
+        for (int k = 0; k < n; k += WU) {
+          const int rem = n - k;  // wave-uniform
+          float4 t[WU][NCH];
+          float ww[WU];
+#pragma unroll
+          for (int u = 0; u < WU; ++u) {
+            const int ku = k + min(u, rem - 1);
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, ku);
+            ww[u] = rlf(my_w, ku);
+            const float4* row = T + (size_t)(r * ld);
+            if (u < rem) {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) t[u][c] = row[cc[c]];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < WU; ++u)
+            if (u < rem) {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                const float4 m = act4(act, pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+                acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
+              }
+            }
+        }
+      }
+    }
+    b = e;
+  }
+  const float n = (float)max(b - seg_b, 1);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (on[c]) {
+      float4 a = acc[c];
+      if (mode == RELGNN_AGG_MEAN) a = make_float4(a.x / n, a.y / n, a.z / n, a.w / n);
+      if (mode == RELGNN_AGG_SQRT_N) { const float s = sqrtf(n); a = make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+      out[v * ldo4 + lane + 64 * c] = a;
+    }
+}
+
+template <int NCH, int KIND>
+__global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
+    const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
+    const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
+    const float* __restrict__ w, const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gA,
+    int64_t ldga4, int32_t act, int64_t nlb) {
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t v = lb * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const int my_b = rowptr[v * L + min(lane, L)];
+  bool on[NCH];
+  uint32_t cc[NCH];
+  float4 g[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    on[c] = lane + 64 * c < D4;
+    cc[c] = (uint32_t)min(lane + 64 * c, D4 - 1);
+    g[c] = gagg[v * ldg4 + cc[c]];
+  }
+  const uint32_t ld = (uint32_t)ldt4;
+  int b = __builtin_amdgcn_readlane(my_b, 0);
+  for (int l = 0; l < L; ++l) {
+    const int e = __builtin_amdgcn_readlane(my_b, l + 1);
+    float4 s1[NCH], s2[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) s1[c] = s2[c] = f4(0.f);
+    if (b < e) {
+      float4 ra[NCH], rb[NCH];
+      const float4* arow = A + (v * L + l) * lda4;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        ra[c] = arow[cc[c]];
+        rb[c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+      }
+      for (int p = b; p < e; p += 64) {
+        const int n = min(64, e - p);
+        const int my_col = (lane < n) ? col[p + lane] : 0;
+        const float my_w = (w && lane < n) ? w[p + lane] : 1.f;
+        for (int k = 0; k < n; k += WU) {
+          const int rem = n - k;
+          float4 t[WU][NCH];
+          float ww[WU];
+#pragma unroll
+          for (int u = 0; u < WU; ++u) {
+            const int ku = k + min(u, rem - 1);
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, ku);
+            ww[u] = rlf(my_w, ku);
+            const float4* row = T + (size_t)(r * ld);
+            if (u < rem) {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) t[u][c] = row[cc[c]];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < WU; ++u)
+            if (u < rem) {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                const float4 gp = g[c] * actg4(act, pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+                if constexpr (KIND == KIND_FILM) {
+                  s1[c] = s1[c] + gp * (ww[u] * t[u][c]);
+                  s2[c] = s2[c] + gp;
+                } else {
+                  s1[c] = s1[c] + ww[u] * gp;
+                }
+              }
+            }
+        }
+      }
+    }
+    float4* grow = gA + (v * L + l) * ldga4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (on[c]) {
+        grow[lane + 64 * c] = s1[c];
+        if constexpr (KIND == KIND_FILM) grow[D4 + lane + 64 * c] = s2[c];
+      }
+    b = e;
+  }
+}
+
+// by-(source,type) rows: one wave per row r of T; per message the bucket row A[frow] and the target's gagg row
+// are gathered (scalar bases), 4 messages (8..12 row loads) in flight.
+template <int NCH, int KIND>
+__global__ __launch_bounds__(256) void edge_bwd_msgs_wave_kernel(
+    const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
+    const int32_t* __restrict__ rowptr_b, int64_t n_rows, const int32_t* __restrict__ tgt_b,
+    const int32_t* __restrict__ frow_b, const float* __restrict__ w_b, const float4* __restrict__ gagg,
+    int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int32_t act, int64_t nlb) {
+  constexpr int MU = 4;
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = lb * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  bool on[NCH];
+  uint32_t cc[NCH];
+  float4 t[NCH], acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    on[c] = lane + 64 * c < D4;
+    cc[c] = (uint32_t)min(lane + 64 * c, D4 - 1);
+    t[c] = T[r * ldt4 + cc[c]];
+    acc[c] = f4(0.f);
+  }
+  const int b = __builtin_amdgcn_readfirstlane(rowptr_b[r]);
+  const int e = __builtin_amdgcn_readfirstlane(rowptr_b[r + 1]);
+  const uint32_t lda = (uint32_t)lda4, ldg = (uint32_t)ldg4;
+  for (int q = b; q < e; q += 64) {
+    const int n = min(64, e - q);
+    const int my_fr = (lane < n) ? frow_b[q + lane] : 0;
+    const int my_tg = (lane < n) ? tgt_b[q + lane] : 0;
+    const float my_w = (w_b && lane < n) ? w_b[q + lane] : 1.f;
+    for (int k = 0; k < n; k += MU) {
+      const int rem = n - k;
+      float4 ra[MU][NCH], rb[MU][NCH], g[MU][NCH];
+      float ww[MU];
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int ku = k + min(u, rem - 1);
+        const uint32_t fr = (uint32_t)__builtin_amdgcn_readlane(my_fr, ku);
+        const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane(my_tg, ku);
+        ww[u] = rlf(my_w, ku);
+        const float4* arow = A + (size_t)(fr * lda);
+        const float4* grow = gagg + (size_t)(tg * ldg);
+        if (u < rem) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            ra[u][c] = arow[cc[c]];
+            rb[u][c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+            g[u][c] = grow[cc[c]];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+        if (u < rem) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const float4 gp = g[u][c] * actg4(act, pre_act<KIND>(ww[u], t[c], ra[u][c], rb[u][c]));
+            if constexpr (KIND == KIND_FILM) acc[c] = acc[c] + ww[u] * (ra[u][c] * gp);
+            else acc[c] = acc[c] + ww[u] * gp;
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (on[c]) gT[r * ldgt4 + lane + 64 * c] = acc[c];
+}
+
 // -----------------------------------------------------------------------------------------
 // materialise per-message hidden states in the ORIGINAL type-major message order:
 //   hidden[m] = act( P[row_src[m]] + Q[row_tgt[m]] )     (rows = node*L + type)
@@ -357,6 +599,19 @@ int launch_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const flo
   const unsigned grid = padded_grid(nlb);
   const bool is_max = mode == RELGNN_AGG_MAX;
   if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (geo.G == 64 && L <= 63 && (int64_t)V * L * (ldt / 4) < ((int64_t)1 << 32)) {
+    const int64_t wnlb = ((int64_t)V + 3) / 4;
+    const unsigned wgrid = padded_grid(wnlb);
+#define EDGE_FWD_WAVE(NN, MX)                                                                                      \
+  edge_fwd_wave_kernel<NN, KIND, MX><<<wgrid, 256, 0, st>>>((const float4*)T, ldt / 4, (const float4*)A, lda / 4,   \
+                                                             D / 4, rowptr, V, L, col, w, mode, act, (float4*)out,  \
+                                                             ldo / 4, wnlb)
+    if (geo.NCH == 1) { if (is_max) EDGE_FWD_WAVE(1, true); else EDGE_FWD_WAVE(1, false); }
+    else if (geo.NCH == 2) { if (is_max) EDGE_FWD_WAVE(2, true); else EDGE_FWD_WAVE(2, false); }
+    else { if (is_max) EDGE_FWD_WAVE(4, true); else EDGE_FWD_WAVE(4, false); }
+#undef EDGE_FWD_WAVE
+    return launch_status();
+  }
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     if (is_max)
       edge_fwd_kernel<GG, NN, KIND, true><<<grid, 256, 0, st>>>(
@@ -378,6 +633,16 @@ int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, in
   const int64_t nlb = logical_blocks(V, geo.G);
   const unsigned grid = padded_grid(nlb);
   if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (geo.G == 64 && L <= 63 && (int64_t)V * L * (ldt / 4) < ((int64_t)1 << 32)) {
+    const int64_t wnlb = ((int64_t)V + 3) / 4;
+#define EDGE_ROWS_WAVE(NN)                                                                                          \
+  edge_bwd_rows_wave_kernel<NN, KIND><<<padded_grid(wnlb), 256, 0, st>>>(                                            \
+      (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4, \
+      (float4*)gA, ldga / 4, act, wnlb)
+    if (geo.NCH == 1) EDGE_ROWS_WAVE(1); else if (geo.NCH == 2) EDGE_ROWS_WAVE(2); else EDGE_ROWS_WAVE(4);
+#undef EDGE_ROWS_WAVE
+    return launch_status();
+  }
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     edge_bwd_rows_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
         (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4,
@@ -396,6 +661,16 @@ int launch_bwd_msgs(int32_t act, const float* T, int64_t ldt, const float* A, in
   const int64_t nlb = logical_blocks(n_rows, geo.G);
   const unsigned grid = padded_grid(nlb);
   if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (geo.G == 64 && n_rows * (lda / 4) < ((int64_t)1 << 32) && n_rows * (ldg / 4) < ((int64_t)1 << 32)) {
+    const int64_t wnlb = (n_rows + 3) / 4;
+#define EDGE_MSGS_WAVE(NN)                                                                                          \
+  edge_bwd_msgs_wave_kernel<NN, KIND><<<padded_grid(wnlb), 256, 0, st>>>(                                            \
+      (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,             \
+      (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, wnlb)
+    if (geo.NCH == 1) EDGE_MSGS_WAVE(1); else if (geo.NCH == 2) EDGE_MSGS_WAVE(2); else EDGE_MSGS_WAVE(4);
+#undef EDGE_MSGS_WAVE
+    return launch_status();
+  }
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     edge_bwd_msgs_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
         (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,
