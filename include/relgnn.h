@@ -212,6 +212,23 @@ int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* ro
 int relgnn_act_bwd_from_output(int32_t act, const float* y, const float* gout, int64_t n,
                                float* gin, void* stream);
 
+/*
+ * Fused aggregate -> transform on the matrix cores (rgcn_fused.hip) for the dense-weight layers:
+ *   out[v,:] = act( f_mode( sum_l ( sum_{p in (v,l)} w[p] * H[src[p],:] ) @ W_l ) ),  mode in {SUM, MEAN, SQRT_N}
+ * = gnns/rgcn.py:87-114 / ggnn.py:76-89 with the per-edge-type Dense applied AFTER the (linear) aggregation as an
+ * exact-f32 MFMA GEMM (v_mfma_f32_32x32x2_f32); the [V, L*D] intermediate never reaches memory.
+ *   H    : [num_nodes, ldh] node states (first Din columns),  src: [M] SOURCE NODE per by-target position
+ *   packed_weights : relgnn_pack_type_weights() of the L kernels [Din, Dout]
+ * Needs Din % 8 == 0, Din <= 384, Dout % 32 == 0, Dout <= 512 (RELGNN_EUNSUPPORTED otherwise; MAX is unsupported:
+ * it does not commute with the transform).
+ */
+int relgnn_pack_type_weights(const float* W, int32_t num_edge_types, int32_t Din, int32_t Dout, int64_t ldw,
+                             int64_t type_stride, float* packed, void* stream);
+int relgnn_rgcn_fused_fwd(int32_t mode, int32_t act, const float* H, int64_t ldh, int32_t Din,
+                          const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
+                          const int32_t* src, const float* w, const float* packed_weights, int32_t Dout,
+                          float* out, int64_t ldo, void* stream);
+
 /* ========================================================================== *
  * 3. GNN-FiLM fused message kernels  (gnns/gnn_film.py:86-116)
  * ========================================================================== */

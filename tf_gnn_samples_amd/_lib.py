@@ -41,6 +41,8 @@ _SIGNATURES = {
     "relgnn_seg_max_count": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_seg_max_bwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_act_bwd_from_output": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_pack_type_weights": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _ptr, _ptr]),
+    "relgnn_rgcn_fused_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
     "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_film_bwd_msg": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),

@@ -15,10 +15,20 @@ from typing import List, Mapping, Optional
 
 import torch
 
+import os
+
+from .. import ops
 from ..dense import dense
 from ..graph import as_rel_graph
 from ._common import concat_edge_kernels, reduce_and_activate, require_weights
 from .pair import pair_messages_reduce
+
+
+def fused_mfma_enabled() -> bool:
+    """RELGNN_FUSED_MFMA=1 selects the fused aggregate -> f32-MFMA transform kernel (csrc/rgcn_fused.hip) for the
+    forward pass.  It is parity-green but measured SLOWER than hipBLASLt GEMM + seg_reduce on MI355X at C2
+    (286 us vs 227 us per layer), so the default is the unfused path."""
+    return os.environ.get("RELGNN_FUSED_MFMA", "0") == "1"
 
 
 def rgcn_layer_variables(num_edge_types: int, in_dim: int, state_dim: int,
@@ -52,6 +62,15 @@ def sparse_rgcn_layer(node_embeddings: torch.Tensor,
     w = graph.degree_scale(type_to_num_incoming_edges) if normalize_by_num_incoming else None
 
     cur_node_states = node_embeddings
+    mode, act = ops.aggregation_mode_id(message_aggregation_function), ops.activation_id(activation_function)
+    if (not use_both_source_and_target and fused_mfma_enabled() and act in ops._FUSABLE_ACTS
+            and ops.fused_transform_supported(in_dim, state_dim, mode) and (num_timesteps == 1 or in_dim == state_dim)):
+        # aggregate-then-transform on the matrix cores: one kernel per timestep (csrc/rgcn_fused.hip)
+        w_stack = torch.stack([weights["Edge_%i_Weight/kernel" % l] for l in range(L)], dim=0)   # [L, D, state_dim]
+        for _ in range(num_timesteps):
+            cur_node_states = ops.fused_aggregate_transform(cur_node_states, w_stack, graph, w,
+                                                            message_aggregation_function, activation_function)
+        return cur_node_states
     if not use_both_source_and_target:
         plan = graph.plan_transformed(w)
         w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")          # [D, L*state_dim]

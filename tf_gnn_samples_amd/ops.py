@@ -373,3 +373,65 @@ class _RgatAttention(torch.autograd.Function):
 def rgat_attention(T, s_src, s_tgt, graph, num_heads: int, slope: float = 0.2):
     """gnns/rgat.py:98-136: segmented softmax over all incoming messages + attention-weighted sum."""
     return _RgatAttention.apply(T, s_src, s_tgt, graph, int(num_heads), float(slope))
+
+
+# ---- fused aggregate -> MFMA transform (csrc/rgcn_fused.hip) ---------------------------------------
+def fused_transform_supported(d_in: int, d_out: int, mode: int) -> bool:
+    return (mode in (_lib.AGG_SUM, _lib.AGG_MEAN, _lib.AGG_SQRT_N) and d_in % 8 == 0 and d_in <= 384
+            and d_out % 32 == 0 and d_out <= 512)
+
+
+class _FusedAggregateTransform(torch.autograd.Function):
+    """out = act(f_mode(sum_l (sum_{p in (v,l)} w_p H[src_p]) @ W_l)); W: [L, Din, Dout].
+    Forward: one kernel (gather in registers -> LDS tile -> f32 MFMA).  Backward: the unfused formulas, which
+    are the exact gradients of the same function: dT = transposed gather-reduce of dOut, dH = dT @ Wcat^T,
+    dW = H^T @ dT (split-K)."""
+
+    @staticmethod
+    def forward(ctx, H, W, graph, w, mode: int, act: int):
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        H, W = H.contiguous(), W.contiguous()
+        L, d_in, d_out = W.shape
+        V = graph.V
+        packed = torch.empty(L * d_in * d_out, dtype=torch.float32, device=H.device)
+        _lib.check(lib.relgnn_pack_type_weights(_lib.ptr(W), L, d_in, d_out, d_out, d_in * d_out, _lib.ptr(packed), st),
+                   "relgnn_pack_type_weights")
+        out = torch.empty((V, d_out), dtype=torch.float32, device=H.device)
+        _lib.check(lib.relgnn_rgcn_fused_fwd(mode, act, _lib.ptr(H), d_in, d_in, _lib.ptr(graph.rowptr_t), V, L,
+                                             _lib.ptr(graph.src_t), _lib.ptr(w), _lib.ptr(packed), d_out, _lib.ptr(out),
+                                             d_out, st), "relgnn_rgcn_fused_fwd")
+        ctx.graph, ctx.w, ctx.mode, ctx.act = graph, w, mode, act
+        ctx.save_for_backward(H, W, out if act != _lib.ACT_LINEAR else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .dense import matmul_tn_splitk
+        lib = _lib.load_library()
+        graph, w, mode, act = ctx.graph, ctx.w, ctx.mode, ctx.act
+        H, W, out = ctx.saved_tensors
+        L, d_in, d_out = W.shape
+        V = graph.V
+        gout = gout.contiguous()
+        if act != _lib.ACT_LINEAR:
+            g = torch.empty_like(gout)
+            _lib.check(lib.relgnn_act_bwd_from_output(act, _lib.ptr(out), _lib.ptr(gout), gout.numel(), _lib.ptr(g),
+                                                      _lib.current_stream()), "relgnn_act_bwd_from_output")
+            gout = g
+        plan = graph.plan_transformed(w)
+        gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
+                             plan.num_rows_x).view(V, L * d_out)                       # row v: [dT_0 | .. | dT_{L-1}]
+        w_cat = W.permute(1, 0, 2).reshape(d_in, L * d_out)
+        gH = gT @ w_cat.t() if ctx.needs_input_grad[0] else None
+        gW = None
+        if ctx.needs_input_grad[1]:
+            gW = matmul_tn_splitk(H, gT).view(d_in, L, d_out).permute(1, 0, 2).contiguous()
+        return gH, gW, None, None, None, None
+
+
+def fused_aggregate_transform(H, W, graph, w, aggregation: str, activation: Optional[str]):
+    mode, act = aggregation_mode_id(aggregation), activation_id(activation)
+    if act not in _FUSABLE_ACTS:
+        raise ValueError("activation %r cannot be fused" % activation)
+    return _FusedAggregateTransform.apply(H, W, graph, w, mode, act)
