@@ -93,6 +93,32 @@ int relgnn_relational_keys(const int32_t* adj, int64_t num_edges, int32_t edge_t
                            int32_t* key_by_target, int32_t* key_by_source,
                            uint32_t* err_flag, void* stream);
 
+/* As relgnn_relational_keys, additionally writing the plain node ids target_node[m], source_node[m] (nullable):
+ * the sort keys of relgnn_relational_plan. */
+int relgnn_relational_keys2(const int32_t* adj, int64_t num_edges, int32_t edge_type,
+                            int32_t num_edge_types, int32_t num_nodes, int64_t msg_base,
+                            int32_t* key_by_target, int32_t* key_by_source, int32_t* target_node,
+                            int32_t* source_node, uint32_t* err_flag, void* stream);
+
+/*
+ * relgnn_relational_plan — the (node, type)-bucketed CSR of the type-major message list in one call.
+ * Because the message list is type-major (gnns/rgcn.py:78), a STABLE sort by node id alone already orders the
+ * messages by (node, type, original edge order): only ceil(log2 V) key bits go through the radix passes.
+ *   sort_node : [M] node id to bucket by (target_node for the forward plan, source_node for the transposed plan)
+ *   full_key  : [M] node*L + type of the same side (defines the V*L buckets of rowptr)
+ *   other_key : [M] node*L + type of the OTHER side
+ * Outputs (sorted position p, original message m = perm[p]):
+ *   rowptr [V*L+1], perm [M], col[p] = other_key[m], col_div[p] = other_key[m] / L (nullable),
+ *   inv_out[m] = p (nullable: the inverse permutation), pos_out[p] = inv_in[m] (nullable pair: position of the
+ *   same message in another plan's order).
+ */
+size_t relgnn_relational_plan_workspace_bytes(int64_t num_messages, int32_t num_nodes);
+int relgnn_relational_plan(const int32_t* sort_node, const int32_t* full_key, const int32_t* other_key,
+                           int64_t num_messages, int32_t num_nodes, int32_t num_edge_types,
+                           int32_t* rowptr, int32_t* perm, int32_t* col, int32_t* col_div,
+                           int32_t* inv_out, const int32_t* inv_in, int32_t* pos_out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /*
  * relgnn_segment_plan — stable bucketing of messages by segment id.
  *

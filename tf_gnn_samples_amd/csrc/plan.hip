@@ -18,7 +18,7 @@ namespace {
 __global__ __launch_bounds__(256) void relational_keys_kernel(
     const int2* __restrict__ adj, int64_t num_edges, int32_t edge_type, int32_t L, int32_t V,
     int64_t msg_base, int32_t* __restrict__ key_t, int32_t* __restrict__ key_s,
-    uint32_t* __restrict__ err_flag) {
+    int32_t* __restrict__ node_t, int32_t* __restrict__ node_s, uint32_t* __restrict__ err_flag) {
   bool bad = false;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < num_edges;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -31,6 +31,8 @@ __global__ __launch_bounds__(256) void relational_keys_kernel(
     }
     key_t[msg_base + e] = t * L + edge_type;
     key_s[msg_base + e] = s * L + edge_type;
+    if (node_t) node_t[msg_base + e] = t;
+    if (node_s) node_s[msg_base + e] = s;
   }
   // one atomic per wave at most, and only on the error path
   if (err_flag != nullptr && __any(bad)) {
@@ -56,6 +58,22 @@ __global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(
     int64_t hi = (p == n) ? num_segments : (int64_t)sorted_keys[p];
     // segments lo..hi start at p (hi itself starts at p only when p < n, or is the end sentinel)
     for (int64_t s = lo; s <= hi; ++s) rowptr[s] = (int32_t)p;
+  }
+}
+
+// one pass over the sorted positions: everything the two CSR orders need from the permutation
+__global__ __launch_bounds__(256) void plan_finalize_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ full_key, const int32_t* __restrict__ other_key,
+    int64_t n, int32_t L, int32_t* __restrict__ sorted_full, int32_t* __restrict__ col, int32_t* __restrict__ col_div,
+    int32_t* __restrict__ inv_out, const int32_t* __restrict__ inv_in, int32_t* __restrict__ pos_out) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t m = perm[p];
+    sorted_full[p] = full_key[m];
+    const int32_t c = other_key[m];
+    col[p] = c;
+    if (col_div) col_div[p] = c / L;
+    if (inv_out) inv_out[m] = (int32_t)p;
+    if (pos_out) pos_out[p] = inv_in[m];
   }
 }
 
@@ -155,7 +173,63 @@ int relgnn_relational_keys(const int32_t* adj, int64_t num_edges, int32_t edge_t
   if (reinterpret_cast<uintptr_t>(adj) & 7u) return RELGNN_EINVAL;
   relational_keys_kernel<<<flat_grid(num_edges, 256), 256, 0, as_stream(stream)>>>(
       reinterpret_cast<const int2*>(adj), num_edges, edge_type, num_edge_types, num_nodes, msg_base,
-      key_by_target, key_by_source, err_flag);
+      key_by_target, key_by_source, nullptr, nullptr, err_flag);
+  return launch_status();
+}
+
+int relgnn_relational_keys2(const int32_t* adj, int64_t num_edges, int32_t edge_type, int32_t num_edge_types,
+                            int32_t num_nodes, int64_t msg_base, int32_t* key_by_target, int32_t* key_by_source,
+                            int32_t* target_node, int32_t* source_node, uint32_t* err_flag, void* stream) {
+  if (num_edges < 0 || num_edge_types <= 0 || num_nodes < 0 || msg_base < 0 || edge_type < 0 ||
+      edge_type >= num_edge_types)
+    return RELGNN_EINVAL;
+  if ((int64_t)num_nodes * num_edge_types > INT32_MAX) return RELGNN_EUNSUPPORTED;
+  if (num_edges == 0) return RELGNN_OK;
+  if (!adj || !key_by_target || !key_by_source || num_nodes == 0) return RELGNN_EINVAL;
+  if (reinterpret_cast<uintptr_t>(adj) & 7u) return RELGNN_EINVAL;
+  relational_keys_kernel<<<flat_grid(num_edges, 256), 256, 0, as_stream(stream)>>>(
+      reinterpret_cast<const int2*>(adj), num_edges, edge_type, num_edge_types, num_nodes, msg_base,
+      key_by_target, key_by_source, target_node, source_node, err_flag);
+  return launch_status();
+}
+
+size_t relgnn_relational_plan_workspace_bytes(int64_t num_messages, int32_t num_nodes) {
+  // [iota | sorted node keys | sorted full keys | rocprim temp]
+  return relgnn_segment_plan_workspace_bytes(num_messages, num_nodes) + align_up((size_t)(num_messages > 0 ? num_messages : 1) * 4, 256);
+}
+
+int relgnn_relational_plan(const int32_t* sort_node, const int32_t* full_key, const int32_t* other_key,
+                           int64_t num_messages, int32_t num_nodes, int32_t num_edge_types, int32_t* rowptr,
+                           int32_t* perm, int32_t* col, int32_t* col_div, int32_t* inv_out, const int32_t* inv_in,
+                           int32_t* pos_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (num_messages < 0 || num_nodes < 0 || num_edge_types <= 0 || !rowptr) return RELGNN_EINVAL;
+  const int64_t S = (int64_t)num_nodes * num_edge_types;
+  if (num_messages > INT32_MAX || S >= INT32_MAX) return RELGNN_EUNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  if (num_messages == 0) {
+    if (hipMemsetAsync(rowptr, 0, (size_t)(S + 1) * 4, st) != hipSuccess) return RELGNN_EHIP;
+    return RELGNN_OK;
+  }
+  if (!sort_node || !full_key || !other_key || !perm || !col || !workspace) return RELGNN_EINVAL;
+  if ((pos_out != nullptr) != (inv_in != nullptr)) return RELGNN_EINVAL;
+  if (workspace_bytes < relgnn_relational_plan_workspace_bytes(num_messages, num_nodes)) return RELGNN_ENOSPC;
+  char* ws = static_cast<char*>(workspace);
+  const size_t seg = align_up((size_t)num_messages * 4, 256);
+  int32_t* iota = reinterpret_cast<int32_t*>(ws);
+  int32_t* sorted_nodes = reinterpret_cast<int32_t*>(ws + seg);
+  int32_t* sorted_full = reinterpret_cast<int32_t*>(ws + 2 * seg);
+  void* temp = ws + 3 * seg;
+  size_t temp_bytes = workspace_bytes - 3 * seg;
+  iota_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(iota, num_messages);
+  // The message list is type-major, so a STABLE sort by node id alone already yields (node, type, edge order):
+  // only ceil(log2(V)) key bits go through the radix passes instead of ceil(log2(V*L)).
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, sort_node, sorted_nodes, iota, perm,
+                                           (size_t)num_messages, 0, key_bits(num_nodes), st);
+  if (e != hipSuccess) return RELGNN_EHIP;
+  plan_finalize_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(perm, full_key, other_key, num_messages,
+                                                                     num_edge_types, sorted_full, col, col_div, inv_out,
+                                                                     inv_in, pos_out);
+  rowptr_from_sorted_kernel<<<flat_grid(num_messages + 1, 256), 256, 0, st>>>(sorted_full, num_messages, S, rowptr);
   return launch_status();
 }
 

@@ -113,35 +113,34 @@ class RelGraph:
         st = _lib.current_stream()
 
         key_t, key_s = _i32(M, dev), _i32(M, dev)
+        node_t, node_s = _i32(M, dev), _i32(M, dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
         base = 0
         for l, a in enumerate(adj):
-            _lib.check(lib.relgnn_relational_keys(_lib.ptr(a), a.shape[0], l, L, V, base,
-                                                  _lib.ptr(key_t), _lib.ptr(key_s), _lib.ptr(err), st),
-                       "relgnn_relational_keys")
+            _lib.check(lib.relgnn_relational_keys2(_lib.ptr(a), a.shape[0], l, L, V, base, _lib.ptr(key_t),
+                                                   _lib.ptr(key_s), _lib.ptr(node_t), _lib.ptr(node_s), _lib.ptr(err), st),
+                       "relgnn_relational_keys2")
             base += a.shape[0]
         self.key_by_target, self.key_by_source = key_t, key_s
 
         S = V * L
+        ws_bytes = lib.relgnn_relational_plan_workspace_bytes(M, V)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         # by (target, type): position p -> original message perm_t[p]; gathers row col_t[p] = src*L + l
-        self.rowptr_t, self.perm_t, _ = build_segment_plan(key_t, S)
-        self.col_t = _i32(M, dev)
-        _lib.check(lib.relgnn_gather_i32(_lib.ptr(key_s), _lib.ptr(self.perm_t), M, _lib.ptr(self.col_t), st),
-                   "relgnn_gather_i32")
-        # by (source, type): position q -> original message perm_s[q]; target node tgt_s[q],
-        # (target, type) row frow_s[q] = tgt*L + l
-        self.rowptr_s, self.perm_s, _ = build_segment_plan(key_s, S)
-        self.frow_s, self.tgt_s = _i32(M, dev), _i32(M, dev)
-        _lib.check(lib.relgnn_gather_i32(_lib.ptr(key_t), _lib.ptr(self.perm_s), M, _lib.ptr(self.frow_s), st),
-                   "relgnn_gather_i32")
-        _lib.check(lib.relgnn_gather_div_i32(_lib.ptr(key_t), _lib.ptr(self.perm_s), M, L,
-                                             _lib.ptr(self.tgt_s), st), "relgnn_gather_div_i32")
-        # cross map: by-source position q -> by-target position p of the same message
+        self.rowptr_t, self.perm_t, self.col_t = _i32(S + 1, dev), _i32(M, dev), _i32(M, dev)
         inv_t = _i32(M, dev)
-        _lib.check(lib.relgnn_invert_perm(_lib.ptr(self.perm_t), M, _lib.ptr(inv_t), st), "relgnn_invert_perm")
-        self.pos_t_of_s = _i32(M, dev)
-        _lib.check(lib.relgnn_gather_i32(_lib.ptr(inv_t), _lib.ptr(self.perm_s), M, _lib.ptr(self.pos_t_of_s), st),
-                   "relgnn_gather_i32")
+        _lib.check(lib.relgnn_relational_plan(_lib.ptr(node_t), _lib.ptr(key_t), _lib.ptr(key_s), M, V, L,
+                                              _lib.ptr(self.rowptr_t), _lib.ptr(self.perm_t), _lib.ptr(self.col_t), None,
+                                              _lib.ptr(inv_t), None, None, _lib.ptr(ws), ws_bytes, st),
+                   "relgnn_relational_plan")
+        # by (source, type): position q -> original message perm_s[q]; (target, type) row frow_s[q] = tgt*L + l,
+        # target node tgt_s[q]; pos_t_of_s[q] = by-target position of the same message
+        self.rowptr_s, self.perm_s = _i32(S + 1, dev), _i32(M, dev)
+        self.frow_s, self.tgt_s, self.pos_t_of_s = _i32(M, dev), _i32(M, dev), _i32(M, dev)
+        _lib.check(lib.relgnn_relational_plan(_lib.ptr(node_s), _lib.ptr(key_s), _lib.ptr(key_t), M, V, L,
+                                              _lib.ptr(self.rowptr_s), _lib.ptr(self.perm_s), _lib.ptr(self.frow_s),
+                                              _lib.ptr(self.tgt_s), None, _lib.ptr(inv_t), _lib.ptr(self.pos_t_of_s),
+                                              _lib.ptr(ws), ws_bytes, st), "relgnn_relational_plan")
         self.inv_perm_t = inv_t
         self._src_t = None
         self._plans = {}
