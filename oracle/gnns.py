@@ -219,3 +219,41 @@ def sparse_gnn_edge_mlp_layer(node_embeddings, adjacency_lists, type_to_num_inco
         aggregated = aggregate(all_messages, message_targets, num_nodes)                # :113-116
         cur = T.layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])   # :119
     return cur
+
+
+def sparse_rgdcn_layer(node_embeddings, adjacency_lists, type_to_num_incoming_edges, num_channels=8, channel_dim=16,
+                       num_timesteps=1, use_full_state_for_channel_weights=False, tie_channel_weights=False,
+                       activation_function="tanh", message_aggregation_function="sum", normalize_by_num_incoming=True,
+                       *, weights):
+    """gnns/rgdcn.py:82-167."""
+    dtype = node_embeddings.dtype
+    weights = _cast(weights, dtype)
+    num_nodes = node_embeddings.shape[0]
+    activation_fn = T.get_activation(activation_function)
+    aggregate = T.get_aggregation_function(message_aggregation_function)
+    message_targets = _targets(adjacency_lists)                                              # :106
+    cur = node_embeddings
+    for _ in range(num_timesteps):
+        chunked = cur.reshape(-1, num_channels, channel_dim)                                 # :110-111
+        new_chunks = []
+        for c in range(num_channels):                                                        # :114
+            cur_channel = chunked[:, c, :]
+            per_type = []
+            for l, adj in enumerate(adjacency_lists):                                        # :119
+                adj = np.asarray(adj).reshape(-1, 2)
+                sources, targets = adj[:, 0], adj[:, 1]
+                src_states = T.embedding_lookup(cur_channel, sources)                        # :122-124
+                wc_in = cur if use_full_state_for_channel_weights else cur_channel           # :126-129
+                kern = weights["Edge_%i_Channel_%i_Weight_Computation/kernel" % (l, 0 if tie_channel_weights else c)]
+                edge_weights = T.dense(wc_in, kern, activation=activation_fn)                # :132-134 (Dense WITH activation)
+                edge_weights = edge_weights.reshape(-1, channel_dim, channel_dim)            # :135
+                w_tgt = T.embedding_lookup(edge_weights, targets)                            # :136-137
+                messages = np.einsum('vi,vij->vj', src_states, w_tgt)                        # :140
+                if normalize_by_num_incoming:                                                # :141-145
+                    messages = _inv_degree(type_to_num_incoming_edges, l, targets, dtype) * messages
+                per_type.append(messages)
+            msgs = np.concatenate(per_type, axis=0)                                          # :149
+            agg = aggregate(msgs, message_targets, num_nodes)                                # :150-153
+            new_chunks.append(T.apply_act(activation_fn, agg))                               # :154
+        cur = np.concatenate(new_chunks, axis=1)                                             # :158
+    return cur

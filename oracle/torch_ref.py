@@ -227,3 +227,30 @@ def sparse_gnn_edge_mlp_layer(h, adj, deg, state_dim, num_timesteps=1, activatio
         new = agg(act(torch.cat(msgs, 0)), tgts, V)
         cur = layer_norm(new, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
     return cur
+
+
+def sparse_rgdcn_layer(h, adj, deg, num_channels=8, channel_dim=16, num_timesteps=1,
+                       use_full_state_for_channel_weights=False, tie_channel_weights=False, activation_function="tanh",
+                       message_aggregation_function="sum", normalize_by_num_incoming=True, *, weights):
+    act, agg = activation(activation_function), aggregation(message_aggregation_function)
+    V = h.shape[0]
+    tgts = _targets(adj)
+    cur = h
+    for _ in range(num_timesteps):
+        chunked = cur.reshape(-1, num_channels, channel_dim)
+        outs = []
+        for c in range(num_channels):
+            ch = chunked[:, c, :]
+            per_type = []
+            for l, a in enumerate(adj):
+                src = ch.index_select(0, a[:, 0].long())
+                inp = cur if use_full_state_for_channel_weights else ch
+                kern = weights["Edge_%i_Channel_%i_Weight_Computation/kernel" % (l, 0 if tie_channel_weights else c)]
+                ew = act(inp @ kern).reshape(-1, channel_dim, channel_dim).index_select(0, a[:, 1].long())
+                m = torch.einsum('vi,vij->vj', src, ew)
+                if normalize_by_num_incoming:
+                    m = _inv_deg(deg, l, a[:, 1], cur.dtype) * m
+                per_type.append(m)
+            outs.append(act(agg(torch.cat(per_type, 0), tgts, V)))
+        cur = torch.cat(outs, 1)
+    return cur

@@ -365,3 +365,46 @@ def test_fused_mfma_aggregate_transform(gpu_device, Din, Dout, agg, norm):
     for l in range(L):
         gr = wr["Edge_%i_Weight/kernel" % l].grad
         assert float((W.grad[l].cpu().double() - gr).abs().max()) < 4e-5 * max(1.0, float(gr.abs().max()))
+
+
+@pytest.mark.parametrize("full_state,tie", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("agg,norm", [("sum", True), ("mean", False)])
+def test_rgdcn_layer(gpu_device, full_state, tie, agg, norm):
+    from tf_gnn_samples_amd.gnns import sparse_rgdcn_layer
+    rng, adj, deg = _graph(31)
+    V, L, C, K = 150, 3, 4, 8
+    D = C * K
+    w = {}
+    for l in range(L):
+        for c in range(1 if tie else C):
+            w["Edge_%i_Channel_%i_Weight_Computation/kernel" % (l, c)] = \
+                (rng.standard_normal((D if full_state else K, K * K)) * 0.3).astype(np.float32)
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    ref = G.sparse_rgdcn_layer(h, adj, deg, C, K, 2, full_state, tie, "tanh", agg, norm, weights=w)
+    out = sparse_rgdcn_layer(_dev(h, gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), C, K, 2, full_state, tie,
+                             "tanh", agg, norm, weights=_dev(w, gpu_device))
+    assert _close(out, ref)
+    adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
+    adj_c, deg_c = [torch.as_tensor(a) for a in adj], torch.as_tensor(deg)
+    _grad_check(lambda x, ww: sparse_rgdcn_layer(x, adj_d, deg_d, C, K, 1, full_state, tie, "tanh", agg, norm, weights=ww),
+                lambda x, ww: R.sparse_rgdcn_layer(x, adj_c, deg_c, C, K, 1, full_state, tie, "tanh", agg, norm, weights=ww),
+                h, w, gpu_device, tol=2e-5)
+
+
+def test_rgdcn_max_is_rejected_and_model_trains(gpu_device):
+    from tf_gnn_samples_amd.gnns import sparse_rgdcn_layer
+    from tf_gnn_samples_amd.models import RGDCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    rng, adj, deg = _graph(32, V=20, E=(40, 10, 0))
+    with pytest.raises(NotImplementedError):
+        sparse_rgdcn_layer(torch.zeros((20, 16), device=gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), 2, 8,
+                           message_aggregation_function="max", weights={})
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(2, 1, seed=5, mean_nodes=150, std_nodes=20, min_nodes=80, max_nodes=250, fwd_edges_per_node=5.0)
+    p = RGDCN_Model.default_params()
+    p.update(hidden_size=64, num_channels=4, graph_num_layers=2, learning_rate=0.01)
+    model = RGDCN_Model(p, task, device=str(gpu_device))
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 6))
+    batch = DeviceBatch(mb, gpu_device)
+    losses = [float(model.train_step(batch)['loss'].detach()) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

@@ -1,16 +1,17 @@
-"""Model adapters (models/__init__.py of the reference; RGDCN is a "next" row)."""
+"""Model adapters (models/__init__.py of the reference)."""
 from .sparse_graph_model import Sparse_Graph_Model
 from .ggnn_model import GGNN_Model
 from .gnn_edge_mlp_model import GNN_Edge_MLP_Model
 from .gnn_film_model import GNN_FiLM_Model
 from .rgat_model import RGAT_Model
 from .rgcn_model import RGCN_Model
+from .rgdcn_model import RGDCN_Model
 from .rgin_model import RGIN_Model
 
 MODEL_CLASSES = {
     # utils/model_utils.py:32-55 (name_to_model_class), lower-cased names
     "ggnn": GGNN_Model, "gnn_edge_mlp": GNN_Edge_MLP_Model, "gnn-edge-mlp": GNN_Edge_MLP_Model,
-    "gnn_film": GNN_FiLM_Model, "gnn-film": GNN_FiLM_Model, "rgat": RGAT_Model, "rgcn": RGCN_Model, "rgin": RGIN_Model,
+    "gnn_film": GNN_FiLM_Model, "gnn-film": GNN_FiLM_Model, "rgat": RGAT_Model, "rgcn": RGCN_Model, "rgdcn": RGDCN_Model, "rgin": RGIN_Model,
 }
 
 

@@ -41,6 +41,12 @@ def _init_tensor(shape, init: str, generator: torch.Generator) -> torch.Tensor:
         if rows < cols:
             q = q.t()
         return q[:rows, :cols].contiguous()
+    if init.startswith("trunc_normal:"):
+        # tf.initializers.truncated_normal(stddev=s): N(0, s) re-drawn beyond 2 s
+        std = float(init.split(":", 1)[1])
+        t = torch.empty(shape)
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=generator)
+        return t
     raise ValueError("unknown initializer %r" % init)
 
 
