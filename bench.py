@@ -96,12 +96,13 @@ def time_segment_kernel(batch, hidden, iters):
 
 def pmc_traffic_bytes():
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_b_seg_reduce_pmc.csv; collected by scripts/gpu_profile.sh, separate --pmc runs):
+    (latest profiles/*_seg_reduce_pmc.csv; collected by scripts/gpu_profile.sh, separate --pmc runs):
     2 * FETCH_SIZE * 1024 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md section HBM)
     + WRITE_SIZE * 1024.  None if the summary is not there."""
-    f = ROOT / "profiles" / "r01_b_seg_reduce_pmc.csv"
-    if not f.exists():
+    files = sorted((ROOT / "profiles").glob("*_seg_reduce_pmc.csv"))
+    if not files:
         return None
+    f = files[-1]
     vals = {}
     for line in f.read_text().splitlines()[1:]:
         parts = line.split(",")
@@ -304,7 +305,7 @@ def main():
         "roofline": {
             "kernel": "seg_reduce_wave_kernel<1,false,true> (gather + 1/deg scale + segment-sum + ReLU, one RGCN layer fwd)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic_bytes(), "traffic_source": "profiles/r01_b_seg_reduce_pmc.csv (rocprofv3 --pmc FETCH_SIZE / "
+            "traffic": pmc_traffic_bytes(), "traffic_source": "latest profiles/*_seg_reduce_pmc.csv (rocprofv3 --pmc FETCH_SIZE / "
             "WRITE_SIZE, separate passes; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)",
             "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
             "messages_per_launch": M, "edge_layers_per_sec": M / (k_ms * 1e-3),
