@@ -429,6 +429,28 @@ int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n,
 int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* gscale,
                           float* glogits, void* stream);
 
+/* ========================================================================== *
+ * 8. GRU cell elementwise halves (node-side; gnns/ggnn.py:92 via utils/utils.py:15-16)
+ * ========================================================================== */
+
+/*
+ * Keras GRUCell, TF 1.13 [TF-internal]: reset_after=False, recurrent_activation=hard_sigmoid, gate order z, r, h.
+ * With xk = x @ kernel + bias [V, 3u], rec = h @ recurrent_kernel[:, :2u] [V, 2u] (caller GEMMs):
+ *   gates_fwd : z = hs(xk[:, :u] + rec[:, :u]), r = hs(xk[:, u:2u] + rec[:, u:]), rh = r * h
+ *   out_fwd   : hh = act(xk[:, 2u:] + q) with q = rh @ recurrent_kernel[:, 2u:] (caller GEMM); out = z*h + (1-z)*hh
+ *   out_bwd   : gxk[:, 2u:] = gq = gout*(1-z)*act'(hh); gz = gout*(h-hh); gh = gout*z
+ *   gates_bwd : gxk[:, :u] = gz*hs'(z); gxk[:, u:2u] = (grh*h)*hs'(r); gh += grh*r       (grh = gq @ U_h^T, caller)
+ * act in {LINEAR, TANH, RELU, LEAKY_RELU, ELU, SELU} (derivative from the output); all tensors contiguous.
+ */
+int relgnn_gru_gates_fwd(const float* xk, const float* rec, const float* h, int64_t num_nodes, int32_t units,
+                         float* z, float* r, float* rh, void* stream);
+int relgnn_gru_out_fwd(const float* xk, const float* q, const float* z, const float* h, int64_t num_nodes,
+                       int32_t units, int32_t act, float* hh, float* out, void* stream);
+int relgnn_gru_out_bwd(const float* gout, const float* z, const float* h, const float* hh, int64_t num_nodes,
+                       int32_t units, int32_t act, float* gxk, float* gq, float* gz, float* gh, void* stream);
+int relgnn_gru_gates_bwd(const float* grh, const float* gz, const float* z, const float* r, const float* h,
+                         int64_t num_nodes, int32_t units, float* gxk, float* gh, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,11 +83,57 @@ def layer_norm(x, gamma, beta, eps: float = 1e-12):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
 
 
+class _FusedGRU(torch.autograd.Function):
+    """Keras GRUCell given xk = x@K+b and rec = h@U[:, :2u]: two fused elementwise kernels around the inner GEMM
+    (r*h) @ U_h forward, two backward (csrc/gru.hip) instead of ~40 elementwise launches."""
+
+    @staticmethod
+    def forward(ctx, xk, rec, h, u_h, act: int):
+        from . import _lib
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        xk, rec, h, u_h = xk.contiguous(), rec.contiguous(), h.contiguous(), u_h.contiguous()
+        V, u = h.shape
+        z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        _lib.check(lib.relgnn_gru_gates_fwd(_lib.ptr(xk), _lib.ptr(rec), _lib.ptr(h), V, u, _lib.ptr(z), _lib.ptr(r),
+                                            _lib.ptr(rh), st), "relgnn_gru_gates_fwd")
+        q = rh @ u_h
+        hh, out = torch.empty_like(h), torch.empty_like(h)
+        _lib.check(lib.relgnn_gru_out_fwd(_lib.ptr(xk), _lib.ptr(q), _lib.ptr(z), _lib.ptr(h), V, u, act, _lib.ptr(hh),
+                                          _lib.ptr(out), st), "relgnn_gru_out_fwd")
+        ctx.act = act
+        ctx.save_for_backward(z, r, rh, h, hh, u_h)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import _lib
+        from .dense import matmul_tn_splitk
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        z, r, rh, h, hh, u_h = ctx.saved_tensors
+        V, u = h.shape
+        gout = gout.contiguous()
+        gxk = torch.empty((V, 3 * u), dtype=torch.float32, device=h.device)
+        gq, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        _lib.check(lib.relgnn_gru_out_bwd(_lib.ptr(gout), _lib.ptr(z), _lib.ptr(h), _lib.ptr(hh), V, u, ctx.act,
+                                          _lib.ptr(gxk), _lib.ptr(gq), _lib.ptr(gz), _lib.ptr(gh), st), "relgnn_gru_out_bwd")
+        grh = gq @ u_h.t()
+        gu_h = matmul_tn_splitk(rh, gq) if ctx.needs_input_grad[3] else None
+        _lib.check(lib.relgnn_gru_gates_bwd(_lib.ptr(grh), _lib.ptr(gz), _lib.ptr(z), _lib.ptr(r), _lib.ptr(h), V, u,
+                                            _lib.ptr(gxk), _lib.ptr(gh), st), "relgnn_gru_gates_bwd")
+        return gxk, gxk[:, :2 * u], gh, gu_h, None
+
+
+_GRU_FUSABLE = {None: 0, "linear": 0, "tanh": 1, "relu": 2, "leaky_relu": 3, "elu": 4, "selu": 5}
+
+
 class _GatedUnit:
     """Callable cell(inputs, [state]) -> (output, [new_state]) like a Keras RNN cell."""
 
-    def __init__(self, units: int, kind: str, activation_fn, weights: Mapping[str, torch.Tensor]):
+    def __init__(self, units: int, kind: str, activation_fn, weights: Mapping[str, torch.Tensor], activation_name=None):
         self.units, self.kind, self.activation_fn, self.w = units, kind, activation_fn, weights
+        self.activation_name = None if activation_name is None else activation_name.lower()
 
     def __call__(self, inputs, states):
         h = states[0]
@@ -101,6 +147,9 @@ class _GatedUnit:
         # GRU, reset_after=False, gate order z, r, h (Keras GRUCell, TF 1.13)
         xk = dense(inputs, K, b)                             # [V, 3u]
         rec = dense(h, U[:, :2 * u])                         # [V, 2u]
+        if h.is_cuda and self.activation_name in _GRU_FUSABLE:
+            out = _FusedGRU.apply(xk, rec, h, U[:, 2 * u:], _GRU_FUSABLE[self.activation_name])
+            return out, [out]
         z = hard_sigmoid(xk[:, :u] + rec[:, :u])
         r = hard_sigmoid(xk[:, u:2 * u] + rec[:, u:])
         hh = apply_activation(act, xk[:, 2 * u:] + dense(r * h, U[:, 2 * u:]))
@@ -136,9 +185,9 @@ def get_gated_unit(units: int, gated_unit: str, activation_function: str, weight
     activation_fn = get_activation(activation_function)
     gated_unit_name = gated_unit.lower()
     if gated_unit_name == 'rnn':
-        return _GatedUnit(units, 'rnn', activation_fn, weights)
+        return _GatedUnit(units, 'rnn', activation_fn, weights, activation_function)
     if gated_unit_name == 'gru':
-        return _GatedUnit(units, 'gru', activation_fn, weights)
+        return _GatedUnit(units, 'gru', activation_fn, weights, activation_function)
     if gated_unit_name == 'lstm':
         # The reference passes a single state to LSTMCell (gnns/ggnn.py:92), which fails inside
         # Keras (LSTM needs [h, c]); there is no behaviour to reproduce.
