@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prime", type=int, default=20, help="untimed one-time initialisation steps before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="skip PyTorch TunableOp selection of the library GEMMs")
     ap.add_argument("--cpu-sample-graphs", type=int, default=1)
     ap.add_argument("--kernel-iters", type=int, default=50)
     return ap.parse_args()
@@ -216,8 +217,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    from tf_gnn_samples_amd.dense import enable_gemm_autotuning
     from tf_gnn_samples_amd.graph import clear_graph_cache
     from tf_gnn_samples_amd.models import RGCN_Model
+    gemm_tuned = (not args.no_gemm_tuning) and enable_gemm_autotuning()
     task, mb, batch, gen_params, local_graphs = build_local_batch(rank, world, device)
     params = RGCN_Model.default_params()
     params.update(hidden_size=256, graph_num_layers=3, graph_num_timesteps_per_layer=1,
@@ -238,6 +241,11 @@ def main():
     # code-object loading per GEMM shape and for the caching allocator reaching its steady state
     for _ in range(args.prime):
         one_step()
+    if gemm_tuned:   # every GEMM shape of the step (forward-only path included) has been tuned: freeze the choices
+        with torch.no_grad():
+            clear_graph_cache(); model.forward_batch(batch, training=False)
+        torch.cuda.synchronize()
+        enable_gemm_autotuning(tune=False)
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
@@ -299,6 +307,7 @@ def main():
             "edges_per_step_all_ranks": int(total_edges), "nodes_per_step_all_ranks": int(total_nodes),
             "graphs_per_rank": len(local_graphs), "generator": gen_params, "parallelism": "dp%d-by-graph" % world,
         },
+        "gemm_autotuned": bool(gemm_tuned),
         "forward_only_ms": fwd_ms,
         "forward_only_edges_per_sec_rank0": mb.num_edges / (fwd_ms * 1e-3),
         "final_loss": loss,
