@@ -214,6 +214,20 @@ int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int6
                           int64_t ldo, void* stream);
 
 /*
+ * Per-MESSAGE activation before the reduction (gnns/gnn_edge_mlp.py:104-116, rgin.py:127-133: scale, activation,
+ * segment reduce on the materialised message tensor) without an elementwise pass over [M, D]:
+ *   relgnn_seg_reduce_msgact_fwd : out[s,:] = finalize_mode( REDUCE_p msg_act( w[p] * X[col[p],:] ) )
+ *   relgnn_msg_act_bwd           : gX[m,:] = w[m] * msg_act'(w[m]*X[m,:]) * gagg[tgt[m],:]   (X [M, D] contiguous,
+ *                                  w / tgt in X's row order, gagg [V, D] = gradient of the un-finalised aggregate)
+ */
+int relgnn_seg_reduce_msgact_fwd(int32_t mode, int32_t msg_act, const float* X, int64_t num_rows_x, int64_t ldx,
+                                 int32_t D, const int32_t* rowptr, int64_t num_segments,
+                                 int32_t seg_stride, const int32_t* col, const float* w, float* out,
+                                 int64_t ldo, void* stream);
+int relgnn_msg_act_bwd(int32_t act, const float* X, int32_t D, const float* w, const int32_t* tgt,
+                       const float* gagg, int64_t num_messages, float* gX, void* stream);
+
+/*
  * unsorted_segment_max gradient w.r.t. the gathered table, TF semantics
  * (math_grad.py _UnsortedSegmentMinOrMaxGrad [TF-internal]): the gradient of out[s,d] is
  * split EQUALLY among all messages p of segment s with w[p]*X[col[p],d] == out[s,d].

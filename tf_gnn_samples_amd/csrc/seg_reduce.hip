@@ -46,11 +46,16 @@ __device__ __forceinline__ float act_apply(int act, float x) {
   }
 }
 
-template <bool IS_MAX>
-__device__ __forceinline__ void combine(float4& acc, float w, const float4& v) {
+template <bool IS_MAX, bool MSGACT = false>
+__device__ __forceinline__ void combine(float4& acc, float w, const float4& v, int msg_act = RELGNN_ACT_LINEAR) {
   // product and add are rounded separately (file is built with -ffp-contract=off):
   // messages = scale * gathered_row; acc = acc + messages, as the reference's op chain.
   float4 m = make_float4(w * v.x, w * v.y, w * v.z, w * v.w);
+  if constexpr (MSGACT) {  // activation applied to every message BEFORE the reduction (separate instantiation:
+                           // the default kernel must not pay for the extra argument / branch — measured +42 %)
+    m.x = act_apply(msg_act, m.x); m.y = act_apply(msg_act, m.y);
+    m.z = act_apply(msg_act, m.z); m.w = act_apply(msg_act, m.w);
+  }
   if constexpr (IS_MAX) {
     acc.x = fmaxf(acc.x, m.x); acc.y = fmaxf(acc.y, m.y);
     acc.z = fmaxf(acc.z, m.z); acc.w = fmaxf(acc.w, m.w);
@@ -77,12 +82,12 @@ __device__ __forceinline__ float4 finalize(int mode, int act, float4 a, int n) {
 // ---------------------------------------------------------------------------------------
 // One wave per output row.  NCH = float4 chunks per lane (row width up to NCH*256 floats).
 // ---------------------------------------------------------------------------------------
-template <int NCH, bool IS_MAX, bool HAS_W, int UNROLL = kUnroll, bool NT = false, bool XCD = true>
+template <int NCH, bool IS_MAX, bool HAS_W, int UNROLL = kUnroll, bool NT = false, bool XCD = true, bool MSGACT = false>
 __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
     const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
     const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4,
-    int64_t n_logical_blocks, int32_t col_block0) {
+    int64_t n_logical_blocks, int32_t col_block0, int32_t msg_act) {
   const int64_t lb = XCD ? xcd_logical_block(n_logical_blocks)
                          : ((int64_t)blockIdx.x < n_logical_blocks ? (int64_t)blockIdx.x : -1);
   if (lb < 0) return;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) combine<IS_MAX>(acc[c], ww[u], v[u][c]);
+        for (int c = 0; c < NCH; ++c) combine<IS_MAX, MSGACT>(acc[c], ww[u], v[u][c], msg_act);
     }
     for (; k < n; ++k) {
       const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k);
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         float4 v = row[cc[c]];
-        combine<IS_MAX>(acc[c], wk, v);
+        combine<IS_MAX, MSGACT>(acc[c], wk, v, msg_act);
       }
     }
   }
@@ -163,12 +168,12 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
 // ---------------------------------------------------------------------------------------
 // 64/GROUP segments per wave (rows of at most GROUP float4 = GROUP*4 floats).
 // ---------------------------------------------------------------------------------------
-template <int GROUP, bool IS_MAX, bool HAS_W>
+template <int GROUP, bool IS_MAX, bool HAS_W, bool MSGACT = false>
 __global__ __launch_bounds__(256) void seg_reduce_group_kernel(
     const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
     const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4,
-    int64_t n_logical_blocks) {
+    int64_t n_logical_blocks, int32_t msg_act) {
   constexpr int SEGS_PER_WAVE = 64 / GROUP;
   constexpr int U = 4;
   const int64_t lb = xcd_logical_block(n_logical_blocks);
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void seg_reduce_group_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float4 t = acc;
-        combine<IS_MAX>(t, ww[u], v[u]);
+        combine<IS_MAX, MSGACT>(t, ww[u], v[u], msg_act);
         if (p0 + k + u < len) acc = t;
       }
     }
@@ -227,7 +232,7 @@ template <bool IS_MAX>
 __global__ __launch_bounds__(256) void seg_reduce_scalar_kernel(
     const float* __restrict__ X, int64_t ldx, int32_t D, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
-    const float* __restrict__ w, int32_t mode, int32_t act, float* __restrict__ out, int64_t ldo) {
+    const float* __restrict__ w, int32_t mode, int32_t act, float* __restrict__ out, int64_t ldo, int32_t msg_act) {
   const int lane = threadIdx.x & 63;
   const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= num_segments) return;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void seg_reduce_scalar_kernel(
   for (int d = lane; d < D; d += 64) {
     float acc = IS_MAX ? -FLT_MAX : 0.f;
     for (int p = beg; p < end; ++p) {
-      float m = (w ? w[p] : 1.f) * X[(int64_t)col[p] * ldx + d];
+      float m = act_apply(msg_act, (w ? w[p] : 1.f) * X[(int64_t)col[p] * ldx + d]);
       acc = IS_MAX ? fmaxf(acc, m) : acc + m;
     }
     float nrm = (float)max(end - beg, 1);
@@ -321,10 +326,39 @@ inline int seg_variant() {
   return v;
 }
 
+// gX[m, :] = w[m] * act'(w[m] * X[m, :]) * gagg[tgt[m], :]   (gradient of  sum_m act(w_m X_m)  w.r.t. the
+// materialised message tensor X; gagg already carries the mean / sqrt_n factor of the target)
+__global__ __launch_bounds__(256) void msg_act_bwd_kernel(int32_t act, const float4* __restrict__ X, int32_t D4,
+                                                          const float* __restrict__ w, const int32_t* __restrict__ tgt,
+                                                          const float4* __restrict__ gagg, int64_t M,
+                                                          float4* __restrict__ gX) {
+  const int64_t total = M * D4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D4;
+    const int c = (int)(i - m * D4);
+    const float wm = w ? w[m] : 1.f;
+    const float4 x = X[i];
+    const float4 g = gagg[(int64_t)tgt[m] * D4 + c];
+    float4 r;
+    switch (act) {
+#define RELGNN_CASE(A)                                                                                             \
+  case A:                                                                                                         \
+    r = make_float4(wm * act_grad<A>(wm * x.x) * g.x, wm * act_grad<A>(wm * x.y) * g.y, wm * act_grad<A>(wm * x.z) * g.z, \
+                    wm * act_grad<A>(wm * x.w) * g.w);                                                             \
+    break;
+      RELGNN_CASE(RELGNN_ACT_TANH) RELGNN_CASE(RELGNN_ACT_RELU) RELGNN_CASE(RELGNN_ACT_LEAKY_RELU)
+      RELGNN_CASE(RELGNN_ACT_ELU) RELGNN_CASE(RELGNN_ACT_SELU) RELGNN_CASE(RELGNN_ACT_GELU)
+#undef RELGNN_CASE
+      default: r = make_float4(wm * g.x, wm * g.y, wm * g.z, wm * g.w); break;
+    }
+    gX[i] = r;
+  }
+}
+
 template <int NCH, bool IS_MAX>
 int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
                 int64_t S, int32_t stride, const int32_t* col, const float* w, int32_t mode,
-                int32_t act, float* out, int64_t ldo, hipStream_t st) {
+                int32_t act, float* out, int64_t ldo, hipStream_t st, int32_t msg_act) {
   const int D4 = D / 4;
   const int64_t nlb = (S + 3) / 4;
   const int col_blocks = (D4 + 64 * NCH - 1) / (64 * NCH);
@@ -336,7 +370,7 @@ int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_
   case ID:                                                                                             \
     seg_reduce_wave_kernel<1, false, true, U, N, X_><<<grid, 256, 0, st>>>(                            \
         reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,         \
-        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0);                                              \
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);                                     \
     return launch_status();
       switch (var) {
         RELGNN_VARIANT_CASE(1, 16, false, true)
@@ -352,64 +386,105 @@ int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_
 #undef RELGNN_VARIANT_CASE
     }
   }
+  if (msg_act != RELGNN_ACT_LINEAR) {
+    if (has_w)
+      seg_reduce_wave_kernel<NCH, IS_MAX, true, kUnroll, false, true, true><<<grid, 256, 0, st>>>(
+          reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
+          reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+    else
+      seg_reduce_wave_kernel<NCH, IS_MAX, false, kUnroll, false, true, true><<<grid, 256, 0, st>>>(
+          reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
+          reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+    return launch_status();
+  }
   if (has_w)
     seg_reduce_wave_kernel<NCH, IS_MAX, true><<<grid, 256, 0, st>>>(
         reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0);
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
   else
     seg_reduce_wave_kernel<NCH, IS_MAX, false><<<grid, 256, 0, st>>>(
         reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0);
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
   return launch_status();
 }
 
 template <int GROUP, bool IS_MAX>
 int launch_group(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
                  int64_t S, int32_t stride, const int32_t* col, const float* w, int32_t mode,
-                 int32_t act, float* out, int64_t ldo, hipStream_t st) {
+                 int32_t act, float* out, int64_t ldo, hipStream_t st, int32_t msg_act) {
   constexpr int SEGS_PER_BLOCK = 4 * (64 / GROUP);
   const int64_t nlb = (S + SEGS_PER_BLOCK - 1) / SEGS_PER_BLOCK;
   dim3 grid((unsigned)(((nlb + 7) / 8) * 8));
+  if (msg_act != RELGNN_ACT_LINEAR) {
+    if (has_w)
+      seg_reduce_group_kernel<GROUP, IS_MAX, true, true><<<grid, 256, 0, st>>>(
+          reinterpret_cast<const float4*>(X), ldx / 4, D / 4, rowptr, S, stride, col, w, mode, act,
+          reinterpret_cast<float4*>(out), ldo / 4, nlb, msg_act);
+    else
+      seg_reduce_group_kernel<GROUP, IS_MAX, false, true><<<grid, 256, 0, st>>>(
+          reinterpret_cast<const float4*>(X), ldx / 4, D / 4, rowptr, S, stride, col, w, mode, act,
+          reinterpret_cast<float4*>(out), ldo / 4, nlb, msg_act);
+    return launch_status();
+  }
   if (has_w)
     seg_reduce_group_kernel<GROUP, IS_MAX, true><<<grid, 256, 0, st>>>(
         reinterpret_cast<const float4*>(X), ldx / 4, D / 4, rowptr, S, stride, col, w, mode, act,
-        reinterpret_cast<float4*>(out), ldo / 4, nlb);
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, msg_act);
   else
     seg_reduce_group_kernel<GROUP, IS_MAX, false><<<grid, 256, 0, st>>>(
         reinterpret_cast<const float4*>(X), ldx / 4, D / 4, rowptr, S, stride, col, w, mode, act,
-        reinterpret_cast<float4*>(out), ldo / 4, nlb);
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, msg_act);
   return launch_status();
 }
 
 template <bool IS_MAX>
 int dispatch_fwd(const float* X, int64_t num_rows_x, int64_t ldx, int32_t D, const int32_t* rowptr, int64_t S,
                  int32_t stride, const int32_t* col, const float* w, int32_t mode, int32_t act,
-                 float* out, int64_t ldo, hipStream_t st) {
+                 float* out, int64_t ldo, hipStream_t st, int32_t msg_act) {
   const bool vec_ok = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(X) &&
                       aligned16(out) && (num_rows_x * (ldx / 4) < ((int64_t)1 << 32));
   if (!vec_ok) {
     seg_reduce_scalar_kernel<IS_MAX><<<(unsigned)((S + 3) / 4), 256, 0, st>>>(
-        X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo);
+        X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, msg_act);
     return launch_status();
   }
   const bool has_w = w != nullptr;
   const int D4 = D / 4;
-  if (D4 <= 8) return launch_group<8, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
-  if (D4 <= 16) return launch_group<16, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
-  if (D4 <= 32) return launch_group<32, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
-  if (D4 <= 64) return launch_wave<1, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
-  if (D4 <= 128) return launch_wave<2, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
-  return launch_wave<4, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st);
+  if (D4 <= 8) return launch_group<8, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act);
+  if (D4 <= 16) return launch_group<16, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act);
+  if (D4 <= 32) return launch_group<32, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act);
+  if (D4 <= 64) return launch_wave<1, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act);
+  if (D4 <= 128) return launch_wave<2, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act);
+  return launch_wave<4, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act);
 }
 
 }  // namespace
 
 extern "C" {
 
+static int seg_reduce_any(int32_t mode, int32_t msg_act, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                          const int32_t* rowptr, int64_t num_segments, int32_t seg_stride, const int32_t* col,
+                          const float* w, int32_t act, float* out, int64_t ldo, void* stream);
+
 int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
                           const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
                           const int32_t* col, const float* w, int32_t act, float* out, int64_t ldo,
                           void* stream) {
+  return seg_reduce_any(mode, RELGNN_ACT_LINEAR, X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, act,
+                        out, ldo, stream);
+}
+
+int relgnn_seg_reduce_msgact_fwd(int32_t mode, int32_t msg_act, const float* X, int64_t num_rows_x, int64_t ldx,
+                                 int32_t D, const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                                 const int32_t* col, const float* w, float* out, int64_t ldo, void* stream) {
+  if (msg_act < RELGNN_ACT_LINEAR || msg_act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  return seg_reduce_any(mode, msg_act, X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w,
+                        RELGNN_ACT_LINEAR, out, ldo, stream);
+}
+
+static int seg_reduce_any(int32_t mode, int32_t msg_act, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                          const int32_t* rowptr, int64_t num_segments, int32_t seg_stride, const int32_t* col,
+                          const float* w, int32_t act, float* out, int64_t ldo, void* stream) {
   if (mode < RELGNN_AGG_SUM || mode > RELGNN_AGG_MAX) return RELGNN_EINVAL;
   if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
   if (D < 0 || num_segments < 0 || seg_stride <= 0 || num_rows_x < 0 || ldx < D || ldo < D)
@@ -420,8 +495,19 @@ int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int6
   if (num_segments > (int64_t)INT32_MAX * 4) return RELGNN_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
   if (mode == RELGNN_AGG_MAX)
-    return dispatch_fwd<true>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st);
-  return dispatch_fwd<false>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st);
+    return dispatch_fwd<true>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st, msg_act);
+  return dispatch_fwd<false>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st, msg_act);
+}
+
+int relgnn_msg_act_bwd(int32_t act, const float* X, int32_t D, const float* w, const int32_t* tgt, const float* gagg,
+                       int64_t num_messages, float* gX, void* stream) {
+  if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU || D < 0 || num_messages < 0) return RELGNN_EINVAL;
+  if (num_messages == 0 || D == 0) return RELGNN_OK;
+  if (!X || !tgt || !gagg || !gX) return RELGNN_EINVAL;
+  if (D % 4 != 0 || !aligned16(X) || !aligned16(gagg) || !aligned16(gX)) return RELGNN_EUNSUPPORTED;
+  msg_act_bwd_kernel<<<flat_grid(num_messages * (D / 4), 256), 256, 0, as_stream(stream)>>>(
+      act, (const float4*)X, D / 4, w, tgt, (const float4*)gagg, num_messages, (float4*)gX);
+  return launch_status();
 }
 
 int relgnn_seg_max_count(const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,

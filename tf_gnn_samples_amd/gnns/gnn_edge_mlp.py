@@ -69,9 +69,7 @@ def sparse_gnn_edge_mlp_layer(node_embeddings: torch.Tensor,
         else:
             msgs = edge_mlp_messages(cur_node_states, graph, weights, "Edge_%i_MLP", num_edge_hidden_layers, "elu",
                                      use_target_state_as_input)                       # [M, state_dim], type-major
-            if w is not None:
-                msgs = graph.w_original_order(w).unsqueeze(1) * msgs
-            msgs = apply_activation(get_activation(activation_function), msgs)
-            aggregated = ops.seg_gather_reduce(msgs, graph.plan_messages(), message_aggregation_function, None)
+            # scale (:104-108) + activation (:112) are folded into the segment reduce (:113-116)
+            aggregated = ops.message_act_reduce(msgs, graph, w, message_aggregation_function, activation_function)
         cur_node_states = layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
     return cur_node_states

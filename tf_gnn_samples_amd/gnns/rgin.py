@@ -91,8 +91,7 @@ def sparse_rgin_layer(node_embeddings: torch.Tensor,
         else:
             msgs = edge_mlp_messages(cur_node_states, graph, weights, "Edge_%i_MLP", num_edge_MLP_hidden_layers,
                                      activation_function, True)
-            msgs = apply_activation(activation_fn, msgs)
-            aggregated = ops.seg_gather_reduce(msgs, graph.plan_messages(), message_aggregation_function, None)
+            aggregated = ops.message_act_reduce(msgs, graph, None, message_aggregation_function, activation_function)
 
         new_node_states = aggregated
         if aggregation_MLP is not None:

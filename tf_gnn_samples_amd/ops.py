@@ -435,3 +435,50 @@ def fused_aggregate_transform(H, W, graph, w, aggregation: str, activation: Opti
     if act not in _FUSABLE_ACTS:
         raise ValueError("activation %r cannot be fused" % activation)
     return _FusedAggregateTransform.apply(H, W, graph, w, mode, act)
+
+
+# ---- materialised messages: scale + activation fused into the segment reduce ------------------------------------
+class _MessageActReduce(torch.autograd.Function):
+    """out[v] = f_mode( sum_{m -> v} act( w_m * msgs[m] ) ) for a message tensor [M, D] in the reference's type-major
+    order (gnns/gnn_edge_mlp.py:104-116): no elementwise pass over [M, D] forward, one fused pass backward."""
+
+    @staticmethod
+    def forward(ctx, msgs, graph, w, mode: int, act: int):
+        lib = _lib.load_library()
+        msgs = msgs.contiguous()
+        M, D = msgs.shape
+        plan = graph.plan_messages()
+        out = torch.empty((graph.V, D), dtype=torch.float32, device=msgs.device)
+        _lib.check(lib.relgnn_seg_reduce_msgact_fwd(mode, act, _lib.ptr(msgs), M, D, D, _lib.ptr(plan.rowptr), graph.V,
+                                                    plan.stride, _lib.ptr(plan.col), _lib.ptr(w), _lib.ptr(out), D,
+                                                    _lib.current_stream()), "relgnn_seg_reduce_msgact_fwd")
+        ctx.graph, ctx.w, ctx.mode, ctx.act = graph, w, mode, act
+        ctx.save_for_backward(msgs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load_library()
+        graph, w, mode, act = ctx.graph, ctx.w, ctx.mode, ctx.act
+        (msgs,) = ctx.saved_tensors
+        M, D = msgs.shape
+        f = _mode_factor(graph, mode)
+        gagg = (gout * f.unsqueeze(1)).contiguous() if f is not None else gout.contiguous()
+        plan = graph.plan_messages()
+        w_orig = graph.w_original_order(w) if w is not None else None
+        gX = torch.empty_like(msgs)
+        _lib.check(lib.relgnn_msg_act_bwd(act, _lib.ptr(msgs), D, _lib.ptr(w_orig), _lib.ptr(plan.col_b), _lib.ptr(gagg), M,
+                                          _lib.ptr(gX), _lib.current_stream()), "relgnn_msg_act_bwd")
+        return gX, None, None, None, None
+
+
+def message_act_reduce(msgs, graph, w, aggregation: str, activation: Optional[str]):
+    """Sum-like aggregations only (max: apply the activation, then seg_gather_reduce over plan_messages())."""
+    mode = aggregation_mode_id(aggregation)
+    if mode == _lib.AGG_MAX or msgs.shape[1] % 4 != 0:
+        from .utils import apply_activation, get_activation
+        if w is not None:
+            msgs = graph.w_original_order(w).unsqueeze(1) * msgs
+        msgs = apply_activation(get_activation(activation), msgs)
+        return seg_gather_reduce(msgs, graph.plan_messages(), aggregation, None)
+    return _MessageActReduce.apply(msgs, graph, w, mode, activation_id(activation))
