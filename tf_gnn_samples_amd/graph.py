@@ -150,7 +150,11 @@ class RelGraph:
         if validate is True:
             self.check()
         elif validate == "deferred":
-            _PENDING_CHECKS.append(self)
+            # only the 4-byte flag is kept alive, not the graph (a training loop may build thousands of graphs
+            # between two fetches)
+            _PENDING_CHECKS.append((self._err_flag, self.V))
+            if len(_PENDING_CHECKS) > 4096:
+                check_pending_graph_errors()
 
     def check(self):
         """Host sync: raise if the device-side validation saw a node id outside [0, V)."""
@@ -310,14 +314,18 @@ _GRAPH_CACHE: "OrderedDict[tuple, RelGraph]" = OrderedDict()
 _GRAPH_CACHE_SIZE = 8
 
 
-_PENDING_CHECKS: List["RelGraph"] = []
+_PENDING_CHECKS: List[tuple] = []
 
 
 def check_pending_graph_errors():
     """Validate every RelGraph built with validate="deferred" since the last call (one host sync each)."""
     pending, _PENDING_CHECKS[:] = list(_PENDING_CHECKS), []
-    for g in pending:
-        g.check()
+    if not pending:
+        return
+    flags = torch.cat([f for f, _ in pending])
+    bad = torch.nonzero(flags).flatten().tolist()          # one host sync for all pending graphs
+    if bad:
+        raise ValueError("adjacency list holds a node id outside [0, %d)" % pending[bad[0]][1])
 
 
 def as_rel_graph(adjacency_lists, num_nodes: int, validate=True) -> RelGraph:
