@@ -465,6 +465,47 @@ int relgnn_gru_out_bwd(const float* gout, const float* z, const float* h, const 
 int relgnn_gru_gates_bwd(const float* grh, const float* gz, const float* z, const float* r, const float* h,
                          int64_t num_nodes, int32_t units, float* gxk, float* gh, void* stream);
 
+/* ========================================================================== *
+ * 9. Host-side disjoint-union batch builder (every pointer here is a HOST pointer)
+ * ========================================================================== */
+
+/*
+ * Replaces: the numpy batching loops of tasks/ppi_task.py:209-256 and
+ * tasks/qm9_task.py:212-261 (input contract tasks/sparse_graph_task.py:139-149).
+ *
+ * The dataset is flattened once by the caller into a STORE of G graphs:
+ *   h_node_off     [G+1] int64   node range of graph g in the flat per-node arrays
+ *   h_edge_off[l]  [G+1] int64   edge range of graph g in h_adj[l]
+ *   h_adj[l]       [E_l_total, 2] int32, {source, target}, node ids LOCAL to their graph
+ *   h_deg[l]       [N_total] float32  per-graph in-degree tables (type_to_node_to_num_incoming_edges)
+ *   h_payload[p]   [N_total, row_bytes_p] any per-node rows (features, labels, ...)
+ * A batch is the list h_graph_ids[0..n_graphs) taken in that order.
+ *
+ * relgnn_batch_count : how many ids from `first` on fit one batch under the reference's rule
+ *                      `node_offset + |V_g| < max_nodes` (strict, ppi_task.py:220).  0 = the first graph
+ *                      never fits (the reference would spin forever); -1 = bad argument.
+ * relgnn_batch_layout: fills h_layout[relgnn_batch_layout_len(L, n_payloads)] with
+ *                      {V, M, arena_bytes, off_deg, off_node_to_graph, off_payload[p]..., off_adj[l]..., E_l...};
+ *                      offsets are bytes into the arena, 256-byte aligned.
+ * relgnn_batch_pack  : writes the arena (pinned host memory for an async copy):
+ *                        payload p      [V, row_bytes_p]
+ *                        deg            [L, V] float32           (concatenated on axis 1, ppi_task.py:237)
+ *                        node_to_graph  [V] int32                (graph_nodes_list, qm9_task.py:238)
+ *                        adj l          [E_l, 2] int32 = local ids + node offset of the graph (ppi_task.py:228);
+ *                                       E_l = 0 gives the empty list of ppi_task.py:248-249
+ *                      with `num_threads` host threads (>= 1).  RELGNN_EUNSUPPORTED if V or M >= 2^31-1.
+ */
+int64_t relgnn_batch_layout_len(int32_t num_types, int32_t n_payloads);
+int64_t relgnn_batch_count(const int64_t* h_node_off, const int64_t* h_graph_ids, int64_t n_ids, int64_t first,
+                           int64_t max_nodes);
+int relgnn_batch_layout(int32_t num_types, int64_t n_graphs, const int64_t* h_graph_ids, const int64_t* h_node_off,
+                        const int64_t* const* h_edge_off, int32_t n_payloads, const int64_t* h_payload_row_bytes,
+                        int64_t* h_layout);
+int relgnn_batch_pack(int32_t num_types, int64_t n_graphs, const int64_t* h_graph_ids, const int64_t* h_node_off,
+                      const int64_t* const* h_edge_off, const int32_t* const* h_adj, const float* const* h_deg,
+                      int32_t n_payloads, const void* const* h_payload, const int64_t* h_payload_row_bytes,
+                      const int64_t* h_layout, void* h_arena, size_t arena_bytes, int32_t num_threads);
+
 #ifdef __cplusplus
 }
 #endif

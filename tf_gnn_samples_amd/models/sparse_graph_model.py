@@ -175,6 +175,7 @@ class Sparse_Graph_Model(ABC):
         self.run_id = run_id
         self.result_dir = result_dir
         self.device = torch.device(device if device is not None else "cuda")
+        self._native_batchers = {}
         self.training = False
         torch.manual_seed(params['random_seed'])
         np.random.seed(params['random_seed'])
@@ -320,15 +321,31 @@ class Sparse_Graph_Model(ABC):
         self.optimizer.clip_and_step(lr_scale)
         return metrics
 
+    def _batches(self, data, data_fold: DataFold):
+        """Batches of one epoch.  On the GPU the data fold is flattened once and batches come from the C++ builder
+        (tasks/batcher.py: packed in pinned memory on a background thread, one async upload each), the stand-in for
+        the reference's ThreadedIterator (:272); `native_batching: false` keeps the numpy iterator."""
+        native = self.params.get('native_batching', True) and torch.device(self.device).type == "cuda" \
+            and hasattr(self.task, "make_graph_store")
+        if not native:
+            return self.task.make_minibatch_iterator(data, data_fold, self.params['max_nodes_in_batch'])
+        from ..tasks.batcher import NativeBatcher
+        key = (id(data), len(data))
+        cached = self._native_batchers.get(key)
+        if cached is None or cached[0] is not data:
+            cached = (data, NativeBatcher(self.task.make_graph_store(data), self.device))
+            self._native_batchers[key] = cached
+        return self.task.make_native_minibatch_iterator(cached[1], data_fold, self.params['max_nodes_in_batch'])
+
     def _run_epoch(self, epoch_name: str, data: Iterable[Any], data_fold: DataFold, quiet: bool = False):
         """__run_epoch, :263-311: returns (avg loss, task metric results, graphs, graphs/s, nodes/s, edges/s)."""
-        batch_iterator = self.task.make_minibatch_iterator(data, data_fold, self.params['max_nodes_in_batch'])
+        batch_iterator = self._batches(data, data_fold)
         start_time = time.time()
         processed_graphs = processed_nodes = processed_edges = 0
         epoch_loss = 0.0
         task_metric_results = []
         for step, mb in enumerate(batch_iterator):
-            batch = DeviceBatch(mb, self.device)
+            batch = mb if isinstance(mb, DeviceBatch) else DeviceBatch(mb, self.device)
             if data_fold == DataFold.TRAIN:
                 m = self.train_step(batch)
             else:

@@ -181,6 +181,8 @@ class PPI_Task(Sparse_Graph_Task):
             f1 = micro_f1(per_node_logits.detach(), labels)
         return {'loss': total_loss / float(num_nodes_in_batch), 'total_loss': total_loss, 'f1_score': f1}
 
+    NODE_PAYLOADS = {"initial_node_features": ("node_features", np.float32), "target_labels": ("node_labels", np.float32)}
+
     # -------------------- Minibatching (tasks/ppi_task.py:197-256) --------------------
     def make_minibatch_iterator(self, data: List[GraphSample], data_fold: DataFold,
                                 max_nodes_per_batch: int, rng: Optional[np.random.RandomState] = None

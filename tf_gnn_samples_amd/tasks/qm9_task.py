@@ -164,6 +164,13 @@ class QM9_Task(Sparse_Graph_Task):
         metrics['total_loss'] = metrics['loss'] * float(num_graphs)
         return metrics
 
+    NODE_PAYLOADS = {"initial_node_features": ("node_features", np.float32)}
+    GRAPH_PAYLOADS = {"target_values": ("target_values", np.float32)}
+
+    def _finish_native_batch(self, batch):
+        batch.extra['target_values'] = batch.extra['target_values'].t()          # [tasks, G] (:254)
+        return batch
+
     # -------------------- Minibatching (tasks/qm9_task.py:200-261) --------------------
     def make_minibatch_iterator(self, data: List[QM9GraphSample], data_fold: DataFold, max_nodes_per_batch: int,
                                 rng: Optional[np.random.RandomState] = None) -> Iterator[MinibatchData]:

@@ -49,6 +49,19 @@ class DeviceBatch:
             if isinstance(v, np.ndarray):
                 self.extra[k] = put(v, torch.float32 if v.dtype.kind == 'f' else torch.int64)
 
+    @classmethod
+    def from_tensors(cls, num_graphs, num_nodes, num_edges, initial_node_features, adjacency_lists,
+                     type_to_num_incoming_edges, graph_nodes_list=None, extra=None) -> "DeviceBatch":
+        """A batch whose tensors already live on the device (tasks/batcher.py: views of one uploaded arena)."""
+        self = cls.__new__(cls)
+        self.num_graphs, self.num_nodes, self.num_edges = int(num_graphs), int(num_nodes), int(num_edges)
+        self.initial_node_features = initial_node_features
+        self.adjacency_lists = list(adjacency_lists)
+        self.type_to_num_incoming_edges = type_to_num_incoming_edges
+        self.graph_nodes_list = graph_nodes_list
+        self.extra = dict(extra or {})
+        return self
+
 
 class Sparse_Graph_Task:
     """Minimal task interface used by Sparse_Graph_Model (tasks/sparse_graph_task.py:23-254)."""
@@ -75,6 +88,31 @@ class Sparse_Graph_Task:
 
     def get_metadata(self) -> Dict[str, Any]:
         return {}
+
+    # ---- native batching (tasks/batcher.py); tasks override the payload tables / post-processing ----
+    NODE_PAYLOADS = {"initial_node_features": ("node_features", np.float32)}
+    GRAPH_PAYLOADS: Dict[str, tuple] = {}
+
+    def make_graph_store(self, data):
+        """Flatten one data fold once for the C++ batch builder (include/relgnn.h section 9)."""
+        from .batcher import GraphStore
+        return GraphStore(data, self.num_edge_types, self.NODE_PAYLOADS, self.GRAPH_PAYLOADS)
+
+    def _finish_native_batch(self, batch: "DeviceBatch") -> "DeviceBatch":
+        return batch
+
+    def make_native_minibatch_iterator(self, batcher, data_fold: DataFold, max_nodes_per_batch: int,
+                                       rng: Optional[np.random.RandomState] = None):
+        """Same batches as make_minibatch_iterator, assembled by relgnn_batch_pack and already on the device.
+        TRAIN shuffles the graph order (the reference shuffles the data list in place, tasks/ppi_task.py:204-206)."""
+        ids = np.arange(batcher.store.num_graphs)
+        if data_fold == DataFold.TRAIN:
+            (rng or np.random).shuffle(ids)
+            batcher.constants['out_layer_dropout_keep_prob'] = self.params.get('out_layer_dropout_keep_prob', 1.0)
+        else:
+            batcher.constants['out_layer_dropout_keep_prob'] = 1.0
+        for batch in batcher.iterate(ids, max_nodes_per_batch):
+            yield self._finish_native_batch(batch)
 
     def restore_from_metadata(self, metadata: Dict[str, Any]) -> None:
         pass
