@@ -287,8 +287,15 @@ int relgnn_rgcn_fused_fwd(int32_t mode, int32_t act, const float* H, int64_t ldh
 int relgnn_film_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const float* film,
                     int64_t ldf, int32_t D, const int32_t* rowptr, int32_t num_nodes,
                     int32_t num_edge_types, const int32_t* col, const float* w, float* out,
-                    int64_t ldo, void* stream);
-/* backward, pass A (by-target plan): with g_p = gagg[v,:] * act'(pre_p),
+                    int64_t ldo, const int32_t* bucket_row, void* stream);
+/* COMPACT ROW TABLES (bucket_row / bucket_row_b, nullable): graphs with many edge types leave most (node,type)
+ * buckets empty (VarMisuse-shaped: 23 types, 2/3 empty), so the caller may keep T / film / gfilm / gT rows only for
+ * non-empty buckets, in any numbering.  bucket_row[v*L+l] is then the film (gfilm) row of bucket (v,l) — read only
+ * for non-empty buckets, and only those gfilm rows are written; `col` already holds arbitrary T row ids;
+ * bucket_row_b[r] is the T / gT row of by-source bucket r (rowptr_b then spans all num_nodes*L buckets).
+ * NULL = the dense numbering row = node*L + type.
+ *
+ * backward, pass A (by-target plan): with g_p = gagg[v,:] * act'(pre_p),
  *   gfilm[v*L+l, 0:D]  = sum_p g_p * (w[p] T[col[p]])      (d gamma)
  *   gfilm[v*L+l, D:2D] = sum_p g_p                          (d beta)
  * every (v,l) row is written.  gagg = d loss / d (un-finalised aggregate), i.e. the caller has
@@ -296,14 +303,16 @@ int relgnn_film_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, cons
 int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
                          int32_t D, const int32_t* rowptr, int32_t num_nodes,
                          int32_t num_edge_types, const int32_t* col, const float* w,
-                         const float* gagg, int64_t ldg, float* gfilm, int64_t ldgf, void* stream);
+                         const float* gagg, int64_t ldg, float* gfilm, int64_t ldgf,
+                         const int32_t* bucket_row, void* stream);
 /* backward, pass B (by-(source,type) plan; row r of T owns its outgoing messages q):
  *   gT[r,:] = sum_q w_b[q] * gamma[frow_b[q],:] * g_q,
  *   g_q = gagg[tgt_b[q],:] * act'(gamma[frow_b[q]] * (w_b[q] * T[r,:]) + beta[frow_b[q]]) */
 int relgnn_film_bwd_msg(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
                         int32_t D, const int32_t* rowptr_b, int64_t num_rows_t,
                         const int32_t* tgt_b, const int32_t* frow_b, const float* w_b,
-                        const float* gagg, int64_t ldg, float* gT, int64_t ldgt, void* stream);
+                        const float* gagg, int64_t ldg, float* gT, int64_t ldgt,
+                        const int32_t* bucket_row_b, void* stream);
 
 /* ========================================================================== *
  * 4. RGAT segmented-softmax attention  (gnns/rgat.py:86-138)

@@ -48,9 +48,9 @@ _SIGNATURES = {
     "relgnn_act_bwd_from_output": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_pack_type_weights": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _ptr, _ptr]),
     "relgnn_rgcn_fused_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
-    "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
-    "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
-    "relgnn_film_bwd_msg": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_film_bwd_msg": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_rgat_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_rgat_bwd_logits": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_rgat_bwd_msg": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),

@@ -93,7 +93,8 @@ template <int G, int NCH, int KIND, bool IS_MAX>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
-    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4, int64_t nlb) {
+    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4, int64_t nlb,
+    const int32_t* __restrict__ brow) {
   const GroupGeom gg = geom<G>(V, nlb);
   if (!gg.valid) return;
   const int64_t v = gg.node;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(
     const int e = rowptr[v * L + l + 1];
     if (b < e) {
       float4 ra[NCH], rb[NCH];
-      const float4* arow = A + (v * L + l) * lda4;
+      const float4* arow = A + (brow ? (int64_t)brow[v * L + l] : v * L + l) * lda4;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         ra[c] = arow[cc[c]];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
     const float* __restrict__ w, const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gA,
-    int64_t ldga4, int32_t act, int64_t nlb) {
+    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow) {
   const GroupGeom gg = geom<G>(V, nlb);
   if (!gg.valid) return;
   const int64_t v = gg.node;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
     for (int c = 0; c < NCH; ++c) s1[c] = s2[c] = f4(0.f);
     if (b < e) {
       float4 ra[NCH], rb[NCH];
-      const float4* arow = A + (v * L + l) * lda4;
+      const float4* arow = A + (brow ? (int64_t)brow[v * L + l] : v * L + l) * lda4;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         ra[c] = arow[cc[c]];
@@ -225,13 +226,17 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
           }
       }
     }
-    float4* grow = gA + (v * L + l) * ldga4;
+    // compact row tables (brow): only non-empty buckets own a row
+    const int64_t orow = brow ? (b < e ? (int64_t)brow[v * L + l] : -1) : v * L + l;
+    if (orow >= 0) {
+      float4* grow = gA + orow * ldga4;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (on[c]) {
-        grow[gg.gl + G * c] = s1[c];
-        if constexpr (KIND == KIND_FILM) grow[D4 + gg.gl + G * c] = s2[c];
-      }
+      for (int c = 0; c < NCH; ++c)
+        if (on[c]) {
+          grow[gg.gl + G * c] = s1[c];
+          if constexpr (KIND == KIND_FILM) grow[D4 + gg.gl + G * c] = s2[c];
+        }
+    }
     b = e;
   }
 }
@@ -246,10 +251,14 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr_b, int64_t n_rows, const int32_t* __restrict__ tgt_b,
     const int32_t* __restrict__ frow_b, const float* __restrict__ w_b, const float4* __restrict__ gagg,
-    int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int32_t act, int64_t nlb) {
+    int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int32_t act, int64_t nlb, const int32_t* __restrict__ trow) {
   const GroupGeom gg = geom<G>(n_rows, nlb);
   if (!gg.valid) return;
   const int64_t r = gg.node;
+  const int b = rowptr_b[r], e = rowptr_b[r + 1];
+  // compact row tables (trow): bucket r owns row trow[r] of T / gT, empty buckets own none
+  const int64_t tr = trow ? (b < e ? (int64_t)trow[r] : -1) : r;
+  if (tr < 0) return;
   bool on[NCH];
   int cc[NCH];
   float4 t[NCH], acc[NCH];
@@ -257,10 +266,9 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_kernel(
   for (int c = 0; c < NCH; ++c) {
     on[c] = gg.gl + G * c < D4;
     cc[c] = min(gg.gl + G * c, D4 - 1);
-    t[c] = T[r * ldt4 + cc[c]];
+    t[c] = T[tr * ldt4 + cc[c]];
     acc[c] = f4(0.f);
   }
-  const int b = rowptr_b[r], e = rowptr_b[r + 1];
   for (int q = b; q < e; q += PU) {
     int fr[PU], tg[PU];
     float ww[PU];
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_kernel(
   }
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
-    if (on[c]) gT[r * ldgt4 + gg.gl + G * c] = acc[c];
+    if (on[c]) gT[tr * ldgt4 + gg.gl + G * c] = acc[c];
 }
 
 // =========================================================================================
@@ -313,7 +321,8 @@ template <int NCH, int KIND, bool IS_MAX>
 __global__ __launch_bounds__(256) void edge_fwd_wave_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
-    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4, int64_t nlb) {
+    const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4, int64_t nlb,
+    const int32_t* __restrict__ brow) {
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(256) void edge_fwd_wave_kernel(
     const int e = __builtin_amdgcn_readlane(my_b, l + 1);
     if (b < e) {
       float4 ra[NCH], rb[NCH];
-      const float4* arow = A + (v * L + l) * lda4;
+      const float4* arow = A + (brow ? (int64_t)brow[v * L + l] : v * L + l) * lda4;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         ra[c] = arow[cc[c]];
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
     const float* __restrict__ w, const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gA,
-    int64_t ldga4, int32_t act, int64_t nlb) {
+    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow) {
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
     for (int c = 0; c < NCH; ++c) s1[c] = s2[c] = f4(0.f);
     if (b < e) {
       float4 ra[NCH], rb[NCH];
-      const float4* arow = A + (v * L + l) * lda4;
+      const float4* arow = A + (brow ? (int64_t)brow[v * L + l] : v * L + l) * lda4;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         ra[c] = arow[cc[c]];
@@ -458,13 +467,16 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
         }
       }
     }
-    float4* grow = gA + (v * L + l) * ldga4;
+    const int64_t orow = brow ? (b < e ? (int64_t)brow[v * L + l] : -1) : v * L + l;
+    if (orow >= 0) {
+      float4* grow = gA + orow * ldga4;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (on[c]) {
-        grow[lane + 64 * c] = s1[c];
-        if constexpr (KIND == KIND_FILM) grow[D4 + lane + 64 * c] = s2[c];
-      }
+      for (int c = 0; c < NCH; ++c)
+        if (on[c]) {
+          grow[lane + 64 * c] = s1[c];
+          if constexpr (KIND == KIND_FILM) grow[D4 + lane + 64 * c] = s2[c];
+        }
+    }
     b = e;
   }
 }
@@ -476,13 +488,17 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_wave_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr_b, int64_t n_rows, const int32_t* __restrict__ tgt_b,
     const int32_t* __restrict__ frow_b, const float* __restrict__ w_b, const float4* __restrict__ gagg,
-    int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int32_t act, int64_t nlb) {
+    int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int32_t act, int64_t nlb, const int32_t* __restrict__ trow) {
   constexpr int MU = 4;
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
   const int64_t r = lb * 4 + (threadIdx.x >> 6);
   if (r >= n_rows) return;
+  const int b = __builtin_amdgcn_readfirstlane(rowptr_b[r]);
+  const int e = __builtin_amdgcn_readfirstlane(rowptr_b[r + 1]);
+  const int64_t tr = trow ? (b < e ? (int64_t)trow[r] : -1) : r;
+  if (tr < 0) return;
   bool on[NCH];
   uint32_t cc[NCH];
   float4 t[NCH], acc[NCH];
@@ -490,11 +506,9 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_wave_kernel(
   for (int c = 0; c < NCH; ++c) {
     on[c] = lane + 64 * c < D4;
     cc[c] = (uint32_t)min(lane + 64 * c, D4 - 1);
-    t[c] = T[r * ldt4 + cc[c]];
+    t[c] = T[tr * ldt4 + cc[c]];
     acc[c] = f4(0.f);
   }
-  const int b = __builtin_amdgcn_readfirstlane(rowptr_b[r]);
-  const int e = __builtin_amdgcn_readfirstlane(rowptr_b[r + 1]);
   const uint32_t lda = (uint32_t)lda4, ldg = (uint32_t)ldg4;
   for (int q = b; q < e; q += 64) {
     const int n = min(64, e - q);
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_wave_kernel(
   }
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
-    if (on[c]) gT[r * ldgt4 + lane + 64 * c] = acc[c];
+    if (on[c]) gT[tr * ldgt4 + lane + 64 * c] = acc[c];
 }
 
 // -----------------------------------------------------------------------------------------
@@ -592,7 +606,7 @@ inline bool vec_ok(const void* p, int64_t ld) { return aligned16(p) && ld % 4 ==
 template <int KIND>
 int launch_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda,
                int32_t D, const int32_t* rowptr, int32_t V, int32_t L, const int32_t* col,
-               const float* w, float* out, int64_t ldo, hipStream_t st) {
+               const float* w, float* out, int64_t ldo, hipStream_t st, const int32_t* brow = nullptr) {
   Geo geo;
   if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(out, ldo)) return RELGNN_EUNSUPPORTED;
   const int64_t nlb = logical_blocks(V, geo.G);
@@ -605,7 +619,7 @@ int launch_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const flo
 #define EDGE_FWD_WAVE(NN, MX)                                                                                      \
   edge_fwd_wave_kernel<NN, KIND, MX><<<wgrid, 256, 0, st>>>((const float4*)T, ldt / 4, (const float4*)A, lda / 4,   \
                                                              D / 4, rowptr, V, L, col, w, mode, act, (float4*)out,  \
-                                                             ldo / 4, wnlb)
+                                                             ldo / 4, wnlb, brow)
     if (geo.NCH == 1) { if (is_max) EDGE_FWD_WAVE(1, true); else EDGE_FWD_WAVE(1, false); }
     else if (geo.NCH == 2) { if (is_max) EDGE_FWD_WAVE(2, true); else EDGE_FWD_WAVE(2, false); }
     else { if (is_max) EDGE_FWD_WAVE(4, true); else EDGE_FWD_WAVE(4, false); }
@@ -615,10 +629,10 @@ int launch_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const flo
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     if (is_max)
       edge_fwd_kernel<GG, NN, KIND, true><<<grid, 256, 0, st>>>(
-          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, mode, act, (float4*)out, ldo / 4, nlb);
+          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, mode, act, (float4*)out, ldo / 4, nlb, brow);
     else
       edge_fwd_kernel<GG, NN, KIND, false><<<grid, 256, 0, st>>>(
-          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, mode, act, (float4*)out, ldo / 4, nlb);
+          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, mode, act, (float4*)out, ldo / 4, nlb, brow);
   });
   return launch_status();
 }
@@ -626,7 +640,8 @@ int launch_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const flo
 template <int KIND>
 int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda, int32_t D,
                     const int32_t* rowptr, int32_t V, int32_t L, const int32_t* col, const float* w,
-                    const float* gagg, int64_t ldg, float* gA, int64_t ldga, hipStream_t st) {
+                    const float* gagg, int64_t ldg, float* gA, int64_t ldga, hipStream_t st,
+                    const int32_t* brow = nullptr) {
   Geo geo;
   if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(gagg, ldg) || !vec_ok(gA, ldga))
     return RELGNN_EUNSUPPORTED;
@@ -638,7 +653,7 @@ int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, in
 #define EDGE_ROWS_WAVE(NN)                                                                                          \
   edge_bwd_rows_wave_kernel<NN, KIND><<<padded_grid(wnlb), 256, 0, st>>>(                                            \
       (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4, \
-      (float4*)gA, ldga / 4, act, wnlb)
+      (float4*)gA, ldga / 4, act, wnlb, brow)
     if (geo.NCH == 1) EDGE_ROWS_WAVE(1); else if (geo.NCH == 2) EDGE_ROWS_WAVE(2); else EDGE_ROWS_WAVE(4);
 #undef EDGE_ROWS_WAVE
     return launch_status();
@@ -646,7 +661,7 @@ int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, in
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     edge_bwd_rows_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
         (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4,
-        (float4*)gA, ldga / 4, act, nlb);
+        (float4*)gA, ldga / 4, act, nlb, brow);
   });
   return launch_status();
 }
@@ -654,7 +669,8 @@ int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, in
 template <int KIND>
 int launch_bwd_msgs(int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda, int32_t D,
                     const int32_t* rowptr_b, int64_t n_rows, const int32_t* tgt_b, const int32_t* frow_b,
-                    const float* w_b, const float* gagg, int64_t ldg, float* gT, int64_t ldgt, hipStream_t st) {
+                    const float* w_b, const float* gagg, int64_t ldg, float* gT, int64_t ldgt, hipStream_t st,
+                    const int32_t* trow = nullptr) {
   Geo geo;
   if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(gagg, ldg) || !vec_ok(gT, ldgt))
     return RELGNN_EUNSUPPORTED;
@@ -666,7 +682,7 @@ int launch_bwd_msgs(int32_t act, const float* T, int64_t ldt, const float* A, in
 #define EDGE_MSGS_WAVE(NN)                                                                                          \
   edge_bwd_msgs_wave_kernel<NN, KIND><<<padded_grid(wnlb), 256, 0, st>>>(                                            \
       (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,             \
-      (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, wnlb)
+      (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, wnlb, trow)
     if (geo.NCH == 1) EDGE_MSGS_WAVE(1); else if (geo.NCH == 2) EDGE_MSGS_WAVE(2); else EDGE_MSGS_WAVE(4);
 #undef EDGE_MSGS_WAVE
     return launch_status();
@@ -674,7 +690,7 @@ int launch_bwd_msgs(int32_t act, const float* T, int64_t ldt, const float* A, in
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     edge_bwd_msgs_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
         (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,
-        (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, nlb);
+        (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, nlb, trow);
   });
   return launch_status();
 }
@@ -688,32 +704,32 @@ extern "C" {
 int relgnn_film_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, const float* film,
                     int64_t ldf, int32_t D, const int32_t* rowptr, int32_t num_nodes,
                     int32_t num_edge_types, const int32_t* col, const float* w, float* out, int64_t ldo,
-                    void* stream) {
+                    const int32_t* bucket_row, void* stream) {
   if (bad_common(D, num_nodes, num_edge_types) || mode < RELGNN_AGG_SUM || mode > RELGNN_AGG_MAX || ldf < 2 * D)
     return RELGNN_EINVAL;
   if (num_nodes == 0 || D == 0) return RELGNN_OK;
   if (!rowptr || !out) return RELGNN_EINVAL;
-  return launch_fwd<KIND_FILM>(mode, act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, out, ldo, as_stream(stream));
+  return launch_fwd<KIND_FILM>(mode, act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, out, ldo, as_stream(stream), bucket_row);
 }
 
 int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
                          int32_t D, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
                          const int32_t* col, const float* w, const float* gagg, int64_t ldg, float* gfilm,
-                         int64_t ldgf, void* stream) {
+                         int64_t ldgf, const int32_t* bucket_row, void* stream) {
   if (bad_common(D, num_nodes, num_edge_types) || ldf < 2 * D || ldgf < 2 * D) return RELGNN_EINVAL;
   if (num_nodes == 0 || D == 0) return RELGNN_OK;
   if (!rowptr || !gagg || !gfilm) return RELGNN_EINVAL;
-  return launch_bwd_rows<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gfilm, ldgf, as_stream(stream));
+  return launch_bwd_rows<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gfilm, ldgf, as_stream(stream), bucket_row);
 }
 
 int relgnn_film_bwd_msg(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
                         int32_t D, const int32_t* rowptr_b, int64_t num_rows_t, const int32_t* tgt_b,
                         const int32_t* frow_b, const float* w_b, const float* gagg, int64_t ldg, float* gT,
-                        int64_t ldgt, void* stream) {
+                        int64_t ldgt, const int32_t* bucket_row_b, void* stream) {
   if (D < 0 || num_rows_t < 0 || ldf < 2 * D) return RELGNN_EINVAL;
   if (num_rows_t == 0 || D == 0) return RELGNN_OK;
   if (!rowptr_b || !T || !gT) return RELGNN_EINVAL;
-  return launch_bwd_msgs<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr_b, num_rows_t, tgt_b, frow_b, w_b, gagg, ldg, gT, ldgt, as_stream(stream));
+  return launch_bwd_msgs<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr_b, num_rows_t, tgt_b, frow_b, w_b, gagg, ldg, gT, ldgt, as_stream(stream), bucket_row_b);
 }
 
 int relgnn_pair_fwd(int32_t mode, int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq,

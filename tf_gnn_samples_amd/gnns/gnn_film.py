@@ -51,11 +51,22 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
     mode = ops.aggregation_mode_id(message_aggregation_function)
     ops.activation_id(activation_function)
     w = graph.degree_scale(type_to_num_incoming_edges) if normalize_by_num_incoming else None
-    w_msg = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")               # [D, L*state_dim]
-    w_film = concat_edge_kernels(weights, L, "Edge_%i_FiLM_Computations/kernel")   # [D, L*2*state_dim]
-
+    # many-type graphs leave most (node,type) buckets empty: transform only the non-empty ones (graph.PairTables)
+    pairs = graph.pair_tables() if (mode != _lib.AGG_MAX and graph.wants_pair_tables()) else None
+    if pairs is None:
+        w_msg = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")               # [D, L*state_dim]
+        w_film = concat_edge_kernels(weights, L, "Edge_%i_FiLM_Computations/kernel")   # [D, L*2*state_dim]
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
+        if pairs is not None:
+            transformed = ops.typed_linear(cur_node_states, pairs.src,
+                                           [weights["Edge_%i_Weight/kernel" % l] for l in range(L)])
+            film = ops.typed_linear(cur_node_states, pairs.tgt,
+                                    [weights["Edge_%i_FiLM_Computations/kernel" % l] for l in range(L)])
+            aggregated = ops.film_messages_reduce(transformed, film, graph, w, message_aggregation_function,
+                                                  activation_function, pairs)
+            cur_node_states = layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+            continue
         transformed = dense(cur_node_states, w_msg).view(num_nodes * L, state_dim)      # row v*L+l = h_v W_l
         film = dense(cur_node_states, w_film).view(num_nodes * L, 2 * state_dim)        # row v*L+l = [gamma | beta]
         if mode == _lib.AGG_MAX:

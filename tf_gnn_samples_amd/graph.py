@@ -15,6 +15,7 @@ All index arithmetic happens on the device through the C ABI (relgnn_relational_
 relgnn_segment_plan, relgnn_gather_*): it is integer work and is tested bit-exact against
 the NumPy oracle.
 """
+import os
 from collections import OrderedDict
 from typing import List, Optional, Sequence
 
@@ -300,6 +301,25 @@ class RelGraph:
                 pos_b=torch.arange(self.M, dtype=torch.int32, device=self.device), num_messages=self.M))
         return self._plans[key][1]
 
+    # ---- compact (node, type) pair tables -------------------------------------------------------
+    def pair_tables(self) -> "PairTables":
+        """Compact numbering of the NON-EMPTY (node, type) buckets (see PairTables); built once, one host sync."""
+        if "pairs" not in self._plans:
+            self._plans["pairs"] = PairTables(self)
+        return self._plans["pairs"]
+
+    def wants_pair_tables(self) -> bool:
+        """Node-side per-type transforms over all V*L (node,type) rows waste work when most buckets are empty
+        (VarMisuse-shaped graphs: 23 edge types, ~2/3 of the buckets empty).  Few-type graphs (PPI: every bucket
+        non-empty) keep the dense [V*L, D] tables and one big GEMM.  RELGNN_PAIR_TABLES=0/1 overrides."""
+        force = os.environ.get("RELGNN_PAIR_TABLES")
+        if force is not None:
+            return force not in ("0", "", "false")
+        if self.L < 8 or self.M == 0:
+            return False
+        pt = self.pair_tables()
+        return (pt.tgt.num_pairs + pt.src.num_pairs) < 0.6 * (2 * self.V * self.L)
+
     @property
     def type_offsets(self):
         """start of every edge type in the type-major message list (python ints), length L+1."""
@@ -307,6 +327,106 @@ class RelGraph:
         for e in self.edge_counts:
             offs.append(offs[-1] + e)
         return offs
+
+
+# rows per GEMM batch entry of the compact tables; every type's row block is padded to a multiple
+PAIR_CHUNK = int(os.environ.get("RELGNN_PAIR_CHUNK", "512"))
+
+
+class SidePairs:
+    """One side (sources or targets) of the compact pair numbering.
+
+    Rows are TYPE-MAJOR and every type's block is padded to a multiple of PAIR_CHUNK rows, so the whole table is a
+    batch of [PAIR_CHUNK, D] tiles that each belong to ONE edge type: the per-type transforms become a single batched
+    GEMM with the weight picked per tile (ops.typed_linear).  Padding rows gather an all-zero input row, are never
+    referenced by a message, and cost <= L * PAIR_CHUNK rows.
+
+    P            number of table rows (including padding); num_pairs = non-empty (node, type) buckets
+    bucket_row   [V*L] int32  node-major bucket (node*L + type) -> row, -1 for empty buckets
+    node         [P]   int64  node of each row (ascending node id inside a type); V for padding rows
+    offsets      L+1 python ints: padded start of every type's block
+    chunk_type   [P / PAIR_CHUNK] int64: edge type of every tile
+    node_rowptr  [V+1] int32, node_col [num_pairs] int32: CSR node -> its rows (for summing per-pair gradients back
+                 into the node in ascending type order, the order the dense GEMM would add them)"""
+
+    def __init__(self, rowptr: torch.Tensor, V: int, L: int, chunk: int = PAIR_CHUNK):
+        dev = rowptr.device
+        self.V, self.L, self.chunk = V, L, chunk
+        nonempty = (rowptr[1:] > rowptr[:-1]).view(V, L)
+        by_type = nonempty.t().contiguous()                                   # [L, V]
+        rank = torch.cumsum(by_type, 1, dtype=torch.int32) - 1                # position inside the type's block
+        counts = rank[:, -1] + 1 if V > 0 else torch.zeros(L, dtype=torch.int32, device=dev)
+        padded = (counts + (chunk - 1)) // chunk * chunk
+        starts = torch.cumsum(padded, 0, dtype=torch.int32) - padded          # [L]
+        ids = torch.where(by_type, rank + starts.unsqueeze(1), torch.full_like(rank, -1))
+        self.bucket_row = ids.t().contiguous().view(-1)                       # [V*L], node-major
+        self._counts_dev = torch.stack([counts, padded])                      # read once by PairTables (one sync)
+        self._by_type, self._ids = by_type, ids
+        per_node = nonempty.sum(1, dtype=torch.int32)
+        self.node_rowptr = torch.zeros(V + 1, dtype=torch.int32, device=dev)
+        torch.cumsum(per_node, 0, dtype=torch.int32, out=self.node_rowptr[1:])
+        self.node_col = self.bucket_row[nonempty.view(-1)].contiguous()       # node-major order
+        self._dw_plans = {}
+
+    def _finish(self, counts: List[int], padded: List[int]):
+        dev = self.bucket_row.device
+        self.offsets = [0]
+        for c in padded:
+            self.offsets.append(self.offsets[-1] + int(c))
+        self.P = self.offsets[-1]
+        self.num_pairs = int(sum(counts))
+        self.type_counts = [int(c) for c in counts]
+        node = torch.full((self.P,), self.V, dtype=torch.int64, device=dev)
+        where = torch.nonzero(self._by_type.view(-1)).view(-1)                # type-major positions of real pairs
+        node[self._ids.view(-1)[where].long()] = where % max(self.V, 1)
+        self.node = node
+        self.pad_rows = torch.nonzero(node == self.V).view(-1)               # <= L * chunk rows
+        chunks = [p // self.chunk for p in padded]
+        self.chunk_counts = chunks
+        self.chunk_type = torch.repeat_interleave(torch.arange(self.L, device=dev),
+                                                  torch.tensor(chunks, device=dev, dtype=torch.int64))
+        del self._by_type, self._ids
+
+    def weight_grad_plan(self, num_sub_rows: int):
+        """CSR that sums per-tile partial weight gradients [num_tiles * K, 1024] (K = num_sub_rows 1024-float slices
+        of one [Din, Dout] partial) into [L * K, 1024]: out row (l, j) <- rows (tile * K + j) for the tiles of type l."""
+        plan = self._dw_plans.get(num_sub_rows)
+        if plan is None:
+            import numpy as np
+            K = num_sub_rows
+            tile_start = np.concatenate([[0], np.cumsum(self.chunk_counts)])
+            rowptr = np.zeros(self.L * K + 1, np.int64)
+            cols = []
+            for l in range(self.L):
+                n = self.chunk_counts[l]
+                tiles = np.arange(tile_start[l], tile_start[l] + n)
+                for j in range(K):
+                    rowptr[l * K + j + 1] = rowptr[l * K + j] + n
+                cols.append((tiles[None, :] * K + np.arange(K)[:, None]).reshape(-1))
+            col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+            dev = self.bucket_row.device
+            plan = (torch.as_tensor(rowptr.astype(np.int32), device=dev), torch.as_tensor(col.astype(np.int32), device=dev))
+            self._dw_plans[num_sub_rows] = plan
+        return plan
+
+
+class PairTables:
+    """Compact row numbering for per-(node, type) tables over the non-empty buckets only.
+
+    tgt : SidePairs of the by-(target, type) buckets (rows of FiLM-weight / target-side tables)
+    src : SidePairs of the by-(source, type) buckets (rows of transformed-message tables)
+    col_t  [M] int32  src-table row gathered by each by-target message   (replaces RelGraph.col_t)
+    frow_s [M] int32  tgt-table row of each by-source message             (replaces RelGraph.frow_s)"""
+
+    def __init__(self, g: "RelGraph"):
+        self.tgt = SidePairs(g.rowptr_t, g.V, g.L)
+        self.src = SidePairs(g.rowptr_s, g.V, g.L)
+        counts = torch.stack([self.tgt._counts_dev, self.src._counts_dev]).tolist()   # the one host sync
+        self.tgt._finish(*counts[0])
+        self.src._finish(*counts[1])
+        self.P_t, self.P_s = self.tgt.P, self.src.P
+        self.col_t = self.src.bucket_row[g.col_t.long()].contiguous()
+        self.frow_s = self.tgt.bucket_row[g.frow_s.long()].contiguous()
 
 
 # ---- cache: the layer functions receive raw adjacency lists on every call ------------------

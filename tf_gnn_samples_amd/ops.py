@@ -202,20 +202,30 @@ class _FusedEdgeMessages(torch.autograd.Function):
        kind 'pair': out[v] = AGG act(w * (T[src,l] + A[v,l])),                  A = Q    [V*L, D]"""
 
     @staticmethod
-    def forward(ctx, T, A, graph, w, mode: int, act: int, kind: str):
+    def forward(ctx, T, A, graph, w, mode: int, act: int, kind: str, pairs=None):
+        """pairs (graph.PairTables, FiLM only): T / A hold rows for the non-empty (node,type) buckets only."""
         lib = _lib.load_library()
         _check_f32(T, "T"); _check_f32(A, "A")
         T, A = T.contiguous(), A.contiguous()
         V, L = graph.V, graph.L
         D = T.shape[1]
-        if T.shape[0] != V * L or A.shape[0] != V * L or A.shape[1] != (2 * D if kind == "film" else D):
+        rows_t, rows_a = (V * L, V * L) if pairs is None else (pairs.P_s, pairs.P_t)
+        if pairs is not None and kind != "film":
+            raise ValueError("compact pair tables are only wired into the FiLM kernels")
+        if T.shape[0] != rows_t or A.shape[0] != rows_a or A.shape[1] != (2 * D if kind == "film" else D):
             raise ValueError("bad operand shapes for fused %s messages" % kind)
         out = torch.empty((V, D), dtype=torch.float32, device=T.device)
-        fn = lib.relgnn_film_fwd if kind == "film" else lib.relgnn_pair_fwd
-        _lib.check(fn(mode, act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t), V, L,
-                      _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(out), D, _lib.current_stream()),
-                   "relgnn_%s_fwd" % kind)
-        ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.kind = graph, w, mode, act, kind
+        if kind == "film":
+            col = graph.col_t if pairs is None else pairs.col_t
+            brow = None if pairs is None else pairs.tgt.bucket_row
+            _lib.check(lib.relgnn_film_fwd(mode, act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t),
+                                           V, L, _lib.ptr(col), _lib.ptr(w), _lib.ptr(out), D, _lib.ptr(brow),
+                                           _lib.current_stream()), "relgnn_film_fwd")
+        else:
+            _lib.check(lib.relgnn_pair_fwd(mode, act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t),
+                                           V, L, _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(out), D,
+                                           _lib.current_stream()), "relgnn_pair_fwd")
+        ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.kind, ctx.pairs = graph, w, mode, act, kind, pairs
         ctx.save_for_backward(T, A)
         return out
 
@@ -223,7 +233,7 @@ class _FusedEdgeMessages(torch.autograd.Function):
     def backward(ctx, gout):
         lib = _lib.load_library()
         st = _lib.current_stream()
-        graph, w, mode, act, kind = ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.kind
+        graph, w, mode, act, kind, pairs = ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.kind, ctx.pairs
         if mode == _lib.AGG_MAX:
             raise RuntimeError("fused %s messages have no max-aggregation backward; the layer uses the unfused path" % kind)
         T, A = ctx.saved_tensors
@@ -233,14 +243,23 @@ class _FusedEdgeMessages(torch.autograd.Function):
         gagg = (gout * f.unsqueeze(1)).contiguous() if f is not None else gout.contiguous()
         gA = torch.empty_like(A)
         gT = torch.empty_like(T)
+        if pairs is not None:
+            # compact tables: every real row is written by the kernels; the few padding rows are not and feed the
+            # batched weight-gradient GEMM (against all-zero inputs, but 0 * NaN garbage would still poison it)
+            gA.index_fill_(0, pairs.tgt.pad_rows, 0.0)
+            gT.index_fill_(0, pairs.src.pad_rows, 0.0)
         if kind == "film":
+            col = graph.col_t if pairs is None else pairs.col_t
+            frow = graph.frow_s if pairs is None else pairs.frow_s
+            brow_t = None if pairs is None else pairs.tgt.bucket_row
+            brow_s = None if pairs is None else pairs.src.bucket_row
             _lib.check(lib.relgnn_film_bwd_film(act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t),
-                                                V, L, _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(gagg), D,
-                                                _lib.ptr(gA), A.shape[1], st), "relgnn_film_bwd_film")
+                                                V, L, _lib.ptr(col), _lib.ptr(w), _lib.ptr(gagg), D,
+                                                _lib.ptr(gA), A.shape[1], _lib.ptr(brow_t), st), "relgnn_film_bwd_film")
             _lib.check(lib.relgnn_film_bwd_msg(act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_s),
-                                               V * L, _lib.ptr(graph.tgt_s), _lib.ptr(graph.frow_s),
-                                               _lib.ptr(graph.w_by_source(w)), _lib.ptr(gagg), D, _lib.ptr(gT), D, st),
-                       "relgnn_film_bwd_msg")
+                                               V * L, _lib.ptr(graph.tgt_s), _lib.ptr(frow),
+                                               _lib.ptr(graph.w_by_source(w)), _lib.ptr(gagg), D, _lib.ptr(gT), D,
+                                               _lib.ptr(brow_s), st), "relgnn_film_bwd_msg")
         else:
             _lib.check(lib.relgnn_pair_bwd_q(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_t), V, L,
                                              _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(gagg), D, _lib.ptr(gA), D, st),
@@ -248,12 +267,75 @@ class _FusedEdgeMessages(torch.autograd.Function):
             _lib.check(lib.relgnn_pair_bwd_p(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_s), V * L,
                                              _lib.ptr(graph.tgt_s), _lib.ptr(graph.frow_s), _lib.ptr(graph.w_by_source(w)),
                                              _lib.ptr(gagg), D, _lib.ptr(gT), D, st), "relgnn_pair_bwd_p")
-        return gT, gA, None, None, None, None, None
+        return gT, gA, None, None, None, None, None, None
 
 
-def film_messages_reduce(T, film, graph, w, aggregation: str, activation: Optional[str]):
-    """gnns/gnn_film.py:92-116 in one kernel (sum / mean / sqrt_n; max forward only)."""
-    return _FusedEdgeMessages.apply(T, film, graph, w, aggregation_mode_id(aggregation), activation_id(activation), "film")
+def film_messages_reduce(T, film, graph, w, aggregation: str, activation: Optional[str], pairs=None):
+    """gnns/gnn_film.py:92-116 in one kernel (sum / mean / sqrt_n; max forward only).  With `pairs`
+    (graph.PairTables) T is [P_s, D] and film [P_t, 2D]: rows for the non-empty (node,type) buckets only."""
+    return _FusedEdgeMessages.apply(T, film, graph, w, aggregation_mode_id(aggregation), activation_id(activation),
+                                    "film", pairs)
+
+
+class _TypedLinear(torch.autograd.Function):
+    """Y[r] = H[node[r]] @ W_{type(r)} for the compact rows of one graph.SidePairs.
+
+    The table is a batch of [chunk, Din] tiles, each of ONE edge type (type blocks are padded to the tile size), so the
+    L per-type transforms are ONE batched GEMM with the weight picked per tile; the dense path computes
+    H @ [W_0|..|W_{L-1}] for ALL V*L (node,type) rows instead.  Backward: dX = dY W^T (batched), per-tile partial
+    weight gradients X^T dY (batched) summed per type by the gather-reduce kernel, and the per-row dX summed back into
+    their nodes over the node -> rows CSR (ascending type order); no atomics anywhere."""
+
+    @staticmethod
+    def forward(ctx, H, side, *weights):
+        V, Din = H.shape
+        Dout = weights[0].shape[1]
+        c = side.chunk
+        Hz = torch.cat([H, H.new_zeros((1, Din))])                            # row V = the padding rows' input
+        X = Hz.index_select(0, side.node)                                     # [P, Din]
+        Wt = torch.stack(weights).index_select(0, side.chunk_type)            # [tiles, Din, Dout]
+        Y = torch.bmm(X.view(-1, c, Din), Wt).view(side.P, Dout)
+        ctx.side, ctx.num_nodes, ctx.shape = side, V, (len(weights), Din, Dout)
+        ctx.save_for_backward(X, Wt)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        X, Wt = ctx.saved_tensors
+        side, c = ctx.side, ctx.side.chunk
+        L, Din, Dout = ctx.shape
+        gY = gY.contiguous()
+        gH = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.bmm(gY.view(-1, c, Dout), Wt.transpose(1, 2)).view(side.P, Din)
+            gH = _seg_reduce_raw(_lib.AGG_SUM, gX, side.node_rowptr, 1, side.node_col, None, ctx.num_nodes)
+        gW = [None] * L
+        if any(ctx.needs_input_grad[2:]):
+            part = torch.bmm(X.view(-1, c, Din).transpose(1, 2), gY.view(-1, c, Dout))   # [tiles, Din, Dout]
+            n = Din * Dout
+            sub = 1024 if n % 1024 == 0 else (n if n <= 1024 and n % 4 == 0 else 0)
+            if sub:
+                K = n // sub
+                rowptr, col = side.weight_grad_plan(K)
+                g = _seg_reduce_raw(_lib.AGG_SUM, part.view(-1, sub), rowptr, 1, col, None, L * K).view(L, Din, Dout)
+            else:                                                                 # odd shapes: per-type sums
+                g = torch.stack([part[a:a + k].sum(0) for a, k in zip(_tile_starts(side), side.chunk_counts)])
+            gW = [g[l] if ctx.needs_input_grad[2 + l] else None for l in range(L)]
+        return (gH, None, *gW)
+
+
+def _tile_starts(side):
+    out, at = [], 0
+    for k in side.chunk_counts:
+        out.append(at)
+        at += k
+    return out
+
+
+def typed_linear(H, side, weights):
+    """[P, Dout] table over the non-empty (node,type) buckets of `side` (graph.SidePairs); weights: L x [Din, Dout]."""
+    _check_f32(H, "H")
+    return _TypedLinear.apply(H.contiguous(), side, *weights)
 
 
 def pair_messages_reduce_fused(P, Q, graph, w, aggregation: str, activation: Optional[str]):
