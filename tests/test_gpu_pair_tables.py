@@ -175,6 +175,6 @@ def test_film_model_trains_with_pair_tables(gpu_device, monkeypatch):
         p = cls.default_params(); p.update(extra)
         p.update(hidden_size=64, graph_num_layers=3, random_seed=0)
         model = cls(p, task, device=gpu_device)
-        losses[flag] = [float(model.train_step(batch)['loss']) for _ in range(4)]
+        losses[flag] = [float(model.train_step(batch)['loss'].detach()) for _ in range(4)]
     assert np.allclose(losses[None], losses["0"], rtol=2e-4, atol=1e-5), losses
     assert losses[None][-1] < losses[None][0]

@@ -157,6 +157,33 @@ class RelGraph:
             if len(_PENDING_CHECKS) > 4096:
                 check_pending_graph_errors()
 
+    # ---- bucketing on a side stream (input pipeline) --------------------------------------------
+    ready_event = None
+
+    @classmethod
+    def build_on_stream(cls, adjacency_lists, num_nodes: int, stream, validate="deferred") -> "RelGraph":
+        """Bucket a batch on `stream` (e.g. the copy stream that just uploaded it) while the previous batch computes
+        on the main stream.  The consumer calls wait_ready() before the first kernel that reads the graph."""
+        with torch.cuda.stream(stream):
+            g = cls(adjacency_lists, num_nodes, validate=validate)
+            g.ready_event = torch.cuda.Event()
+            g.ready_event.record(stream)
+        return g
+
+    def wait_ready(self):
+        """Make the current stream wait for a graph built by build_on_stream (no host sync) and tell the caching
+        allocator that the graph's arrays are now used on this stream."""
+        ev, self.ready_event = self.ready_event, None
+        if ev is None:
+            return self
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for t in (self.key_by_target, self.key_by_source, self.rowptr_t, self.perm_t, self.col_t, self.inv_perm_t,
+                  self.rowptr_s, self.perm_s, self.frow_s, self.tgt_s, self.pos_t_of_s, self._err_flag,
+                  *self.adjacency_lists):
+            t.record_stream(cur)
+        return self
+
     def check(self):
         """Host sync: raise if the device-side validation saw a node id outside [0, V)."""
         if not self._checked:
@@ -453,7 +480,7 @@ def as_rel_graph(adjacency_lists, num_nodes: int, validate=True) -> RelGraph:
     if isinstance(adjacency_lists, RelGraph):
         if adjacency_lists.V != num_nodes:
             raise ValueError("RelGraph was built for %d nodes, got %d" % (adjacency_lists.V, num_nodes))
-        return adjacency_lists
+        return adjacency_lists.wait_ready()
     key = tuple((a.data_ptr(), tuple(a.shape), a._version, str(a.dtype)) for a in adjacency_lists) + (int(num_nodes),)
     g = _GRAPH_CACHE.get(key)
     if g is not None:

@@ -303,8 +303,11 @@ class Sparse_Graph_Model(ABC):
     # -------------------- Training Loop --------------------
     def forward_batch(self, batch: DeviceBatch, training: bool):
         keep = self.params['graph_layer_input_dropout_keep_prob'] if training else 1.0
+        # a batch from the input pipeline may carry its bucketing, built on a side stream (tasks/batcher.py)
+        graph = getattr(batch, "graph", None)
         final = self.compute_final_node_representations(
-            batch.initial_node_features, batch.adjacency_lists, batch.type_to_num_incoming_edges, keep)
+            batch.initial_node_features, graph if graph is not None else batch.adjacency_lists,
+            batch.type_to_num_incoming_edges, keep)
         return self.task.compute_task_metrics(final, batch, self.variables.scope(self._task_scope))
 
     def train_step(self, batch: DeviceBatch, grad_hook=None) -> Dict[str, torch.Tensor]:
@@ -344,13 +347,20 @@ class Sparse_Graph_Model(ABC):
         processed_graphs = processed_nodes = processed_edges = 0
         epoch_loss = 0.0
         task_metric_results = []
-        for step, mb in enumerate(batch_iterator):
+        batch_iterator = iter(batch_iterator)
+        upcoming = next(batch_iterator, None)
+        step = 0
+        while upcoming is not None:
+            mb = upcoming
             batch = mb if isinstance(mb, DeviceBatch) else DeviceBatch(mb, self.device)
             if data_fold == DataFold.TRAIN:
                 m = self.train_step(batch)
             else:
                 with torch.no_grad():
                     m = self.forward_batch(batch, training=False)
+            # ask for the next batch BEFORE reading this step's metrics back: its upload and bucketing (copy stream)
+            # then overlap with this step's kernels instead of waiting behind the host sync below
+            upcoming = next(batch_iterator, None)
             m = {k: float(v) for k, v in m.items()}   # one sync per step, like sess.run's fetch
             check_pending_graph_errors()
             processed_graphs += mb.num_graphs
@@ -361,6 +371,7 @@ class Sparse_Graph_Model(ABC):
             if not quiet:
                 print("Running %s, batch %i (has %i graphs). Loss so far: %.4f"
                       % (epoch_name, step, mb.num_graphs, epoch_loss / processed_graphs), end='\r')
+            step += 1
         epoch_time = time.time() - start_time
         per_graph_loss = epoch_loss / max(processed_graphs, 1)
         return (per_graph_loss, task_metric_results, processed_graphs, processed_graphs / epoch_time,

@@ -131,16 +131,21 @@ class NativeBatcher:
     """Packs batches of a GraphStore into pinned arenas and uploads each with a single async copy."""
 
     def __init__(self, store: GraphStore, device, num_threads: Optional[int] = None, depth: int = 2,
-                 features: str = "initial_node_features", constants: Optional[dict] = None):
+                 features: str = "initial_node_features", constants: Optional[dict] = None, bucket: bool = True):
         self.store, self.device = store, torch.device(device)
         self.num_threads = int(num_threads or min(8, os.cpu_count() or 1))
         self.depth = max(2, int(depth))
         self.features = features
         self.constants = dict(constants or {})
+        # bucket: also run the (target,type)/(source,type) bucketing of the batch on the copy stream right behind its
+        # upload, so that it overlaps with the previous batch's compute (the batch then carries `.graph`)
+        self.bucket = bool(bucket) and self.device.type == "cuda"
         self._host = [None] * self.depth      # pinned uint8 arenas
         self._dev = [None] * self.depth       # device uint8 arenas
         self._h2d_done = [None] * self.depth  # event: upload out of host arena k finished
+        self._released = [None] * self.depth  # event: every consumer kernel of device arena k's last batch is enqueued
         self._slot = 0
+        self._last = None
         self._copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def _arena(self, pool, k, nbytes, pinned):
@@ -182,7 +187,10 @@ class NativeBatcher:
         else:
             dev = self._arena(self._dev, slot, nbytes, pinned=False)
             cur = torch.cuda.current_stream(self.device)
-            self._copy_stream.wait_stream(cur)          # consumers of this arena's previous batch are enqueued on `cur`
+            # the arena's previous batch must be fully consumed before it is overwritten; NOT a wait on everything
+            # enqueued so far, or the upload could never overlap with the batch that is computing right now
+            if self._released[slot] is not None:
+                self._copy_stream.wait_event(self._released[slot])
             with torch.cuda.stream(self._copy_stream):
                 dev[:nbytes].copy_(host[:nbytes], non_blocking=True)
                 ev = torch.cuda.Event()
@@ -193,18 +201,37 @@ class NativeBatcher:
         for name, (off, rows, cols, dtype) in tail.items():   # per-graph rows: [n_graphs, cols]
             tdt = torch.from_numpy(np.zeros(1, dtype)).dtype
             payload[name] = dev[off:off + rows * cols * dtype.itemsize].view(tdt).view(rows, cols)
-        return DeviceBatch.from_tensors(
+        graph = None
+        if self.bucket and int(lay[_LAY_M]) > 0:
+            from ..graph import RelGraph
+            graph = RelGraph.build_on_stream(adj, int(lay[_LAY_V]), self._copy_stream)
+        batch = DeviceBatch.from_tensors(
             num_graphs=len(graph_ids), num_nodes=int(lay[_LAY_V]), num_edges=int(lay[_LAY_M]),
             initial_node_features=payload[self.features], adjacency_lists=adj, type_to_num_incoming_edges=deg,
             graph_nodes_list=n2g,
             extra={**{k: v for k, v in payload.items() if k != self.features}, **self.constants})
+        batch.graph = graph
+        batch._arena_slot = slot
+        return batch
+
+    def release(self, batch: DeviceBatch):
+        """The consumer has enqueued all work that reads `batch` (on the current stream): its arena may be reused once
+        that work has run.  iterate() / pack() call this themselves when the next batch is requested."""
+        slot = getattr(batch, "_arena_slot", None)
+        if slot is not None and self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._released[slot] = ev
 
     def pack(self, graph_ids) -> DeviceBatch:
         """One batch, synchronously packed, asynchronously uploaded.  The batch stays valid until `depth` more
         batches have been produced by this batcher (its arena is then reused)."""
         slot = self._slot
         self._slot = (slot + 1) % self.depth
-        return self.upload(self.pack_host(graph_ids, slot), slot)
+        if self._last is not None:
+            self.release(self._last)
+        self._last = self.upload(self.pack_host(graph_ids, slot), slot)
+        return self._last
 
     def iterate(self, graph_ids: Sequence[int], max_nodes_per_batch: int) -> Iterator[DeviceBatch]:
         """All batches of `graph_ids` in order; batch i+1 is packed on a background thread while batch i is consumed
@@ -233,6 +260,8 @@ class NativeBatcher:
             if isinstance(item, BaseException):
                 raise item
             slot, packed = item
-            yield self.upload(packed, slot)
+            batch = self.upload(packed, slot)
+            yield batch
+            self.release(batch)          # the consumer is back: everything reading `batch` is enqueued
             free.release()
         t.join()
