@@ -372,6 +372,24 @@ int relgnn_rgat_dz(const float* T, int64_t num_rows_t, int64_t ldt, int32_t D, i
                    int32_t num_edge_types, const int32_t* col, float slope, const float* alpha,
                    const float* out, const float* gout, int64_t ldo, float* dz, void* stream);
 
+/*
+ * Attention-logit tables and their gradients (gnns/rgat.py:103-115: the [E, K, 2*Dh] concat + einsum with
+ * `Edge_%i_Attention_Parameters` reshaped (K, 2*Dh), :110-111, restated on (node, type) rows):
+ *   fwd : s_src[r,k] = <T[r, head k], att[l, k, 0:Dh]>,  s_tgt[r,k] = <T[r, head k], att[l, k, Dh:2Dh]>,  r = v*L + l
+ *   bwd : gT[r, head k] += gs_src[r,k] * att[l,k,0:Dh] + gs_tgt[r,k] * att[l,k,Dh:2Dh]        (in place; gT nullable)
+ *         att_partial[g, l, :] = sum over the nodes of group g of gs_*[r,k] * T[r, head k]  in att's (K, 2*Dh) layout;
+ *         the caller column-sums the [num_groups, L*2*D] partials (relgnn_column_sum) into d att [L, 2*D].
+ *         num_groups must equal relgnn_rgat_scores_groups(num_nodes).  att_partial nullable.
+ * att: [L, 2*D] contiguous.  Supported geometry: D/4 in {8,16,32,64} and (D/4)/K a power of two
+ * (RELGNN_EUNSUPPORTED otherwise: the caller falls back to library reductions).
+ */
+int64_t relgnn_rgat_scores_groups(int64_t num_nodes);
+int relgnn_rgat_scores_fwd(const float* T, int64_t ldt, int32_t D, int32_t num_heads, const float* att,
+                           int32_t num_edge_types, int64_t num_nodes, float* s_src, float* s_tgt, void* stream);
+int relgnn_rgat_scores_bwd(const float* T, int64_t ldt, int32_t D, int32_t num_heads, const float* att,
+                           int32_t num_edge_types, int64_t num_nodes, const float* gs_src, const float* gs_tgt,
+                           float* gT, int64_t ldg, float* att_partial, int64_t num_groups, void* stream);
+
 /* ========================================================================== *
  * 5. Messages from BOTH endpoint states  (gnns/gnn_edge_mlp.py:91-116, rgin.py:110-129,
  *    rgcn.py:91-104 use_both_source_and_target)

@@ -72,6 +72,9 @@ _SIGNATURES = {
     "relgnn_gru_out_bwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_gru_gates_bwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_pair_materialize": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr]),
+    "relgnn_rgat_scores_groups": (_c_i64, [_c_i64]),
+    "relgnn_rgat_scores_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _c_i32, _c_i64, _ptr, _ptr, _ptr]),
+    "relgnn_rgat_scores_bwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _c_i32, _c_i64, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     # host-side batch builder (section 9): host pointers only
     "relgnn_batch_layout_len": (_c_i64, [_c_i32, _c_i32]),
     "relgnn_batch_count": (_c_i64, [_ptr, _ptr, _c_i64, _c_i64, _c_i64]),

@@ -25,6 +25,10 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 __device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -188,7 +192,9 @@ __global__ __launch_bounds__(256) void headw_reduce_kernel(
 
 // ---- dz: one wave per target, lanes across features ---------------------------------------------
 // requires NCH == 1 and Dh4 a power of two (lanes of a head are one aligned group): the per-message
-// per-head dot product is a log2(Dh4)-step butterfly.
+// per-head dot product is a log2(Dh4)-step butterfly (DPP lane selects inside a 16-lane row: 349 -> 236 us at C4;
+// a transposed reduction that takes Dh4 messages at a time and needs Dh4-1 shuffles per Dh4 messages was tried and
+// was slower, 477 us: 16 float4 rows + 16 partials per lane cost more occupancy than the shuffles it saves).
 template <int K>
 __global__ __launch_bounds__(256) void rgat_dz_kernel(
     const float4* __restrict__ T, int64_t ldt4, int32_t D4, int32_t Dh4, const float* __restrict__ s_src,
@@ -207,8 +213,15 @@ __global__ __launch_bounds__(256) void rgat_dz_kernel(
   const uint32_t cc = (uint32_t)min(lane, D4 - 1);
   const int head = (int)cc / Dh4;
   const float4 go = on ? gout[v * ldo4 + cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // all-reduce over the Dh4 aligned lanes of a head.  Up to 16 lanes (one DPP row) it is four full-rate VALU adds
+  // with DPP lane selects (xor 1, xor 2, half-row mirror, row mirror) instead of LDS-crossbar shuffles.
   auto head_sum = [&](float x) {
-    for (int off = Dh4 >> 1; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    if (Dh4 >= 2) x += dpp_f32<0xB1>(x);    // quad_perm [1,0,3,2]
+    if (Dh4 >= 4) x += dpp_f32<0x4E>(x);    // quad_perm [2,3,0,1]
+    if (Dh4 >= 8) x += dpp_f32<0x141>(x);   // row_half_mirror: the other quad of the 8-lane half
+    if (Dh4 >= 16) x += dpp_f32<0x140>(x);  // row_mirror: the other half of the 16-lane row
+    if (Dh4 >= 32) x += __shfl_xor(x, 16);
+    if (Dh4 >= 64) x += __shfl_xor(x, 32);
     return x;  // total of this lane's head
   };
   const float cdot = head_sum(on ? dot4(go, out[v * ldo4 + cc]) : 0.f);

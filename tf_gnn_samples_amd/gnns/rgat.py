@@ -53,13 +53,18 @@ def sparse_rgat_layer(node_embeddings: torch.Tensor,
     L = graph.L
     activation_fn = get_activation(activation_function)
     w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")                        # [D, L*state_dim]
-    att = torch.stack([weights["Edge_%i_Attention_Parameters" % l] for l in range(L)], dim=0)
-    att = att.view(L, num_heads, 2 * per_head_dim)
+    att_flat = torch.stack([weights["Edge_%i_Attention_Parameters" % l] for l in range(L)], dim=0)    # [L, 2D]
+    att = att_flat.view(L, num_heads, 2 * per_head_dim)
     att_src, att_tgt = att[:, :, :per_head_dim], att[:, :, per_head_dim:]                   # [L, K, Dh] each
+    fused_scores = node_embeddings.is_cuda and ops.rgat_scores_supported(state_dim, num_heads)
 
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
         transformed = dense(cur_node_states, w_cat)                                               # [V, L*state_dim]
+        if fused_scores:   # score tables, softmax and weighted sum as one autograd node (csrc/rgat_scores.hip)
+            aggregated = ops.rgat_layer_attention(transformed.view(num_nodes * L, state_dim), att_flat, graph, num_heads, 0.2)
+            cur_node_states = apply_activation(activation_fn, aggregated)
+            continue
         t4 = transformed.view(num_nodes, L, num_heads, per_head_dim)
         s_src = (t4 * att_src.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)       # [V*L, K]
         s_tgt = (t4 * att_tgt.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)

@@ -452,6 +452,54 @@ class _RgatAttention(torch.autograd.Function):
         return gT, gs_src, gs_tgt, None, None, None
 
 
+def rgat_scores_supported(D: int, K: int) -> bool:
+    g = D // 4
+    return D % 4 == 0 and g in (8, 16, 32, 64) and K > 0 and g % K == 0 and ((g // K) & (g // K - 1)) == 0
+
+
+class _RgatLayerAttention(torch.autograd.Function):
+    """rgat.py:103-136 from the transformed rows T [V*L, D] and the stacked attention parameters att [L, 2D]:
+    score tables (csrc/rgat_scores.hip) -> segmented softmax -> attention-weighted sum, one autograd node; the
+    backward folds the score-table gradients into gT in place and reduces d att without atomics."""
+
+    @staticmethod
+    def forward(ctx, T, att, graph, num_heads: int, slope: float):
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        T, att = T.contiguous(), att.contiguous()
+        V, L = graph.V, graph.L
+        D = T.shape[1]
+        s_src = torch.empty((V * L, num_heads), dtype=torch.float32, device=T.device)
+        s_tgt = torch.empty_like(s_src)
+        _lib.check(lib.relgnn_rgat_scores_fwd(_lib.ptr(T), D, D, num_heads, _lib.ptr(att), L, V, _lib.ptr(s_src),
+                                              _lib.ptr(s_tgt), st), "relgnn_rgat_scores_fwd")
+        out = _RgatAttention.forward(ctx, T, s_src, s_tgt, graph, num_heads, slope)   # saves T, s_*, alpha, out
+        ctx.att = att
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .dense import column_sum
+        lib = _lib.load_library()
+        T = ctx.saved_tensors[0]
+        att, graph, K = ctx.att, ctx.graph, ctx.K
+        V, L = graph.V, graph.L
+        D = T.shape[1]
+        gT, gs_src, gs_tgt = _RgatAttention.backward(ctx, gout)[:3]
+        groups = int(lib.relgnn_rgat_scores_groups(V))
+        partial = torch.empty((groups, L * 2 * D), dtype=torch.float32, device=T.device)
+        _lib.check(lib.relgnn_rgat_scores_bwd(_lib.ptr(T), D, D, K, _lib.ptr(att), L, V, _lib.ptr(gs_src), _lib.ptr(gs_tgt),
+                                              _lib.ptr(gT), D, _lib.ptr(partial), groups, _lib.current_stream()),
+                   "relgnn_rgat_scores_bwd")
+        gatt = column_sum(partial).view(L, 2 * D)
+        return gT, gatt, None, None, None
+
+
+def rgat_layer_attention(T, att, graph, num_heads: int, slope: float = 0.2):
+    """T [V*L, D] (row v*L+l = h_v W_l), att [L, 2D] = the stacked Edge_%i_Attention_Parameters."""
+    return _RgatLayerAttention.apply(T, att, graph, int(num_heads), float(slope))
+
+
 def rgat_attention(T, s_src, s_tgt, graph, num_heads: int, slope: float = 0.2):
     """gnns/rgat.py:98-136: segmented softmax over all incoming messages + attention-weighted sum."""
     return _RgatAttention.apply(T, s_src, s_tgt, graph, int(num_heads), float(slope))
