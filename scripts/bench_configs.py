@@ -75,7 +75,7 @@ if any(w in which for w in ("C4", "RGIN", "MLP0", "MLP1")):
             p = cls.default_params(); p.update(extra); p.update(hidden_size=256, graph_num_layers=3)
             run("%s %s on C2 PPI-shaped batch D=256 3 layers" % (key, mname), quiet_model(cls, p, task), batch, mb, steps=10, prime=8)
 
-if "C5" in which:
+if "C5" in which or "VM" in which:
     graphs = make_varmisuse_shaped_graphs(42, seed=0)       # ~ one rank's share of the 10M-edge batch
     task = PPI_Task(PPI_Task.default_params())
     task._PPI_Task__num_edge_types = 23; task._PPI_Task__initial_node_feature_size = 128; task._PPI_Task__num_labels = 1
@@ -84,4 +84,12 @@ if "C5" in which:
     cls, extra = name_to_model_class("GNN-FiLM")
     p = cls.default_params(); p.update(hidden_size=128, graph_num_layers=10, graph_dense_between_every_num_gnn_layers=1,
                                        graph_residual_connection_every_num_layers=2)
-    run("C5 GNN-FiLM VarMisuse-shaped 23 types D=128 10 layers (1 rank share)", quiet_model(cls, p, task), batch, mb, steps=5, prime=5)
+    if "C5" in which:
+        run("C5 GNN-FiLM VarMisuse-shaped 23 types D=128 10 layers (1 rank share)", quiet_model(cls, p, task), batch, mb, steps=5, prime=5)
+    if "VM" in which:     # the other models of the reference's VarMisuse runs on the same batch (tasks/default_hypers/VarMisuse_*.json)
+        for mname in ("RGCN", "GGNN"):
+            cls, extra = name_to_model_class(mname)
+            p = cls.default_params(); p.update(extra)
+            p.update(hidden_size=128, graph_num_layers=10, graph_dense_between_every_num_gnn_layers=1,
+                     graph_residual_connection_every_num_layers=2)
+            run("VM %s VarMisuse-shaped 23 types D=128 10 layers" % mname, quiet_model(cls, p, task), batch, mb, steps=5, prime=5)

@@ -178,3 +178,56 @@ def test_film_model_trains_with_pair_tables(gpu_device, monkeypatch):
         losses[flag] = [float(model.train_step(batch)['loss'].detach()) for _ in range(4)]
     assert np.allclose(losses[None], losses["0"], rtol=2e-4, atol=1e-5), losses
     assert losses[None][-1] < losses[None][0]
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean", "max", "sqrt_n"])
+def test_rgcn_layer_compact_vs_oracle(gpu_device, monkeypatch, agg):
+    from tf_gnn_samples_amd.gnns import sparse_rgcn_layer
+    from tf_gnn_samples_amd.graph import clear_graph_cache
+    rng, adj, deg = _sparse_many_type_graph(5)
+    V, L, D = 300, 12, 64
+    w = rgcn_weights(rng, L, D, D)
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    ref = G.sparse_rgcn_layer(h, adj, deg, D, 2, "tanh", agg, True, weights=w)
+    dev = lambda x: torch.as_tensor(x, device=gpu_device)
+    adj_d, deg_d = [dev(a) for a in adj], dev(deg)
+    grads = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RELGNN_PAIR_TABLES", flag)
+        clear_graph_cache()
+        hd = dev(h).requires_grad_(True)
+        wd = {k: dev(v).requires_grad_(True) for k, v in w.items()}
+        out = sparse_rgcn_layer(hd, adj_d, deg_d, D, 2, "tanh", agg, True, weights=wd)
+        assert np.abs(out.detach().cpu().numpy() - ref).max() < 1e-5, flag
+        gout = np.random.default_rng(1).standard_normal(out.shape).astype(np.float32)
+        out.backward(dev(gout))
+        grads[flag] = (hd.grad.cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in wd.items()})
+    hr = torch.as_tensor(h, dtype=torch.float64).requires_grad_(True)
+    wr = {k: torch.as_tensor(v, dtype=torch.float64).requires_grad_(True) for k, v in w.items()}
+    r = R.sparse_rgcn_layer(hr, [torch.as_tensor(a) for a in adj], torch.as_tensor(deg), D, 2, "tanh", agg, True, weights=wr)
+    r.backward(torch.as_tensor(gout, dtype=torch.float64))
+    for flag in ("1", "0"):
+        gh, gw = grads[flag]
+        assert np.abs(gh - hr.grad.numpy()).max() < 5e-5 * max(1.0, float(hr.grad.abs().max())), flag
+        for k in w:
+            assert np.abs(gw[k] - wr[k].grad.numpy()).max() < 5e-5 * max(1.0, float(wr[k].grad.abs().max())), (flag, k)
+
+
+@pytest.mark.parametrize("agg", ["sum", "max"])
+def test_ggnn_layer_compact_vs_oracle(gpu_device, monkeypatch, agg):
+    from tf_gnn_samples_amd.gnns import sparse_ggnn_layer
+    from tf_gnn_samples_amd.graph import clear_graph_cache
+    rng, adj, deg = _sparse_many_type_graph(6)
+    V, L, D = 300, 12, 32
+    w = rgcn_weights(rng, L, D, D)
+    w["gru_cell/kernel"] = glorot(rng, (D, 3 * D))
+    w["gru_cell/recurrent_kernel"] = glorot(rng, (D, 3 * D))
+    w["gru_cell/bias"] = (0.1 * rng.standard_normal(3 * D)).astype(np.float32)
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    ref = G.sparse_ggnn_layer(h, adj, D, 2, "gru", "tanh", agg, weights=w)
+    dev = lambda x: torch.as_tensor(x, device=gpu_device)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RELGNN_PAIR_TABLES", flag)
+        clear_graph_cache()
+        out = sparse_ggnn_layer(dev(h), [dev(a) for a in adj], D, 2, "gru", "tanh", agg, weights={k: dev(v) for k, v in w.items()})
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-5, flag

@@ -46,11 +46,19 @@ def sparse_ggnn_layer(node_embeddings: torch.Tensor,
         if gated_unit_type.lower() != 'lstm'}
     gated_cell = get_gated_unit(state_dim, gated_unit_type, activation_function, cell_weights)
 
-    plan = graph.plan_transformed(None)
-    w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")
+    pairs = graph.pair_tables() if graph.wants_pair_tables() else None     # many-type graphs: non-empty buckets only
+    if pairs is not None:
+        plan = pairs.plan_transformed(None)
+        kernels = [weights["Edge_%i_Weight/kernel" % l] for l in range(L)]
+    else:
+        plan = graph.plan_transformed(None)
+        w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
-        transformed = dense(cur_node_states, w_cat).view(num_nodes * L, state_dim)
+        if pairs is not None:
+            transformed = ops.typed_linear(cur_node_states, pairs.src, kernels)
+        else:
+            transformed = dense(cur_node_states, w_cat).view(num_nodes * L, state_dim)
         aggregated_messages = ops.seg_gather_reduce(transformed, plan, message_aggregation_function, None)
         cur_node_states = gated_cell(aggregated_messages, [cur_node_states])[0]
     return cur_node_states

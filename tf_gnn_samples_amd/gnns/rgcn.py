@@ -71,6 +71,16 @@ def sparse_rgcn_layer(node_embeddings: torch.Tensor,
             cur_node_states = ops.fused_aggregate_transform(cur_node_states, w_stack, graph, w,
                                                             message_aggregation_function, activation_function)
         return cur_node_states
+    if not use_both_source_and_target and graph.wants_pair_tables():
+        # many edge types, most (node,type) buckets empty: transform the non-empty ones only (graph.PairTables)
+        pairs = graph.pair_tables()
+        plan = pairs.plan_transformed(w)
+        kernels = [weights["Edge_%i_Weight/kernel" % l] for l in range(L)]
+        for _ in range(num_timesteps):
+            transformed = ops.typed_linear(cur_node_states, pairs.src, kernels)          # [P_s, state_dim]
+            cur_node_states = reduce_and_activate(transformed, plan, message_aggregation_function,
+                                                  activation_function)
+        return cur_node_states
     if not use_both_source_and_target:
         plan = graph.plan_transformed(w)
         w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")          # [D, L*state_dim]

@@ -454,6 +454,38 @@ class PairTables:
         self.P_t, self.P_s = self.tgt.P, self.src.P
         self.col_t = self.src.bucket_row[g.col_t.long()].contiguous()
         self.frow_s = self.tgt.bucket_row[g.frow_s.long()].contiguous()
+        self._graph = g
+        self._by_row = None
+        self._plans = {}
+
+    def _messages_by_source_row(self):
+        """Stable bucketing of the messages by the compact row of their (source, type) bucket: the transposed plan
+        whose output rows ARE the compact rows (the table is type-major, the by-source order of RelGraph node-major)."""
+        if self._by_row is None:
+            g = self._graph
+            lib = _lib.load_library()
+            st = _lib.current_stream()
+            keys = self.src.bucket_row[g.key_by_source.long()].contiguous()            # row of every original message
+            rowptr, perm, _ = build_segment_plan(keys, self.P_s)
+            tgt, pos_t = _i32(g.M, g.device), _i32(g.M, g.device)
+            _lib.check(lib.relgnn_gather_div_i32(_lib.ptr(g.key_by_target), _lib.ptr(perm), g.M, g.L, _lib.ptr(tgt), st),
+                       "relgnn_gather_div_i32")
+            _lib.check(lib.relgnn_gather_i32(_lib.ptr(g.inv_perm_t), _lib.ptr(perm), g.M, _lib.ptr(pos_t), st),
+                       "relgnn_gather_i32")
+            self._by_row = (rowptr, tgt, pos_t)
+        return self._by_row
+
+    def plan_transformed(self, w: Optional[torch.Tensor] = None) -> GatherReducePlan:
+        """RelGraph.plan_transformed for a compact source table T [P_s, D]: messages gather row col_t[p]; the gradient
+        is reduced straight into the compact rows (padding rows own no message and come out zero)."""
+        key = None if w is None else w.data_ptr()
+        if key not in self._plans:
+            g = self._graph
+            rowptr_b, tgt_b, pos_b = self._messages_by_source_row()
+            self._plans[key] = (w, GatherReducePlan(
+                rowptr=g.rowptr_t, stride=g.L, col=self.col_t, w=w, num_out=g.V, num_rows_x=self.P_s,
+                rowptr_b=rowptr_b, stride_b=1, col_b=tgt_b, pos_b=pos_b, num_messages=g.M))
+        return self._plans[key][1]
 
 
 # ---- cache: the layer functions receive raw adjacency lists on every call ------------------
