@@ -138,3 +138,20 @@ def test_qm9_golden_batches_with_per_graph_targets():
         assert np.array_equal(b.type_to_num_incoming_edges.numpy(), fd["type_to_num_incoming_edges"].astype(np.float32))
         for l in range(task.num_edge_types):
             assert np.array_equal(b.adjacency_lists[l].numpy(), fd["adjacency_lists"][l])
+
+
+def test_iterator_can_be_abandoned_and_reports_packing_errors():
+    import threading
+    graphs = _random_graphs(np.random.default_rng(7), 30, 3)
+    store = GraphStore(graphs, 3, PAYLOADS)
+    nb = NativeBatcher(store, "cpu", num_threads=2)
+    before = threading.active_count()
+    it = nb.iterate(np.arange(30), 120)
+    first = next(it)
+    assert first.num_graphs >= 1
+    it.close()                                   # consumer walks away: the producer thread must end
+    assert threading.active_count() == before
+    # all batches again after an abandoned run (arenas are reused)
+    assert sum(b.num_graphs for b in nb.iterate(np.arange(30), 120)) == 30
+    with pytest.raises(ValueError):              # a graph that never fits is reported before any packing starts
+        list(nb.iterate(np.arange(30), 1))

@@ -237,15 +237,22 @@ class NativeBatcher:
         """All batches of `graph_ids` in order; batch i+1 is packed on a background thread while batch i is consumed
         (the reference's ThreadedIterator, models/sparse_graph_model.py:272)."""
         batches = self.store.split_batches(graph_ids, max_nodes_per_batch)
-        q = queue.Queue(maxsize=self.depth - 1)
-        # `depth` arenas in flight: one being consumed, up to depth-1 packed ahead
-        free = threading.Semaphore(self.depth - 1)
+        q = queue.Queue()
+        # A host arena may be re-packed only after the consumer has ISSUED the upload of the batch it holds (pack_host
+        # then waits for that copy to finish): one token per arena, taken by the producer, returned by the consumer.
+        # The producer therefore runs at most `depth` batches ahead, packing while the consumer enqueues GPU work.
+        slot_free = [threading.Semaphore(1) for _ in range(self.depth)]
+        stop = threading.Event()
 
         def produce():
             try:
                 for i, ids in enumerate(batches):
-                    free.acquire()
                     slot = i % self.depth
+                    while not slot_free[slot].acquire(timeout=0.05):
+                        if stop.is_set():
+                            return
+                    if stop.is_set():
+                        return
                     q.put((slot, self.pack_host(ids, slot)))
                 q.put(None)
             except BaseException as e:   # surface packing errors in the consumer
@@ -253,15 +260,18 @@ class NativeBatcher:
 
         t = threading.Thread(target=produce, daemon=True)
         t.start()
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            slot, packed = item
-            batch = self.upload(packed, slot)
-            yield batch
-            self.release(batch)          # the consumer is back: everything reading `batch` is enqueued
-            free.release()
-        t.join()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                slot, packed = item
+                batch = self.upload(packed, slot)
+                slot_free[slot].release()
+                yield batch
+                self.release(batch)      # the consumer is back: everything reading `batch` is enqueued
+        finally:                         # also runs when the consumer abandons the iterator early
+            stop.set()
+            t.join()
