@@ -349,7 +349,24 @@ class Sparse_Graph_Model(ABC):
         task_metric_results = []
         batch_iterator = iter(batch_iterator)
         upcoming = next(batch_iterator, None)
-        step = 0
+        state = {"graphs": 0, "nodes": 0, "edges": 0, "loss": 0.0, "step": 0}
+
+        def fetch(pending):
+            """Read one step's metrics back (the host sync of sess.run's fetch, :293)."""
+            m, mb = pending
+            m = {k: float(v) for k, v in m.items()}
+            check_pending_graph_errors()
+            state["graphs"] += mb.num_graphs
+            state["nodes"] += mb.num_nodes
+            state["edges"] += mb.num_edges
+            state["loss"] += m['loss'] * mb.num_graphs
+            task_metric_results.append(m)
+            if not quiet:
+                print("Running %s, batch %i (has %i graphs). Loss so far: %.4f"
+                      % (epoch_name, state["step"], mb.num_graphs, state["loss"] / state["graphs"]), end='\r')
+            state["step"] += 1
+
+        pending = None
         while upcoming is not None:
             mb = upcoming
             batch = mb if isinstance(mb, DeviceBatch) else DeviceBatch(mb, self.device)
@@ -358,20 +375,18 @@ class Sparse_Graph_Model(ABC):
             else:
                 with torch.no_grad():
                     m = self.forward_batch(batch, training=False)
-            # ask for the next batch BEFORE reading this step's metrics back: its upload and bucketing (copy stream)
-            # then overlap with this step's kernels instead of waiting behind the host sync below
+            # Pipeline: ask for the next batch (its upload and bucketing run on the copy stream under this step's
+            # kernels), THEN read back the metrics of the PREVIOUS step: that sync returns at once because the GPU
+            # is already past it, so the device never idles behind a host round trip.  Every step's metrics are
+            # still fetched, one step late.
             upcoming = next(batch_iterator, None)
-            m = {k: float(v) for k, v in m.items()}   # one sync per step, like sess.run's fetch
-            check_pending_graph_errors()
-            processed_graphs += mb.num_graphs
-            processed_nodes += mb.num_nodes
-            processed_edges += mb.num_edges
-            epoch_loss += m['loss'] * mb.num_graphs
-            task_metric_results.append(m)
-            if not quiet:
-                print("Running %s, batch %i (has %i graphs). Loss so far: %.4f"
-                      % (epoch_name, step, mb.num_graphs, epoch_loss / processed_graphs), end='\r')
-            step += 1
+            if pending is not None:
+                fetch(pending)
+            pending = ({k: (v.detach() if torch.is_tensor(v) else v) for k, v in m.items()}, mb)   # drops the autograd graph
+        if pending is not None:
+            fetch(pending)
+        processed_graphs, processed_nodes, processed_edges = state["graphs"], state["nodes"], state["edges"]
+        epoch_loss = state["loss"]
         epoch_time = time.time() - start_time
         per_graph_loss = epoch_loss / max(processed_graphs, 1)
         return (per_graph_loss, task_metric_results, processed_graphs, processed_graphs / epoch_time,
