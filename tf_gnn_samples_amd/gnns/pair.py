@@ -57,12 +57,10 @@ def edge_mlp_messages(cur: torch.Tensor, graph, weights: Mapping[str, torch.Tens
     hidden = ops.pair_materialize(p, q, graph, hidden_activation)                     # [M, Dh]
     act_fn = get_activation(hidden_activation)
     offs = graph.type_offsets
-    outs = []
-    for l in range(L):
-        h = hidden[offs[l]:offs[l + 1]]
-        for i in range(1, num_hidden_layers + 1):
-            h = dense(h, weights["%s/%s/kernel" % (mlp_name_pattern % l, names[i])])
-            if i < num_hidden_layers:
-                h = apply_activation(act_fn, h)
-        outs.append(h)
-    return torch.cat(outs, dim=0)
+    h = hidden
+    for i in range(1, num_hidden_layers + 1):
+        # one per-edge GEMM per edge type on its contiguous [E_l, D] block, written in place of a concat
+        h = ops.blocked_linear(h, offs, [weights["%s/%s/kernel" % (mlp_name_pattern % l, names[i])] for l in range(L)])
+        if i < num_hidden_layers:
+            h = apply_activation(act_fn, h)
+    return h

@@ -332,6 +332,49 @@ def _tile_starts(side):
     return out
 
 
+class _BlockedLinear(torch.autograd.Function):
+    """Y[a_l:b_l] = X[a_l:b_l] @ W_l for consecutive row blocks (the per-edge-type Dense layers of an edge MLP on the
+    type-major message list, utils/utils.py:120-126 via gnns/gnn_edge_mlp.py:102).  One autograd node instead of L
+    slices + L GEMM nodes + cat: outputs and input gradients are written straight into their row blocks (no concat,
+    no zero-filled accumulation buffer), weight gradients use the split-K reduction over the block's rows."""
+
+    @staticmethod
+    def forward(ctx, X, offsets, *weights):
+        X = X.contiguous()
+        Y = torch.empty((X.shape[0], weights[0].shape[1]), dtype=X.dtype, device=X.device)
+        for l, W in enumerate(weights):
+            a, b = offsets[l], offsets[l + 1]
+            if b > a:
+                torch.mm(X[a:b], W, out=Y[a:b])
+        ctx.offsets = offsets
+        ctx.save_for_backward(X, *weights)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        from .dense import matmul_tn_splitk
+        X, *weights = ctx.saved_tensors
+        offsets = ctx.offsets
+        gY = gY.contiguous()
+        gX = torch.empty_like(X) if ctx.needs_input_grad[0] else None
+        gW = []
+        for l, W in enumerate(weights):
+            a, b = offsets[l], offsets[l + 1]
+            if b > a:
+                if gX is not None:
+                    torch.mm(gY[a:b], W.t(), out=gX[a:b])
+                gW.append(matmul_tn_splitk(X[a:b], gY[a:b]) if ctx.needs_input_grad[2 + l] else None)
+            else:
+                gW.append(torch.zeros_like(W) if ctx.needs_input_grad[2 + l] else None)
+        return (gX, None, *gW)
+
+
+def blocked_linear(X, offsets, weights):
+    """X [M, Din] in consecutive row blocks offsets[l]:offsets[l+1]; weights: one [Din, Dout] kernel per block."""
+    _check_f32(X, "X")
+    return _BlockedLinear.apply(X, [int(o) for o in offsets], *weights)
+
+
 def typed_linear(H, side, weights):
     """[P, Dout] table over the non-empty (node,type) buckets of `side` (graph.SidePairs); weights: L x [Din, Dout]."""
     _check_f32(H, "H")
