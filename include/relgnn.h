@@ -492,6 +492,21 @@ int relgnn_gru_out_bwd(const float* gout, const float* z, const float* h, const 
 int relgnn_gru_gates_bwd(const float* grh, const float* gz, const float* z, const float* r, const float* h,
                          int64_t num_nodes, int32_t units, float* gxk, float* gh, void* stream);
 
+/* ---- layer normalisation of node states ------------------------------------------------------------------
+ * Replaces: tf.contrib.layers.layer_norm at gnns/gnn_film.py:120, gnns/rgin.py:139, gnns/gnn_edge_mlp.py:120 and
+ * models/sparse_graph_model.py:192-193: moments over the last axis (biased variance), y = (x-mean)*rsqrt(var+eps)*gamma+beta.
+ *   fwd : Y [rows, D]; mean, rstd [rows] are saved for the backward.
+ *   bwd : dX = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));
+ *         partial [num_groups, 2*D]: per lane-group sums of g*xhat (d gamma) and g (d beta); the caller column-sums
+ *         them (relgnn_column_sum).  num_groups = relgnn_layer_norm_groups(rows, D).
+ * D % 4 == 0, D <= 1024, 16-byte aligned rows (RELGNN_EUNSUPPORTED otherwise). */
+int64_t relgnn_layer_norm_groups(int64_t rows, int32_t D);
+int relgnn_layer_norm_fwd(const float* X, int64_t ldx, int64_t rows, int32_t D, const float* gamma, const float* beta,
+                          float eps, float* Y, int64_t ldy, float* mean, float* rstd, void* stream);
+int relgnn_layer_norm_bwd(const float* X, int64_t ldx, const float* gY, int64_t ldg, int64_t rows, int32_t D,
+                          const float* gamma, const float* mean, const float* rstd, float* dX, int64_t ldd,
+                          float* partial, int64_t num_groups, void* stream);
+
 /* ========================================================================== *
  * 9. Host-side disjoint-union batch builder (every pointer here is a HOST pointer)
  * ========================================================================== */

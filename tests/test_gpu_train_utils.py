@@ -55,3 +55,46 @@ def test_sigmoid_ce_stats_and_gradient(gpu_device):
     assert abs(float(stats[4]) - float(micro_f1(xd.detach(), zd))) < 1e-6
     gref = (1.0 / (1.0 + np.exp(-x.astype(np.float64))) - z) / V
     assert np.abs(xd.grad.cpu().numpy() - gref).max() < 1e-7
+
+
+@pytest.mark.parametrize("rows,D", [(1, 64), (7, 128), (5000, 128), (3001, 256), (513, 320), (257, 1000), (100, 32), (64, 6)])
+def test_layer_norm_kernel_matches_fp64_reference(gpu_device, rows, D):
+    """csrc/layer_norm.hip (tf.contrib.layers.layer_norm semantics: biased variance, eps 1e-12) forward and backward
+    against a float64 restatement; D = 6 takes the library fallback (not a multiple of 4)."""
+    from tf_gnn_samples_amd.utils import layer_norm
+    rng = np.random.default_rng(rows * 31 + D)
+    x = (rng.standard_normal((rows, D)) * 2.0 + 0.5).astype(np.float32)
+    gamma = (1.0 + 0.2 * rng.standard_normal(D)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    g = rng.standard_normal((rows, D)).astype(np.float32)
+    xd = torch.as_tensor(x, device=gpu_device).requires_grad_(True)
+    gd = torch.as_tensor(gamma, device=gpu_device).requires_grad_(True)
+    bd = torch.as_tensor(beta, device=gpu_device).requires_grad_(True)
+    y = layer_norm(xd, gd, bd)
+    y.backward(torch.as_tensor(g, device=gpu_device))
+    xr = torch.as_tensor(x, dtype=torch.float64).requires_grad_(True)
+    gr = torch.as_tensor(gamma, dtype=torch.float64).requires_grad_(True)
+    br = torch.as_tensor(beta, dtype=torch.float64).requires_grad_(True)
+    mean = xr.mean(1, keepdim=True)
+    var = ((xr - mean) ** 2).mean(1, keepdim=True)
+    yr = (xr - mean) / torch.sqrt(var + 1e-12) * gr + br
+    yr.backward(torch.as_tensor(g, dtype=torch.float64))
+    assert np.abs(y.detach().cpu().numpy() - yr.detach().numpy()).max() < 1e-5
+    assert np.abs(xd.grad.cpu().numpy() - xr.grad.numpy()).max() < 1e-5 * max(1.0, float(xr.grad.abs().max()))
+    assert np.abs(gd.grad.cpu().numpy() - gr.grad.numpy()).max() < 2e-5 * max(1.0, float(gr.grad.abs().max()))
+    assert np.abs(bd.grad.cpu().numpy() - br.grad.numpy()).max() < 2e-5 * max(1.0, float(br.grad.abs().max()))
+
+
+def test_layer_norm_constant_rows_and_determinism(gpu_device):
+    from tf_gnn_samples_amd.utils import layer_norm
+    x = torch.full((33, 128), 3.25, device=gpu_device)
+    gamma = torch.ones(128, device=gpu_device); beta = torch.full((128,), 0.5, device=gpu_device)
+    y = layer_norm(x, gamma, beta)
+    assert torch.equal(y, torch.full_like(y, 0.5))          # zero variance: (x - mean) == 0 exactly, eps keeps it finite
+    a = torch.randn(1000, 256, device=gpu_device, generator=torch.Generator(device=gpu_device).manual_seed(0))
+    outs = []
+    for _ in range(2):
+        xa = a.clone().requires_grad_(True); ga = gamma.new_ones(256).requires_grad_(True); ba = gamma.new_zeros(256).requires_grad_(True)
+        ya = layer_norm(xa, ga, ba); ya.square().sum().backward()
+        outs.append((ya.detach(), xa.grad, ga.grad, ba.grad))
+    assert all(torch.equal(p, q) for p, q in zip(*outs))

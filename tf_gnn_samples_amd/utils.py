@@ -8,8 +8,8 @@ error behaviour) on PyTorch-ROCm tensors.
   micro_f1                  utils/utils.py:61-74
   SMALL_NUMBER, BIG_NUMBER  utils/utils.py:6-7
 
-Node-wise dense work (Dense, GRU, layer norm) is plain PyTorch-ROCm (hipBLASLt / elementwise);
-it is not the gather/segment hot path.
+Node-wise GEMMs (Dense, GRU) are hipBLASLt through PyTorch-ROCm; the elementwise halves of the GRU cell and the layer
+normalisation are HIP kernels of librelgnn (csrc/gru.hip, csrc/layer_norm.hip).
 """
 import math
 from typing import Callable, List, Mapping, Optional, Union
@@ -77,10 +77,50 @@ def hard_sigmoid(x):
     return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """csrc/layer_norm.hip: one read + one write forward, d gamma / d beta without atomics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        from . import _lib
+        lib = _lib.load_library()
+        x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        V, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(V, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _lib.check(lib.relgnn_layer_norm_fwd(_lib.ptr(x), D, V, D, _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(y), D,
+                                             _lib.ptr(mean), _lib.ptr(rstd), _lib.current_stream()), "relgnn_layer_norm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        from .dense import column_sum
+        lib = _lib.load_library()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        V, D = x.shape
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        if V == 0:
+            return dx, torch.zeros_like(gamma), torch.zeros_like(gamma), None
+        groups = int(lib.relgnn_layer_norm_groups(V, D))
+        partial = torch.empty((groups, 2 * D), dtype=torch.float32, device=x.device)
+        _lib.check(lib.relgnn_layer_norm_bwd(_lib.ptr(x), D, _lib.ptr(gy), D, V, D, _lib.ptr(gamma), _lib.ptr(mean),
+                                             _lib.ptr(rstd), _lib.ptr(dx), D, _lib.ptr(partial), groups,
+                                             _lib.current_stream()), "relgnn_layer_norm_bwd")
+        gsum = column_sum(partial)
+        return dx, gsum[:D], gsum[D:], None
+
+
 def layer_norm(x, gamma, beta, eps: float = 1e-12):
     """tf.contrib.layers.layer_norm on a [V, D] tensor: moments over the last axis (biased
     variance), variance_epsilon 1e-12, learnable gamma/beta over the last axis."""
-    return torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
+    D = x.shape[-1]
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and D % 4 == 0 and D <= 1024:
+        return _LayerNormFn.apply(x, gamma, beta, float(eps))
+    return torch.nn.functional.layer_norm(x, (D,), gamma, beta, eps)
 
 
 class _FusedGRU(torch.autograd.Function):
