@@ -304,7 +304,11 @@ int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* 
                          int32_t D, const int32_t* rowptr, int32_t num_nodes,
                          int32_t num_edge_types, const int32_t* col, const float* w,
                          const float* gagg, int64_t ldg, float* gfilm, int64_t ldgf,
-                         const int32_t* bucket_row, void* stream);
+                         const int32_t* bucket_row, float* dmsg, void* stream);
+/* dmsg (nullable, [num_messages, D] contiguous, by-target order): pass A also writes every message's gradient
+ * w.r.t. its gathered row, dmsg[p] = w[p] * gamma * g_p (pair kernels: w[p] * g_p).  gT is then ONE plain
+ * gather-reduce of dmsg over the by-source buckets (relgnn_seg_reduce_fwd with col = by-target position of each
+ * by-source message) and pass B below, which re-gathers the 8*D-byte film row per MESSAGE, is not needed. */
 /* backward, pass B (by-(source,type) plan; row r of T owns its outgoing messages q):
  *   gT[r,:] = sum_q w_b[q] * gamma[frow_b[q],:] * g_q,
  *   g_q = gagg[tgt_b[q],:] * act'(gamma[frow_b[q]] * (w_b[q] * T[r,:]) + beta[frow_b[q]]) */
@@ -409,7 +413,7 @@ int relgnn_pair_fwd(int32_t mode, int32_t act, const float* P, int64_t ldp, cons
 int relgnn_pair_bwd_q(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq,
                       int32_t D, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
                       const int32_t* col, const float* w, const float* gagg, int64_t ldg, float* gQ,
-                      int64_t ldgq, void* stream);
+                      int64_t ldgq, float* dmsg /* nullable, see relgnn_film_bwd_film */, void* stream);
 int relgnn_pair_bwd_p(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq,
                       int32_t D, const int32_t* rowptr_b, int64_t num_rows_p, const int32_t* tgt_b,
                       const int32_t* frow_b, const float* w_b, const float* gagg, int64_t ldg,

@@ -408,3 +408,36 @@ def test_rgdcn_max_is_rejected_and_model_trains(gpu_device):
     batch = DeviceBatch(mb, gpu_device)
     losses = [float(model.train_step(batch)['loss'].detach()) for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("layer", ["film", "edge_mlp0"])
+def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer):
+    """The by-source backward has two implementations: gather-reduce of per-message gradients emitted by the by-target
+    pass (default) and the pass that re-gathers the per-bucket rows per message (RELGNN_EDGE_BWD_REGATHER=1,
+    relgnn_film_bwd_msg / relgnn_pair_bwd_p).  Same gradients from both."""
+    from tf_gnn_samples_amd.gnns import sparse_gnn_edge_mlp_layer, sparse_gnn_film_layer
+    rng, adj, deg = _graph(21)
+    V, L, D = 150, 3, 128
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    if layer == "film":
+        w = dict(rgcn_weights(rng, L, D, D), **LN(D))
+        for l in range(L):
+            w["Edge_%i_FiLM_Computations/kernel" % l] = glorot(rng, (D, 2 * D))
+        fn = lambda x, ww, a, d: sparse_gnn_film_layer(x, a, d, D, 1, "tanh", "mean", True, weights=ww)
+    else:
+        w = dict({"Edge_%i_MLP/dense/kernel" % l: glorot(rng, (2 * D, D)) for l in range(L)}, **LN(D))
+        fn = lambda x, ww, a, d: sparse_gnn_edge_mlp_layer(x, a, d, D, 1, "elu", "sum", True, True, 0, weights=ww)
+    adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
+    grads = []
+    for flag in (None, "1"):
+        if flag is None:
+            monkeypatch.delenv("RELGNN_EDGE_BWD_REGATHER", raising=False)
+        else:
+            monkeypatch.setenv("RELGNN_EDGE_BWD_REGATHER", flag)
+        hd = torch.as_tensor(h, device=gpu_device).requires_grad_(True)
+        wd = {k: torch.as_tensor(v, device=gpu_device).requires_grad_(True) for k, v in w.items()}
+        out = fn(hd, wd, adj_d, deg_d)
+        out.backward(torch.as_tensor(np.random.default_rng(2).standard_normal(out.shape).astype(np.float32), device=gpu_device))
+        grads.append([hd.grad] + [wd[k].grad for k in sorted(wd)])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))

@@ -49,7 +49,7 @@ _SIGNATURES = {
     "relgnn_pack_type_weights": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _ptr, _ptr]),
     "relgnn_rgcn_fused_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
-    "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_film_bwd_msg": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_rgat_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_rgat_bwd_logits": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
@@ -58,7 +58,7 @@ _SIGNATURES = {
     "relgnn_headw_reduce": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr]),
     "relgnn_rgat_dz": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_pair_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
-    "relgnn_pair_bwd_q": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_pair_bwd_q": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_pair_bwd_p": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_column_sum_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i32]),
     "relgnn_column_sum": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i64, _ptr, _ptr, ctypes.c_size_t, _ptr]),

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
     const float* __restrict__ w, const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gA,
-    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow) {
+    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow, float4* __restrict__ dmsg) {
   const GroupGeom gg = geom<G>(V, nlb);
   if (!gg.valid) return;
   const int64_t v = gg.node;
@@ -222,6 +222,9 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
               } else {
                 s1[c] = s1[c] + ww[u] * gp;
               }
+              // gradient w.r.t. the gathered row of THIS message, for the by-source reduction that follows
+              if (dmsg && on[c])
+                dmsg[(int64_t)(p + u) * D4 + gg.gl + G * c] = (KIND == KIND_FILM) ? ww[u] * (ra[c] * gp) : ww[u] * gp;
             }
           }
       }
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
     const float* __restrict__ w, const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gA,
-    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow) {
+    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow, float4* __restrict__ dmsg) {
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
@@ -462,6 +465,8 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
                 } else {
                   s1[c] = s1[c] + ww[u] * gp;
                 }
+                if (dmsg && on[c])
+                  dmsg[(int64_t)(p + k + u) * D4 + lane + 64 * c] = (KIND == KIND_FILM) ? ww[u] * (ra[c] * gp) : ww[u] * gp;
               }
             }
         }
@@ -641,9 +646,10 @@ template <int KIND>
 int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda, int32_t D,
                     const int32_t* rowptr, int32_t V, int32_t L, const int32_t* col, const float* w,
                     const float* gagg, int64_t ldg, float* gA, int64_t ldga, hipStream_t st,
-                    const int32_t* brow = nullptr) {
+                    const int32_t* brow = nullptr, float* dmsg = nullptr) {
   Geo geo;
-  if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(gagg, ldg) || !vec_ok(gA, ldga))
+  if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(gagg, ldg) || !vec_ok(gA, ldga) ||
+      !aligned16(dmsg))
     return RELGNN_EUNSUPPORTED;
   const int64_t nlb = logical_blocks(V, geo.G);
   const unsigned grid = padded_grid(nlb);
@@ -653,7 +659,7 @@ int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, in
 #define EDGE_ROWS_WAVE(NN)                                                                                          \
   edge_bwd_rows_wave_kernel<NN, KIND><<<padded_grid(wnlb), 256, 0, st>>>(                                            \
       (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4, \
-      (float4*)gA, ldga / 4, act, wnlb, brow)
+      (float4*)gA, ldga / 4, act, wnlb, brow, (float4*)dmsg)
     if (geo.NCH == 1) EDGE_ROWS_WAVE(1); else if (geo.NCH == 2) EDGE_ROWS_WAVE(2); else EDGE_ROWS_WAVE(4);
 #undef EDGE_ROWS_WAVE
     return launch_status();
@@ -661,7 +667,7 @@ int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, in
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     edge_bwd_rows_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
         (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4,
-        (float4*)gA, ldga / 4, act, nlb, brow);
+        (float4*)gA, ldga / 4, act, nlb, brow, (float4*)dmsg);
   });
   return launch_status();
 }
@@ -715,11 +721,11 @@ int relgnn_film_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, cons
 int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
                          int32_t D, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
                          const int32_t* col, const float* w, const float* gagg, int64_t ldg, float* gfilm,
-                         int64_t ldgf, const int32_t* bucket_row, void* stream) {
+                         int64_t ldgf, const int32_t* bucket_row, float* dmsg, void* stream) {
   if (bad_common(D, num_nodes, num_edge_types) || ldf < 2 * D || ldgf < 2 * D) return RELGNN_EINVAL;
   if (num_nodes == 0 || D == 0) return RELGNN_OK;
   if (!rowptr || !gagg || !gfilm) return RELGNN_EINVAL;
-  return launch_bwd_rows<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gfilm, ldgf, as_stream(stream), bucket_row);
+  return launch_bwd_rows<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gfilm, ldgf, as_stream(stream), bucket_row, dmsg);
 }
 
 int relgnn_film_bwd_msg(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
@@ -743,11 +749,12 @@ int relgnn_pair_fwd(int32_t mode, int32_t act, const float* P, int64_t ldp, cons
 
 int relgnn_pair_bwd_q(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq, int32_t D,
                       const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types, const int32_t* col,
-                      const float* w, const float* gagg, int64_t ldg, float* gQ, int64_t ldgq, void* stream) {
+                      const float* w, const float* gagg, int64_t ldg, float* gQ, int64_t ldgq, float* dmsg,
+                      void* stream) {
   if (bad_common(D, num_nodes, num_edge_types)) return RELGNN_EINVAL;
   if (num_nodes == 0 || D == 0) return RELGNN_OK;
   if (!rowptr || !gagg || !gQ) return RELGNN_EINVAL;
-  return launch_bwd_rows<KIND_PAIR>(act, P, ldp, Q, ldq, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gQ, ldgq, as_stream(stream));
+  return launch_bwd_rows<KIND_PAIR>(act, P, ldp, Q, ldq, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gQ, ldgq, as_stream(stream), nullptr, dmsg);
 }
 
 int relgnn_pair_bwd_p(int32_t act, const float* P, int64_t ldp, const float* Q, int64_t ldq, int32_t D,

@@ -5,6 +5,7 @@ get_aggregation_function (utils/utils.py:23-33), same argument names and meaning
 `seg_gather_reduce` is the fused form the layer functions use: the gather
 (tf.nn.embedding_lookup), the per-message scale and the segment reduction in ONE kernel.
 """
+import os
 from typing import Optional
 
 import torch
@@ -242,28 +243,44 @@ class _FusedEdgeMessages(torch.autograd.Function):
         f = _mode_factor(graph, mode)
         gagg = (gout * f.unsqueeze(1)).contiguous() if f is not None else gout.contiguous()
         gA = torch.empty_like(A)
-        gT = torch.empty_like(T)
         if pairs is not None:
             # compact tables: every real row is written by the kernels; the few padding rows are not and feed the
             # batched weight-gradient GEMM (against all-zero inputs, but 0 * NaN garbage would still poison it)
             gA.index_fill_(0, pairs.tgt.pad_rows, 0.0)
-            gT.index_fill_(0, pairs.src.pad_rows, 0.0)
+        # Pass A (by target) also emits every message's gradient w.r.t. its gathered row; gT is then one plain
+        # gather-reduce of those rows over the by-source buckets.  (The alternative pass B re-gathers the per-bucket
+        # row -- 8D bytes for FiLM -- once per MESSAGE in by-source order: RELGNN_EDGE_BWD_REGATHER=1 keeps it.)
+        emit = os.environ.get("RELGNN_EDGE_BWD_REGATHER") is None
+        dmsg = torch.empty((graph.M, D), dtype=torch.float32, device=T.device) if emit else None
         if kind == "film":
             col = graph.col_t if pairs is None else pairs.col_t
-            frow = graph.frow_s if pairs is None else pairs.frow_s
             brow_t = None if pairs is None else pairs.tgt.bucket_row
-            brow_s = None if pairs is None else pairs.src.bucket_row
             _lib.check(lib.relgnn_film_bwd_film(act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t),
                                                 V, L, _lib.ptr(col), _lib.ptr(w), _lib.ptr(gagg), D,
-                                                _lib.ptr(gA), A.shape[1], _lib.ptr(brow_t), st), "relgnn_film_bwd_film")
+                                                _lib.ptr(gA), A.shape[1], _lib.ptr(brow_t), _lib.ptr(dmsg), st),
+                       "relgnn_film_bwd_film")
+        else:
+            _lib.check(lib.relgnn_pair_bwd_q(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_t), V, L,
+                                             _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(gagg), D, _lib.ptr(gA), D,
+                                             _lib.ptr(dmsg), st), "relgnn_pair_bwd_q")
+        if emit:
+            if pairs is None:
+                gT = _seg_reduce_raw(_lib.AGG_SUM, dmsg, graph.rowptr_s, 1, graph.pos_t_of_s, None, V * L)
+            else:
+                rowptr_c, _, pos_c = pairs._messages_by_source_row()
+                gT = _seg_reduce_raw(_lib.AGG_SUM, dmsg, rowptr_c, 1, pos_c, None, pairs.P_s)   # padding rows: zero
+        elif kind == "film":
+            gT = torch.empty_like(T)
+            if pairs is not None:
+                gT.index_fill_(0, pairs.src.pad_rows, 0.0)
+            frow = graph.frow_s if pairs is None else pairs.frow_s
+            brow_s = None if pairs is None else pairs.src.bucket_row
             _lib.check(lib.relgnn_film_bwd_msg(act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_s),
                                                V * L, _lib.ptr(graph.tgt_s), _lib.ptr(frow),
                                                _lib.ptr(graph.w_by_source(w)), _lib.ptr(gagg), D, _lib.ptr(gT), D,
                                                _lib.ptr(brow_s), st), "relgnn_film_bwd_msg")
         else:
-            _lib.check(lib.relgnn_pair_bwd_q(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_t), V, L,
-                                             _lib.ptr(graph.col_t), _lib.ptr(w), _lib.ptr(gagg), D, _lib.ptr(gA), D, st),
-                       "relgnn_pair_bwd_q")
+            gT = torch.empty_like(T)
             _lib.check(lib.relgnn_pair_bwd_p(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_s), V * L,
                                              _lib.ptr(graph.tgt_s), _lib.ptr(graph.frow_s), _lib.ptr(graph.w_by_source(w)),
                                              _lib.ptr(gagg), D, _lib.ptr(gT), D, st), "relgnn_pair_bwd_p")
