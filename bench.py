@@ -156,7 +156,7 @@ def time_native_batch(task, graphs, device, iters=11):
     return float(np.median(pack_s)) * 1e3, float(np.median(upload_s)) * 1e3, int(packed[3]), nb.num_threads
 
 
-def epoch_pipeline_throughput(model, device, num_graphs=64, epochs=2):
+def epoch_pipeline_throughput(model, device, num_graphs=64, epochs=5):
     """edges/sec the way the reference prints it (models/sparse_graph_model.py:263-311): whole training epochs over
     DISTINCT batches, host batching and the feed included, one metrics fetch (host sync) per step.  Here the feed is
     the input pipeline of tasks/batcher.py (C++ packing -> one H2D copy -> bucketing on the copy stream, one batch
@@ -169,19 +169,20 @@ def epoch_pipeline_throughput(model, device, num_graphs=64, epochs=2):
     rng_state = np.random.get_state()
     model._run_epoch("pipeline warm-up", data, DataFold.TRAIN, quiet=True)      # store flattening, arenas, code objects
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    edges = graphs = steps = 0
+    edges_per_epoch = sum(sum(len(a) for a in g.adjacency_lists) for g in data)
+    times, steps = [], 0
     for _ in range(epochs):
-        _, res, n, _, _, es = model._run_epoch("pipeline", data, DataFold.TRAIN, quiet=True)
-        graphs += n
-        steps += len(res)
-        edges += sum(sum(len(a) for a in g.adjacency_lists) for g in data)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, res, n, _, _, _ = model._run_epoch("pipeline", data, DataFold.TRAIN, quiet=True)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        steps = len(res)
     np.random.set_state(rng_state)
-    return {"edges_per_sec": edges / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "graphs": graphs,
-            "edges_per_step": edges / steps, "what": "training epochs over distinct PPI-shaped batches incl. C++ batch "
-            "packing, H2D, bucketing and one host metrics fetch per step (the reference's own edges/sec definition)"}
+    med = float(np.median(times))
+    return {"edges_per_sec": edges_per_epoch / med, "ms_per_step": med / steps * 1e3, "steps_per_epoch": steps,
+            "epoch_ms": [t * 1e3 for t in times], "edges_per_step": edges_per_epoch / steps,
+            "what": "median of %d training epochs over distinct PPI-shaped batches incl. C++ batch packing, H2D, "
+                    "bucketing and one host metrics fetch per step (the reference's own edges/sec definition)" % epochs}
 
 
 def cpu_baseline(sample_graphs, params):
@@ -189,8 +190,9 @@ def cpu_baseline(sample_graphs, params):
     -> concat -> index_add -> ReLU), full training step (fwd + bwd through autograd) on a bounded
     sample of the same workload, all host cores."""
     from oracle import torch_ref as R
+    from tf_gnn_samples_amd.parallel import effective_cpu_count
     from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
-    cores = os.cpu_count() or 1
+    cores = effective_cpu_count()          # the cgroup quota, not the host's hardware threads
     torch.set_num_threads(cores)
     task = PPI_Task(PPI_Task.default_params())
     mb = next(PPI_Task.make_minibatch_iterator(task, list(sample_graphs), DataFold.VALIDATION, 10 ** 9))
@@ -222,13 +224,13 @@ def cpu_baseline(sample_graphs, params):
         loss.backward()
         return float(loss.detach())
 
-    # torch-CPU with every hardware thread can be far slower than with fewer (OpenMP barriers on the
-    # many small ops): probe a truncated problem at a few thread counts and keep the fastest.
+    # torch-CPU with every available thread can be slower than with fewer (OpenMP barriers on the many small ops):
+    # probe a truncated problem at a few thread counts and keep the fastest.
     full_adj, full_deg = adj, deg
     probe_edges = 20000
     adj = [a[:probe_edges] for a in full_adj]
     best = None
-    for threads in sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True):
+    for threads in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
         torch.set_num_threads(threads)
         step()
         t0 = time.time()
@@ -249,7 +251,9 @@ def cpu_baseline(sample_graphs, params):
         if time.time() - t0 > 10.0 or n >= 5:
             break
     dt = (time.time() - t0) / n
+    torch.set_num_threads(max(1, effective_cpu_count() // 2))
     return {"value": mb.num_edges / dt, "unit": "edges/sec", "cores": cores, "kind": "port",
+            "host": "%d hardware threads visible, cgroup CPU quota %d" % (os.cpu_count() or 1, effective_cpu_count()),
             "sample": "full train step (fwd+bwd) on %d of the batch's graphs (%d edges), %d timed steps, torch-CPU fp32 "
                       "restatement of gnns/rgcn.py op order incl. per-edge matmul" % (len(sample_graphs), mb.num_edges, n),
             "ms_per_step": dt * 1e3}
@@ -262,7 +266,11 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    from tf_gnn_samples_amd.parallel import GradientAllReducer, init_distributed
+    from tf_gnn_samples_amd.parallel import GradientAllReducer, effective_cpu_count, init_distributed
+    # torch's CPU thread pool defaults to the host's hardware threads (256); the container may be capped far below
+    # that, and a burst of busy threads beyond the quota stalls the whole process for tens of milliseconds
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    torch.set_num_threads(max(1, effective_cpu_count() // (2 * max(1, local_world))))
     # debug knobs (single-GPU dry run of the N>1 path): RELGNN_DIST_BACKEND=gloo RELGNN_FORCE_DEVICE=0
     force_dev = os.environ.get("RELGNN_FORCE_DEVICE")
     if force_dev is not None:

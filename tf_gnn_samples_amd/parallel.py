@@ -33,6 +33,31 @@ def shard_graphs_by_edges(edge_counts: Sequence[int], world_size: int) -> List[L
     return [sorted(s) for s in shards]
 
 
+def effective_cpu_count() -> int:
+    """CPUs this process may actually keep busy: the cgroup CPU quota (v2 cpu.max, v1 cfs quota) and the affinity
+    mask, whichever is smaller.  os.cpu_count() reports the host's hardware threads (256 on the MI355X boxes) even when
+    the container is capped at 16 CPUs; running more busy threads than the quota gets the whole process throttled for
+    the rest of the 100 ms scheduler period (observed: 30-60 ms stalls in host-side batching)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p_ > 0:
+                n = min(n, max(1, q // p_))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def init_distributed(backend: str = None):
     """One process per GPU; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -133,7 +133,8 @@ class NativeBatcher:
     def __init__(self, store: GraphStore, device, num_threads: Optional[int] = None, depth: int = 2,
                  features: str = "initial_node_features", constants: Optional[dict] = None, bucket: bool = True):
         self.store, self.device = store, torch.device(device)
-        self.num_threads = int(num_threads or min(8, os.cpu_count() or 1))
+        from ..parallel import effective_cpu_count
+        self.num_threads = int(num_threads or max(1, min(8, effective_cpu_count() // 2)))   # leave the quota's other half to torch
         self.depth = max(2, int(depth))
         self.features = features
         self.constants = dict(constants or {})
