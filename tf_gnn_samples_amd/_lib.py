@@ -6,7 +6,6 @@ call fails loudly.  (The NumPy oracle under oracle/ is test infrastructure and i
 imported from here.)
 """
 import ctypes
-import os
 from pathlib import Path
 
 import torch  # imported first on purpose: makes torch's libamdhip64.so.7 the process-wide HIP runtime

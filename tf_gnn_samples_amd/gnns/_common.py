@@ -4,7 +4,6 @@ from typing import Mapping, Optional
 import torch
 
 from .. import _lib, ops
-from ..graph import RelGraph, as_rel_graph
 from ..utils import apply_activation, get_activation
 
 

@@ -14,7 +14,7 @@ import torch
 from .. import ops
 from ..dense import dense
 from ..graph import as_rel_graph
-from ..utils import MLP, apply_activation, get_activation, layer_norm
+from ..utils import MLP, layer_norm
 from ._common import require_weights
 from .pair import edge_mlp_messages, pair_messages_reduce
 

@@ -6,7 +6,7 @@ The first Dense layer on the concatenation splits into two node-side GEMMs,
 P = H @ W[:D] (rows src*L+l) and Q = H @ W[D:] (rows tgt*L+l); the per-message sum
 P[col[p]] + Q[v*L+l] is formed inside the HIP kernel (csrc/edge_fused.hip).
 """
-from typing import Mapping, Optional, Sequence
+from typing import Mapping, Optional
 
 import torch
 

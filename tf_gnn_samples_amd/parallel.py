@@ -15,7 +15,6 @@ is applied AFTER the all-reduce.
 import os
 from typing import List, Sequence
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

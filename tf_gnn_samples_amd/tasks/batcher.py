@@ -11,7 +11,6 @@ host threads directly in pinned memory, and the whole batch crosses PCIe as ONE 
 previous batch computes (NativeBatcher.iterate: double-buffered arenas, packing on a background thread).
 """
 import ctypes
-import os
 import queue
 import threading
 from typing import Dict, Iterator, List, Optional, Sequence

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from ..dense import dense
-from ..utils import micro_f1, micro_f1_label_masks
+from ..utils import micro_f1
 from .sparse_graph_task import DataFold, MinibatchData, Sparse_Graph_Task
 from .synthetic import GraphSample, make_ppi_shaped_graphs
 

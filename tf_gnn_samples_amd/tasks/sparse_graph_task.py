@@ -6,7 +6,7 @@ A minibatch is ONE disjoint-union graph:
   type_to_num_incoming_edges  float32 [L, V]   (float despite the reference docstring, :144-145)
 """
 from enum import Enum
-from typing import Any, Dict, List, NamedTuple, Optional
+from typing import Any, Dict, NamedTuple, Optional
 
 import numpy as np
 import torch
