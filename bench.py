@@ -426,6 +426,8 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic_bytes(), "traffic_source": "latest profiles/*_seg_reduce_pmc.csv (rocprofv3 --pmc FETCH_SIZE / "
             "WRITE_SIZE, separate passes; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)",
+            "traffic_GBps": (pmc_traffic_bytes() / (k_ms * 1e-3) / 1e9) if pmc_traffic_bytes() else None,
+            "traffic_frac_of_peak": (pmc_traffic_bytes() / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc_traffic_bytes() else None,
             "avg_kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
             "messages_per_launch": M, "edge_layers_per_sec": M / (k_ms * 1e-3),
         },

@@ -31,7 +31,13 @@ def step(mode):
 for _ in range(25):
     step("serial")
 enable_gemm_autotuning(tune=False)
-for mode in ("serial", "side", "cached"):
+hi = torch.cuda.Stream(priority=-1)
+print("priority range:", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "n/a")
+for mode in ("serial", "side", "cached", "side-hiprio-main"):
+    if mode == "side-hiprio-main":
+        hi.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hi)
+        mode = "side"
     for _ in range(5):
         step(mode)
     torch.cuda.synchronize()
