@@ -75,3 +75,26 @@ def test_qm9_native_batches_train_step(gpu_device):
         loss, res, n, *_ = model._run_epoch("valid", data[:64], DataFold.VALIDATION, quiet=True)
         outs.append((loss, n, [r['abs_err_task0'] for r in res]))
     assert outs[0] == outs[1]
+
+
+def test_train_loop_early_stopping_and_restore(gpu_device, tmp_path):
+    """Sparse_Graph_Model.train() end to end on the GPU (native input pipeline, deferred metric fetch, best-model
+    pickle in the reference's format, :318-371) and test() on the restored weights."""
+    import pickle
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold
+    task = _ppi_task(8, 3)
+    params = RGCN_Model.default_params()
+    params.update(hidden_size=64, graph_num_layers=2, max_nodes_in_batch=900, max_epochs=4, patience=2, random_seed=0)
+    model = RGCN_Model(params, task, run_id="t", result_dir=str(tmp_path), device=gpu_device)
+    first = model._run_epoch("probe", task._loaded_data[DataFold.VALIDATION], DataFold.VALIDATION, quiet=True)[0]
+    model.train(quiet=True)
+    with open(model.best_model_file, "rb") as f:
+        saved = pickle.load(f)
+    assert set(saved) >= {"weights", "model_params", "task_params", "model_class"}      # models/sparse_graph_model.py:91-107
+    assert all(k.endswith(":0") for k in saved["weights"])
+    restored = RGCN_Model(params, task, run_id="r", result_dir=str(tmp_path), device=gpu_device)
+    restored.load_weights(saved["weights"])
+    loss = restored._run_epoch("valid", task._loaded_data[DataFold.VALIDATION], DataFold.VALIDATION, quiet=True)[0]
+    assert np.isfinite(loss) and loss < first          # training improved the validation loss, restore carries it over
+    restored.test(task._loaded_data[DataFold.VALIDATION], quiet=True)
