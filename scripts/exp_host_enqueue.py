@@ -31,6 +31,8 @@ def step(mode):
 for _ in range(25):
     step("serial")
 enable_gemm_autotuning(tune=False)
+if os.environ.get("SINGLE_THREAD_AUTOGRAD"):
+    torch.autograd.set_multithreading_enabled(False)
 hi = torch.cuda.Stream(priority=-1)
 print("priority range:", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "n/a")
 for mode in ("serial", "side", "cached", "side-hiprio-main"):

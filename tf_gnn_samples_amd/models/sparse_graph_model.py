@@ -314,7 +314,10 @@ class Sparse_Graph_Model(ABC):
         """forward + backward + per-variable clip + optimizer update == one sess.run with train_step (:287-293)."""
         self.optimizer.zero_grad()
         metrics = self.forward_batch(batch, training=True)
-        metrics['loss'].backward()
+        # one process drives one GPU: running the backward on the calling thread instead of the autograd engine's
+        # device thread saves the hand-off per node (host enqueue 1.56 -> 1.29 ms per C2 step) and a busy CPU thread
+        with torch.autograd.set_multithreading_enabled(False):
+            metrics['loss'].backward()
         if grad_hook is not None:  # data-parallel gradient all-reduce goes here (before clipping)
             grad_hook(self.optimizer.params)
         lr_scale = 1.0
