@@ -456,8 +456,9 @@ int relgnn_column_sum(const float* X, int64_t rows, int32_t cols, int64_t ld, fl
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller) [TF-internal update rule]
  * h_* are HOST arrays of n <= RELGNN_MT_MAX device pointers / element counts; norms is a device [n] array.
  */
+size_t relgnn_mt_l2norm_workspace_bytes(void);
 int relgnn_mt_l2norm(const float* const* h_grads, const int64_t* h_sizes, int32_t n, float* norms,
-                     void* stream);
+                     void* workspace, size_t workspace_bytes, void* stream);
 int relgnn_mt_adam_clip(float* const* h_params, const float* const* h_grads, float* const* h_m,
                         float* const* h_v, const int64_t* h_sizes, int32_t n, const float* norms,
                         float clip, float lr_t, float beta1, float beta2, float eps, void* stream);

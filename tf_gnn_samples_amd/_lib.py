@@ -61,7 +61,8 @@ _SIGNATURES = {
     "relgnn_pair_bwd_p": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_column_sum_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i32]),
     "relgnn_column_sum": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i64, _ptr, _ptr, ctypes.c_size_t, _ptr]),
-    "relgnn_mt_l2norm": (ctypes.c_int, [_ptr, _ptr, _c_i32, _ptr, _ptr]),
+    "relgnn_mt_l2norm_workspace_bytes": (ctypes.c_size_t, []),
+    "relgnn_mt_l2norm": (ctypes.c_int, [_ptr, _ptr, _c_i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     "relgnn_mt_adam_clip": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _ptr]),
     "relgnn_sigmoid_ce_stats_workspace_bytes": (ctypes.c_size_t, []),
     "relgnn_sigmoid_ce_stats": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr, ctypes.c_size_t, _ptr]),

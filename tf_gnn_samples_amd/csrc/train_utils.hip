@@ -36,19 +36,35 @@ __device__ __forceinline__ double block_sum_1024(double x, double* red) {
   return t;  // valid in thread 0
 }
 
-// one 1024-thread block per tensor: norms[t] = sqrt(sum g^2)
-__global__ __launch_bounds__(1024) void mt_l2norm_kernel(NormArgs a, float* __restrict__ norms) {
-  __shared__ double red[16];
-  const int t = blockIdx.x;
+// norms[t] = sqrt(sum g^2): grid (kNormChunks, tensors) of partial sums in double, then one small block per tensor
+// adds the kNormChunks partials in a fixed order (deterministic; a single block per tensor took 35 us for the
+// 196 k-element kernels of C2, this pair takes ~10 us)
+constexpr int kNormChunks = 32;
+
+__global__ __launch_bounds__(256) void mt_l2norm_partial_kernel(NormArgs a, double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int t = blockIdx.y;
   const float* g = a.g[t];
   const long long n = a.n[t];
   double acc = 0.0;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double x = g[i];
     acc += x * x;
   }
-  const double s = block_sum_1024(acc, red);
-  if (threadIdx.x == 0) norms[t] = (float)sqrt(s);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long long)t * kNormChunks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void mt_l2norm_final_kernel(const double* __restrict__ partial, float* __restrict__ norms) {
+  const int t = blockIdx.x;
+  double x = threadIdx.x < kNormChunks ? partial[(long long)t * kNormChunks + threadIdx.x] : 0.0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+  if (threadIdx.x == 0) norms[t] = (float)sqrt(x);
 }
 
 // grid (chunks, tensors): g' = g * clip / max(||g||, clip)  (tf.clip_by_norm), then TF1 Adam:
@@ -104,17 +120,33 @@ __global__ __launch_bounds__(1024) void sigmoid_ce_stats_kernel(const float* __r
   s = block_sum_1024(fn, red);   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = s;
 }
 
-__global__ void sigmoid_ce_stats_final_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ stats) {
+// 256 threads: thread b holds the four partial sums of block b; fixed-shape tree reduction
+__global__ __launch_bounds__(256) void sigmoid_ce_stats_final_kernel(const double* __restrict__ partial, int nblk,
+                                                                     float* __restrict__ stats) {
+  __shared__ double red[4][4];
   __shared__ double tot[4];
-  const int k = threadIdx.x;
-  if (k < 4) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[b * 4 + k];
-    stats[k] = (float)s;
-    tot[k] = s;
+  const int b = threadIdx.x;
+  double v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = b < nblk ? partial[b * 4 + k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off);
+  }
+  const int wave = b >> 6, lane = b & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wave][k] = v[k];
   }
   __syncthreads();
-  if (k == 0) {
+  if (b < 4) {
+    const double s = (red[0][b] + red[1][b]) + (red[2][b] + red[3][b]);
+    stats[b] = (float)s;
+    tot[b] = s;
+  }
+  __syncthreads();
+  if (b == 0) {
     // utils/utils.py:70-74: int64 counts, float64 true division, cast to float32
     const double precision = tot[1] / (tot[1] + tot[2]);
     const double recall = tot[1] / (tot[1] + tot[3]);
@@ -139,17 +171,23 @@ constexpr int kStatsBlocks = 256;
 
 extern "C" {
 
-int relgnn_mt_l2norm(const float* const* h_grads, const int64_t* h_sizes, int32_t n, float* norms, void* stream) {
+size_t relgnn_mt_l2norm_workspace_bytes(void) { return (size_t)RELGNN_MT_MAX * kNormChunks * sizeof(double); }
+
+int relgnn_mt_l2norm(const float* const* h_grads, const int64_t* h_sizes, int32_t n, float* norms, void* workspace,
+                     size_t workspace_bytes, void* stream) {
   if (n < 0 || n > RELGNN_MT_MAX) return RELGNN_EINVAL;
   if (n == 0) return RELGNN_OK;
   if (!h_grads || !h_sizes || !norms) return RELGNN_EINVAL;
+  if (!workspace || workspace_bytes < relgnn_mt_l2norm_workspace_bytes()) return RELGNN_ENOSPC;
   NormArgs a;
   for (int i = 0; i < n; ++i) {
     if (h_sizes[i] < 0 || (h_sizes[i] > 0 && !h_grads[i])) return RELGNN_EINVAL;
     a.g[i] = h_grads[i];
     a.n[i] = h_sizes[i];
   }
-  mt_l2norm_kernel<<<n, 1024, 0, as_stream(stream)>>>(a, norms);
+  double* partial = static_cast<double*>(workspace);
+  mt_l2norm_partial_kernel<<<dim3(kNormChunks, (unsigned)n), 256, 0, as_stream(stream)>>>(a, partial);
+  mt_l2norm_final_kernel<<<n, 64, 0, as_stream(stream)>>>(partial, norms);
   return launch_status();
 }
 
@@ -184,7 +222,7 @@ int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n,
   if (nblk < 1) nblk = 1;
   if (nblk > kStatsBlocks) nblk = kStatsBlocks;
   sigmoid_ce_stats_kernel<<<nblk, 1024, 0, st>>>(logits, labels, n, static_cast<double*>(workspace));
-  sigmoid_ce_stats_final_kernel<<<1, 64, 0, st>>>(static_cast<const double*>(workspace), nblk, stats);
+  sigmoid_ce_stats_final_kernel<<<1, 256, 0, st>>>(static_cast<const double*>(workspace), nblk, stats);
   return launch_status();
 }
 

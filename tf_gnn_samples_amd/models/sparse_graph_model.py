@@ -82,7 +82,9 @@ class TFStyleOptimizer:
             h_v = arr(*[self.v[i].data_ptr() for i in chunk])
             h_n = (ctypes.c_int64 * n)(*[self.params[i].numel() for i in chunk])
             norms = torch.empty(n, dtype=torch.float32, device=self.params[chunk[0]].device)
-            _lib.check(lib.relgnn_mt_l2norm(h_g, h_n, n, _lib.ptr(norms), st), "relgnn_mt_l2norm")
+            ws_bytes = lib.relgnn_mt_l2norm_workspace_bytes()
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=norms.device)
+            _lib.check(lib.relgnn_mt_l2norm(h_g, h_n, n, _lib.ptr(norms), _lib.ptr(ws), ws_bytes, st), "relgnn_mt_l2norm")
             _lib.check(lib.relgnn_mt_adam_clip(h_p, h_g, h_m, h_v, h_n, n, _lib.ptr(norms), float(self.clip), lr_t,
                                                b1, b2, eps, st), "relgnn_mt_adam_clip")
 
