@@ -55,19 +55,32 @@ def sparse_rgat_layer(node_embeddings: torch.Tensor,
     w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")                        # [D, L*state_dim]
     att_flat = torch.stack([weights["Edge_%i_Attention_Parameters" % l] for l in range(L)], dim=0)    # [L, 2D]
     att = att_flat.view(L, num_heads, 2 * per_head_dim)
-    att_src, att_tgt = att[:, :, :per_head_dim], att[:, :, per_head_dim:]                   # [L, K, Dh] each
-    fused_scores = node_embeddings.is_cuda and ops.rgat_scores_supported(state_dim, num_heads)
+    # The kernels give every head whole float4 lanes.  A head width that is not a multiple of 4 (state_dim 36 with
+    # 2 heads, ...) is zero-padded: zero COLUMNS appended to every head of the edge kernels and zero entries to both
+    # halves of the attention parameters change neither the logits nor the weighted sums; the pad columns of the
+    # result are dropped again.  (Weights only: the padding costs one small copy per layer call.)
+    pad = (-per_head_dim) % 4
+    dh = per_head_dim + pad
+    width = num_heads * dh
+    if pad:
+        w_cat = torch.nn.functional.pad(w_cat.view(in_dim, L, num_heads, per_head_dim), (0, pad)).reshape(in_dim, L * width)
+        att = torch.cat([torch.nn.functional.pad(att[:, :, :per_head_dim], (0, pad)),
+                         torch.nn.functional.pad(att[:, :, per_head_dim:], (0, pad))], dim=2)          # [L, K, 2*dh]
+        att_flat = att.reshape(L, 2 * width)
+    att_src, att_tgt = att[:, :, :dh], att[:, :, dh:]                                       # [L, K, dh] each
+    fused_scores = node_embeddings.is_cuda and ops.rgat_scores_supported(width, num_heads)
 
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
-        transformed = dense(cur_node_states, w_cat)                                               # [V, L*state_dim]
+        transformed = dense(cur_node_states, w_cat)                                               # [V, L*width]
         if fused_scores:   # score tables, softmax and weighted sum as one autograd node (csrc/rgat_scores.hip)
-            aggregated = ops.rgat_layer_attention(transformed.view(num_nodes * L, state_dim), att_flat, graph, num_heads, 0.2)
-            cur_node_states = apply_activation(activation_fn, aggregated)
-            continue
-        t4 = transformed.view(num_nodes, L, num_heads, per_head_dim)
-        s_src = (t4 * att_src.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)       # [V*L, K]
-        s_tgt = (t4 * att_tgt.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)
-        aggregated = ops.rgat_attention(transformed.view(num_nodes * L, state_dim), s_src, s_tgt, graph, num_heads, 0.2)
+            aggregated = ops.rgat_layer_attention(transformed.view(num_nodes * L, width), att_flat, graph, num_heads, 0.2)
+        else:
+            t4 = transformed.view(num_nodes, L, num_heads, dh)
+            s_src = (t4 * att_src.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)   # [V*L, K]
+            s_tgt = (t4 * att_tgt.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)
+            aggregated = ops.rgat_attention(transformed.view(num_nodes * L, width), s_src, s_tgt, graph, num_heads, 0.2)
+        if pad:
+            aggregated = aggregated.view(num_nodes, num_heads, dh)[:, :, :per_head_dim].reshape(num_nodes, state_dim)
         cur_node_states = apply_activation(activation_fn, aggregated)
     return cur_node_states
