@@ -138,10 +138,18 @@ class SegmentPlanCache:
             return hit[1]
         ids = segment_ids.to(torch.int32).contiguous()
         M = ids.numel()
+        segments = int(num_segments)
         if M > 0:
             lo, hi = int(ids.min()), int(ids.max())
-            if lo < 0 or hi >= num_segments:  # TF-CPU: InvalidArgumentError
+            if hi >= num_segments:  # TF-CPU: InvalidArgumentError
                 raise ValueError("segment id out of range [0, %d)" % num_segments)
+            if lo < 0:
+                # tf.unsorted_segment_*: "if the given segment ID is negative, the value is dropped".  Dropped rows go
+                # to one extra bucket behind the real ones; the caller slices it off (and autograd's slice backward
+                # hands those rows a zero gradient).
+                ids = torch.where(ids < 0, torch.full_like(ids, segments), ids)
+                segments += 1
+        num_segments = segments
         rowptr, perm, _ = build_segment_plan(ids, num_segments)
         lib = _lib.load_library()
         inv = torch.empty_like(perm)
@@ -168,6 +176,8 @@ def _unsorted_segment(mode_name, data, segment_ids, num_segments):
     flat = data.reshape(lead, -1)
     plan = _SEGMENT_PLANS.get(segment_ids, int(num_segments))
     out = _SegGatherReduce.apply(flat, plan, aggregation_mode_id(mode_name), _lib.ACT_LINEAR)
+    if plan.num_out > int(num_segments):          # the bucket of rows with negative ids (dropped, like TF)
+        out = out[:int(num_segments)]
     return out.reshape((int(num_segments),) + tuple(data.shape[1:]))
 
 
