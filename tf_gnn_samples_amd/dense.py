@@ -49,11 +49,12 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     N = b.shape[1]
     S = _split_count(V, M, N)
     if S <= 1:
-        return a.t() @ b
+        return torch.mm(a.t(), b)
     c = V // S
-    out = torch.bmm(a[:c * S].view(S, c, M).transpose(1, 2), b[:c * S].view(S, c, N)).sum(0)
-    if c * S < V:
-        out = out + a[c * S:].t() @ b[c * S:]
+    head = c * S
+    out = torch.bmm(a[:head].view(S, c, M).transpose(1, 2), b[:head].view(S, c, N)).sum(0)
+    if head < V:
+        out.addmm_(a[head:].t(), b[head:])       # the < c leftover rows, accumulated in place
     return out
 
 
