@@ -1,0 +1,23 @@
+"""Soak: many training steps / epochs through the native input pipeline; device memory must stay flat."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np, torch
+from tf_gnn_samples_amd.models import RGCN_Model
+from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
+task = PPI_Task(PPI_Task.default_params())
+task.load_synthetic(24, 4, seed=0, mean_nodes=600.0, std_nodes=150.0, min_nodes=200, max_nodes=1000)
+p = RGCN_Model.default_params(); p.update(hidden_size=128, graph_num_layers=3, max_nodes_in_batch=3000, random_seed=0)
+so = sys.stdout; sys.stdout = sys.stderr
+model = RGCN_Model(p, task, device="cuda:0")
+sys.stdout = so
+data = task._loaded_data[DataFold.TRAIN]
+marks = []
+t0 = time.time()
+for ep in range(150):
+    loss, res, n, *_ = model._run_epoch("e", data, DataFold.TRAIN, quiet=True)
+    if ep % 30 == 0 or ep == 149:
+        torch.cuda.synchronize()
+        marks.append((ep, len(res), round(loss, 4), torch.cuda.memory_allocated() >> 20, torch.cuda.memory_reserved() >> 20))
+print("epochs/steps per epoch/loss/allocated MiB/reserved MiB:", marks, "wall %.1f s" % (time.time() - t0))
+assert marks[-1][3] <= marks[1][3] * 1.2 + 16, "device memory grows"
