@@ -10,6 +10,7 @@
 #include "common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 using namespace relgnn;
 
@@ -38,12 +39,6 @@ __global__ __launch_bounds__(256) void relational_keys_kernel(
   if (err_flag != nullptr && __any(bad)) {
     if ((threadIdx.x & (RELGNN_WAVE - 1)) == 0) atomicOr(err_flag, RELGNN_ERRFLAG_INDEX_OUT_OF_RANGE);
   }
-}
-
-__global__ __launch_bounds__(256) void iota_kernel(int32_t* __restrict__ out, int64_t n) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = (int32_t)i;
 }
 
 // rowptr[s] = first sorted position whose key >= s.  Every rowptr entry is written by
@@ -194,7 +189,7 @@ int relgnn_relational_keys2(const int32_t* adj, int64_t num_edges, int32_t edge_
 }
 
 size_t relgnn_relational_plan_workspace_bytes(int64_t num_messages, int32_t num_nodes) {
-  // [iota | sorted node keys | sorted full keys | rocprim temp]
+  // [spare | sorted node keys | sorted full keys | rocprim temp]
   return relgnn_segment_plan_workspace_bytes(num_messages, num_nodes) + align_up((size_t)(num_messages > 0 ? num_messages : 1) * 4, 256);
 }
 
@@ -220,11 +215,13 @@ int relgnn_relational_plan(const int32_t* sort_node, const int32_t* full_key, co
   int32_t* sorted_full = reinterpret_cast<int32_t*>(ws + 2 * seg);
   void* temp = ws + 3 * seg;
   size_t temp_bytes = workspace_bytes - 3 * seg;
-  iota_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(iota, num_messages);
   // The message list is type-major, so a STABLE sort by node id alone already yields (node, type, edge order):
-  // only ceil(log2(V)) key bits go through the radix passes instead of ceil(log2(V*L)).
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, sort_node, sorted_nodes, iota, perm,
-                                           (size_t)num_messages, 0, key_bits(num_nodes), st);
+  // only ceil(log2(V)) key bits go through the radix passes instead of ceil(log2(V*L)).  The values are the
+  // message indices 0..M-1, fed from a counting iterator (no index array to write and read back).
+  (void)iota;
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, sort_node, sorted_nodes,
+                                           rocprim::counting_iterator<int32_t>(0), perm, (size_t)num_messages, 0,
+                                           key_bits(num_nodes), st);
   if (e != hipSuccess) return RELGNN_EHIP;
   plan_finalize_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(perm, full_key, other_key, num_messages,
                                                                      num_edge_types, sorted_full, col, col_div, inv_out,
@@ -239,7 +236,7 @@ size_t relgnn_segment_plan_workspace_bytes(int64_t num_messages, int64_t num_seg
   int32_t* nk = nullptr;
   rocprim::radix_sort_pairs(nullptr, temp, nk, nk, nk, nk, (size_t)num_messages, 0,
                             key_bits(num_segments), (hipStream_t)0);
-  // layout: [iota values | sorted keys scratch | rocprim temp]
+  // layout: [spare | sorted keys scratch | rocprim temp]
   return align_up((size_t)num_messages * 4, 256) * 2 + align_up(temp, 256) + 256;
 }
 
@@ -263,9 +260,9 @@ int relgnn_segment_plan(const int32_t* keys, int64_t num_messages, int64_t num_s
   void* temp = ws + 2 * seg;
   size_t temp_bytes = workspace_bytes - 2 * seg;
 
-  iota_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(iota, num_messages);
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, iota, perm,
-                                           (size_t)num_messages, 0, key_bits(num_segments), st);
+  (void)iota;
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, rocprim::counting_iterator<int32_t>(0),
+                                           perm, (size_t)num_messages, 0, key_bits(num_segments), st);
   if (e != hipSuccess) return RELGNN_EHIP;
   rowptr_from_sorted_kernel<<<flat_grid(num_messages + 1, 256), 256, 0, st>>>(
       keys_out, num_messages, num_segments, rowptr);
