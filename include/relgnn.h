@@ -100,6 +100,13 @@ int relgnn_relational_keys2(const int32_t* adj, int64_t num_edges, int32_t edge_
                             int32_t* key_by_target, int32_t* key_by_source, int32_t* target_node,
                             int32_t* source_node, uint32_t* err_flag, void* stream);
 
+/* relgnn_relational_keys2 for ALL edge types of a batch in one launch per 32 types: h_adj / h_num_edges are HOST arrays
+ * of num_edge_types device pointers / edge counts; messages are numbered type-major (type 0 first), as in the reference's
+ * tf.concat over the per-type lists (gnns/rgcn.py:78). */
+int relgnn_relational_keys_all(const int32_t* const* h_adj, const int64_t* h_num_edges, int32_t num_edge_types,
+                               int32_t num_nodes, int32_t* key_by_target, int32_t* key_by_source, int32_t* target_node,
+                               int32_t* source_node, uint32_t* err_flag, void* stream);
+
 /*
  * relgnn_relational_plan — the (node, type)-bucketed CSR of the type-major message list in one call.
  * Because the message list is type-major (gnns/rgcn.py:78), a STABLE sort by node id alone already orders the

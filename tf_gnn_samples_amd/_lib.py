@@ -29,6 +29,7 @@ _SIGNATURES = {
     "relgnn_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "relgnn_relational_keys": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i64, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_relational_keys2": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "relgnn_relational_keys_all": (ctypes.c_int, [_ptr, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_relational_plan_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i32]),
     "relgnn_relational_plan": (ctypes.c_int, [_ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     "relgnn_segment_plan_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i64]),

@@ -41,6 +41,41 @@ __global__ __launch_bounds__(256) void relational_keys_kernel(
   }
 }
 
+// All edge types of a batch in one launch (up to kKeysTypes per launch): the per-type kernel above costs one ~8 us
+// launch per edge type, 23 of them for a VarMisuse-shaped batch.
+constexpr int kKeysTypes = 32;
+struct KeysArgs {
+  const int2* adj[kKeysTypes];
+  long long base[kKeysTypes + 1];   // message offset of every type inside this launch's range; base[n] = end
+};
+
+__global__ __launch_bounds__(256) void relational_keys_all_kernel(
+    KeysArgs a, int32_t n_types, int32_t first_type, int32_t L, int32_t V, long long msg_base,
+    int32_t* __restrict__ key_t, int32_t* __restrict__ key_s, int32_t* __restrict__ node_t,
+    int32_t* __restrict__ node_s, uint32_t* __restrict__ err_flag) {
+  bool bad = false;
+  const long long total = a.base[n_types];
+  for (long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x; m < total; m += (long long)gridDim.x * blockDim.x) {
+    int t = 0;
+    while (t + 1 < n_types && m >= a.base[t + 1]) ++t;
+    const int2 st = a.adj[t][m - a.base[t]];
+    int32_t s = st.x, tg = st.y;
+    if ((uint32_t)s >= (uint32_t)V || (uint32_t)tg >= (uint32_t)V) {
+      bad = true;
+      s = min(max(s, 0), V - 1);
+      tg = min(max(tg, 0), V - 1);
+    }
+    const int32_t l = first_type + t;
+    key_t[msg_base + m] = tg * L + l;
+    key_s[msg_base + m] = s * L + l;
+    node_t[msg_base + m] = tg;
+    node_s[msg_base + m] = s;
+  }
+  if (err_flag != nullptr && __any(bad)) {
+    if ((threadIdx.x & (RELGNN_WAVE - 1)) == 0) atomicOr(err_flag, RELGNN_ERRFLAG_INDEX_OUT_OF_RANGE);
+  }
+}
+
 // rowptr[s] = first sorted position whose key >= s.  Every rowptr entry is written by
 // exactly one thread (the one that owns the position where the key changes), so the
 // result is deterministic and needs no atomics / histogram.
@@ -185,6 +220,33 @@ int relgnn_relational_keys2(const int32_t* adj, int64_t num_edges, int32_t edge_
   relational_keys_kernel<<<flat_grid(num_edges, 256), 256, 0, as_stream(stream)>>>(
       reinterpret_cast<const int2*>(adj), num_edges, edge_type, num_edge_types, num_nodes, msg_base,
       key_by_target, key_by_source, target_node, source_node, err_flag);
+  return launch_status();
+}
+
+int relgnn_relational_keys_all(const int32_t* const* h_adj, const int64_t* h_num_edges, int32_t num_edge_types,
+                               int32_t num_nodes, int32_t* key_by_target, int32_t* key_by_source, int32_t* target_node,
+                               int32_t* source_node, uint32_t* err_flag, void* stream) {
+  if (num_edge_types <= 0 || num_nodes < 0 || !h_adj || !h_num_edges) return RELGNN_EINVAL;
+  if ((int64_t)num_nodes * num_edge_types > INT32_MAX) return RELGNN_EUNSUPPORTED;
+  long long msg_base = 0;
+  for (int32_t first = 0; first < num_edge_types; first += kKeysTypes) {
+    const int32_t n = (num_edge_types - first < kKeysTypes) ? (num_edge_types - first) : kKeysTypes;
+    KeysArgs a;
+    a.base[0] = 0;
+    for (int32_t t = 0; t < n; ++t) {
+      const int64_t e = h_num_edges[first + t];
+      if (e < 0 || (e > 0 && (!h_adj[first + t] || (reinterpret_cast<uintptr_t>(h_adj[first + t]) & 7u)))) return RELGNN_EINVAL;
+      a.adj[t] = reinterpret_cast<const int2*>(h_adj[first + t]);
+      a.base[t + 1] = a.base[t] + e;
+    }
+    const long long total = a.base[n];
+    if (total > 0) {
+      if (!key_by_target || !key_by_source || !target_node || !source_node || num_nodes == 0) return RELGNN_EINVAL;
+      relational_keys_all_kernel<<<flat_grid(total, 256), 256, 0, as_stream(stream)>>>(
+          a, n, first, num_edge_types, num_nodes, msg_base, key_by_target, key_by_source, target_node, source_node, err_flag);
+    }
+    msg_base += total;
+  }
   return launch_status();
 }
 

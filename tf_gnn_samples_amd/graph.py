@@ -15,6 +15,7 @@ All index arithmetic happens on the device through the C ABI (relgnn_relational_
 relgnn_segment_plan, relgnn_gather_*): it is integer work and is tested bit-exact against
 the NumPy oracle.
 """
+import ctypes
 import os
 from collections import OrderedDict
 from typing import List, Optional, Sequence
@@ -116,12 +117,10 @@ class RelGraph:
         key_t, key_s = _i32(M, dev), _i32(M, dev)
         node_t, node_s = _i32(M, dev), _i32(M, dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-        base = 0
-        for l, a in enumerate(adj):
-            _lib.check(lib.relgnn_relational_keys2(_lib.ptr(a), a.shape[0], l, L, V, base, _lib.ptr(key_t),
-                                                   _lib.ptr(key_s), _lib.ptr(node_t), _lib.ptr(node_s), _lib.ptr(err), st),
-                       "relgnn_relational_keys2")
-            base += a.shape[0]
+        h_adj = (ctypes.c_void_p * L)(*[_lib.ptr(a) if a.shape[0] else None for a in adj])    # refuses host tensors
+        h_cnt = (ctypes.c_int64 * L)(*self.edge_counts)
+        _lib.check(lib.relgnn_relational_keys_all(h_adj, h_cnt, L, V, _lib.ptr(key_t), _lib.ptr(key_s), _lib.ptr(node_t),
+                                                  _lib.ptr(node_s), _lib.ptr(err), st), "relgnn_relational_keys_all")
         self.key_by_target, self.key_by_source = key_t, key_s
 
         S = V * L
