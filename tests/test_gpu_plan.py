@@ -21,7 +21,8 @@ def _check_graph(adj, V, dev):
     return g, ref
 
 
-@pytest.mark.parametrize("V,L,E,empty", [(1, 1, 1, ()), (7, 3, 20, (1,)), (300, 5, 2000, ()), (5000, 23, 3000, (3, 4, 22))])
+@pytest.mark.parametrize("V,L,E,empty", [(1, 1, 1, ()), (7, 3, 20, (1,)), (300, 5, 2000, ()), (5000, 23, 3000, (3, 4, 22)),
+                                         (400, 70, 150, (0, 31, 32, 33, 69))])   # > 32 types: several key launches
 def test_relgraph_matches_oracle(gpu_device, V, L, E, empty):
     rng = np.random.default_rng(V + L)
     adj = random_relational_graph(rng, V, L, E, empty_types=empty)
