@@ -104,8 +104,7 @@ class GradientAllReducer:
         self.flat[-1] = float(local_weight)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat[:-1].div_(self.flat[-1])
+        # the reduced gradients stay where they are: every .grad becomes a view of the flat buffer (no unpack copies;
+        # the next backward allocates fresh .grad tensors after zero_grad() and this buffer is overwritten by the pack)
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+            p.grad = v
