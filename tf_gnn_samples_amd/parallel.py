@@ -68,9 +68,15 @@ def init_distributed(backend: str = None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # bind the communicator to this rank's GPU up front (no device guessing inside barrier()/collectives)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        except TypeError:        # older torch without device_id
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
