@@ -74,3 +74,18 @@ def test_every_model_declares_its_variables_on_cpu():
         if p.get('graph_inter_layer_norm') and "graph_model/gnn_layer_0/LayerNorm/gamma" in m.variables.names() \
                 and cls.__name__ in ("RGIN_Model", "GNN_Edge_MLP_Model"):
             assert "graph_model/gnn_layer_0/LayerNorm_1/gamma" in m.variables.names()
+
+
+def test_effective_cpu_count_is_bounded_by_quota_and_affinity():
+    import os
+    from tf_gnn_samples_amd.parallel import effective_cpu_count
+    n = effective_cpu_count()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            assert n <= max(1, int(int(quota) / int(period)))
+    except OSError:
+        pass
