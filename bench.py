@@ -158,9 +158,11 @@ def time_native_batch(task, graphs, device, iters=11):
 
 def epoch_pipeline_throughput(model, device, num_graphs=64, epochs=5):
     """edges/sec the way the reference prints it (models/sparse_graph_model.py:263-311): whole training epochs over
-    DISTINCT batches, host batching and the feed included, one metrics fetch (host sync) per step.  Here the feed is
-    the input pipeline of tasks/batcher.py (C++ packing -> one H2D copy -> bucketing on the copy stream, one batch
-    ahead).  GEMM shapes differ per batch, so the library GEMMs run with their default (untuned) solutions."""
+    DISTINCT batches, batching and the feed included, one metrics fetch (host sync) per step.  Here the fold is small
+    enough to live in HBM (tasks/resident.py: batches are gathered on the device and their bucketing is re-based from
+    the fold-level bucketing, relgnn_plan_assemble); folds that do not fit go through tasks/batcher.py (C++ packing ->
+    one H2D copy -> bucketing on the copy stream, one batch ahead).  GEMM shapes differ per batch, so the library GEMMs
+    run with their default (untuned) solutions."""
     from tf_gnn_samples_amd.tasks import DataFold
     from tf_gnn_samples_amd.tasks.synthetic import make_ppi_shaped_graphs
     data = make_ppi_shaped_graphs(num_graphs, seed=1)
@@ -181,8 +183,9 @@ def epoch_pipeline_throughput(model, device, num_graphs=64, epochs=5):
     med = float(np.median(times))
     return {"edges_per_sec": edges_per_epoch / med, "ms_per_step": med / steps * 1e3, "steps_per_epoch": steps,
             "epoch_ms": [t * 1e3 for t in times], "edges_per_step": edges_per_epoch / steps,
-            "what": "median of %d training epochs over distinct PPI-shaped batches incl. C++ batch packing, H2D, "
-                    "bucketing and one host metrics fetch per step (the reference's own edges/sec definition)" % epochs}
+            "input_pipeline": type(next(iter(model._native_batchers.values()))[1]).__name__ if model._native_batchers else None,
+            "what": "median of %d training epochs over distinct PPI-shaped batches incl. batch assembly, bucketing and "
+                    "one host metrics fetch per step (the reference's own edges/sec definition)" % epochs}
 
 
 def cpu_baseline(sample_graphs, params):

@@ -560,6 +560,34 @@ int relgnn_batch_pack(int32_t num_types, int64_t n_graphs, const int64_t* h_grap
                       int32_t n_payloads, const void* const* h_payload, const int64_t* h_payload_row_bytes,
                       const int64_t* h_layout, void* h_arena, size_t arena_bytes, int32_t num_threads);
 
+/* ========================================================================== *
+ * 10. Batch bucketing from dataset-resident plans
+ * ========================================================================== */
+
+/*
+ * The (node,type)-bucketed orders of a disjoint-union batch are graph-major, so they are the per-graph slices of the
+ * orders of ANY other union that holds the same graphs.  Bucket the whole data fold once as one union
+ * (relgnn_relational_keys_all + relgnn_relational_plan, arrays suffixed _d, kept in HBM), then a batch = the graph
+ * list ids[0..K) needs no sort: this call re-bases the slices (node ids, positions, type-major message numbering of
+ * the batch) with three streaming kernels and produces exactly the arrays relgnn_relational_plan would
+ * (bit-identical: same stable order).  All pointers are DEVICE pointers.
+ *   ids          [K]        dataset graph id per batch slot (graphs may repeat)
+ *   node_off_b   [K+1]      node offset of slot k in the batch            (tasks/ppi_task.py:228)
+ *   msg_off_b    [K+1]      messages of the slots before k (all types)
+ *   edge_off_b   [L][K+1]   messages of type l in the slots before k
+ *   type_off_b   [L+1]      start of type l in the batch's type-major message list (gnns/rgcn.py:78)
+ *   *_d                     the same four tables for the dataset union (G = num_dataset_graphs)
+ */
+int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t num_edge_types, int64_t num_dataset_graphs,
+                         const int64_t* node_off_b, const int64_t* msg_off_b, const int64_t* edge_off_b,
+                         const int64_t* type_off_b, const int64_t* node_off_d, const int64_t* msg_off_d,
+                         const int64_t* edge_off_d, const int64_t* type_off_d, int64_t num_nodes, int64_t num_messages,
+                         const int32_t* rowptr_t_d, const int32_t* perm_t_d, const int32_t* col_t_d,
+                         const int32_t* rowptr_s_d, const int32_t* perm_s_d, const int32_t* frow_s_d,
+                         const int32_t* pos_t_of_s_d, int32_t* rowptr_t, int32_t* perm_t, int32_t* col_t,
+                         int32_t* inv_perm_t, int32_t* rowptr_s, int32_t* perm_s, int32_t* frow_s, int32_t* tgt_s,
+                         int32_t* pos_t_of_s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""Data fold resident in HBM (tasks/resident.py, relgnn_plan_assemble): every batch tensor equals the host packer's and
+every bucketing array equals a freshly built RelGraph of that batch, bit for bit."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.bookkeeping import GraphSample
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+PLAN_ARRAYS = ("key_by_target", "key_by_source", "rowptr_t", "perm_t", "col_t", "inv_perm_t", "rowptr_s", "perm_s",
+               "frow_s", "tgt_s", "pos_t_of_s")
+
+
+def _graphs(rng, n_graphs, L, max_nodes=70):
+    out = []
+    for g in range(n_graphs):
+        n = int(rng.integers(1, max_nodes))
+        adj = []
+        for l in range(L):
+            e = 0 if (l == L - 1 and g % 2 == 0) or (g == 3) else int(rng.integers(0, 5 * n))
+            adj.append(np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64).reshape(-1, 2))
+        deg = np.stack([np.bincount(a[:, 1], minlength=n) for a in adj])
+        out.append(GraphSample(adj, deg, rng.standard_normal((n, 9)).astype(np.float32),
+                               (rng.random((n, 4)) < 0.3).astype(np.float32)))
+    return out
+
+
+def _same_batch(a, b):
+    assert (a.num_graphs, a.num_nodes, a.num_edges) == (b.num_graphs, b.num_nodes, b.num_edges)
+    assert torch.equal(a.initial_node_features, b.initial_node_features)
+    assert torch.equal(a.type_to_num_incoming_edges, b.type_to_num_incoming_edges)
+    assert torch.equal(a.graph_nodes_list, b.graph_nodes_list)
+    for x, y in zip(a.adjacency_lists, b.adjacency_lists):
+        assert x.dtype == torch.int32 and x.shape == y.shape and torch.equal(x, y)
+    for k in a.extra:
+        if torch.is_tensor(a.extra[k]):
+            assert torch.equal(a.extra[k], b.extra[k]), k
+
+
+def _same_plan(graph, adjacency_lists, V):
+    from tf_gnn_samples_amd.graph import RelGraph
+    fresh = RelGraph(adjacency_lists, V)
+    for name in PLAN_ARRAYS:
+        assert torch.equal(getattr(graph, name), getattr(fresh, name)), name
+    assert (graph.V, graph.L, graph.M, graph.edge_counts) == (fresh.V, fresh.L, fresh.M, fresh.edge_counts)
+
+
+PAYLOADS = {"initial_node_features": ("node_features", np.float32), "target_labels": ("node_labels", np.float32)}
+
+
+@pytest.mark.parametrize("L", [1, 3, 12])
+def test_resident_batches_and_plans_are_bit_identical(gpu_device, L):
+    from tf_gnn_samples_amd.tasks.batcher import GraphStore, NativeBatcher
+    from tf_gnn_samples_amd.tasks.resident import ResidentDataset
+    rng = np.random.default_rng(L)
+    graphs = _graphs(rng, 30, L)
+    store = GraphStore(graphs, L, PAYLOADS)
+    resident = ResidentDataset(store, gpu_device)
+    host = NativeBatcher(store, gpu_device, bucket=False)
+    for ids in ([0], [5, 2, 2, 17], list(range(30)), [3], [29, 0, 3, 4]):          # order, repeats, an edge-free graph
+        a = resident.assemble(np.array(ids))
+        b = host.pack(np.array(ids))
+        _same_batch(a, b)
+        _same_plan(a.graph, b.adjacency_lists, b.num_nodes)
+    got = [x.num_graphs for x in resident.iterate(np.arange(30), 200)]
+    want = [x.num_graphs for x in host.iterate(np.arange(30), 200)]
+    assert got == want and sum(got) == 30
+
+
+def test_resident_qm9_with_per_graph_targets_and_training(gpu_device):
+    from tf_gnn_samples_amd.models import GGNN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, QM9_Task
+    from tf_gnn_samples_amd.tasks.batcher import NativeBatcher
+    from tf_gnn_samples_amd.tasks.resident import ResidentDataset
+    task = QM9_Task(QM9_Task.default_params())
+    with gzip.open(os.path.join(HERE, "golden", "qm9_valid_256.jsonl.gz"), "rt") as f:
+        data = task.load_raw([json.loads(line) for line in f])
+    store = task.make_graph_store(data)
+    resident = ResidentDataset(store, gpu_device)
+    host = NativeBatcher(store, gpu_device, bucket=False)
+    ids = np.array([7, 200, 13, 13, 99, 0])
+    a, b = resident.assemble(ids), host.pack(ids)
+    _same_batch(a, b)
+    _same_plan(a.graph, b.adjacency_lists, b.num_nodes)
+    # the model sees the same epoch through either pipeline
+    task._loaded_data[DataFold.TRAIN] = data
+    task._loaded_data[DataFold.VALIDATION] = data[:64]
+    outs = []
+    for mode in (True, False):
+        params = GGNN_Model.default_params()
+        params.update(hidden_size=32, graph_num_layers=2, max_nodes_in_batch=1500, resident_dataset=mode, random_seed=0)
+        model = GGNN_Model(params, task, device=gpu_device)
+        loss, res, n, *_ = model._run_epoch("valid", data[:64], DataFold.VALIDATION, quiet=True)
+        outs.append((loss, n, [r['abs_err_task0'] for r in res]))
+    assert outs[0] == outs[1]

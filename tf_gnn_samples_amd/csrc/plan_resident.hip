@@ -1,0 +1,143 @@
+// Batch bucketing from DATASET-RESIDENT per-graph plans (include/relgnn.h section 10).
+//
+// A batch is a disjoint union of graphs, and both bucketed orders of a batch are graph-major (nodes of one graph are
+// contiguous, so all messages into / out of that graph are contiguous in the (node, type)-sorted orders).  If the
+// whole dataset has been bucketed ONCE as one big disjoint union and its index arrays stay in HBM, the arrays of any
+// batch are the per-graph slices of the dataset arrays, re-based: node ids by the graph's node offset, positions by the
+// graph's message offset, original message ids through the type-major numbering of the batch.  Three streaming kernels
+// replace the two radix sorts + finalise passes per batch (bit-identical result: same stable order).
+#include "common.h"
+
+using namespace relgnn;
+
+namespace {
+
+// largest k with table[k] <= x  (table ascending, table[0] <= x < table[n])
+__device__ __forceinline__ int upper_slot(const int64_t* __restrict__ table, int n, int64_t x) {
+  int lo = 0, hi = n;                  // invariant: table[lo] <= x < table[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (table[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+struct BatchTables {
+  const int64_t* ids;          // [K] dataset graph id of batch slot k
+  const int64_t* node_off_b;   // [K+1]
+  const int64_t* msg_off_b;    // [K+1] first by-target / by-source position of slot k
+  const int64_t* edge_off_b;   // [L][K+1] messages of type l before slot k (inside the type's block)
+  const int64_t* type_off_b;   // [L+1]
+  const int64_t* node_off_d;   // [G+1]
+  const int64_t* msg_off_d;    // [G+1]
+  const int64_t* edge_off_d;   // [L][G+1]
+  const int64_t* type_off_d;   // [L+1]
+  int32_t K, L;
+  int64_t G;
+};
+
+// original message id: dataset numbering -> batch numbering (both type-major, graphs in their order inside a type)
+__device__ __forceinline__ int32_t translate_message(const BatchTables& t, int32_t m_d, int l, int k, int64_t g) {
+  const int64_t e = (int64_t)m_d - t.type_off_d[l] - t.edge_off_d[(int64_t)l * (t.G + 1) + g];
+  return (int32_t)(t.type_off_b[l] + t.edge_off_b[(int64_t)l * (t.K + 1) + k] + e);
+}
+
+__global__ __launch_bounds__(256) void assemble_by_target_kernel(
+    BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ col_d,
+    int32_t* __restrict__ perm_b, int32_t* __restrict__ col_b, int32_t* __restrict__ inv_b) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < M; p += (int64_t)gridDim.x * blockDim.x) {
+    const int k = upper_slot(t.msg_off_b, t.K, p);
+    const int64_t g = t.ids[k];
+    const int64_t pd = t.msg_off_d[g] + (p - t.msg_off_b[k]);
+    const int32_t c = col_d[pd];
+    const int l = c % t.L;
+    const int64_t src = c / t.L - t.node_off_d[g] + t.node_off_b[k];
+    col_b[p] = (int32_t)(src * t.L + l);
+    const int32_t mb = translate_message(t, perm_d[pd], l, k, g);
+    perm_b[p] = mb;
+    inv_b[mb] = (int32_t)p;
+  }
+}
+
+__global__ __launch_bounds__(256) void assemble_by_source_kernel(
+    BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ frow_d,
+    const int32_t* __restrict__ pos_d, int32_t* __restrict__ perm_b, int32_t* __restrict__ frow_b,
+    int32_t* __restrict__ tgt_b, int32_t* __restrict__ pos_b) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < M; q += (int64_t)gridDim.x * blockDim.x) {
+    const int k = upper_slot(t.msg_off_b, t.K, q);
+    const int64_t g = t.ids[k];
+    const int64_t qd = t.msg_off_d[g] + (q - t.msg_off_b[k]);
+    const int32_t f = frow_d[qd];
+    const int l = f % t.L;
+    const int64_t tgt = f / t.L - t.node_off_d[g] + t.node_off_b[k];
+    frow_b[q] = (int32_t)(tgt * t.L + l);
+    tgt_b[q] = (int32_t)tgt;
+    perm_b[q] = translate_message(t, perm_d[qd], l, k, g);
+    pos_b[q] = (int32_t)((int64_t)pos_d[qd] - t.msg_off_d[g] + t.msg_off_b[k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void assemble_rowptr_kernel(
+    BatchTables t, int64_t num_buckets, int64_t M, const int32_t* __restrict__ rowptr_t_d,
+    const int32_t* __restrict__ rowptr_s_d, int32_t* __restrict__ rowptr_t_b, int32_t* __restrict__ rowptr_s_b) {
+  for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b <= num_buckets; b += (int64_t)gridDim.x * blockDim.x) {
+    if (b == num_buckets) {
+      rowptr_t_b[b] = (int32_t)M;
+      rowptr_s_b[b] = (int32_t)M;
+      continue;
+    }
+    const int64_t v = b / t.L;
+    const int l = (int)(b - v * t.L);
+    const int k = upper_slot(t.node_off_b, t.K, v);
+    const int64_t g = t.ids[k];
+    const int64_t bd = (v - t.node_off_b[k] + t.node_off_d[g]) * t.L + l;
+    const int64_t shift = t.msg_off_b[k] - t.msg_off_d[g];
+    rowptr_t_b[b] = (int32_t)((int64_t)rowptr_t_d[bd] + shift);
+    rowptr_s_b[b] = (int32_t)((int64_t)rowptr_s_d[bd] + shift);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t num_edge_types, int64_t num_dataset_graphs,
+                         const int64_t* node_off_b, const int64_t* msg_off_b, const int64_t* edge_off_b,
+                         const int64_t* type_off_b, const int64_t* node_off_d, const int64_t* msg_off_d,
+                         const int64_t* edge_off_d, const int64_t* type_off_d, int64_t num_nodes, int64_t num_messages,
+                         const int32_t* rowptr_t_d, const int32_t* perm_t_d, const int32_t* col_t_d,
+                         const int32_t* rowptr_s_d, const int32_t* perm_s_d, const int32_t* frow_s_d,
+                         const int32_t* pos_t_of_s_d, int32_t* rowptr_t, int32_t* perm_t, int32_t* col_t,
+                         int32_t* inv_perm_t, int32_t* rowptr_s, int32_t* perm_s, int32_t* frow_s, int32_t* tgt_s,
+                         int32_t* pos_t_of_s, void* stream) {
+  if (num_batch_graphs < 0 || num_edge_types <= 0 || num_dataset_graphs < 0 || num_nodes < 0 || num_messages < 0)
+    return RELGNN_EINVAL;
+  const int64_t buckets = num_nodes * num_edge_types;
+  if (buckets >= INT32_MAX || num_messages >= INT32_MAX) return RELGNN_EUNSUPPORTED;
+  if (!rowptr_t || !rowptr_s) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (num_batch_graphs == 0 || num_nodes == 0) {
+    if (hipMemsetAsync(rowptr_t, 0, (size_t)(buckets + 1) * 4, st) != hipSuccess) return RELGNN_EHIP;
+    if (hipMemsetAsync(rowptr_s, 0, (size_t)(buckets + 1) * 4, st) != hipSuccess) return RELGNN_EHIP;
+    return RELGNN_OK;
+  }
+  if (!ids || !node_off_b || !msg_off_b || !edge_off_b || !type_off_b || !node_off_d || !msg_off_d || !edge_off_d ||
+      !type_off_d || !rowptr_t_d || !rowptr_s_d)
+    return RELGNN_EINVAL;
+  BatchTables t{ids, node_off_b, msg_off_b, edge_off_b, type_off_b, node_off_d, msg_off_d, edge_off_d, type_off_d,
+                num_batch_graphs, num_edge_types, num_dataset_graphs};
+  assemble_rowptr_kernel<<<flat_grid(buckets + 1, 256), 256, 0, st>>>(t, buckets, num_messages, rowptr_t_d, rowptr_s_d,
+                                                                      rowptr_t, rowptr_s);
+  if (num_messages > 0) {
+    if (!perm_t_d || !col_t_d || !perm_s_d || !frow_s_d || !pos_t_of_s_d || !perm_t || !col_t || !inv_perm_t || !perm_s ||
+        !frow_s || !tgt_s || !pos_t_of_s)
+      return RELGNN_EINVAL;
+    assemble_by_target_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, perm_t_d, col_t_d, perm_t,
+                                                                            col_t, inv_perm_t);
+    assemble_by_source_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, perm_s_d, frow_s_d,
+                                                                            pos_t_of_s_d, perm_s, frow_s, tgt_s, pos_t_of_s);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

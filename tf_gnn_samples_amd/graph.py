@@ -156,6 +156,38 @@ class RelGraph:
             if len(_PENDING_CHECKS) > 4096:
                 check_pending_graph_errors()
 
+    @classmethod
+    def from_arrays(cls, adjacency_lists, num_nodes: int, *, rowptr_t, perm_t, col_t, inv_perm_t, rowptr_s, perm_s,
+                    frow_s, tgt_s, pos_t_of_s) -> "RelGraph":
+        """A RelGraph whose bucketing was produced elsewhere (tasks/resident.py: slices of a fold-level bucketing
+        re-based by relgnn_plan_assemble).  The arrays must be what __init__ would compute; the node-id range check is
+        the producer's job."""
+        lib = _lib.load_library()
+        self = cls.__new__(cls)
+        adj = [a if a.dtype == torch.int32 else a.to(torch.int32) for a in adjacency_lists]
+        self.adjacency_lists = adj
+        self.L = L = len(adj)
+        self.V = V = int(num_nodes)
+        self.edge_counts = [int(a.shape[0]) for a in adj]
+        self.M = M = sum(self.edge_counts)
+        self.device = dev = rowptr_t.device
+        key_t, key_s, node_t, node_s = _i32(M, dev), _i32(M, dev), _i32(M, dev), _i32(M, dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        h_adj = (ctypes.c_void_p * L)(*[_lib.ptr(a) if a.shape[0] else None for a in adj])
+        h_cnt = (ctypes.c_int64 * L)(*self.edge_counts)
+        _lib.check(lib.relgnn_relational_keys_all(h_adj, h_cnt, L, V, _lib.ptr(key_t), _lib.ptr(key_s), _lib.ptr(node_t),
+                                                  _lib.ptr(node_s), _lib.ptr(err), _lib.current_stream()),
+                   "relgnn_relational_keys_all")
+        self.key_by_target, self.key_by_source = key_t, key_s
+        self.rowptr_t, self.perm_t, self.col_t, self.inv_perm_t = rowptr_t, perm_t, col_t, inv_perm_t
+        self.rowptr_s, self.perm_s, self.frow_s, self.tgt_s, self.pos_t_of_s = rowptr_s, perm_s, frow_s, tgt_s, pos_t_of_s
+        self._src_t = None
+        self._plans = {}
+        self._scales = OrderedDict()
+        self._err_flag = err
+        self._checked = True
+        return self
+
     # ---- bucketing on a side stream (input pipeline) --------------------------------------------
     ready_event = None
 

@@ -341,9 +341,33 @@ class Sparse_Graph_Model(ABC):
         key = (id(data), len(data))
         cached = self._native_batchers.get(key)
         if cached is None or cached[0] is not data:
-            cached = (data, NativeBatcher(self.task.make_graph_store(data), self.device))
+            store = self.task.make_graph_store(data)
+            pipeline = None
+            # small enough folds simply live in HBM, bucketed once (tasks/resident.py); `resident_dataset: false`
+            # keeps the host packer, `true` insists
+            want = self.params.get('resident_dataset', 'auto')
+            if want is True or (want == 'auto' and self._fold_fits_hbm(store)):
+                from ..tasks.resident import ResidentDataset
+                try:
+                    pipeline = ResidentDataset(store, self.device)
+                except ValueError:
+                    if want is True:
+                        raise
+            if pipeline is None:
+                pipeline = NativeBatcher(store, self.device)
+            cached = (data, pipeline)
             self._native_batchers[key] = cached
         return self.task.make_native_minibatch_iterator(cached[1], data_fold, self.params['max_nodes_in_batch'])
+
+    @staticmethod
+    def _fold_fits_hbm(store, budget_bytes: int = 32 << 30) -> bool:
+        """Flat arrays + fold-level bucketing (~9 int32 per message) well inside the 288 GB of an MI355X."""
+        nbytes = sum(a.nbytes for a in store.payload) + sum(a.nbytes for a in store.adj) + sum(a.nbytes for a in store.deg)
+        messages = sum(int(o[-1]) for o in store.edge_off)
+        nodes = int(store.node_off[-1])
+        if nodes * max(store.num_edge_types, 1) >= 2 ** 31 - 1 or messages >= 2 ** 31 - 1:
+            return False
+        return nbytes + 40 * messages + 8 * nodes * max(store.num_edge_types, 1) < budget_bytes
 
     def _run_epoch(self, epoch_name: str, data: Iterable[Any], data_fold: DataFold, quiet: bool = False):
         """__run_epoch, :263-311: returns (avg loss, task metric results, graphs, graphs/s, nodes/s, edges/s)."""
