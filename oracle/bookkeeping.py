@@ -106,7 +106,8 @@ def in_degree_table(adjacency_lists, num_nodes: int) -> np.ndarray:
 def qm9_graph_to_adjacency_lists(graph, num_nodes, num_edge_types, add_self_loop_edges=True, tie_fwd_bkwd_edges=True):
     """Restatement of tasks/qm9_task.py:114-147 (raw triples (src, e, dst), e in 1..4):
     list-append in triple order, both directions when tied, self loops appended last on type 0,
-    every list sorted lexicographically (:135).  Returns (adjacency lists, in-degree table [L, V])."""
+    every list sorted lexicographically (:135); untied: the forward half, then one reversed list per forward type
+    (:137-145).  Returns (adjacency lists, in-degree table [L, V])."""
     lists = [[] for _ in range(num_edge_types)]
     deg = np.zeros(shape=(num_edge_types, num_nodes))
     for src, e, dest in graph:
@@ -121,4 +122,13 @@ def qm9_graph_to_adjacency_lists(graph, num_nodes, num_edge_types, add_self_loop
             deg[0, node] = 1
             lists[0].append((node, node))
     adj = [np.array(sorted(a), dtype=np.int32) if len(a) > 0 else np.zeros(shape=(0, 2), dtype=np.int32) for a in lists]
+    if not tie_fwd_bkwd_edges:                                                          # :137-145
+        adj = adj[:num_edge_types // 2]
+        for edge_type, a in enumerate(list(adj)):
+            bwd = num_edge_types // 2 + edge_type
+            adj.append(np.array(sorted((y, x) for (x, y) in a), dtype=np.int32).reshape(-1, 2))
+            for (x, y) in a:
+                # :145 of the reference increments the count at y, the TARGET of the forward edge, although the
+                # reversed edge (y -> x) lands on x.  Restated as written: the table is fed to the model as is.
+                deg[bwd][y] += 1
     return adj, deg

@@ -9,7 +9,7 @@ relative to the layer's variable scope (e.g. "Edge_0_Weight/kernel", Dense kerne
 import numpy as np
 
 from . import tf_ops as T
-from .tf_ops import SMALL_NUMBER
+from .tf_ops import SMALL_NUMBER, layer_norm_scope
 
 
 def _cast(weights, dtype):
@@ -27,12 +27,53 @@ def _inv_degree(type_to_num_incoming_edges, edge_type_idx, edge_targets, dtype):
     return (np.asarray(1.0, dtype) / (c + np.asarray(SMALL_NUMBER, dtype)))[:, None]
 
 
+def _rgcn_layer_node_side(cur, adjacency_lists, type_to_num_incoming_edges, weights, normalize, activation_fn):
+    """BASELINE-size variant of the sum-aggregating, source-only RGCN message pass (gnns/rgcn.py:84-114): the message
+    of edge (u, v) of type l is the row (h_u W_l); it is evaluated once per (l, u) instead of once per edge and the
+    [M, D] message tensor is never materialised — the C fold walks the messages in the reference's order
+    (type-major, then edge order) and adds scale * row sequentially in fp32.  tests/test_oracle.py checks it against
+    the op-for-op path above."""
+    dtype = cur.dtype
+    V, L = cur.shape[0], len(adjacency_lists)
+    table = np.concatenate([T.dense(cur, weights["Edge_%i_Weight/kernel" % l]) for l in range(L)], axis=0)   # [L*V, D]
+    rows, scales, ids = [], [], []
+    for l, adj in enumerate(adjacency_lists):
+        adj = np.asarray(adj).reshape(-1, 2)
+        rows.append(adj[:, 0].astype(np.int64) + l * V)
+        ids.append(adj[:, 1].astype(np.int32))
+        if normalize:
+            scales.append(_inv_degree(type_to_num_incoming_edges, l, adj[:, 1], dtype)[:, 0])
+    rows, ids = np.ascontiguousarray(np.concatenate(rows)), np.ascontiguousarray(np.concatenate(ids))
+    scale = np.ascontiguousarray(np.concatenate(scales)) if normalize else None
+    lib = T._clib()
+    D = table.shape[1]
+    if lib is not None and dtype == np.float32:
+        out = np.empty((V, D), np.float32)
+        table = np.ascontiguousarray(table)
+        lib.oracle_gather_scaled_seg_sum_f32(table.ctypes.data, rows.ctypes.data, scale.ctypes.data if normalize else None,
+                                             ids.ctypes.data, len(rows), D, V, out.ctypes.data)
+    else:
+        msgs = table[rows]
+        if normalize:
+            msgs = scale[:, None] * msgs
+        out = T.unsorted_segment_sum(msgs, ids, V)
+    return T.apply_act(activation_fn, out)
+
+
 def sparse_rgcn_layer(node_embeddings, adjacency_lists, type_to_num_incoming_edges, state_dim,
                       num_timesteps=1, activation_function="tanh", message_aggregation_function="sum",
-                      normalize_by_num_incoming=True, use_both_source_and_target=False, *, weights):
-    """gnns/rgcn.py:60-117."""
+                      normalize_by_num_incoming=True, use_both_source_and_target=False, *, weights,
+                      node_side_transform=False):
+    """gnns/rgcn.py:60-117.  node_side_transform=True (sum aggregation, source-only inputs): the BASELINE-size
+    evaluation order of _rgcn_layer_node_side."""
     dtype = node_embeddings.dtype
     weights = _cast(weights, dtype)
+    if node_side_transform and not use_both_source_and_target and message_aggregation_function in ("sum", "unsorted_segment_sum"):
+        cur = node_embeddings
+        for _ in range(num_timesteps):
+            cur = _rgcn_layer_node_side(cur, adjacency_lists, type_to_num_incoming_edges, weights,
+                                        normalize_by_num_incoming, T.get_activation(activation_function))
+        return cur
     num_nodes = node_embeddings.shape[0]
     activation_fn = T.get_activation(activation_function)
     aggregate = T.get_aggregation_function(message_aggregation_function)
@@ -137,7 +178,7 @@ def sparse_rgin_layer(node_embeddings, adjacency_lists, state_dim, num_timesteps
     aggregate = T.get_aggregation_function(message_aggregation_function)
     message_targets = _targets(adjacency_lists)
     cur = node_embeddings
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         messages_per_type = []
         for l, adj in enumerate(adjacency_lists):
             adj = np.asarray(adj).reshape(-1, 2)
@@ -156,7 +197,7 @@ def sparse_rgin_layer(node_embeddings, adjacency_lists, state_dim, num_timesteps
         if num_aggr_MLP_hidden_layers is not None:                                      # :136-137
             new_states = T.mlp(new_states, weights, "Aggregation_MLP", num_aggr_MLP_hidden_layers, activation_fn)
         new_states = T.apply_act(activation_fn, new_states)                             # :138
-        cur = T.layer_norm(new_states, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])   # :139
+        cur = T.layer_norm(new_states, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])   # :139
     return cur
 
 
@@ -173,7 +214,7 @@ def sparse_gnn_film_layer(node_embeddings, adjacency_lists, type_to_num_incoming
     aggregate = T.get_aggregation_function(message_aggregation_function)
     message_targets = _targets(adjacency_lists)
     cur = node_embeddings
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         messages_per_type = []
         for l, adj in enumerate(adjacency_lists):
             adj = np.asarray(adj).reshape(-1, 2)
@@ -187,7 +228,7 @@ def sparse_gnn_film_layer(node_embeddings, adjacency_lists, type_to_num_incoming
             messages_per_type.append(gamma * messages + beta)                           # :108
         all_messages = T.apply_act(activation_fn, np.concatenate(messages_per_type, axis=0))   # :111-112
         aggregated = aggregate(all_messages, message_targets, num_nodes)                # :113-116
-        cur = T.layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])   # :120
+        cur = T.layer_norm(aggregated, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])   # :120
     return cur
 
 
@@ -203,7 +244,7 @@ def sparse_gnn_edge_mlp_layer(node_embeddings, adjacency_lists, type_to_num_inco
     aggregate = T.get_aggregation_function(message_aggregation_function)
     message_targets = _targets(adjacency_lists)
     cur = node_embeddings
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         messages_per_type = []
         for l, adj in enumerate(adjacency_lists):
             adj = np.asarray(adj).reshape(-1, 2)
@@ -217,7 +258,7 @@ def sparse_gnn_edge_mlp_layer(node_embeddings, adjacency_lists, type_to_num_inco
             messages_per_type.append(messages)
         all_messages = T.apply_act(activation_fn, np.concatenate(messages_per_type, axis=0))   # :111-112
         aggregated = aggregate(all_messages, message_targets, num_nodes)                # :113-116
-        cur = T.layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])   # :119
+        cur = T.layer_norm(aggregated, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])   # :119
     return cur
 
 

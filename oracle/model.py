@@ -37,20 +37,24 @@ def graph_propagation(initial_node_features, adjacency_lists, type_to_num_incomi
         cur = apply_gnn_layer(layer_idx, cur, adjacency_lists, type_to_num_incoming_edges,
                               params['graph_num_timesteps_per_layer'], layer_weights)   # :186-191
         if params['graph_inter_layer_norm']:                                            # :192-193
-            cur = T.layer_norm(cur, np.asarray(layer_weights["LayerNorm/gamma"], dtype),
-                               np.asarray(layer_weights["LayerNorm/beta"], dtype))
+            # the LAST LayerNorm scope of the layer's variable scope: the layer's own per-timestep norms come first
+            n_ln = sum(1 for k in layer_weights if k.startswith("LayerNorm") and k.endswith("/gamma"))
+            ln = T.layer_norm_scope(n_ln - 1)
+            cur = T.layer_norm(cur, np.asarray(layer_weights[ln + "/gamma"], dtype),
+                               np.asarray(layer_weights[ln + "/beta"], dtype))
         if layer_idx % params['graph_dense_between_every_num_gnn_layers'] == 0:        # :194-200
             cur = T.dense(cur, np.asarray(layer_weights["Dense/kernel"], dtype), activation=activation_fn)
     return cur
 
 
-def rgcn_apply(params):
+def rgcn_apply(params, node_side_transform=False):
     """models/rgcn_model.py:31-44: normalize_by_num_incoming is NOT passed, so the layer default True applies."""
     def apply(layer_idx, h, adj, deg, timesteps, w):
         return gnns.sparse_rgcn_layer(h, adj, deg, params['hidden_size'], num_timesteps=timesteps,
                                       activation_function=params['graph_activation_function'],
                                       message_aggregation_function=params['message_aggregation_function'],
-                                      weights={k: v for k, v in w.items() if k.startswith("Edge_")})
+                                      weights={k: v for k, v in w.items() if k.startswith("Edge_")},
+                                      node_side_transform=node_side_transform)
     return apply
 
 

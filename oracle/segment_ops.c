@@ -43,3 +43,21 @@ void oracle_scaled_seg_sum_f32(const float* msgs, const float* scale, const int3
     }
   }
 }
+
+/* The same chain with the gather folded in, for BASELINE-size parity cases (a [M, D] message tensor of 2 GB is
+ * slow to materialise in NumPy): out[tgt[j], :] += scale[j] * table[row[j], :], sequential in j, product and
+ * add rounded separately.  table row = the message value the reference would have computed for edge j
+ * (gnns/rgcn.py:87-104 with the per-edge MatMul evaluated once per (edge type, source node)). */
+void oracle_gather_scaled_seg_sum_f32(const float* table, const int64_t* row, const float* scale, const int32_t* ids,
+                                      int64_t M, int64_t D, int64_t S, float* out) {
+  memset(out, 0, sizeof(float) * (size_t)(S * D));
+  for (int64_t j = 0; j < M; ++j) {
+    float* o = out + (int64_t)ids[j] * D;
+    const float* x = table + row[j] * D;
+    const float sc = scale ? scale[j] : 1.0f;
+    for (int64_t d = 0; d < D; ++d) {
+      float m = sc * x[d];
+      o[d] = o[d] + m;
+    }
+  }
+}

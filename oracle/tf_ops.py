@@ -35,6 +35,8 @@ def _clib():
             lib.oracle_scaled_seg_sum_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
             lib.oracle_scaled_seg_sum_f32.restype = None
+            lib.oracle_gather_scaled_seg_sum_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 3 + [ctypes.c_void_p]
+            lib.oracle_gather_scaled_seg_sum_f32.restype = None
             _CLIB = lib
         else:
             _CLIB = False
@@ -198,6 +200,14 @@ def hard_sigmoid(x):
 
 
 # ---- node-wise cells / norms --------------------------------------------------------------
+def layer_norm_scope(i):
+    """Variable scope of the i-th tf.contrib.layers.layer_norm call inside one variable_scope: TF uniquifies repeated
+    default scopes as LayerNorm, LayerNorm_1, LayerNorm_2, ...  The layer functions call layer_norm once per TIMESTEP
+    (gnns/gnn_film.py:120, rgin.py:139, gnn_edge_mlp.py:119), so every timestep owns its gamma/beta, and the driver's
+    inter-layer norm (models/sparse_graph_model.py:192-193) comes after them in the same scope [TF-internal]."""
+    return "LayerNorm" if i == 0 else "LayerNorm_%d" % i
+
+
 def layer_norm(x, gamma, beta, eps=1e-12):
     """tf.contrib.layers.layer_norm on [V, D] (gnns/rgin.py:139, gnn_film.py:120,
     gnn_edge_mlp.py:119, models/sparse_graph_model.py:193) [TF-internal]: moments over the last

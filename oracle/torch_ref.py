@@ -9,6 +9,8 @@ import math
 
 import torch
 
+from .tf_ops import layer_norm_scope
+
 SMALL_NUMBER = 1e-7
 
 
@@ -168,7 +170,7 @@ def sparse_rgin_layer(h, adj, state_dim, num_timesteps=1, activation_function="R
     V = h.shape[0]
     tgts = _targets(adj)
     cur = h
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         msgs = []
         for l, a in enumerate(adj):
             x = cur.index_select(0, a[:, 0].long())
@@ -183,7 +185,7 @@ def sparse_rgin_layer(h, adj, state_dim, num_timesteps=1, activation_function="R
         new = agg(m, tgts, V)
         if num_aggr_MLP_hidden_layers is not None:
             new = mlp(new, weights, "Aggregation_MLP", num_aggr_MLP_hidden_layers, act)
-        cur = layer_norm(act(new), weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+        cur = layer_norm(act(new), weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])
     return cur
 
 
@@ -194,7 +196,7 @@ def sparse_gnn_film_layer(h, adj, deg, state_dim, num_timesteps=1, activation_fu
     D = state_dim if state_dim is not None else h.shape[1]
     tgts = _targets(adj)
     cur = h
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         msgs = []
         for l, a in enumerate(adj):
             m = cur.index_select(0, a[:, 0].long()) @ weights["Edge_%i_Weight/kernel" % l]
@@ -203,7 +205,7 @@ def sparse_gnn_film_layer(h, adj, deg, state_dim, num_timesteps=1, activation_fu
             film = (cur @ weights["Edge_%i_FiLM_Computations/kernel" % l]).index_select(0, a[:, 1].long())
             msgs.append(film[:, :D] * m + film[:, D:])
         new = agg(act(torch.cat(msgs, 0)), tgts, V)
-        cur = layer_norm(new, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+        cur = layer_norm(new, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])
     return cur
 
 
@@ -214,7 +216,7 @@ def sparse_gnn_edge_mlp_layer(h, adj, deg, state_dim, num_timesteps=1, activatio
     V = h.shape[0]
     tgts = _targets(adj)
     cur = h
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         msgs = []
         for l, a in enumerate(adj):
             x = cur.index_select(0, a[:, 0].long())
@@ -225,7 +227,7 @@ def sparse_gnn_edge_mlp_layer(h, adj, deg, state_dim, num_timesteps=1, activatio
                 m = _inv_deg(deg, l, a[:, 1], cur.dtype) * m
             msgs.append(m)
         new = agg(act(torch.cat(msgs, 0)), tgts, V)
-        cur = layer_norm(new, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+        cur = layer_norm(new, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])
     return cur
 
 

@@ -44,6 +44,12 @@ def layer_cases(seed=1234, V=48, D=16, L=3, K=4):
     h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
     ln = {"LayerNorm/gamma": (1 + 0.1 * rng.standard_normal(D)).astype(np.float32),
           "LayerNorm/beta": (0.1 * rng.standard_normal(D)).astype(np.float32)}
+    # the layers below run 2 timesteps: the reference's tf.contrib.layers.layer_norm call of the SECOND timestep owns
+    # its own variables (TF scope LayerNorm_1).  Drawn from a separate stream so that every other fixture entry stays
+    # what it was.
+    rng_ln = np.random.default_rng(seed + 1)
+    ln["LayerNorm_1/gamma"] = (1 + 0.1 * rng_ln.standard_normal(D)).astype(np.float32)
+    ln["LayerNorm_1/beta"] = (0.1 * rng_ln.standard_normal(D)).astype(np.float32)
     w = {}
     w["rgcn"] = rgcn_weights(rng, L, D, D)
     w["ggnn"] = dict(rgcn_weights(rng, L, D, D), **{"gru_cell/kernel": glorot(rng, (D, 3 * D)),

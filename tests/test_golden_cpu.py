@@ -67,18 +67,23 @@ def test_qm9_loader_matches_reference_restatement(self_loops, tie):
     expect_types = (4 + (1 if self_loops else 0)) * (1 if tie else 2)
     assert task.num_edge_types == expect_types and task.initial_node_feature_size == 15
     for d, s in zip(raw[:64], samples[:64]):
-        if tie:  # untied layout re-uses the tied restatement for the forward half only
-            adj, deg = bookkeeping.qm9_graph_to_adjacency_lists(d["graph"], len(d["node_features"]), expect_types,
-                                                                self_loops, tie)
-            assert len(adj) == len(s.adjacency_lists)
-            for a, b in zip(adj, s.adjacency_lists):
-                assert b.dtype == np.int32
-                np.testing.assert_array_equal(a, b)
-            np.testing.assert_array_equal(deg, s.type_to_node_to_num_incoming_edges)
-        # in every layout the degree table must equal the true in-degrees of the adjacency lists
+        adj, deg = bookkeeping.qm9_graph_to_adjacency_lists(d["graph"], len(d["node_features"]), expect_types,
+                                                            self_loops, tie)
+        assert len(adj) == len(s.adjacency_lists) == expect_types
+        for a, b in zip(adj, s.adjacency_lists):
+            assert b.dtype == np.int32 and b.shape[1] == 2
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(deg, s.type_to_node_to_num_incoming_edges)
         n = len(d["node_features"])
         true_deg = np.stack([np.bincount(a[:, 1], minlength=n) if len(a) else np.zeros(n) for a in s.adjacency_lists])
-        np.testing.assert_array_equal(true_deg, s.type_to_node_to_num_incoming_edges)
+        if tie:
+            np.testing.assert_array_equal(true_deg, s.type_to_node_to_num_incoming_edges)
+        else:
+            # the reference's untied table counts the backward types at the forward edge's target (qm9_task.py:145):
+            # forward half = true in-degrees, backward half = the forward half's counts again
+            half = expect_types // 2
+            np.testing.assert_array_equal(true_deg[:half], s.type_to_node_to_num_incoming_edges[:half])
+            np.testing.assert_array_equal(true_deg[:half], s.type_to_node_to_num_incoming_edges[half:])
 
 
 def _assert_batches_equal(mine, ref):

@@ -1,0 +1,130 @@
+"""Parity at the sizes BASELINE.json states, every output row, at the north-star tolerance (1e-5 ABSOLUTE on fp32
+node states for the normalised layers; max-abs and max-rel recorded for all):
+
+  C2  the full synthetic PPI-shaped batch of the bench (16 graphs, 32 203 nodes, 1 854 895 messages, 3 edge types,
+      h = 256): three chained sparse_rgcn_layer calls and the whole 3-layer RGCN_Model forward, HIP vs the C-backed
+      oracle (oracle.gnns.sparse_rgcn_layer(node_side_transform=True): the reference's message values and
+      sequential fp32 fold in the reference's message order; tests/test_oracle.py pins it to the op-for-op path)
+  C4  sparse_rgat_layer (h = 256, 4 heads) on the same C2 batch
+  C5  sparse_gnn_film_layer on a VarMisuse-shaped batch of one rank's share (~1.04 M messages, 23 edge types, h = 128)
+
+The oracle needs a few seconds per layer at these sizes (host BLAS + the sequential C fold)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bookkeeping, gnns as G, model as OM
+from helpers import assert_parity, glorot, parity_log, rgcn_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dev):
+    if isinstance(x, dict):
+        return {k: _dev(v, dev) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_dev(v, dev) for v in x]
+    return torch.as_tensor(x, device=dev)
+
+
+@pytest.fixture(scope="module")
+def c2():
+    from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(16, 1, seed=0)
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
+    assert mb.num_nodes == 32203 and mb.num_edges == 1854895          # the batch the bench line and DESIGN.md quote
+    return task, mb
+
+
+def test_c2_full_batch_three_rgcn_layers_every_row(gpu_device, c2):
+    from tf_gnn_samples_amd.gnns import sparse_rgcn_layer
+    _, mb = c2
+    fd = mb.feed_dict
+    rng = np.random.default_rng(0)
+    D = 256
+    adj, deg = fd["adjacency_lists"], fd["type_to_num_incoming_edges"].astype(np.float32)
+    adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
+    h_ref = (rng.random((mb.num_nodes, D), dtype=np.float32) * 2 - 1)     # post-tanh-like states
+    h_hip = _dev(h_ref, gpu_device)
+    for layer in range(3):
+        w = rgcn_weights(rng, 3, D, D)
+        h_ref = G.sparse_rgcn_layer(h_ref, adj, deg, D, 1, "ReLU", "sum", weights=w, node_side_transform=True)
+        h_hip = sparse_rgcn_layer(h_hip, adj_d, deg_d, D, 1, "ReLU", "sum", weights=_dev(w, gpu_device))
+        assert h_hip.shape == h_ref.shape
+        assert_parity(h_hip, h_ref, strict_abs=True, what="C2 full batch rgcn layer %d (chained)" % layer)
+    assert float(np.abs(h_ref).max()) > 0.05        # the chain did not collapse to zero
+
+
+def test_c2_full_batch_rgcn_model_forward(gpu_device, c2):
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DeviceBatch
+    task, mb = c2
+    p = RGCN_Model.default_params()
+    p.update(hidden_size=256, graph_num_layers=3, graph_activation_function="ReLU", message_aggregation_function="sum",
+             graph_layer_input_dropout_keep_prob=1.0)                      # README.md:32 of the reference
+    model = RGCN_Model(p, task, device=str(gpu_device))
+    batch = DeviceBatch(mb, gpu_device)
+    with torch.no_grad():
+        final = model.compute_final_node_representations(batch.initial_node_features, batch.adjacency_lists,
+                                                         batch.type_to_num_incoming_edges)
+    W = {n[len("graph_model/"):]: model.variables[n].detach().cpu().numpy() for n in model.variables.names()
+         if n.startswith("graph_model/")}
+    fd = mb.feed_dict
+    ref = OM.graph_propagation(fd['initial_node_features'].astype(np.float32), fd['adjacency_lists'],
+                               fd['type_to_num_incoming_edges'].astype(np.float32), p, W,
+                               OM.rgcn_apply(p, node_side_transform=True))
+    assert_parity(final, ref, strict_abs=True, what="C2 full batch RGCN_Model forward (3 layers + dense)")
+
+
+def test_c4_rgat_on_the_c2_batch(gpu_device, c2):
+    from tf_gnn_samples_amd.gnns import sparse_rgat_layer
+    _, mb = c2
+    fd = mb.feed_dict
+    rng = np.random.default_rng(1)
+    D, L, K, V = 256, 3, 4, mb.num_nodes
+    w = rgcn_weights(rng, L, D, D)
+    for l in range(L):
+        w["Edge_%i_Attention_Parameters" % l] = glorot(rng, (2 * D, 1))[:, 0]
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    ref = G.sparse_rgat_layer(h, fd["adjacency_lists"], D, K, 1, "tanh", weights=w)
+    out = sparse_rgat_layer(_dev(h, gpu_device), _dev(fd["adjacency_lists"], gpu_device), D, K, 1, "tanh",
+                            weights=_dev(w, gpu_device))
+    assert_parity(out, ref, strict_abs=True, what="C4 rgat on the full C2 batch")
+
+
+def test_c5_film_rank_share(gpu_device):
+    from tf_gnn_samples_amd.gnns import sparse_gnn_film_layer
+    from tf_gnn_samples_amd.tasks.synthetic import make_varmisuse_shaped_graphs
+    graphs = make_varmisuse_shaped_graphs(40, seed=0)      # ~100 k nodes, ~1.04 M messages: 1/8 of BASELINE's 10 M
+    L = 23
+    samples = [bookkeeping.GraphSample(g.adjacency_lists, g.type_to_node_to_num_incoming_edges, g.node_features, None)
+               for g in graphs]
+    b = next(bookkeeping.pack_batches(samples, L, 10 ** 9))
+    rng = np.random.default_rng(2)
+    D, V = 128, b["num_nodes"]
+    M = sum(len(a) for a in b["adjacency_lists"])
+    assert 0.9e6 < M < 1.2e6, M
+    w = dict(rgcn_weights(rng, L, D, D), **{"LayerNorm/gamma": np.ones(D, np.float32), "LayerNorm/beta": np.zeros(D, np.float32)})
+    for l in range(L):
+        w["Edge_%i_FiLM_Computations/kernel" % l] = glorot(rng, (D, 2 * D))
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    adj = [a.astype(np.int32) for a in b["adjacency_lists"]]
+    deg = b["type_to_num_incoming_edges"].astype(np.float32)
+    ref = G.sparse_gnn_film_layer(h, adj, deg, D, 1, "ReLU", "sum", False, weights=w)
+    out = sparse_gnn_film_layer(_dev(h, gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), D, 1, "ReLU", "sum", False,
+                                weights=_dev(w, gpu_device))
+    # un-normalised sum followed by layer norm: the pre-norm states are O(sqrt(degree)); relative budget
+    assert_parity(out, ref, strict_abs=False, what="C5 film, one rank's share (%d messages)" % M)
+
+
+def test_zz_report_parity_numbers():
+    """Not a check: prints the recorded max-abs / max-rel of this module's cases (and writes them under gpurun_out/)."""
+    import json
+    import os
+    rows = [r for r in parity_log() if r["what"].startswith(("C2", "C4", "C5"))]
+    for r in rows:
+        print("%-60s abs %.3e  rel %.3e  max|ref| %.3g" % (r["what"], r["abs"], r["rel"], r["max_ref"]))
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/parity_baseline_size.json", "w") as f:
+            json.dump(rows, f, indent=1)

@@ -3,14 +3,16 @@
   C3      GGNN on REAL QM9 graphs (tests/golden/qm9_valid_256.jsonl.gz), GRU cell, mean / max aggregation
   C4      RGAT on a PPI-shaped batch, h=256, 4 heads
   C5      GNN-FiLM on a VarMisuse-shaped batch (23 edge types, h=128)
-HIP path vs the NumPy oracle on identical inputs and weights; 1e-5 abs on node states (scaled by the state
-magnitude where an un-normalised sum grows past O(1))."""
+HIP path vs the NumPy oracle on identical inputs and weights.  Tolerance (helpers.assert_parity): 1e-5 ABSOLUTE on node
+states for the layers whose states are bounded by construction (RGCN with 1/in-degree normalisation, RGAT, GGNN's GRU
+output); for un-normalised sums that grow past O(1) the error is taken relative to max|ref|.  Max-abs and max-rel are
+both recorded.  The BASELINE-size cases live in tests/test_gpu_baseline_size.py."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import gnns as G, model as OM
-from helpers import glorot, rgcn_weights
+from helpers import assert_parity, glorot, rgcn_weights
 from test_golden_cpu import load_layers_fixture, read_qm9_fixture
 
 pytestmark = pytest.mark.gpu
@@ -25,9 +27,7 @@ def _dev(x, dev):
     return torch.as_tensor(x, device=dev)
 
 
-def _close(out, ref, tol=TOL):
-    out = out.detach().cpu().numpy() if torch.is_tensor(out) else out
-    return float(np.abs(out - ref).max()) < tol * max(1.0, float(np.abs(ref).max()))
+STRICT_ABS = {"rgcn": True, "ggnn": True, "rgat": True, "film": False, "rgin": False, "edge_mlp": False}
 
 
 def test_golden_fixture_all_layers(gpu_device):
@@ -44,7 +44,7 @@ def test_golden_fixture_all_layers(gpu_device):
         "edge_mlp": H.sparse_gnn_edge_mlp_layer(hd, ad, dd, D, 2, "gelu", "sum", weights=_dev(w["edge_mlp"], gpu_device)),
     }
     for name, ref in outs.items():
-        assert _close(got[name], ref), name
+        assert_parity(got[name], ref, strict_abs=STRICT_ABS[name], what="golden/" + name)
 
 
 def _qm9_batch(max_nodes=3000):
@@ -70,7 +70,7 @@ def test_c3_ggnn_qm9_real_graphs(gpu_device, agg):
     adj = fd["adjacency_lists"]
     ref = G.sparse_ggnn_layer(h, adj, D, 3, "GRU", "tanh", agg, weights=w)
     out = sparse_ggnn_layer(_dev(h, gpu_device), _dev(adj, gpu_device), D, 3, "GRU", "tanh", agg, weights=_dev(w, gpu_device))
-    assert _close(out, ref)
+    assert_parity(out, ref, strict_abs=True, what="C3 ggnn/qm9 " + agg)     # GRU states live in (-1, 1)
 
 
 def test_c3_ggnn_model_with_qm9_head(gpu_device):
@@ -96,10 +96,10 @@ def test_c3_ggnn_model_with_qm9_head(gpu_device):
                                    weights={k: v for k, v in lw.items() if k.startswith(("Edge_", "gru_cell"))})
     ref = OM.graph_propagation(fd['initial_node_features'].astype(np.float32), fd['adjacency_lists'],
                                fd['type_to_num_incoming_edges'].astype(np.float32), p, W, apply)
-    assert _close(final, ref)
+    assert_parity(final, ref, strict_abs=True, what="C3 ggnn model")
     # oracle restatement of the head (tasks/qm9_task.py:176-193)
-    s = "dense_1/out_layer_task0/" if "dense_1/out_layer_task0/regression/dense/kernel" in model.variables else None
-    scope = model._task_scope + "/out_layer_task0/"
+    assert model._task_scope == "" and "out_layer_task0/regression/dense/kernel" in model.variables   # reference names
+    scope = "out_layer_task0/"
     g = lambda n: model.variables[scope + n].detach().cpu().numpy()
     per_node = ref @ g("regression/dense/kernel") + g("regression/dense/bias")
     gate_in = np.concatenate([ref, fd['initial_node_features'].astype(np.float32)], -1)
@@ -129,7 +129,7 @@ def test_c4_rgat_ppi_shaped(gpu_device):
     ref = G.sparse_rgat_layer(h, fd["adjacency_lists"], D, K, 1, "tanh", weights=w)
     out = sparse_rgat_layer(_dev(h, gpu_device), _dev(fd["adjacency_lists"], gpu_device), D, K, 1, "tanh",
                             weights=_dev(w, gpu_device))
-    assert _close(out, ref)
+    assert_parity(out, ref, strict_abs=True, what="C4 rgat small")
 
 
 def test_c5_film_varmisuse_shaped(gpu_device):
@@ -154,4 +154,4 @@ def test_c5_film_varmisuse_shaped(gpu_device):
     ref = G.sparse_gnn_film_layer(h, adj, deg, D, 1, "ReLU", "sum", False, weights=w)
     out = sparse_gnn_film_layer(_dev(h, gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), D, 1, "ReLU", "sum", False,
                                 weights=_dev(w, gpu_device))
-    assert _close(out, ref)
+    assert_parity(out, ref, strict_abs=False, what="C5 film small")

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import gnns as G
-from helpers import degree_table, glorot, rgcn_weights
+from helpers import degree_table, glorot, layer_norm_weights, rgcn_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -64,8 +64,7 @@ def _build(seed, gpu_device, Ref, smooth=False):
         act = "elu"
     adj, deg = _graph(rng, V, L)
     h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
-    ln = {"LayerNorm/gamma": (1 + 0.1 * rng.standard_normal(D)).astype(np.float32),
-          "LayerNorm/beta": (0.1 * rng.standard_normal(D)).astype(np.float32)}
+    ln = layer_norm_weights(D, 2, rng)
     dev = lambda x: torch.as_tensor(x, device=gpu_device)
     adj_d, deg_d = [dev(a) for a in adj], dev(deg)
     if Ref is G:
@@ -171,8 +170,7 @@ def test_random_layer_configuration_matches_oracle(gpu_device, seed):
     rng, layer, D, L, V, agg, act = _case(seed)
     adj, deg = _graph(rng, V, L)
     h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
-    ln = {"LayerNorm/gamma": (1 + 0.1 * rng.standard_normal(D)).astype(np.float32),
-          "LayerNorm/beta": (0.1 * rng.standard_normal(D)).astype(np.float32)}
+    ln = layer_norm_weights(D, 2, rng)
     dev = lambda x: torch.as_tensor(x, device=gpu_device)
     dd = lambda w: {k: dev(v) for k, v in w.items()}
     adj_d, deg_d, h_d = [dev(a) for a in adj], dev(deg), dev(h)

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import gnns as G, torch_ref as R
-from helpers import degree_table, glorot, random_relational_graph, rgcn_weights
+from helpers import degree_table, glorot, layer_norm_weights, random_relational_graph, rgcn_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -118,8 +118,7 @@ def test_film_layer_compact_vs_oracle_and_dense(gpu_device, monkeypatch, agg, no
     w = rgcn_weights(rng, L, D, D)
     for l in range(L):
         w["Edge_%i_FiLM_Computations/kernel" % l] = glorot(rng, (D, 2 * D))
-    w["LayerNorm/gamma"] = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32)
-    w["LayerNorm/beta"] = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    w.update(layer_norm_weights(D, 2, rng))
     h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
     ref = G.sparse_gnn_film_layer(h, adj, deg, D, 2, act, agg, norm, weights=w)
     dev = lambda x: torch.as_tensor(x, device=gpu_device)

@@ -72,8 +72,9 @@ def test_bit_deterministic_forward_and_backward(gpu_device, layer):
     elif layer == "film":
         for l in range(L):
             w_d["Edge_%i_FiLM_Computations/kernel" % l] = torch.as_tensor(glorot(rng, (D, 2 * D)), device=gpu_device)
-        w_d["LayerNorm/gamma"] = torch.ones(D, device=gpu_device)
-        w_d["LayerNorm/beta"] = torch.zeros(D, device=gpu_device)
+        for t in ("LayerNorm", "LayerNorm_1"):
+            w_d[t + "/gamma"] = torch.ones(D, device=gpu_device)
+            w_d[t + "/beta"] = torch.zeros(D, device=gpu_device)
         fn = lambda x, ww: H.sparse_gnn_film_layer(x, adj_d, deg_d, D, 1, "ReLU", "sum", weights=ww)
     else:
         fn = lambda x, ww: H.sparse_rgcn_layer(x, adj_d, deg_d, D, 1, "tanh", "sum", weights=ww)

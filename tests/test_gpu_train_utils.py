@@ -30,6 +30,32 @@ def test_fused_clip_adam_matches_unfused_tf_rules(gpu_device):
     assert oa.t == ob.t == 4
 
 
+@pytest.mark.parametrize("name", ["Adam", "RMSProp", "SGD"])
+def test_device_optimizer_matches_the_numpy_restatement_of_the_tf_rules(gpu_device, name):
+    """The GPU update path (Adam: the two fused multi-tensor HIP launches relgnn_mt_l2norm + relgnn_mt_adam_clip;
+    RMSProp / SGD: foreach kernels) against oracle/optim.py — an independent restatement of tf.clip_by_norm and the TF1
+    ApplyAdam / ApplyRMSProp / ApplyGradientDescent rules (models/sparse_graph_model.py:227-260)."""
+    from oracle import optim as O
+    from tf_gnn_samples_amd.models.sparse_graph_model import TFStyleOptimizer
+    rng = np.random.default_rng(11)
+    shapes = [(50, 256), (256, 768), (121,), (1,), (256, 121), (3, 5, 7)]
+    vs = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    params = [torch.nn.Parameter(torch.as_tensor(v, device=gpu_device)) for v in vs]
+    opt = TFStyleOptimizer(params, name, 1e-3, 1.0, decay=0.98, momentum=0.85)
+    ref = O.make_optimizer(name, vs, 1e-3, decay=0.98, momentum=0.85)
+    for step in range(5):
+        gs = [(rng.standard_normal(s) * (5.0 if (i + step) % 2 == 0 else 0.01)).astype(np.float32) for i, s in enumerate(shapes)]
+        if step == 1:
+            gs[3] = None
+        for p, g in zip(params, gs):
+            p.grad = None if g is None else torch.as_tensor(g, device=gpu_device)
+        scale = 0.5 if step == 3 else 1.0
+        opt.clip_and_step(scale)
+        O.train_step(ref, gs, 1.0, scale)
+        for p, r in zip(params, ref.vars):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=3e-6, atol=3e-7)
+
+
 def test_sigmoid_ce_stats_and_gradient(gpu_device):
     from tf_gnn_samples_amd.tasks.ppi_task import _SigmoidCEStats
     from tf_gnn_samples_amd.utils import micro_f1

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import bookkeeping, gnns as G, model as OM, tf_ops as T
-from helpers import degree_table, glorot, random_relational_graph, rgcn_weights
+from helpers import degree_table, glorot, layer_norm_weights, random_relational_graph, rgcn_weights
 
 
 def test_parameter_count_known_answer():
@@ -81,8 +81,7 @@ def test_rgin_distinguishes_docstring_graphs():
     for l in range(2):
         w["Edge_%i_MLP/dense/kernel" % l] = glorot(rng, (D, D))
         w["Edge_%i_MLP/dense_1/kernel" % l] = glorot(rng, (D, D))
-    w["LayerNorm/gamma"] = np.ones(D, np.float32)
-    w["LayerNorm/beta"] = np.zeros(D, np.float32)
+    w.update(layer_norm_weights(D, 2))
     g1 = [np.array([[0, 1]], np.int32), np.array([[2, 1]], np.int32)]
     g2 = [np.array([[2, 1]], np.int32), np.array([[0, 1]], np.int32)]
     o1 = G.sparse_rgin_layer(h, g1, D, weights=w)
@@ -149,7 +148,7 @@ def test_all_layers_run_and_agree_with_fp64():
     adj = random_relational_graph(rng, V, L, 90, empty_types=(2,))
     deg = degree_table(adj, V)
     h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
-    ln = {"LayerNorm/gamma": np.ones(D, np.float32), "LayerNorm/beta": np.zeros(D, np.float32)}
+    ln = layer_norm_weights(D, 2)
     w_rgat = dict(rgcn_weights(rng, L, D, D))
     for l in range(L):
         w_rgat["Edge_%i_Attention_Parameters" % l] = rng.standard_normal(2 * D).astype(np.float32) * 0.3
@@ -173,3 +172,27 @@ def test_all_layers_run_and_agree_with_fp64():
         o32, o64 = f(h), f(h.astype(np.float64))
         assert o32.shape == (V, D) and o32.dtype == np.float32 and o64.dtype == np.float64
         assert np.abs(o32 - o64).max() < 2e-5
+
+
+def test_rgcn_node_side_evaluation_order_equals_op_for_op_path():
+    """oracle.gnns.sparse_rgcn_layer(node_side_transform=True) — the BASELINE-size evaluation order used by
+    tests/test_gpu_baseline_size.py — against the op-for-op restatement (per-edge MatMul, concat, segment sum):
+    same message values, same sequential fold, so the results agree to the last bit or two of fp32 (BLAS may
+    pick a different micro-kernel for the [V, D] and the [E_l, D] GEMM)."""
+    from oracle import gnns as G, model as OM
+    from helpers import degree_table, random_relational_graph, rgcn_weights
+    rng = np.random.default_rng(5)
+    V, D, L = 400, 64, 3
+    adj = random_relational_graph(rng, V, L, [3000, 400, 0])
+    deg = degree_table(adj, V)
+    w = rgcn_weights(rng, L, D, D)
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    for norm in (True, False):
+        for steps in (1, 2):
+            a = G.sparse_rgcn_layer(h, adj, deg, D, steps, "ReLU", "sum", norm, weights=w)
+            b = G.sparse_rgcn_layer(h, adj, deg, D, steps, "ReLU", "sum", norm, weights=w, node_side_transform=True)
+            assert np.abs(a - b).max() <= 4e-7 * max(1.0, np.abs(a).max())
+    # aggregations the fast path does not cover fall through to the op-for-op path
+    a = G.sparse_rgcn_layer(h, adj, deg, D, 1, "tanh", "max", weights=w)
+    b = G.sparse_rgcn_layer(h, adj, deg, D, 1, "tanh", "max", weights=w, node_side_transform=True)
+    assert np.array_equal(a, b)

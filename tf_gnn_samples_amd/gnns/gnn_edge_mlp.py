@@ -14,19 +14,19 @@ import torch
 from .. import ops
 from ..dense import dense
 from ..graph import as_rel_graph
-from ..utils import MLP, layer_norm
+from ..utils import MLP, layer_norm, layer_norm_scope, layer_norm_variables
 from ._common import require_weights
 from .pair import edge_mlp_messages, pair_messages_reduce
 
 
 def gnn_edge_mlp_layer_variables(num_edge_types: int, in_dim: int, state_dim: int,
-                                 use_target_state_as_input: bool = True, num_edge_hidden_layers: int = 1):
+                                 use_target_state_as_input: bool = True, num_edge_hidden_layers: int = 1,
+                                 num_timesteps: int = 1):
     specs = {}
     mlp_in = 2 * in_dim if use_target_state_as_input else in_dim
     for l in range(num_edge_types):
         specs.update(MLP.variable_shapes(mlp_in, state_dim, num_edge_hidden_layers, name="Edge_%i_MLP" % l))
-    specs["LayerNorm/beta"] = ((state_dim,), "zeros")
-    specs["LayerNorm/gamma"] = ((state_dim,), "ones")
+    specs.update(layer_norm_variables(state_dim, num_timesteps))      # one LayerNorm scope per timestep
     return specs
 
 
@@ -43,7 +43,7 @@ def sparse_gnn_edge_mlp_layer(node_embeddings: torch.Tensor,
                               *,
                               weights: Mapping[str, torch.Tensor] = None,
                               ) -> torch.Tensor:
-    """See gnns/gnn_edge_mlp.py:19-62.  `weights`: "Edge_%i_MLP/dense[_j]/kernel", "LayerNorm/{gamma,beta}"."""
+    """See gnns/gnn_edge_mlp.py:19-62.  `weights`: "Edge_%i_MLP/dense[_j]/kernel", "LayerNorm[_t]/{gamma,beta}" (one scope per timestep)."""
     weights = require_weights(weights, "sparse_gnn_edge_mlp_layer")
     num_nodes, in_dim = node_embeddings.shape
     if state_dim is None:
@@ -55,7 +55,7 @@ def sparse_gnn_edge_mlp_layer(node_embeddings: torch.Tensor,
     w = graph.degree_scale(type_to_num_incoming_edges) if normalize_by_num_incoming else None
 
     cur_node_states = node_embeddings
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         d = cur_node_states.shape[1]
         if num_edge_hidden_layers == 0:
             k = [weights["Edge_%i_MLP/dense/kernel" % l] for l in range(L)]
@@ -71,5 +71,5 @@ def sparse_gnn_edge_mlp_layer(node_embeddings: torch.Tensor,
                                      use_target_state_as_input)                       # [M, state_dim], type-major
             # scale (:104-108) + activation (:112) are folded into the segment reduce (:113-116)
             aggregated = ops.message_act_reduce(msgs, graph, w, message_aggregation_function, activation_function)
-        cur_node_states = layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+        cur_node_states = layer_norm(aggregated, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])
     return cur_node_states

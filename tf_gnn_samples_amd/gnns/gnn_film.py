@@ -15,17 +15,16 @@ import torch
 from .. import _lib, ops
 from ..dense import dense
 from ..graph import as_rel_graph
-from ..utils import apply_activation, get_activation, layer_norm
+from ..utils import apply_activation, get_activation, layer_norm, layer_norm_scope, layer_norm_variables
 from ._common import concat_edge_kernels, require_weights
 
 
-def gnn_film_layer_variables(num_edge_types: int, in_dim: int, state_dim: int):
+def gnn_film_layer_variables(num_edge_types: int, in_dim: int, state_dim: int, num_timesteps: int = 1):
     specs = {}
     for l in range(num_edge_types):
         specs["Edge_%i_Weight/kernel" % l] = ((in_dim, state_dim), "glorot_uniform")
         specs["Edge_%i_FiLM_Computations/kernel" % l] = ((in_dim, 2 * state_dim), "glorot_uniform")
-    specs["LayerNorm/beta"] = ((state_dim,), "zeros")
-    specs["LayerNorm/gamma"] = ((state_dim,), "ones")
+    specs.update(layer_norm_variables(state_dim, num_timesteps))      # one LayerNorm scope per timestep
     return specs
 
 
@@ -41,7 +40,7 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
                           weights: Mapping[str, torch.Tensor] = None,
                           ) -> torch.Tensor:
     """See gnns/gnn_film.py:17-57.  `weights`: "Edge_%i_Weight/kernel" [D, state_dim],
-    "Edge_%i_FiLM_Computations/kernel" [D, 2*state_dim], "LayerNorm/{gamma,beta}"."""
+    "Edge_%i_FiLM_Computations/kernel" [D, 2*state_dim], "LayerNorm[_t]/{gamma,beta}" (one scope per timestep)."""
     weights = require_weights(weights, "sparse_gnn_film_layer")
     num_nodes, in_dim = node_embeddings.shape
     if state_dim is None:
@@ -57,7 +56,7 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
         w_msg = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")               # [D, L*state_dim]
         w_film = concat_edge_kernels(weights, L, "Edge_%i_FiLM_Computations/kernel")   # [D, L*2*state_dim]
     cur_node_states = node_embeddings
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         if pairs is not None:
             transformed = ops.typed_linear(cur_node_states, pairs.src,
                                            [weights["Edge_%i_Weight/kernel" % l] for l in range(L)])
@@ -65,7 +64,7 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
                                     [weights["Edge_%i_FiLM_Computations/kernel" % l] for l in range(L)])
             aggregated = ops.film_messages_reduce(transformed, film, graph, w, message_aggregation_function,
                                                   activation_function, pairs)
-            cur_node_states = layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+            cur_node_states = layer_norm(aggregated, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])
             continue
         transformed = dense(cur_node_states, w_msg).view(num_nodes * L, state_dim)      # row v*L+l = h_v W_l
         film = dense(cur_node_states, w_film).view(num_nodes * L, 2 * state_dim)        # row v*L+l = [gamma | beta]
@@ -81,5 +80,5 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
         else:
             aggregated = ops.film_messages_reduce(transformed, film, graph, w, message_aggregation_function,
                                                   activation_function)
-        cur_node_states = layer_norm(aggregated, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+        cur_node_states = layer_norm(aggregated, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])
     return cur_node_states

@@ -15,13 +15,14 @@ import torch
 from .. import ops
 from ..dense import dense
 from ..graph import as_rel_graph
-from ..utils import MLP, apply_activation, get_activation, layer_norm
+from ..utils import MLP, apply_activation, get_activation, layer_norm, layer_norm_scope, layer_norm_variables
 from ._common import require_weights
 from .pair import edge_mlp_messages, pair_messages_reduce
 
 
 def rgin_layer_variables(num_edge_types: int, in_dim: int, state_dim: int, use_target_state_as_input: bool = False,
-                         num_edge_MLP_hidden_layers: Optional[int] = 1, num_aggr_MLP_hidden_layers: Optional[int] = None):
+                         num_edge_MLP_hidden_layers: Optional[int] = 1, num_aggr_MLP_hidden_layers: Optional[int] = None,
+                         num_timesteps: int = 1):
     specs = {}
     mlp_in = 2 * in_dim if use_target_state_as_input else in_dim
     if num_aggr_MLP_hidden_layers is not None:
@@ -30,8 +31,7 @@ def rgin_layer_variables(num_edge_types: int, in_dim: int, state_dim: int, use_t
     if num_edge_MLP_hidden_layers is not None:
         for l in range(num_edge_types):
             specs.update(MLP.variable_shapes(mlp_in, state_dim, num_edge_MLP_hidden_layers, name="Edge_%i_MLP" % l))
-    specs["LayerNorm/beta"] = ((state_dim,), "zeros")
-    specs["LayerNorm/gamma"] = ((state_dim,), "ones")
+    specs.update(layer_norm_variables(state_dim, num_timesteps))      # one LayerNorm scope per timestep
     return specs
 
 
@@ -48,7 +48,7 @@ def sparse_rgin_layer(node_embeddings: torch.Tensor,
                       weights: Mapping[str, torch.Tensor] = None,
                       ) -> torch.Tensor:
     """See gnns/rgin.py:18-68.  `weights`: "Edge_%i_MLP/dense[_j]/kernel", "Aggregation_MLP/dense[_j]/kernel",
-    "LayerNorm/{gamma,beta}"."""
+    "LayerNorm[_t]/{gamma,beta}" (one scope per timestep)."""
     weights = require_weights(weights, "sparse_rgin_layer")
     num_nodes, in_dim = node_embeddings.shape
     if state_dim is None:
@@ -63,7 +63,7 @@ def sparse_rgin_layer(node_embeddings: torch.Tensor,
                               activation_fun=activation_fn, name="Aggregation_MLP", weights=weights)
 
     cur_node_states = node_embeddings
-    for _ in range(num_timesteps):
+    for t in range(num_timesteps):
         d = cur_node_states.shape[1]
         if num_edge_MLP_hidden_layers is None:
             # messages are the raw (concatenated) states, no message activation (rgin.py:125-129)
@@ -97,5 +97,5 @@ def sparse_rgin_layer(node_embeddings: torch.Tensor,
         if aggregation_MLP is not None:
             new_node_states = aggregation_MLP(new_node_states)
         new_node_states = apply_activation(activation_fn, new_node_states)
-        cur_node_states = layer_norm(new_node_states, weights["LayerNorm/gamma"], weights["LayerNorm/beta"])
+        cur_node_states = layer_norm(new_node_states, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])
     return cur_node_states

@@ -79,7 +79,8 @@ SPECS: List[AdapterSpec] = [
         lambda m, d: gnns.rgin_layer_variables(m.task.num_edge_types, d, m.params['hidden_size'],
                                                m.params['use_target_state_as_input'],
                                                m.params['graph_num_edge_MLP_hidden_layers'],
-                                               m.params['graph_num_aggr_MLP_hidden_layers'])),
+                                               m.params['graph_num_aggr_MLP_hidden_layers'],
+                                               m.params['graph_num_timesteps_per_layer'])),
     AdapterSpec(
         "GNN_FiLM_Model", lambda p: "GNN-FiLM",
         {"hidden_size": 128, "graph_activation_function": "ReLU", "message_aggregation_function": "sum",
@@ -89,7 +90,8 @@ SPECS: List[AdapterSpec] = [
          "message_aggregation_function": "message_aggregation_function",
          "normalize_by_num_incoming": "normalize_messages_by_num_incoming"},
         True,
-        lambda m, d: gnns.gnn_film_layer_variables(m.task.num_edge_types, d, m.params['hidden_size'])),
+        lambda m, d: gnns.gnn_film_layer_variables(m.task.num_edge_types, d, m.params['hidden_size'],
+                                                   m.params['graph_num_timesteps_per_layer'])),
     AdapterSpec(
         "GNN_Edge_MLP_Model", lambda p: "GNN-Edge-MLP%i" % (p['num_edge_hidden_layers']),
         {'max_nodes_in_batch': 25000, 'hidden_size': 128, "graph_activation_function": "gelu",
@@ -102,7 +104,8 @@ SPECS: List[AdapterSpec] = [
         True,
         lambda m, d: gnns.gnn_edge_mlp_layer_variables(m.task.num_edge_types, d, m.params['hidden_size'],
                                                        m.params['use_target_state_as_input'],
-                                                       m.params['num_edge_hidden_layers'])),
+                                                       m.params['num_edge_hidden_layers'],
+                                                       m.params['graph_num_timesteps_per_layer'])),
     AdapterSpec(
         "RGDCN_Model", lambda p: "RGDCN",
         {'max_nodes_in_batch': 25000, 'hidden_size': 128, 'num_channels': 8,

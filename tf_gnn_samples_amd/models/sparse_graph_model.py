@@ -22,7 +22,7 @@ import torch
 from ..dense import dense
 from ..graph import as_rel_graph, check_pending_graph_errors
 from ..tasks import DataFold, DeviceBatch, Sparse_Graph_Task
-from ..utils import apply_activation, get_activation, layer_norm
+from ..utils import apply_activation, get_activation, layer_norm, layer_norm_scope
 from ..variables import VariableStore
 
 
@@ -138,6 +138,44 @@ class TFStyleOptimizer:
         for p in self.params:
             p.grad = None
 
+    # ---- optimizer state under TF's GLOBAL_VARIABLES names (the reference pickles those too, :91-107) ----
+    def _slots(self):
+        """(TF slot suffix, tensors) per optimizer [TF-internal slot names: Adam -> '<var>/Adam', '<var>/Adam_1';
+        RMSProp -> '<var>/RMSProp' (mean square), '<var>/RMSProp_1' (momentum)]."""
+        if self.name == 'adam':
+            return [("Adam", self.m), ("Adam_1", self.v)]
+        if self.name == 'rmsprop':
+            return [("RMSProp", self.ms), ("RMSProp_1", self.mom)]
+        return []
+
+    def tf_slot_weights(self, names: List[str]) -> Dict[str, np.ndarray]:
+        assert len(names) == len(self.params)
+        out = {}
+        for suffix, tensors in self._slots():
+            for n, t in zip(names, tensors):
+                out["%s/%s:0" % (n, suffix)] = t.detach().cpu().numpy().copy()
+        if self.name == 'adam':      # TF 1.13 keeps beta^(t+1) in two non-trainable scalars
+            out["beta1_power:0"] = np.float32(0.9 ** (self.t + 1))
+            out["beta2_power:0"] = np.float32(0.999 ** (self.t + 1))
+        return out
+
+    @torch.no_grad()
+    def load_tf_slots(self, weights, names: List[str]) -> set:
+        """Restore the slots a reference pickle carries; returns the consumed keys.  The step count is recovered from
+        beta1_power (= 0.9^(t+1))."""
+        used = set()
+        for suffix, tensors in self._slots():
+            for n, t in zip(names, tensors):
+                key = "%s/%s:0" % (n, suffix)
+                if key in weights:
+                    t.copy_(torch.as_tensor(np.asarray(weights[key]), dtype=torch.float32))
+                    used.add(key)
+        if self.name == 'adam' and "beta1_power:0" in weights:
+            import math
+            self.t = max(0, int(round(math.log(float(weights["beta1_power:0"])) / math.log(0.9))) - 1)
+            used.update(k for k in ("beta1_power:0", "beta2_power:0") if k in weights)
+        return used
+
 
 class Sparse_Graph_Model(ABC):
     """Abstract superclass of all graph models (reference docstring: models/sparse_graph_model.py:16-20)."""
@@ -210,13 +248,23 @@ class Sparse_Graph_Model(ABC):
             "model_params": self.params,
             "task_params": self.task.params,
             "task_metadata": self.task.get_metadata(),
-            "weights": self.variables.tf_weights(),
+            # every GLOBAL_VARIABLE of the TF graph: the model variables and the optimizer's slots
+            "weights": dict(self.variables.tf_weights(), **self.optimizer.tf_slot_weights(self._trainable_names())),
         }
         with open(path, 'wb') as out_file:
             pickle.dump(data_to_save, out_file, pickle.HIGHEST_PROTOCOL)
 
+    def _trainable_names(self) -> List[str]:
+        return [n for n in self.variables.names() if self.variables[n].requires_grad]
+
     def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
-        self.variables.load_tf_weights(weights)
+        """:109-126: assign every variable the pickle names (model variables and optimizer slots), freshly initialise
+        (= keep the initial value of) the ones it does not, report saved entries nothing consumed."""
+        used = self.variables.load_tf_weights(weights, report_unused=False)
+        used |= self.optimizer.load_tf_slots(weights, self._trainable_names())
+        for var_name in weights:
+            if var_name not in used:
+                print('Saved weights for %s not used by model.' % var_name)
 
     # -------------------- Model Construction --------------------
     @abstractmethod
@@ -236,7 +284,8 @@ class Sparse_Graph_Model(ABC):
             scope = "graph_model/gnn_layer_%i" % layer_idx
             specs = dict(self._gnn_layer_variables(h_dim))
             if p['graph_inter_layer_norm']:
-                ln = "LayerNorm_1" if "LayerNorm/gamma" in specs else "LayerNorm"   # TF uniquifies the 2nd scope
+                own = sum(1 for k in specs if k.startswith("LayerNorm") and k.endswith("/gamma"))
+                ln = layer_norm_scope(own)          # TF uniquifies: the scope after the layer's own per-timestep norms
                 specs[ln + "/beta"] = ((h_dim,), "zeros")
                 specs[ln + "/gamma"] = ((h_dim,), "ones")
                 self._inter_norm_name.append(ln)
@@ -245,9 +294,12 @@ class Sparse_Graph_Model(ABC):
             if layer_idx % p['graph_dense_between_every_num_gnn_layers'] == 0:
                 specs["Dense/kernel"] = ((h_dim, h_dim), "glorot_uniform")
             vs.create_all(scope, specs)
-        out_scope = "dense_1" if self.task.initial_node_feature_size != h_dim else "dense"
-        self._task_scope = out_scope
-        vs.create_all(out_scope, self.task.output_variables(h_dim))
+        # The task names its own output variables (absolute TF scope): PPI's head is an UNNAMED Keras Dense, which TF
+        # auto-names after the model's unnamed input projection ("dense" -> "dense_1", tasks/ppi_task.py:176-179);
+        # QM9's heads live under variable_scope("out_layer_task%i") at the root (tasks/qm9_task.py:163-176).
+        has_projection = self.task.initial_node_feature_size != h_dim
+        self._task_scope = self.task.output_variable_scope(has_projection)
+        vs.create_all(self._task_scope, self.task.output_variables(h_dim))
         self.log_line("Model has %i parameters." % vs.num_parameters())
 
     def compute_final_node_representations(self, initial_node_features: torch.Tensor,

@@ -165,6 +165,11 @@ class PPI_Task(Sparse_Graph_Task):
         return graphs
 
     # -------------------- Output head (tasks/ppi_task.py:165-194) --------------------
+    def output_variable_scope(self, model_has_input_projection: bool) -> str:
+        # tasks/ppi_task.py:176-179: an unnamed tf.keras.layers.Dense; Keras numbers unnamed layers per graph, and the
+        # model's unnamed input projection (models/sparse_graph_model.py:165-170) already took "dense"
+        return "dense_1" if model_has_input_projection else "dense"
+
     def output_variables(self, hidden_size: int):
         # unnamed Keras Dense with bias (:176-179); TF auto-names it after the model's input projection
         return {"kernel": ((hidden_size, self.__num_labels), "glorot_uniform"), "bias": ((self.__num_labels,), "zeros")}

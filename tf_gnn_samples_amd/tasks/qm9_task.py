@@ -130,7 +130,11 @@ class QM9_Task(Sparse_Graph_Task):
             for t, a in enumerate(list(adj)):
                 adj.append(np.array(sorted((y, x) for (x, y) in a), dtype=np.int32).reshape(-1, 2))
                 for (x, y) in a:
-                    deg[half + t][x] += 1   # incoming edge of the reversed edge (y -> x) lands on x
+                    # Reference behaviour kept bit for bit (tasks/qm9_task.py:144-145): the count goes to y, the target
+                    # of the FORWARD edge, although the reversed edge (y -> x) lands on x.  So with
+                    # tie_fwd_bkwd_edges=False the backward types' table is NOT the true in-degree of their adjacency
+                    # lists; it only reaches layers that normalise by it (RGCN default, FiLM/Edge-MLP when asked).
+                    deg[half + t][y] += 1
         return adj, deg
 
     # -------------------- Output head (tasks/qm9_task.py:150-197) --------------------

@@ -89,6 +89,10 @@ class Sparse_Graph_Task:
     def get_metadata(self) -> Dict[str, Any]:
         return {}
 
+    def output_variable_scope(self, model_has_input_projection: bool) -> str:
+        """Absolute TF variable scope of the task's output variables ("" = the graph's root scope)."""
+        return ""
+
     # ---- native batching (tasks/batcher.py); tasks override the payload tables / post-processing ----
     NODE_PAYLOADS = {"initial_node_features": ("node_features", np.float32)}
     GRAPH_PAYLOADS: Dict[str, tuple] = {}

@@ -114,6 +114,22 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, gsum[:D], gsum[D:], None
 
 
+def layer_norm_scope(i: int) -> str:
+    """Variable scope of the i-th tf.contrib.layers.layer_norm call inside one variable_scope (TF uniquifies the default
+    scope: LayerNorm, LayerNorm_1, ...).  The reference's layers call it once per TIMESTEP (gnns/gnn_film.py:120,
+    rgin.py:139, gnn_edge_mlp.py:119): every timestep owns its gamma/beta; the driver's inter-layer norm
+    (models/sparse_graph_model.py:192-193) is the next scope after them."""
+    return "LayerNorm" if i == 0 else "LayerNorm_%d" % i
+
+
+def layer_norm_variables(state_dim: int, count: int):
+    specs = {}
+    for i in range(count):
+        specs[layer_norm_scope(i) + "/beta"] = ((state_dim,), "zeros")
+        specs[layer_norm_scope(i) + "/gamma"] = ((state_dim,), "ones")
+    return specs
+
+
 def layer_norm(x, gamma, beta, eps: float = 1e-12):
     """tf.contrib.layers.layer_norm on a [V, D] tensor: moments over the last axis (biased
     variance), variance_epsilon 1e-12, learnable gamma/beta over the last axis."""

@@ -115,10 +115,10 @@ class VariableStore(nn.Module):
     def tf_weights(self) -> Dict[str, np.ndarray]:
         return {n + ":0": self[n].detach().cpu().numpy().copy() for n in self.names()}
 
-    def load_tf_weights(self, weights: Mapping[str, np.ndarray], strict: bool = False):
+    def load_tf_weights(self, weights: Mapping[str, np.ndarray], strict: bool = False, report_unused: bool = True):
         """Assign by variable name like Sparse_Graph_Model.load_weights
         (models/sparse_graph_model.py:109-126): unknown saved names are reported, missing ones
-        keep their fresh initialisation."""
+        keep their fresh initialisation.  Returns the set of consumed keys."""
         used = set()
         with torch.no_grad():
             for n in self.names():
@@ -133,6 +133,8 @@ class VariableStore(nn.Module):
                     raise KeyError("no saved value for %s" % n)
                 else:
                     print('Freshly initializing %s since no saved value was found.' % n)
-        for k in weights:
-            if k not in used:
-                print('Saved weights for %s not used by model.' % k)
+        if report_unused:
+            for k in weights:
+                if k not in used:
+                    print('Saved weights for %s not used by model.' % k)
+        return used
