@@ -588,6 +588,32 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
                          int32_t* inv_perm_t, int32_t* rowptr_s, int32_t* perm_s, int32_t* frow_s, int32_t* tgt_s,
                          int32_t* pos_t_of_s, void* stream);
 
+/* ========================================================================== *
+ * 11. Dynamic per-target convolution kernels  (gnns/rgdcn.py:126-160)
+ * ========================================================================== */
+
+/*
+ * Replaces, for sum / mean / sqrt_n aggregation: the per-channel, per-type loop of gnns/rgdcn.py:121-160 —
+ * tf.reshape of the computed weights to [V, K, K] (:139), their tf.nn.embedding_lookup per edge (:140-141), the
+ * per-edge tf.einsum('vi,vij->vj') (:146), tf.concat over types (:155), tf.unsorted_segment_* (:156-159) and the
+ * activation (:160).  The K x K kernel depends on the target node only, so it is applied once per
+ * (target, type, channel) to A = the source states summed into the (target, type) buckets by relgnn_seg_reduce_fwd
+ * (seg_stride 1, num_segments V*L):
+ *     out[v, c*K + j] = out_act( f_mode( sum_l sum_i A[(v*L + l)*C*K + c*K + i] * weight_act(P[v,l,c][i*K + j]) ) )
+ * P (pre-activation output of the weight-computation Dense, :134-138) is addressed in place as
+ *     P + v*p_node_stride + l*p_type_stride + c*p_channel_stride  (K*K contiguous floats).
+ * rowptr_t: the [V*L+1] (target, type) bucket pointers (message count of a target for mean / sqrt_n; may be NULL for
+ * sum).  Backward: G = d loss / d f_mode(sum) [V, C*K] -> gA (layout of A) and gP (layout of P).
+ * channel_dim must be a power of two <= 64 for the backward (RELGNN_EUNSUPPORTED otherwise).
+ */
+int relgnn_rgdcn_apply_fwd(int32_t mode, int32_t weight_act, int32_t out_act, const float* A, const float* P,
+                           int64_t p_node_stride, int64_t p_type_stride, int64_t p_channel_stride, int32_t num_nodes,
+                           int32_t num_edge_types, int32_t num_channels, int32_t channel_dim, const int32_t* rowptr_t,
+                           float* out, void* stream);
+int relgnn_rgdcn_apply_bwd(int32_t weight_act, const float* A, const float* P, int64_t p_node_stride, int64_t p_type_stride,
+                           int64_t p_channel_stride, int32_t num_nodes, int32_t num_edge_types, int32_t num_channels,
+                           int32_t channel_dim, const float* G, float* gA, float* gP, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

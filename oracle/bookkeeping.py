@@ -132,3 +132,49 @@ def qm9_graph_to_adjacency_lists(graph, num_nodes, num_edge_types, add_self_loop
                 # reversed edge (y -> x) lands on x.  Restated as written: the table is fed to the model as is.
                 deg[bwd][y] += 1
     return adj, deg
+
+
+def ppi_graphs_from_dgl_arrays(links, node_to_features, node_to_labels, node_to_graph_id,
+                               add_self_loop_edges=True, tie_fwd_bkwd_edges=False):
+    """Restatement of PPI_Task.__load_data, tasks/ppi_task.py:92-162, on the already-read file contents
+    ({fold}_graph.json['links'], _feats.npy, _labels.npy, _graph_id.npy): edge type 0 = forward links, then the
+    self-loop type, then the backward type (:99-106); graphs in order of first appearance of their id (:112-121);
+    node ids shifted by the graph's first node id (:117,139-142); an edge belongs to the graph of its SOURCE node
+    (:140); self loops ascend by node id (:124-126); per-type in-degree tables counted while reading (:143-147).
+    Returns [(adjacency lists, in-degree table [L, V_g], features, labels)] per graph."""
+    fwd_t, n_types = 0, 1
+    self_t = bkwd_t = None
+    if add_self_loop_edges:
+        self_t, n_types = n_types, n_types + 1
+    if not tie_fwd_bkwd_edges:
+        bkwd_t, n_types = n_types, n_types + 1
+    graphs, offset = {}, {}
+    for node_id in range(node_to_features.shape[0]):
+        gid = node_to_graph_id[node_id]
+        if gid not in graphs:
+            graphs[gid] = dict(adj=[[] for _ in range(n_types)], deg=[[] for _ in range(n_types)], feats=[], labels=[])
+            offset[gid] = node_id
+        g = graphs[gid]
+        g["feats"].append(node_to_features[node_id])
+        g["labels"].append(node_to_labels[node_id])
+        shifted = node_id - offset[gid]
+        if add_self_loop_edges:
+            g["adj"][self_t].append((shifted, shifted))
+            g["deg"][self_t].append(1)
+    for g in graphs.values():
+        n = len(g["feats"])
+        g["deg"][fwd_t] = np.zeros([n], np.int32)
+        if not tie_fwd_bkwd_edges:
+            g["deg"][bkwd_t] = np.zeros([n], np.int32)
+    for edge in links:
+        src, tgt = edge['source'], edge['target']
+        gid = node_to_graph_id[src]
+        src, tgt = src - offset[gid], tgt - offset[gid]
+        g = graphs[gid]
+        g["adj"][fwd_t].append((src, tgt))
+        g["deg"][fwd_t][tgt] += 1
+        if not tie_fwd_bkwd_edges:
+            g["adj"][bkwd_t].append((tgt, src))
+            g["deg"][bkwd_t][src] += 1
+    return [([np.array(a) for a in g["adj"]], np.array(g["deg"]), np.array(g["feats"]), np.array(g["labels"]))
+            for g in graphs.values()]

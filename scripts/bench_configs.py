@@ -2,7 +2,7 @@
   C3  GGNN on QM9 graphs (real molecules from tests/golden tiled to a 50k-node batch), GRU, mean/max, D=128, 6 layers
   C4  RGAT on the C2 PPI-shaped batch, D=256, 4 heads, 3 layers
   C5  GNN-FiLM on a VarMisuse-shaped batch (~1.25M edges = one rank's share), 23 edge types, D=128, 10 layers
-  also RGIN / GNN-Edge-MLP0/1 on the C2 batch.
+  also RGIN / GNN-Edge-MLP0/1 / GNN-FiLM / RGDCN (16 channels x 16) on the C2 batch.
 Each line: forward+backward+optimizer step time, edges/s, and forward-only time."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -78,15 +78,17 @@ if "C3" in which:
         p = cls.default_params(); p.update(hidden_size=128, graph_num_layers=6, graph_rnn_cell="GRU", message_aggregation_function=agg)
         run("C3 GGNN/QM9 GRU %s D=128 6 layers" % agg, quiet_model(cls, p, task), batch, mb)
 
-if any(w in which for w in ("C4", "RGIN", "MLP0", "MLP1", "FILM")):
+if any(w in which for w in ("C4", "RGIN", "MLP0", "MLP1", "FILM", "RGDCN")):
     task = PPI_Task(PPI_Task.default_params()); task.load_synthetic(16, 1, seed=0)
     mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
     batch = DeviceBatch(mb, dev)
     for key, mname in (("C4", "RGAT"), ("RGIN", "RGIN"), ("MLP0", "GNN-Edge-MLP0"), ("MLP1", "GNN-Edge-MLP1"),
-                       ("FILM", "GNN-FiLM")):
+                       ("FILM", "GNN-FiLM"), ("RGDCN", "RGDCN")):
         if key in which:
             cls, extra = name_to_model_class(mname)
             p = cls.default_params(); p.update(extra); p.update(hidden_size=256, graph_num_layers=3)
+            if key == "RGDCN":
+                p.update(num_channels=16)       # channel_dim = 256 / 16 = 16
             run("%s %s on C2 PPI-shaped batch D=256 3 layers" % (key, mname), quiet_model(cls, p, task), batch, mb, steps=10, prime=8)
 
 if "C5" in which or "VM" in which:

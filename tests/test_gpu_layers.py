@@ -391,14 +391,58 @@ def test_rgdcn_layer(gpu_device, full_state, tie, agg, norm):
                 h, w, gpu_device, tol=2e-5)
 
 
-def test_rgdcn_max_is_rejected_and_model_trains(gpu_device):
+@pytest.mark.parametrize("full_state,tie,norm", [(False, False, True), (True, True, False)])
+def test_rgdcn_max_aggregation(gpu_device, full_state, tie, norm):
+    """max does not commute with the per-target kernels: the layer evaluates the reference's per-message einsum
+    (gnns/rgdcn.py:140-159 with tf.unsorted_segment_max) and must agree with the oracle, gradients included."""
     from tf_gnn_samples_amd.gnns import sparse_rgdcn_layer
+    rng, adj, deg = _graph(33)
+    V, L, C, K = 150, 3, 4, 8
+    D = C * K
+    w = {}
+    for l in range(L):
+        for c in range(1 if tie else C):
+            w["Edge_%i_Channel_%i_Weight_Computation/kernel" % (l, c)] = \
+                (rng.standard_normal((D if full_state else K, K * K)) * 0.3).astype(np.float32)
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    ref = G.sparse_rgdcn_layer(h, adj, deg, C, K, 2, full_state, tie, "tanh", "max", norm, weights=w)
+    adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
+    out = sparse_rgdcn_layer(_dev(h, gpu_device), adj_d, deg_d, C, K, 2, full_state, tie, "tanh", "max", norm,
+                             weights=_dev(w, gpu_device))
+    assert _close(out, ref, strict_abs=True, what="rgdcn max")
+    adj_c, deg_c = [torch.as_tensor(a) for a in adj], torch.as_tensor(deg)
+    _grad_check(lambda x, ww: sparse_rgdcn_layer(x, adj_d, deg_d, C, K, 1, full_state, tie, "tanh", "max", norm, weights=ww),
+                lambda x, ww: R.sparse_rgdcn_layer(x, adj_c, deg_c, C, K, 1, full_state, tie, "tanh", "max", norm, weights=ww),
+                h, w, gpu_device, tol=2e-5)
+
+
+@pytest.mark.parametrize("K,act", [(16, "ReLU"), (12, "tanh"), (8, "gelu")])
+def test_rgdcn_kernel_and_library_paths(gpu_device, K, act):
+    """K a power of two + an activation whose derivative is recoverable from the output: the HIP apply kernels
+    (relgnn_rgdcn_apply_fwd/bwd); otherwise (K = 12, gelu) the same arithmetic through library ops."""
+    from tf_gnn_samples_amd.gnns import sparse_rgdcn_layer
+    rng, adj, deg = _graph(34)
+    V, L, C = 150, 3, 3
+    D = C * K
+    w = {"Edge_%i_Channel_%i_Weight_Computation/kernel" % (l, c): (rng.standard_normal((K, K * K)) * 0.3).astype(np.float32)
+         for l in range(L) for c in range(C)}
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
+    for agg in ("sum", "mean", "sqrt_n"):
+        ref = G.sparse_rgdcn_layer(h, adj, deg, C, K, 1, False, False, act, agg, True, weights=w)
+        out = sparse_rgdcn_layer(_dev(h, gpu_device), adj_d, deg_d, C, K, 1, False, False, act, agg, True,
+                                 weights=_dev(w, gpu_device))
+        assert _close(out, ref, what="rgdcn K=%d %s %s" % (K, act, agg))
+    if act != "ReLU":     # (kink at 0: finite-precision gradient comparisons are meaningful for smooth activations)
+        adj_c, deg_c = [torch.as_tensor(a) for a in adj], torch.as_tensor(deg)
+        _grad_check(lambda x, ww: sparse_rgdcn_layer(x, adj_d, deg_d, C, K, 1, False, False, act, "mean", True, weights=ww),
+                    lambda x, ww: R.sparse_rgdcn_layer(x, adj_c, deg_c, C, K, 1, False, False, act, "mean", True, weights=ww),
+                    h, w, gpu_device, tol=2e-5)
+
+
+def test_rgdcn_model_trains(gpu_device):
     from tf_gnn_samples_amd.models import RGDCN_Model
     from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
-    rng, adj, deg = _graph(32, V=20, E=(40, 10, 0))
-    with pytest.raises(NotImplementedError):
-        sparse_rgdcn_layer(torch.zeros((20, 16), device=gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), 2, 8,
-                           message_aggregation_function="max", weights={})
     task = PPI_Task(PPI_Task.default_params())
     task.load_synthetic(2, 1, seed=5, mean_nodes=150, std_nodes=20, min_nodes=80, max_nodes=250, fwd_edges_per_node=5.0)
     p = RGDCN_Model.default_params()

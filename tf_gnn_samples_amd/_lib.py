@@ -79,6 +79,8 @@ _SIGNATURES = {
     "relgnn_layer_norm_groups": (_c_i64, [_c_i64, _c_i32]),
     "relgnn_layer_norm_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_layer_norm_bwd": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_rgdcn_apply_fwd": (ctypes.c_int, [_c_i32, _c_i32, _c_i32, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
+    "relgnn_rgdcn_apply_bwd": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_plan_assemble": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i64] + [_ptr] * 8 + [_c_i64, _c_i64] + [_ptr] * 16 + [_ptr]),
     # host-side batch builder (section 9): host pointers only
     "relgnn_batch_layout_len": (_c_i64, [_c_i32, _c_i32]),

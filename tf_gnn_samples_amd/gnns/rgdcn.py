@@ -8,7 +8,9 @@ The K x K kernel depends on the TARGET node only, and sum / mean / sqrt_n are li
 the edge-side work is ONE gather + scale + segment-sum of raw source states into the (target, type) buckets
 (relgnn_seg_reduce_fwd, seg_stride 1) and the dynamic kernels are applied node-side to the V*L*C aggregated
 channel vectors instead of to M*C gathered ones (the reference materialises an [E, K, K] gather per channel and
-type, rgdcn.py:140-146).  `max` aggregation does not commute with the kernel application and is not supported.
+type, rgdcn.py:140-146): all L*C weight-computation Dense layers are ONE GEMM call and the kernels are applied by one HIP
+launch (csrc/rgdcn.hip, relgnn_rgdcn_apply_fwd/bwd).  `max` aggregation does not commute with the kernel application:
+it runs the reference's per-message evaluation (see the branch below).
 """
 from typing import List, Mapping, Optional
 
@@ -69,28 +71,57 @@ def sparse_rgdcn_layer(node_embeddings: torch.Tensor,
     graph = as_rel_graph(adjacency_lists, num_nodes)
     L = graph.L
     mode = ops.aggregation_mode_id(message_aggregation_function)
-    if mode == _lib.AGG_MAX:
-        raise NotImplementedError("sparse_rgdcn_layer: max aggregation does not commute with the per-target kernels")
+    act_id = ops.activation_id(activation_function)
     activation_fn = get_activation(activation_function)
     w = graph.degree_scale(type_to_num_incoming_edges) if normalize_by_num_incoming else None
-    plan = _bucket_plan(graph, w)
+    kernel = lambda l, c: weights["Edge_%i_Channel_%i_Weight_Computation/kernel" % (l, 0 if tie_channel_weights else c)]
+
+    def dynamic_weights_pre(cur):
+        """Pre-activation output of every weight-computation Dense (rgdcn.py:134-138) in ONE GEMM call:
+        full state: [V, D] @ [D, L*C*K*K] -> [V, L, C, K*K]; per channel: bmm [C, V, K] @ [C, K, L*K*K] -> [C, V, L, K*K]."""
+        if use_full_state_for_channel_weights:
+            w_cat = torch.cat([kernel(l, c) for l in range(L) for c in range(C)], dim=1)        # [D, L*C*K*K]
+            return dense(cur, w_cat), False
+        w_c = torch.stack([torch.cat([kernel(l, c) for l in range(L)], dim=1) for c in range(C)])  # [C, K, L*K*K]
+        return torch.bmm(cur.view(num_nodes, C, K).transpose(0, 1), w_c), True                  # [C, V, L*K*K]
 
     cur_node_states = node_embeddings
+    if mode == _lib.AGG_MAX:
+        # max does not commute with the kernel application: evaluate the reference's per-MESSAGE einsum (rgdcn.py:140-146,
+        # an [E, K, K] gather per channel and type) and reduce the materialised messages with the HIP segment-max
+        # (equal gradient split among ties, like tf.unsorted_segment_max).  Not a shipped configuration; O(M*K*K) memory.
+        src = graph.key_by_source.long() // L                                                    # type-major message order
+        tgt_row = graph.key_by_target.long()                                                     # tgt*L + l per message
+        w_orig = graph.w_original_order(w).unsqueeze(1) if w is not None else None
+        for _ in range(num_timesteps):
+            pre, channel_major = dynamic_weights_pre(cur_node_states)
+            dyn = apply_activation(activation_fn, pre)
+            dyn = dyn.view(C, num_nodes * L, K, K) if channel_major else dyn.view(num_nodes * L, C, K, K)
+            chunked = cur_node_states.view(num_nodes, C, K)
+            per_channel = []
+            for c in range(C):
+                kern = (dyn[c] if channel_major else dyn[:, c]).index_select(0, tgt_row)         # [M, K, K]
+                msg = torch.bmm(chunked[:, c, :].index_select(0, src).unsqueeze(1), kern).squeeze(1)   # einsum vi,vij->vj
+                per_channel.append(msg * w_orig if w_orig is not None else msg)
+            msgs = torch.cat(per_channel, dim=1)                                                 # [M, C*K]
+            agg = ops.seg_gather_reduce(msgs, graph.plan_messages(), message_aggregation_function, None)
+            cur_node_states = apply_activation(activation_fn, agg)
+        return cur_node_states
+
+    plan = _bucket_plan(graph, w)
+    fused = ops.rgdcn_apply_supported(K, act_id)
     for _ in range(num_timesteps):
         # A[v, l, c, :] = sum_{e in (v,l)} s_e * h_{u_e, c, :}          (one fused gather + scale + segment-sum)
-        agg = ops.seg_gather_reduce(cur_node_states, plan, "sum", None).view(num_nodes, L, C, K)
-        chunked = cur_node_states.view(num_nodes, C, K)
-        new_channels = []
-        for c in range(C):
-            wc_in = cur_node_states if use_full_state_for_channel_weights else chunked[:, c, :]
-            acc = None
-            for l in range(L):
-                kern = weights["Edge_%i_Channel_%i_Weight_Computation/kernel" % (l, 0 if tie_channel_weights else c)]
-                dyn = apply_activation(activation_fn, dense(wc_in.contiguous(), kern)).view(num_nodes, K, K)
-                msg = torch.bmm(agg[:, l, c, :].unsqueeze(1), dyn).squeeze(1)           # einsum('vi,vij->vj')
-                acc = msg if acc is None else acc + msg
-            new_channels.append(acc)
-        new_states = torch.stack(new_channels, dim=1)                                  # [V, C, K]
+        agg = ops.seg_gather_reduce(cur_node_states, plan, "sum", None)                          # [V*L, C*K]
+        pre, channel_major = dynamic_weights_pre(cur_node_states)
+        if fused:
+            cur_node_states = ops.rgdcn_apply(agg, pre, graph, C, K, message_aggregation_function, activation_function,
+                                              activation_function, channel_major)
+            continue
+        # odd channel widths / gelu: the same arithmetic through library ops
+        dyn = apply_activation(activation_fn, pre)
+        dyn = dyn.view(C, num_nodes, L, K, K).permute(1, 2, 0, 3, 4) if channel_major else dyn.view(num_nodes, L, C, K, K)
+        new_states = torch.einsum('vlci,vlcij->vcj', agg.view(num_nodes, L, C, K), dyn)
         if mode != _lib.AGG_SUM:
             n = graph.messages_per_target().view(num_nodes, 1, 1)
             new_states = new_states / (n if mode == _lib.AGG_MEAN else torch.sqrt(n))

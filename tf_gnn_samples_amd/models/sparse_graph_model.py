@@ -392,6 +392,8 @@ class Sparse_Graph_Model(ABC):
         from ..tasks.batcher import NativeBatcher
         key = (id(data), len(data))
         cached = self._native_batchers.get(key)
+        if cached is not None and cached[0] is data:
+            self._native_batchers[key] = self._native_batchers.pop(key)      # most recently used last
         if cached is None or cached[0] is not data:
             store = self.task.make_graph_store(data)
             pipeline = None
@@ -409,6 +411,10 @@ class Sparse_Graph_Model(ABC):
                 pipeline = NativeBatcher(store, self.device)
             cached = (data, pipeline)
             self._native_batchers[key] = cached
+            # train + validation folds (and one more) stay; anything older — e.g. the fresh list every test() call
+            # passes — is dropped so that its resident copy of the fold and its pinned arenas are released
+            while len(self._native_batchers) > 3:
+                self._native_batchers.pop(next(iter(self._native_batchers)))
         return self.task.make_native_minibatch_iterator(cached[1], data_fold, self.params['max_nodes_in_batch'])
 
     @staticmethod

@@ -637,6 +637,59 @@ def fused_aggregate_transform(H, W, graph, w, aggregation: str, activation: Opti
     return _FusedAggregateTransform.apply(H, W, graph, w, mode, act)
 
 
+# ---- RGDCN dynamic kernels applied node-side (csrc/rgdcn.hip) --------------------------------------------------------
+class _RgdcnApply(torch.autograd.Function):
+    """out[v,c,:] = out_act(f_mode(sum_l A[v,l,c,:] @ weight_act(P[v,l,c]))); A [V*L, C*K] (bucket-aggregated source
+    states), P pre-activation dynamic weights in either GEMM layout ([V, L, C, K*K] or [C, V, L, K*K])."""
+
+    @staticmethod
+    def forward(ctx, A, P, graph, C: int, K: int, mode: int, weight_act: int, out_act: int, channel_major: bool):
+        lib = _lib.load_library()
+        A, P = A.contiguous(), P.contiguous()
+        V, L = graph.V, graph.L
+        KK = K * K
+        strides = (L * KK, KK, V * L * KK) if channel_major else (L * C * KK, C * KK, KK)
+        out = torch.empty((V, C * K), dtype=torch.float32, device=A.device)
+        _lib.check(lib.relgnn_rgdcn_apply_fwd(mode, weight_act, out_act, _lib.ptr(A), _lib.ptr(P), *strides, V, L, C, K,
+                                              _lib.ptr(graph.rowptr_t), _lib.ptr(out), _lib.current_stream()),
+                   "relgnn_rgdcn_apply_fwd")
+        ctx.graph, ctx.geom, ctx.strides = graph, (C, K, mode, weight_act, out_act), strides
+        ctx.save_for_backward(A, P, out if out_act != _lib.ACT_LINEAR else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        A, P, out = ctx.saved_tensors
+        graph = ctx.graph
+        C, K, mode, weight_act, out_act = ctx.geom
+        V, L = graph.V, graph.L
+        g = gout.contiguous()
+        if out_act != _lib.ACT_LINEAR:
+            g2 = torch.empty_like(g)
+            _lib.check(lib.relgnn_act_bwd_from_output(out_act, _lib.ptr(out), _lib.ptr(g), g.numel(), _lib.ptr(g2), st),
+                       "relgnn_act_bwd_from_output")
+            g = g2
+        f = _mode_factor(graph, mode)
+        if f is not None:
+            g = (g * f.unsqueeze(1)).contiguous()
+        gA, gP = torch.empty_like(A), torch.empty_like(P)
+        _lib.check(lib.relgnn_rgdcn_apply_bwd(weight_act, _lib.ptr(A), _lib.ptr(P), *ctx.strides, V, L, C, K, _lib.ptr(g),
+                                              _lib.ptr(gA), _lib.ptr(gP), st), "relgnn_rgdcn_apply_bwd")
+        return gA, gP, None, None, None, None, None, None, None
+
+
+def rgdcn_apply_supported(K: int, out_act: int) -> bool:
+    return 0 < K <= 64 and (K & (K - 1)) == 0 and out_act in _FUSABLE_ACTS
+
+
+def rgdcn_apply(A, P, graph, num_channels: int, channel_dim: int, aggregation: str, weight_activation: Optional[str],
+                output_activation: Optional[str], channel_major: bool):
+    return _RgdcnApply.apply(A, P, graph, int(num_channels), int(channel_dim), aggregation_mode_id(aggregation),
+                             activation_id(weight_activation), activation_id(output_activation), bool(channel_major))
+
+
 # ---- materialised messages: scale + activation fused into the segment reduce ------------------------------------
 class _MessageActReduce(torch.autograd.Function):
     """out[v] = f_mode( sum_{m -> v} act( w_m * msgs[m] ) ) for a message tensor [M, D] in the reference's type-major

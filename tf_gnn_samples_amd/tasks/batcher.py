@@ -185,8 +185,19 @@ class NativeBatcher:
         if self.device.type != "cuda":
             dev = host[:nbytes].clone()
         else:
+            before = self._dev[slot]
             dev = self._arena(self._dev, slot, nbytes, pinned=False)
             cur = torch.cuda.current_stream(self.device)
+            if dev is not before:
+                # A fresh block from the caching allocator (first use, or the arena grew): the allocator hands out
+                # memory whose previous owner's kernels may still be QUEUED on the current stream (the training loop
+                # runs the host ahead of the GPU on purpose).  The copy stream must not write into it before those
+                # kernels have run, and the allocator must know the block is used on the copy stream too.
+                fresh = torch.cuda.Event()
+                fresh.record(cur)
+                self._copy_stream.wait_event(fresh)
+                dev.record_stream(self._copy_stream)
+                self._released[slot] = None
             # the arena's previous batch must be fully consumed before it is overwritten; NOT a wait on everything
             # enqueued so far, or the upload could never overlap with the batch that is computing right now
             if self._released[slot] is not None:
