@@ -338,10 +338,17 @@ def test_every_model_trains_a_step(gpu_device, model_name):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize("Din,Dout", [(256, 256), (320, 320), (128, 64), (64, 512), (48, 96)])
+def test_fused_mfma_kernel_reports_unsupported_widths(gpu_device):
+    from tf_gnn_samples_amd import _lib, ops
+    assert ops.fused_transform_supported(256, 256, _lib.AGG_SUM) and ops.fused_transform_supported(128, 256, _lib.AGG_MEAN)
+    assert not ops.fused_transform_supported(320, 320, _lib.AGG_SUM)      # widths the kernel is not instantiated for
+    assert not ops.fused_transform_supported(256, 256, _lib.AGG_MAX)      # max does not commute with the transform
+
+
+@pytest.mark.parametrize("Din,Dout", [(256, 256), (128, 128), (256, 128), (128, 256)])
 @pytest.mark.parametrize("agg,norm", [("sum", True), ("mean", False), ("sqrt_n", False)])
 def test_fused_mfma_aggregate_transform(gpu_device, Din, Dout, agg, norm):
-    """csrc/rgcn_fused.hip (f32 MFMA, aggregate-then-transform) == the oracle's transform-then-aggregate RGCN."""
+    """csrc/agg_transform.hip (f32 MFMA, aggregate-then-transform) == the oracle's transform-then-aggregate RGCN."""
     from tf_gnn_samples_amd import ops
     from tf_gnn_samples_amd.graph import RelGraph
     rng, adj, deg = _graph(21)
@@ -484,4 +491,7 @@ def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer):
         out.backward(torch.as_tensor(np.random.default_rng(2).standard_normal(out.shape).astype(np.float32), device=gpu_device))
         grads.append([hd.grad] + [wd[k].grad for k in sorted(wd)])
     for a, b in zip(*grads):
+        if a is None or b is None:          # the second timestep's LayerNorm scope is not touched by a 1-step layer
+            assert a is None and b is None
+            continue
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))

@@ -46,8 +46,10 @@ _SIGNATURES = {
     "relgnn_seg_max_count": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_seg_max_bwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_act_bwd_from_output": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr]),
-    "relgnn_pack_type_weights": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _ptr, _ptr]),
-    "relgnn_rgcn_fused_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
+    "relgnn_agg_transform_supported": (ctypes.c_int, [_c_i32, _c_i32]),
+    "relgnn_agg_transform_pack_weights": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _c_i64, _ptr, _ptr]),
+    "relgnn_agg_transform_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr,
+                                                _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_film_bwd_msg": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
@@ -79,8 +81,11 @@ _SIGNATURES = {
     "relgnn_layer_norm_groups": (_c_i64, [_c_i64, _c_i32]),
     "relgnn_layer_norm_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_layer_norm_bwd": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "relgnn_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_rgdcn_apply_fwd": (ctypes.c_int, [_c_i32, _c_i32, _c_i32, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_rgdcn_apply_bwd": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr]),
+    "relgnn_batch_gather": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i64] + [_ptr] * 6 + [_c_i64, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _ptr,
+                                           _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_plan_assemble": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i64] + [_ptr] * 8 + [_c_i64, _c_i64] + [_ptr] * 16 + [_ptr]),
     # host-side batch builder (section 9): host pointers only
     "relgnn_batch_layout_len": (_c_i64, [_c_i32, _c_i32]),

@@ -97,9 +97,85 @@ __global__ __launch_bounds__(256) void assemble_rowptr_kernel(
   }
 }
 
+// ---- the batch's TENSORS, gathered from the fold's flat arrays (packing rules of relgnn_batch_pack) -----------------
+// Nodes of a graph are contiguous in the fold and in the batch: every copy below is K contiguous segment copies, found
+// per element by a binary search over the K+1 batch offsets (K <= a few hundred; the tables sit in L1/L2).
+
+// dst[v, :] = src[node_d(v), :]   rows of `cols` 4-byte elements
+__global__ __launch_bounds__(256) void gather_node_rows_kernel(BatchTables t, int64_t V, int32_t cols,
+                                                               const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
+  const int64_t total = V * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / cols;
+    const int k = upper_slot(t.node_off_b, t.K, v);
+    const int64_t vd = v - t.node_off_b[k] + t.node_off_d[t.ids[k]];
+    dst[i] = src[vd * cols + (i - v * cols)];
+  }
+}
+
+// deg_b[l, v] = deg_d[l, node_d(v)];  node_to_graph[v] = batch slot of v   (tasks/ppi_task.py:231-237)
+__global__ __launch_bounds__(256) void gather_degree_kernel(BatchTables t, int64_t V, int64_t N, const float* __restrict__ deg_d,
+                                                            float* __restrict__ deg_b, int32_t* __restrict__ node_to_graph) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+    const int k = upper_slot(t.node_off_b, t.K, v);
+    const int64_t vd = v - t.node_off_b[k] + t.node_off_d[t.ids[k]];
+    for (int l = 0; l < t.L; ++l) deg_b[(int64_t)l * V + v] = deg_d[(int64_t)l * N + vd];
+    node_to_graph[v] = k;
+  }
+}
+
+// adj_b[p] = adj_d[message_d(p)] + node offset of the slot   (tasks/ppi_task.py:228); both lists type-major [M, 2]
+__global__ __launch_bounds__(256) void gather_adjacency_kernel(BatchTables t, int64_t M, const int2* __restrict__ adj_d,
+                                                               int2* __restrict__ adj_b) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < M; p += (int64_t)gridDim.x * blockDim.x) {
+    const int l = upper_slot(t.type_off_b, t.L, p);
+    const int64_t e = p - t.type_off_b[l];
+    const int64_t* eob = t.edge_off_b + (int64_t)l * (t.K + 1);
+    const int k = upper_slot(eob, t.K, e);
+    const int64_t g = t.ids[k];
+    const int64_t pd = t.type_off_d[l] + t.edge_off_d[(int64_t)l * (t.G + 1) + g] + (e - eob[k]);
+    int2 a = adj_d[pd];
+    const int off = (int)t.node_off_b[k];
+    a.x += off; a.y += off;
+    adj_b[p] = a;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int relgnn_batch_gather(const int64_t* ids, int32_t num_batch_graphs, int32_t num_edge_types, int64_t num_dataset_graphs,
+                        const int64_t* node_off_b, const int64_t* edge_off_b, const int64_t* type_off_b,
+                        const int64_t* node_off_d, const int64_t* edge_off_d, const int64_t* type_off_d, int64_t num_nodes,
+                        int64_t num_messages, int64_t num_dataset_nodes, int32_t n_payloads, const void* const* h_payload_d,
+                        const int32_t* h_payload_cols, void* const* h_payload_b, const float* deg_d, float* deg_b,
+                        const int32_t* adj_d, int32_t* adj_b, int32_t* node_to_graph, void* stream) {
+  if (num_batch_graphs < 0 || num_edge_types <= 0 || num_dataset_graphs < 0 || num_nodes < 0 || num_messages < 0 ||
+      n_payloads < 0 || num_dataset_nodes < 0)
+    return RELGNN_EINVAL;
+  if (num_batch_graphs == 0 || num_nodes == 0) return RELGNN_OK;
+  if (!ids || !node_off_b || !edge_off_b || !type_off_b || !node_off_d || !edge_off_d || !type_off_d) return RELGNN_EINVAL;
+  if (n_payloads > 0 && (!h_payload_d || !h_payload_cols || !h_payload_b)) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  BatchTables t{ids, node_off_b, nullptr, edge_off_b, type_off_b, node_off_d, nullptr, edge_off_d, type_off_d,
+                num_batch_graphs, num_edge_types, num_dataset_graphs};
+  for (int p = 0; p < n_payloads; ++p) {
+    if (h_payload_cols[p] <= 0) continue;
+    if (!h_payload_d[p] || !h_payload_b[p]) return RELGNN_EINVAL;
+    gather_node_rows_kernel<<<flat_grid(num_nodes * h_payload_cols[p], 256), 256, 0, st>>>(
+        t, num_nodes, h_payload_cols[p], (const uint32_t*)h_payload_d[p], (uint32_t*)h_payload_b[p]);
+  }
+  if (deg_b || node_to_graph) {
+    if (!deg_d || !deg_b || !node_to_graph) return RELGNN_EINVAL;
+    gather_degree_kernel<<<flat_grid(num_nodes, 256), 256, 0, st>>>(t, num_nodes, num_dataset_nodes, deg_d, deg_b, node_to_graph);
+  }
+  if (num_messages > 0) {
+    if (!adj_d || !adj_b) return RELGNN_EINVAL;
+    gather_adjacency_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, (const int2*)adj_d, (int2*)adj_b);
+  }
+  return launch_status();
+}
 
 int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t num_edge_types, int64_t num_dataset_graphs,
                          const int64_t* node_off_b, const int64_t* msg_off_b, const int64_t* edge_off_b,

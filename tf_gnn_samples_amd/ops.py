@@ -575,34 +575,54 @@ def rgat_attention(T, s_src, s_tgt, graph, num_heads: int, slope: float = 0.2):
     return _RgatAttention.apply(T, s_src, s_tgt, graph, int(num_heads), float(slope))
 
 
-# ---- fused aggregate -> MFMA transform (csrc/rgcn_fused.hip) ---------------------------------------
+# ---- fused aggregate -> MFMA transform (csrc/agg_transform.hip) -------------------------------------
 def fused_transform_supported(d_in: int, d_out: int, mode: int) -> bool:
-    return (mode in (_lib.AGG_SUM, _lib.AGG_MEAN, _lib.AGG_SQRT_N) and d_in % 8 == 0 and d_in <= 384
-            and d_out % 32 == 0 and d_out <= 512)
+    return (mode in (_lib.AGG_SUM, _lib.AGG_MEAN, _lib.AGG_SQRT_N)
+            and bool(_lib.load_library().relgnn_agg_transform_supported(int(d_in), int(d_out))))
+
+
+def _agg_transform(X, rowptr, num_out, L, col, w, packed, d_in, d_out, mode, act, want_agg):
+    lib = _lib.load_library()
+    out = torch.empty((num_out, d_out), dtype=torch.float32, device=X.device)
+    agg = torch.empty((num_out, L * d_in), dtype=torch.float32, device=X.device) if want_agg else None
+    _lib.check(lib.relgnn_agg_transform_fwd(mode, act, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), d_in,
+                                            _lib.ptr(rowptr), num_out, L, _lib.ptr(col), _lib.ptr(w), _lib.ptr(packed), d_out,
+                                            _lib.ptr(out), d_out, _lib.ptr(agg), L * d_in, _lib.current_stream()),
+               "relgnn_agg_transform_fwd")
+    return out, agg
+
+
+def _pack_agg_weights(W, transposed: bool):
+    """W [L, Din, Dout] -> MFMA operand order of W_l (or of W_l^T for the input gradient)."""
+    lib = _lib.load_library()
+    L, d_in, d_out = W.shape
+    packed = torch.empty(L * d_in * d_out, dtype=torch.float32, device=W.device)
+    if transposed:      # matrix l = W_l^T [Dout, Din]: element (k, n) = W_l[n, k]
+        args = (d_out, d_in, d_in * d_out, 1, d_out)
+    else:
+        args = (d_in, d_out, d_in * d_out, d_out, 1)
+    _lib.check(lib.relgnn_agg_transform_pack_weights(_lib.ptr(W), L, *args, _lib.ptr(packed), _lib.current_stream()),
+               "relgnn_agg_transform_pack_weights")
+    return packed
 
 
 class _FusedAggregateTransform(torch.autograd.Function):
     """out = act(f_mode(sum_l (sum_{p in (v,l)} w_p H[src_p]) @ W_l)); W: [L, Din, Dout].
-    Forward: one kernel (gather in registers -> LDS tile -> f32 MFMA).  Backward: the unfused formulas, which
-    are the exact gradients of the same function: dT = transposed gather-reduce of dOut, dH = dT @ Wcat^T,
-    dW = H^T @ dT (split-K)."""
+    Forward: ONE kernel (wave-specialised: gather into LDS tiles under exact-f32 MFMAs); it also emits the aggregated
+    rows A [V, L*Din] when a gradient is needed.  Backward: dH = the SAME kernel on the by-source buckets with W_l^T
+    (the [V, L*Dout] per-type gradient table of the unfused path never exists either); dW_l = A_l^T @ dOut, one
+    split-K GEMM over the node dimension."""
 
     @staticmethod
     def forward(ctx, H, W, graph, w, mode: int, act: int):
-        lib = _lib.load_library()
-        st = _lib.current_stream()
         H, W = H.contiguous(), W.contiguous()
         L, d_in, d_out = W.shape
         V = graph.V
-        packed = torch.empty(L * d_in * d_out, dtype=torch.float32, device=H.device)
-        _lib.check(lib.relgnn_pack_type_weights(_lib.ptr(W), L, d_in, d_out, d_out, d_in * d_out, _lib.ptr(packed), st),
-                   "relgnn_pack_type_weights")
-        out = torch.empty((V, d_out), dtype=torch.float32, device=H.device)
-        _lib.check(lib.relgnn_rgcn_fused_fwd(mode, act, _lib.ptr(H), d_in, d_in, _lib.ptr(graph.rowptr_t), V, L,
-                                             _lib.ptr(graph.src_t), _lib.ptr(w), _lib.ptr(packed), d_out, _lib.ptr(out),
-                                             d_out, st), "relgnn_rgcn_fused_fwd")
+        need_grad = H.requires_grad or W.requires_grad
+        out, agg = _agg_transform(H, graph.rowptr_t, V, L, graph.src_t, w, _pack_agg_weights(W, False), d_in, d_out,
+                                  mode, act, need_grad and W.requires_grad)
         ctx.graph, ctx.w, ctx.mode, ctx.act = graph, w, mode, act
-        ctx.save_for_backward(H, W, out if act != _lib.ACT_LINEAR else None)
+        ctx.save_for_backward(W, agg, out if act != _lib.ACT_LINEAR else None)
         return out
 
     @staticmethod
@@ -610,7 +630,7 @@ class _FusedAggregateTransform(torch.autograd.Function):
         from .dense import matmul_tn_splitk
         lib = _lib.load_library()
         graph, w, mode, act = ctx.graph, ctx.w, ctx.mode, ctx.act
-        H, W, out = ctx.saved_tensors
+        W, agg, out = ctx.saved_tensors
         L, d_in, d_out = W.shape
         V = graph.V
         gout = gout.contiguous()
@@ -619,14 +639,15 @@ class _FusedAggregateTransform(torch.autograd.Function):
             _lib.check(lib.relgnn_act_bwd_from_output(act, _lib.ptr(out), _lib.ptr(gout), gout.numel(), _lib.ptr(g),
                                                       _lib.current_stream()), "relgnn_act_bwd_from_output")
             gout = g
-        plan = graph.plan_transformed(w)
-        gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
-                             plan.num_rows_x).view(V, L * d_out)                       # row v: [dT_0 | .. | dT_{L-1}]
-        w_cat = W.permute(1, 0, 2).reshape(d_in, L * d_out)
-        gH = gT @ w_cat.t() if ctx.needs_input_grad[0] else None
-        gW = None
+        gH = gW = None
+        if ctx.needs_input_grad[0]:
+            plan = graph.plan_transformed(w)            # by-source buckets + weights (mean / sqrt_n factor folded in)
+            gH, _ = _agg_transform(gout, graph.rowptr_s, V, L, graph.tgt_s, plan.w_bwd(mode), _pack_agg_weights(W, True),
+                                   d_out, d_in, _lib.AGG_SUM, _lib.ACT_LINEAR, False)
         if ctx.needs_input_grad[1]:
-            gW = matmul_tn_splitk(H, gT).view(d_in, L, d_out).permute(1, 0, 2).contiguous()
+            f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
+            gsc = gout if f is None else gout * f.unsqueeze(1)
+            gW = matmul_tn_splitk(agg, gsc).view(L, d_in, d_out)
         return gH, gW, None, None, None, None
 
 
@@ -635,6 +656,72 @@ def fused_aggregate_transform(H, W, graph, w, aggregation: str, activation: Opti
     if act not in _FUSABLE_ACTS:
         raise ValueError("activation %r cannot be fused" % activation)
     return _FusedAggregateTransform.apply(H, W, graph, w, mode, act)
+
+
+# ---- aggregate, then transform (two kernels, no fusion): gather from the SMALL table -------------------------------------
+class _AggregateThenTransform(torch.autograd.Function):
+    """out = act(f_mode(sum_l A_l @ W_l)),  A_l[v] = sum_{p in (v,l)} w_p H[src_p]   (W: [L, Din, Dout]).
+
+    Same function as transform-then-aggregate (gnns/rgcn.py:84-114: sum / mean / sqrt_n commute with the per-type linear
+    map), different memory behaviour: the gather reads the [V, Din] state table (C2: 33 MB, one graph's slab fits the 4 MiB
+    L2 of its XCD) instead of the L-times larger table of transformed states, and the GEMM gets K = L*Din.  Measured on
+    MI355X, C2, one layer forward: 86.6 + 107.5 us vs 120.8 + 107.4 us (scripts/exp_agg_first.py).
+    Backward: dH through the by-source buckets exactly as before (gather dOut rows, GEMM with the stacked W_l^T),
+    dW_l = A_l^T @ dOut from the saved aggregated rows."""
+
+    @staticmethod
+    def forward(ctx, H, W, graph, w, mode: int, act: int, act_name):
+        H, W = H.contiguous(), W.contiguous()
+        L, d_in, d_out = W.shape
+        V = graph.V
+        agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L).view(V, L * d_in)
+        out = agg @ W.view(L * d_in, d_out)
+        f = _mode_factor(graph, mode)
+        if f is not None:
+            out.mul_(f.unsqueeze(1))
+        if act == _lib.ACT_RELU:
+            out.relu_()
+        elif act == _lib.ACT_TANH:
+            out.tanh_()
+        elif act != _lib.ACT_LINEAR:
+            from .utils import apply_activation, get_activation
+            out = apply_activation(get_activation(act_name), out)
+        ctx.graph, ctx.w, ctx.mode, ctx.act = graph, w, mode, act
+        ctx.save_for_backward(W, agg if W.requires_grad else None, out if act != _lib.ACT_LINEAR else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .dense import matmul_tn_splitk
+        lib = _lib.load_library()
+        graph, w, mode, act = ctx.graph, ctx.w, ctx.mode, ctx.act
+        W, agg, out = ctx.saved_tensors
+        L, d_in, d_out = W.shape
+        V = graph.V
+        gout = gout.contiguous()
+        if act != _lib.ACT_LINEAR:
+            g = torch.empty_like(gout)
+            _lib.check(lib.relgnn_act_bwd_from_output(act, _lib.ptr(out), _lib.ptr(gout), gout.numel(), _lib.ptr(g),
+                                                      _lib.current_stream()), "relgnn_act_bwd_from_output")
+            gout = g
+        gH = gW = None
+        if ctx.needs_input_grad[0]:
+            plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
+            gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
+                                 plan.num_rows_x).view(V, L * d_out)                   # row u: [dT_0 | .. | dT_{L-1}]
+            gH = gT @ W.permute(0, 2, 1).reshape(L * d_out, d_in)
+        if ctx.needs_input_grad[1]:
+            f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
+            gsc = gout if f is None else gout * f.unsqueeze(1)
+            gW = matmul_tn_splitk(agg, gsc).view(L, d_in, d_out)
+        return gH, gW, None, None, None, None, None
+
+
+def aggregate_then_transform(H, W, graph, w, aggregation: str, activation: Optional[str]):
+    mode, act = aggregation_mode_id(aggregation), activation_id(activation)
+    if mode == _lib.AGG_MAX or act not in _FUSABLE_ACTS:
+        raise ValueError("aggregate_then_transform: max aggregation / %r do not apply" % activation)
+    return _AggregateThenTransform.apply(H, W, graph, w, mode, act, activation)
 
 
 # ---- RGDCN dynamic kernels applied node-side (csrc/rgdcn.hip) --------------------------------------------------------

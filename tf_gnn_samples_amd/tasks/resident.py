@@ -6,8 +6,9 @@ packer + one H2D copy per batch.  An MI355X has 288 GB of HBM: the data folds of
 1.6 M edges, QM9 2.4 M nodes, even VarMisuse-sized folds) fit many times over, so the fold can simply live on the
 device.  A batch is then a list of graph ids, and
 
-  * its tensors are gathered on the device from the fold's flat arrays (same packing rules as relgnn_batch_pack:
-    adjacency + node offset, payload / degree rows concatenated on the node axis, graph index per node);
+  * its tensors are gathered on the device from the fold's flat arrays by relgnn_batch_gather (same packing rules as
+    relgnn_batch_pack: adjacency + node offset, payload / degree rows concatenated on the node axis, graph index per
+    node) — one C call, four streaming kernels;
   * its (target,type)/(source,type) bucketing is NOT recomputed: the fold was bucketed once as one big disjoint union,
     and relgnn_plan_assemble re-bases the per-graph slices of those arrays (include/relgnn.h section 10) —
     three streaming kernels instead of two radix sorts per batch, bit-identical arrays.
@@ -63,10 +64,32 @@ class ResidentDataset:
         g = RelGraph(union, N, validate=True)                                    # node-id range check, once
         self.plan_d = dict(rowptr_t=g.rowptr_t, perm_t=g.perm_t, col_t=g.col_t, rowptr_s=g.rowptr_s, perm_s=g.perm_s,
                            frow_s=g.frow_s, pos_t_of_s=g.pos_t_of_s)
-        self._tables = None                                                      # pinned staging for the offset tables
+        # operands of relgnn_batch_gather: the fold's adjacency as ONE type-major [M_fold, 2] list, payload rows as
+        # 4-byte elements (anything else is gathered with index_select)
+        self.adj_flat_d = torch.cat(self.adj_d).contiguous() if L else torch.zeros((0, 2), dtype=torch.int32, device=dev)
+        self._fast = [i for i, t in enumerate(self.payload_d) if t.element_size() == 4 and t.is_contiguous()]
+        self._fast_cols = [int(self.payload_d[i][0].numel()) if self.payload_d[i].shape[0] else 1 for i in self._fast]
+        self._num_nodes_fold = N
+        # pinned staging ring for the per-batch offset tables (one small H2D per batch); a slot is rewritten only after
+        # the copy that read it has run
+        self._stage = [None] * 4
+        self._stage_done = [None] * 4
+        self._stage_at = 0
+
+    def _staging(self, n: int) -> torch.Tensor:
+        k = self._stage_at
+        self._stage_at = (k + 1) % len(self._stage)
+        if self._stage_done[k] is not None:
+            self._stage_done[k].synchronize()
+        buf = self._stage[k]
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 1024) * 2, dtype=torch.int64).pin_memory()
+            self._stage[k] = buf
+        return buf, k
 
     # ---- one batch ----------------------------------------------------------------------------
     def assemble(self, graph_ids: Sequence[int]) -> DeviceBatch:
+        import ctypes
         lib = _lib.load_library()
         st = _lib.current_stream()
         dev, L, G = self.device, self.store.num_edge_types, self.store.num_graphs
@@ -82,34 +105,45 @@ class ResidentDataset:
         # ONE small H2D: [ids | node_off_b | msg_off_b | type_off_b | edge_off_b]
         sizes = [K, K + 1, K + 1, L + 1, L * (K + 1)]
         total = sum(sizes)
-        host = torch.empty(total, dtype=torch.int64).pin_memory()
+        host, slot = self._staging(total)
         hn = host.numpy()
         at = 0
         for part in (ids, node_off_b, msg_off_b, type_off_b, edge_off_b.reshape(-1)):
             hn[at:at + part.size] = part
             at += part.size
-        tab = host.to(dev, non_blocking=True)
-        self._tables = host                                                      # keep the staging buffer alive until the copy ran
+        tab = host[:total].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._stage_done[slot] = ev
         o = np.cumsum([0] + sizes)
         ids_d, node_off_bd, msg_off_bd, type_off_bd, edge_off_bd = (tab[o[i]:o[i + 1]] for i in range(5))
 
-        # ---- tensors of the batch, gathered on the device (packing rules of relgnn_batch_pack) ----
-        slots = torch.arange(K, device=dev)
-        slot_of_node = torch.repeat_interleave(slots, node_off_bd[1:] - node_off_bd[:-1], output_size=V)
-        node_idx = (torch.arange(V, device=dev) - node_off_bd[slot_of_node] + self.node_off_d[ids_d[slot_of_node]])
-        payload = {name: self.payload_d[p].index_select(0, node_idx) for p, name in enumerate(self.store.payload_names)}
-        deg = self.deg_d.index_select(1, node_idx)
-        adj = []
-        for l in range(L):
-            E = int(edge_off_b[l, -1])
-            if E == 0:
-                adj.append(torch.zeros((0, 2), dtype=torch.int32, device=dev))
-                continue
-            eoff_l = edge_off_bd[l * (K + 1):(l + 1) * (K + 1)]
-            slot_of_edge = torch.repeat_interleave(slots, eoff_l[1:] - eoff_l[:-1], output_size=E)
-            e_idx = torch.arange(E, device=dev) - eoff_l[slot_of_edge] + self.edge_off_d[l][ids_d[slot_of_edge]]
-            adj.append((self.adj_d[l].index_select(0, e_idx)
-                        + node_off_bd[slot_of_edge].to(torch.int32).unsqueeze(1)).contiguous())
+        # ---- tensors of the batch: one C call, a handful of gather kernels (packing rules of relgnn_batch_pack) ----
+        names = self.store.payload_names
+        payload = {}
+        out_fast = []
+        for i in self._fast:
+            src = self.payload_d[i]
+            out_fast.append(torch.empty((V,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev))
+            payload[names[i]] = out_fast[-1]
+        deg = torch.empty((L, V), dtype=torch.float32, device=dev)
+        n2g = torch.empty(V, dtype=torch.int32, device=dev)
+        adj_flat = torch.empty((M, 2), dtype=torch.int32, device=dev)
+        nf = len(self._fast)
+        arr = ctypes.c_void_p * max(nf, 1)
+        _lib.check(lib.relgnn_batch_gather(
+            _lib.ptr(ids_d), K, L, G, _lib.ptr(node_off_bd), _lib.ptr(edge_off_bd), _lib.ptr(type_off_bd),
+            _lib.ptr(self.node_off_d), _lib.ptr(self.edge_off_d), _lib.ptr(self.type_off_d), V, M, self._num_nodes_fold, nf,
+            arr(*[self.payload_d[i].data_ptr() for i in self._fast]), (ctypes.c_int32 * max(nf, 1))(*self._fast_cols),
+            arr(*[t.data_ptr() for t in out_fast]), _lib.ptr(self.deg_d), _lib.ptr(deg), _lib.ptr(self.adj_flat_d),
+            _lib.ptr(adj_flat), _lib.ptr(n2g), st), "relgnn_batch_gather")
+        type_off = [int(x) for x in type_off_b]
+        adj = [adj_flat[type_off[l]:type_off[l + 1]] for l in range(L)]
+        if len(self._fast) < len(names):          # payloads that are not 4-byte rows
+            node_idx = (torch.arange(V, device=dev) - node_off_bd[n2g.long()] + self.node_off_d[ids_d[n2g.long()]])
+            for i, name in enumerate(names):
+                if i not in self._fast:
+                    payload[name] = self.payload_d[i].index_select(0, node_idx)
         for name, flat in self.graph_payload_d.items():
             payload[name] = flat.index_select(0, ids_d)
 
@@ -130,7 +164,7 @@ class ResidentDataset:
                                      rowptr_s=rowptr_s, perm_s=perm_s, frow_s=frow_s, tgt_s=tgt_s, pos_t_of_s=pos)
         batch = DeviceBatch.from_tensors(
             num_graphs=K, num_nodes=V, num_edges=M, initial_node_features=payload[self.features], adjacency_lists=adj,
-            type_to_num_incoming_edges=deg, graph_nodes_list=slot_of_node.to(torch.int32),
+            type_to_num_incoming_edges=deg, graph_nodes_list=n2g,
             extra={**{k: v for k, v in payload.items() if k != self.features}, **self.constants})
         batch.graph = graph
         return batch
