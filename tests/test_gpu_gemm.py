@@ -9,6 +9,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _route_gemms_through_the_mfma_kernel(monkeypatch):
+    """The package's default for the node-side GEMMs is the library (measured faster at K = 256); these tests exercise
+    the hand-written kernel, i.e. what RELGNN_GEMM=mfma selects."""
+    from tf_gnn_samples_amd import dense
+    monkeypatch.setattr(dense, "_OWN_GEMM", True)
+
+
 def _err(out, ref):
     return float((out.double().cpu() - ref).abs().max())
 

@@ -357,6 +357,7 @@ class Sparse_Graph_Model(ABC):
     # -------------------- Training Loop --------------------
     def forward_batch(self, batch: DeviceBatch, training: bool):
         keep = self.params['graph_layer_input_dropout_keep_prob'] if training else 1.0
+        batch.wait_ready()               # assembled on a side stream (tasks/resident.py)? wait on the GPU, not the host
         # a batch from the input pipeline may carry its bucketing, built on a side stream (tasks/batcher.py)
         graph = getattr(batch, "graph", None)
         final = self.compute_final_node_representations(

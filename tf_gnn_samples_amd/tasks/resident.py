@@ -75,6 +75,7 @@ class ResidentDataset:
         self._stage = [None] * 4
         self._stage_done = [None] * 4
         self._stage_at = 0
+        self._side = None
 
     def _staging(self, n: int) -> torch.Tensor:
         k = self._stage_at
@@ -170,5 +171,17 @@ class ResidentDataset:
         return batch
 
     def iterate(self, graph_ids: Sequence[int], max_nodes_per_batch: int) -> Iterator[DeviceBatch]:
+        """Batches of one epoch.  Each batch is assembled on a SIDE stream: the training loop asks for batch i+1 right
+        after it has enqueued step i, so the gather / re-basing kernels (bandwidth-light) run under step i's GEMMs
+        instead of behind them.  The consumer's stream waits for the batch's event (DeviceBatch.wait_ready /
+        RelGraph.wait_ready) before its first kernel touches the tensors."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
         for ids in self.store.split_batches(graph_ids, max_nodes_per_batch):
-            yield self.assemble(ids)
+            with torch.cuda.stream(self._side):
+                batch = self.assemble(ids)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            batch.ready_event = ev
+            batch.graph.ready_event = ev
+            yield batch

@@ -62,6 +62,24 @@ class DeviceBatch:
         self.extra = dict(extra or {})
         return self
 
+    ready_event = None
+
+    def wait_ready(self) -> "DeviceBatch":
+        """A batch assembled on a side stream (tasks/resident.py) carries the event recorded behind its last kernel: make
+        the CURRENT stream wait for it (no host sync) and tell the caching allocator that the batch's tensors are now
+        used on this stream."""
+        ev, self.ready_event = self.ready_event, None
+        if ev is None:
+            return self
+        cur = torch.cuda.current_stream(self.initial_node_features.device)
+        cur.wait_event(ev)
+        tensors = [self.initial_node_features, self.type_to_num_incoming_edges, self.graph_nodes_list,
+                   *self.adjacency_lists, *[v for v in self.extra.values() if torch.is_tensor(v)]]
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(cur)
+        return self
+
 
 class Sparse_Graph_Task:
     """Minimal task interface used by Sparse_Graph_Model (tasks/sparse_graph_task.py:23-254)."""
