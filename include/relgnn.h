@@ -273,6 +273,8 @@ int relgnn_act_bwd_from_output(int32_t act, const float* y, const float* gout, i
  *                    W + l*type_stride + k*row_stride + n*col_stride
  *   agg_out : optional [num_out, ld_agg >= L*Din]: the aggregated rows A[s, l*Din:(l+1)*Din] = sum_p w_p X[col_p]
  *             (operand of the weight gradient dW_l = A_l^T @ dOut), or NULL
+ *   err_flag: device int32 (zeroed by the caller); bit 0 is set if an in-kernel producer/consumer hand-off timed out
+ *             (results are then undefined; the Python wrapper raises) — every in-kernel wait is bounded.
  * relgnn_agg_transform_supported(Din, Dout) != 0 for the widths the kernel is instantiated for (128 / 256 each);
  * RELGNN_EUNSUPPORTED otherwise and for MAX (it does not commute with the transform).
  */
@@ -282,7 +284,7 @@ int relgnn_agg_transform_pack_weights(const float* W, int32_t num_edge_types, in
 int relgnn_agg_transform_fwd(int32_t mode, int32_t act, const float* X, int64_t num_rows_x, int64_t ldx, int32_t Din,
                              const int32_t* rowptr, int64_t num_out, int32_t num_edge_types, const int32_t* col, const float* w,
                              const float* packed_weights, int32_t Dout, float* out, int64_t ldo, float* agg_out, int64_t ld_agg,
-                             void* stream);
+                             int32_t* err_flag, void* stream);
 
 /* ========================================================================== *
  * 3. GNN-FiLM fused message kernels  (gnns/gnn_film.py:86-116)

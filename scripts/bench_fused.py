@@ -45,3 +45,10 @@ print("grad diff dH %.3e (scale %.3e)  dW %.3e (scale %.3e)" % (float((H.grad - 
 with torch.no_grad():
     print("forward only  : unfused %.1f us   fused %.1f us" % (timeit(unfused), timeit(fused)))
 print("forward+backward: unfused %.1f us   fused %.1f us" % (timeit(train(unfused)), timeit(train(fused))))
+def agg_first():
+    return ops.aggregate_then_transform(H, W, g, w, "sum", "relu")
+with torch.no_grad():
+    print("aggregate-then-transform (two kernels): forward %.1f us" % timeit(agg_first))
+print("aggregate-then-transform (two kernels): forward+backward %.1f us" % timeit(train(agg_first)))
+ops.check_agg_transform_errors()
+print("variant:", os.environ.get("RELGNN_AGG_VARIANT", "ring"))

@@ -47,3 +47,5 @@ fused = lambda: _agg_transform(H, g.rowptr_t, V, L, g.src_t, w, packed, D, D, _l
 print("(c) fused kernel %.1f us (RELGNN_AGG_ABLATE=%s)" % (timeit(fused), os.environ.get("RELGNN_AGG_ABLATE", "0")))
 fused_agg = lambda: _agg_transform(H, g.rowptr_t, V, L, g.src_t, w, packed, D, D, _lib.AGG_SUM, _lib.ACT_RELU, True)[0]
 print("(c') fused kernel + aggregated-row output %.1f us" % timeit(fused_agg))
+ops.check_agg_transform_errors()
+print("max diff fused vs (a): %.3e   variant %s" % (float((fused() - oa).abs().max()), os.environ.get("RELGNN_AGG_VARIANT", "ring")))

@@ -587,9 +587,28 @@ def _agg_transform(X, rowptr, num_out, L, col, w, packed, d_in, d_out, mode, act
     agg = torch.empty((num_out, L * d_in), dtype=torch.float32, device=X.device) if want_agg else None
     _lib.check(lib.relgnn_agg_transform_fwd(mode, act, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), d_in,
                                             _lib.ptr(rowptr), num_out, L, _lib.ptr(col), _lib.ptr(w), _lib.ptr(packed), d_out,
-                                            _lib.ptr(out), d_out, _lib.ptr(agg), L * d_in, _lib.current_stream()),
-               "relgnn_agg_transform_fwd")
+                                            _lib.ptr(out), d_out, _lib.ptr(agg), L * d_in, _lib.ptr(_agg_error_flag(X.device)),
+                                            _lib.current_stream()), "relgnn_agg_transform_fwd")
     return out, agg
+
+
+_AGG_ERR = {}
+
+
+def _agg_error_flag(device):
+    """One device int32 per GPU that the fused kernel ORs a bit into if an in-kernel hand-off timed out; read back by
+    check_agg_transform_errors() at the next natural sync point (never silently ignored)."""
+    key = (device.type, device.index)
+    if key not in _AGG_ERR:
+        _AGG_ERR[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _AGG_ERR[key]
+
+
+def check_agg_transform_errors():
+    for flag in _AGG_ERR.values():
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise _lib.RelGnnLibraryError("fused aggregate->transform kernel: producer/consumer hand-off timed out")
 
 
 def _pack_agg_weights(W, transposed: bool):
