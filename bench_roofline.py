@@ -12,6 +12,9 @@ bytes cross HBM depends on whether the gathered table stays in the 4 MiB-per-XCD
           NOT by HBM.  HBM only sees the compulsory bytes (each gathered row once + indices + output).
   ppi256  256 PPI-shaped graphs (scripts/exp_c2_big.py): table 1.8 GB, past the Infinity Cache as a whole, but a
           batch is a disjoint union and each XCD walks one graph's ~7 MB slab at a time -> same regime as c2.
+  c2h     the same C2 batch in the order the RGCN layer uses since round 2 (aggregate, then transform): rows of the
+          [V, 256] node-state table (33 MB; one graph's 2.3 MB slab fits the 4 MiB L2) are gathered into the V*L
+          (target, type) buckets; same messages, 3x the output rows.
   giant   ONE graph with PPI degree statistics and 2^20 nodes: table 3.2 GB, sources uniform over the whole
           table -> no reuse survives in any cache, every gathered row crosses HBM: algorithmic bytes ARE the HBM
           bytes.  This is the HBM-bound size the `roofline` object of the bench line is quoted on (frac <= 1).
@@ -39,7 +42,7 @@ import torch
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s float4-copy measured)
 HBM_COPY_GBS = 6290.0      # measured float4 copy ceiling of the same guide
 L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth, same guide
-WORKLOADS = ("c2", "ppi256", "giant")
+WORKLOADS = ("c2", "c2h", "ppi256", "giant")
 HIDDEN = 256
 KERNEL_NAME = "seg_reduce_wave_kernel"
 
@@ -75,7 +78,7 @@ def _giant(device, log2_nodes=20, fwd_edges_per_node=28.3, sigma=0.9, seed=0):
 
 def build_workload(name, device):
     from tf_gnn_samples_amd.graph import RelGraph
-    if name == "c2":
+    if name in ("c2", "c2h"):
         adj, deg, V = _ppi_union(16, 0, device)
     elif name == "ppi256":
         adj, deg, V = _ppi_union(256, 0, device)
@@ -85,22 +88,29 @@ def build_workload(name, device):
         raise ValueError(name)
     g = RelGraph(adj, V)
     w = g.degree_scale(deg)
-    plan = g.plan_transformed(w)
     L, M, D = g.L, g.M, HIDDEN
-    # distinct gathered rows = non-empty (source, type) buckets
-    unique_rows = int((g.rowptr_s[1:] > g.rowptr_s[:-1]).sum())
-    table_bytes = V * L * D * 4
+    if name == "c2h":
+        from tf_gnn_samples_amd.graph import GatherReducePlan
+        plan = GatherReducePlan(rowptr=g.rowptr_t, stride=1, col=g.src_t, w=w, num_out=V * L, num_rows_x=V,
+                                rowptr_b=g.rowptr_s, stride_b=L, col_b=g.frow_s, pos_b=g.pos_t_of_s, num_messages=M)
+        unique_rows = int(((g.rowptr_s[L::L] - g.rowptr_s[:-1:L]) > 0).sum())     # source NODES with any out-edge
+        table_rows, out_rows = V, V * L
+    else:
+        plan = g.plan_transformed(w)
+        unique_rows = int((g.rowptr_s[1:] > g.rowptr_s[:-1]).sum())     # non-empty (source, type) buckets
+        table_rows, out_rows = V * L, V
+    table_bytes = table_rows * D * 4
     free = torch.cuda.mem_get_info(device)[0]
     copies = int(max(1, min(4, (free - (6 << 30)) // table_bytes)))
     gen = torch.Generator(device=device).manual_seed(0)
-    tables = [torch.rand((V * L, D), device=device, generator=gen) * 2 - 1 for _ in range(copies)]
+    tables = [torch.rand((table_rows, D), device=device, generator=gen) * 2 - 1 for _ in range(copies)]
     return {
         "name": name, "plan": plan, "tables": tables, "graph": g, "V": V, "L": L, "M": M, "D": D,
         "unique_rows": unique_rows, "table_bytes": table_bytes,
         # per message one D-float row + (col, w); per node one D-float output row; row pointers
-        "algorithmic_bytes": M * (4 * D + 8) + V * 4 * D + 4 * (V * L + 1),
+        "algorithmic_bytes": M * (4 * D + 8) + out_rows * 4 * D + 4 * (V * L + 1),
         # what HBM must move at least once: every distinct gathered row, the index/weight streams, rowptr, output
-        "compulsory_bytes": unique_rows * 4 * D + M * 8 + V * 4 * D + 4 * (V * L + 1),
+        "compulsory_bytes": unique_rows * 4 * D + M * 8 + out_rows * 4 * D + 4 * (V * L + 1),
     }
 
 

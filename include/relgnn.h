@@ -479,6 +479,13 @@ int relgnn_mt_l2norm(const float* const* h_grads, const int64_t* h_sizes, int32_
 int relgnn_mt_adam_clip(float* const* h_params, const float* const* h_grads, float* const* h_m,
                         float* const* h_v, const int64_t* h_sizes, int32_t n, const float* norms,
                         float clip, float lr_t, float beta1, float beta2, float eps, void* stream);
+/* The same update with the step size read from DEVICE memory, for a training step captured in a hipGraph (a host
+ * scalar would be frozen into the graph): relgnn_adam_step_size advances d_state[0] (steps taken) by one and writes
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) to d_state[1]; relgnn_mt_adam_clip_devlr reads *d_lr_t (= d_state + 1). */
+int relgnn_adam_step_size(float* d_state, float lr, float beta1, float beta2, void* stream);
+int relgnn_mt_adam_clip_devlr(float* const* h_params, const float* const* h_grads, float* const* h_m,
+                              float* const* h_v, const int64_t* h_sizes, int32_t n, const float* norms,
+                              float clip, const float* d_lr_t, float beta1, float beta2, float eps, void* stream);
 
 /*
  * PPI output head in one pass (tasks/ppi_task.py:181-191 + utils/utils.py:61-74):
@@ -587,6 +594,9 @@ int relgnn_batch_pack(int32_t num_types, int64_t n_graphs, const int64_t* h_grap
  *   edge_off_b   [L][K+1]   messages of type l in the slots before k
  *   type_off_b   [L+1]      start of type l in the batch's type-major message list (gnns/rgcn.py:78)
  *   *_d                     the same four tables for the dataset union (G = num_dataset_graphs)
+ * Optional (NULL to skip), fused into the same passes: src_t [M] = source NODE per by-target position; w_t / w_s [M] =
+ * the per-message scales of the batch in by-target / by-source order, copied from the dataset-level arrays w_t_d / w_s_d
+ * (1/(in-degree + 1e-7), gnns/rgcn.py:100-104, is a property of the graph, not of the batch).
  */
 /*
  * The batch's TENSORS from the fold's flat device arrays, same packing rules as relgnn_batch_pack (replaces the numpy
@@ -612,7 +622,8 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
                          const int32_t* rowptr_s_d, const int32_t* perm_s_d, const int32_t* frow_s_d,
                          const int32_t* pos_t_of_s_d, int32_t* rowptr_t, int32_t* perm_t, int32_t* col_t,
                          int32_t* inv_perm_t, int32_t* rowptr_s, int32_t* perm_s, int32_t* frow_s, int32_t* tgt_s,
-                         int32_t* pos_t_of_s, void* stream);
+                         int32_t* pos_t_of_s, const float* w_t_d, const float* w_s_d, int32_t* src_t, float* w_t, float* w_s,
+                         void* stream);
 
 /* ========================================================================== *
  * 12. Node-side Dense layers on the matrix cores, exact fp32

@@ -51,8 +51,24 @@ def run(name, model, batch, mb, steps=20, prime=15):
         fms = (time.perf_counter() - t0) / steps * 1e3
     if TUNE:
         enable_gemm_autotuning(tune=True)
+    graph_ms = None
+    if os.environ.get("RELGNN_CAPTURE", "1") != "0":
+        # the same step recorded as ONE hipGraph on this fixed batch (model.capture_train_step)
+        try:
+            cap = model.capture_train_step(batch)
+            for _ in range(3):
+                cap.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                cap.replay()
+            torch.cuda.synchronize()
+            graph_ms = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        except Exception as e:
+            graph_ms = "capture failed: %r" % (e,)
     print(json.dumps({"config": name + (" [GEMMs autotuned]" if TUNE else ""), "nodes": mb.num_nodes, "edges": mb.num_edges, "graphs": mb.num_graphs,
                       "train_ms": round(ms, 3), "train_edges_per_s": round(mb.num_edges / ms * 1e3),
+                      "train_ms_hipgraph": graph_ms,
                       "fwd_ms": round(fms, 3), "fwd_edges_per_s": round(mb.num_edges / fms * 1e3)}), flush=True)
 
 

@@ -7,6 +7,7 @@ node states for the normalised layers; max-abs and max-rel recorded for all):
       sequential fp32 fold in the reference's message order; tests/test_oracle.py pins it to the op-for-op path)
   C4  sparse_rgat_layer (h = 256, 4 heads) on the same C2 batch
   C5  sparse_gnn_film_layer on a VarMisuse-shaped batch of one rank's share (~1.04 M messages, 23 edge types, h = 128)
+  C3  sparse_ggnn_layer (GRU, mean / max) on one 50 000-node batch of real QM9 molecules (153 206 messages, 5 edge types)
 
 The oracle needs a few seconds per layer at these sizes (host BLAS + the sequential C fold)."""
 import numpy as np
@@ -118,11 +119,36 @@ def test_c5_film_rank_share(gpu_device):
     assert_parity(out, ref, strict_abs=False, what="C5 film, one rank's share (%d messages)" % M)
 
 
+@pytest.mark.parametrize("agg", ["mean", "max"])
+def test_c3_ggnn_qm9_full_batch(gpu_device, agg):
+    """BASELINE configs[2] at its stated size: one max_nodes_in_batch = 50 000 batch of REAL QM9 molecules (the 256
+    committed molecules repeated 11x: 2 768 graphs, 49 986 nodes, 153 206 messages, 5 edge types), GGNN with the GRU
+    cell, D = 128, three timesteps, mean / max aggregation."""
+    from test_golden_cpu import read_qm9_fixture
+    from tf_gnn_samples_amd.gnns import sparse_ggnn_layer
+    from tf_gnn_samples_amd.tasks import DataFold, QM9_Task
+    task = QM9_Task(QM9_Task.default_params())
+    samples = task.load_raw(read_qm9_fixture() * 11)
+    mb = next(task.make_minibatch_iterator(list(samples), DataFold.VALIDATION, 50000))
+    assert mb.num_nodes == 49986 and mb.num_edges == 153206 and task.num_edge_types == 5
+    fd = mb.feed_dict
+    rng = np.random.default_rng(0)
+    D, L = 128, 5
+    w = rgcn_weights(rng, L, D, D)
+    w.update({"gru_cell/kernel": glorot(rng, (D, 3 * D)), "gru_cell/recurrent_kernel": glorot(rng, (D, 3 * D)),
+              "gru_cell/bias": (0.05 * rng.standard_normal(3 * D)).astype(np.float32)})
+    h = np.tanh(fd["initial_node_features"].astype(np.float32) @ glorot(rng, (15, D)))
+    adj = fd["adjacency_lists"]
+    ref = G.sparse_ggnn_layer(h, adj, D, 3, "GRU", "tanh", agg, weights=w)
+    out = sparse_ggnn_layer(_dev(h, gpu_device), _dev(adj, gpu_device), D, 3, "GRU", "tanh", agg, weights=_dev(w, gpu_device))
+    assert_parity(out, ref, strict_abs=True, what="C3 ggnn/qm9 full batch %s" % agg)     # GRU states live in (-1, 1)
+
+
 def test_zz_report_parity_numbers():
     """Not a check: prints the recorded max-abs / max-rel of this module's cases (and writes them under gpurun_out/)."""
     import json
     import os
-    rows = [r for r in parity_log() if r["what"].startswith(("C2", "C4", "C5"))]
+    rows = [r for r in parity_log() if r["what"].startswith(("C2", "C3", "C4", "C5"))]
     for r in rows:
         print("%-60s abs %.3e  rel %.3e  max|ref| %.3g" % (r["what"], r["abs"], r["rel"], r["max_ref"]))
     if os.path.isdir("gpurun_out"):

@@ -495,3 +495,25 @@ def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer):
             assert a is None and b is None
             continue
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_edge_free_batch_through_every_rgcn_order(gpu_device, monkeypatch):
+    """A batch without a single edge (tasks/ppi_task.py:248-249: every type zeros((0, 2))) is legal: every node's
+    aggregate is the empty sum, the layer returns activation(0) — with and without 1/in-degree normalisation, in both
+    evaluation orders, forward and backward."""
+    from tf_gnn_samples_amd.gnns import sparse_rgcn_layer
+    from tf_gnn_samples_amd.graph import clear_graph_cache
+    rng = np.random.default_rng(0)
+    V, D, L = 7, 64, 3
+    adj = [torch.zeros((0, 2), dtype=torch.int32, device=gpu_device) for _ in range(L)]
+    deg = torch.zeros((L, V), device=gpu_device)
+    w = {k: torch.as_tensor(v, device=gpu_device).requires_grad_(True) for k, v in rgcn_weights(rng, L, D, D).items()}
+    for order in ("aggregate_first", "transform_first"):
+        monkeypatch.setenv("RELGNN_RGCN_ORDER", order)
+        for norm in (True, False):
+            clear_graph_cache()
+            h = torch.randn((V, D), device=gpu_device, requires_grad=True)
+            out = sparse_rgcn_layer(h, adj, deg, D, 1, "tanh", "sum", norm, weights=w)
+            assert out.shape == (V, D) and float(out.abs().max()) == 0.0
+            out.sum().backward()
+            assert float(h.grad.abs().max()) == 0.0

@@ -45,9 +45,24 @@ def _same_batch(a, b):
 def _same_plan(graph, adjacency_lists, V):
     from tf_gnn_samples_amd.graph import RelGraph
     fresh = RelGraph(adjacency_lists, V)
-    for name in PLAN_ARRAYS:
+    for name in PLAN_ARRAYS + ("key_by_target", "key_by_source", "src_t"):      # keys are computed lazily; src_t is preset
         assert torch.equal(getattr(graph, name), getattr(fresh, name)), name
     assert (graph.V, graph.L, graph.M, graph.edge_counts) == (fresh.V, fresh.L, fresh.M, fresh.edge_counts)
+
+
+def _same_scales(batch):
+    """The per-message 1/(in-degree + 1e-7) scales copied from the fold-level arrays == what RelGraph computes from the
+    batch's own degree table, in by-target and by-source order, bit for bit."""
+    from tf_gnn_samples_amd import _lib
+    from tf_gnn_samples_amd.graph import RelGraph
+    g = batch.graph
+    deg = batch.type_to_num_incoming_edges
+    w = g.degree_scale(deg)                                         # preset by tasks/resident.py
+    fresh = RelGraph(batch.adjacency_lists, batch.num_nodes)
+    w_ref = fresh.degree_scale(deg.clone())
+    assert torch.equal(w, w_ref)
+    assert torch.equal(g.plan_transformed(w).w_bwd(_lib.AGG_SUM), fresh.plan_transformed(w_ref).w_bwd(_lib.AGG_SUM))
+    assert torch.equal(g.w_by_source(w), fresh.w_by_source(w_ref))
 
 
 PAYLOADS = {"initial_node_features": ("node_features", np.float32), "target_labels": ("node_labels", np.float32)}
@@ -67,6 +82,7 @@ def test_resident_batches_and_plans_are_bit_identical(gpu_device, L):
         b = host.pack(np.array(ids))
         _same_batch(a, b)
         _same_plan(a.graph, b.adjacency_lists, b.num_nodes)
+        _same_scales(a)
     got = [x.num_graphs for x in resident.iterate(np.arange(30), 200)]
     want = [x.num_graphs for x in host.iterate(np.arange(30), 200)]
     assert got == want and sum(got) == 30

@@ -98,3 +98,46 @@ def test_int64_and_noncontiguous_adjacency_inputs(gpu_device):
     wide = [torch.cat([a, a], dim=1)[:, :2] for a in adj64]       # non-contiguous views
     out = sparse_rgcn_layer(h_d, wide, deg_d, 128, 1, "ReLU", "mean", weights=w_d)
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("which", ["rgcn_ppi", "ggnn_qm9"])
+def test_captured_train_step_matches_eager_steps(gpu_device, which):
+    """Sparse_Graph_Model.capture_train_step: a whole training step (forward, backward, per-variable clip, Adam with the
+    step count in device memory) recorded as ONE hipGraph on a fixed batch.  N replays must train exactly like N eager
+    steps (same kernels, same order; the only difference is lr_t evaluated in fp32 on the device)."""
+    from tf_gnn_samples_amd.models import GGNN_Model, RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task, QM9_Task
+    if which == "rgcn_ppi":
+        task = PPI_Task(PPI_Task.default_params())
+        task.load_synthetic(3, 1, seed=4, mean_nodes=300, std_nodes=50, min_nodes=100, max_nodes=500, fwd_edges_per_node=6.0)
+        cls, extra = RGCN_Model, dict(hidden_size=128, graph_num_layers=2)
+        data = task._loaded_data[DataFold.TRAIN]
+    else:
+        from test_golden_cpu import read_qm9_fixture
+        task = QM9_Task(QM9_Task.default_params())
+        data = task.load_raw(read_qm9_fixture())
+        cls, extra = GGNN_Model, dict(hidden_size=64, graph_num_layers=2, graph_rnn_cell="GRU",
+                                      message_aggregation_function="mean")
+    mb = next(task.make_minibatch_iterator(list(data), DataFold.VALIDATION, 3000))
+
+    def fresh():
+        p = cls.default_params()
+        p.update(extra)
+        p.update(graph_layer_input_dropout_keep_prob=1.0, random_seed=3)
+        return cls(p, task, device=str(gpu_device)), DeviceBatch(mb, gpu_device)
+
+    eager, batch_e = fresh()
+    losses_e = [float(eager.train_step(batch_e)['loss'].detach()) for _ in range(6)]
+    captured, batch_c = fresh()
+    step = captured.capture_train_step(batch_c, warmup_steps=3)           # 3 real steps, then the recorded one
+    losses_c = [float(step.replay()['loss']) for _ in range(3)]            # steps 4, 5, 6
+    torch.cuda.synchronize()
+    assert captured.optimizer.t == eager.optimizer.t == 6
+    np.testing.assert_allclose(losses_c, losses_e[3:], rtol=2e-5)
+    for n in eager.variables.names():
+        a, b = eager.variables[n].detach().cpu().numpy(), captured.variables[n].detach().cpu().numpy()
+        # Adam normalises every gradient element by its own running magnitude: an element whose gradient is at the fp32
+        # noise floor moves by O(lr) in a direction the last bit decides, so a handful of elements may differ by ~lr * 1e-2
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=5e-5, err_msg=n)
+        assert float(np.mean(np.abs(b - a) > 1e-6)) < 0.01, n
+    assert losses_e[-1] < losses_e[0]

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "relgnn_mt_l2norm_workspace_bytes": (ctypes.c_size_t, []),
     "relgnn_mt_l2norm": (ctypes.c_int, [_ptr, _ptr, _c_i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     "relgnn_mt_adam_clip": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_f32, _c_f32, _c_f32, _c_f32, _c_f32, _ptr]),
+    "relgnn_adam_step_size": (ctypes.c_int, [_ptr, _c_f32, _c_f32, _c_f32, _ptr]),
+    "relgnn_mt_adam_clip_devlr": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_f32, _ptr, _c_f32, _c_f32, _c_f32, _ptr]),
     "relgnn_sigmoid_ce_stats_workspace_bytes": (ctypes.c_size_t, []),
     "relgnn_sigmoid_ce_stats": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     "relgnn_sigmoid_ce_bwd": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
@@ -86,7 +88,7 @@ _SIGNATURES = {
     "relgnn_rgdcn_apply_bwd": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_batch_gather": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i64] + [_ptr] * 6 + [_c_i64, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _ptr,
                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "relgnn_plan_assemble": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i64] + [_ptr] * 8 + [_c_i64, _c_i64] + [_ptr] * 16 + [_ptr]),
+    "relgnn_plan_assemble": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i64] + [_ptr] * 8 + [_c_i64, _c_i64] + [_ptr] * 16 + [_ptr] * 5 + [_ptr]),
     # host-side batch builder (section 9): host pointers only
     "relgnn_batch_layout_len": (_c_i64, [_c_i32, _c_i32]),
     "relgnn_batch_count": (_c_i64, [_ptr, _ptr, _c_i64, _c_i64, _c_i64]),

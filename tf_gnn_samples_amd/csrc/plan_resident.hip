@@ -44,7 +44,8 @@ __device__ __forceinline__ int32_t translate_message(const BatchTables& t, int32
 
 __global__ __launch_bounds__(256) void assemble_by_target_kernel(
     BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ col_d,
-    int32_t* __restrict__ perm_b, int32_t* __restrict__ col_b, int32_t* __restrict__ inv_b) {
+    int32_t* __restrict__ perm_b, int32_t* __restrict__ col_b, int32_t* __restrict__ inv_b,
+    const float* __restrict__ w_t_d, int32_t* __restrict__ src_b, float* __restrict__ w_t_b) {
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < M; p += (int64_t)gridDim.x * blockDim.x) {
     const int k = upper_slot(t.msg_off_b, t.K, p);
     const int64_t g = t.ids[k];
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(256) void assemble_by_target_kernel(
     const int l = c % t.L;
     const int64_t src = c / t.L - t.node_off_d[g] + t.node_off_b[k];
     col_b[p] = (int32_t)(src * t.L + l);
+    if (src_b) src_b[p] = (int32_t)src;            // source NODE per by-target position (row of the state table)
+    if (w_t_b) w_t_b[p] = w_t_d[pd];                // per-message scale: a property of the graph, not of the batch
     const int32_t mb = translate_message(t, perm_d[pd], l, k, g);
     perm_b[p] = mb;
     inv_b[mb] = (int32_t)p;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void assemble_by_target_kernel(
 __global__ __launch_bounds__(256) void assemble_by_source_kernel(
     BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ frow_d,
     const int32_t* __restrict__ pos_d, int32_t* __restrict__ perm_b, int32_t* __restrict__ frow_b,
-    int32_t* __restrict__ tgt_b, int32_t* __restrict__ pos_b) {
+    int32_t* __restrict__ tgt_b, int32_t* __restrict__ pos_b, const float* __restrict__ w_s_d, float* __restrict__ w_s_b) {
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < M; q += (int64_t)gridDim.x * blockDim.x) {
     const int k = upper_slot(t.msg_off_b, t.K, q);
     const int64_t g = t.ids[k];
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void assemble_by_source_kernel(
     tgt_b[q] = (int32_t)tgt;
     perm_b[q] = translate_message(t, perm_d[qd], l, k, g);
     pos_b[q] = (int32_t)((int64_t)pos_d[qd] - t.msg_off_d[g] + t.msg_off_b[k]);
+    if (w_s_b) w_s_b[q] = w_s_d[qd];
   }
 }
 
@@ -185,7 +189,8 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
                          const int32_t* rowptr_s_d, const int32_t* perm_s_d, const int32_t* frow_s_d,
                          const int32_t* pos_t_of_s_d, int32_t* rowptr_t, int32_t* perm_t, int32_t* col_t,
                          int32_t* inv_perm_t, int32_t* rowptr_s, int32_t* perm_s, int32_t* frow_s, int32_t* tgt_s,
-                         int32_t* pos_t_of_s, void* stream) {
+                         int32_t* pos_t_of_s, const float* w_t_d, const float* w_s_d, int32_t* src_t, float* w_t, float* w_s,
+                         void* stream) {
   if (num_batch_graphs < 0 || num_edge_types <= 0 || num_dataset_graphs < 0 || num_nodes < 0 || num_messages < 0)
     return RELGNN_EINVAL;
   const int64_t buckets = num_nodes * num_edge_types;
@@ -208,10 +213,12 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
     if (!perm_t_d || !col_t_d || !perm_s_d || !frow_s_d || !pos_t_of_s_d || !perm_t || !col_t || !inv_perm_t || !perm_s ||
         !frow_s || !tgt_s || !pos_t_of_s)
       return RELGNN_EINVAL;
+    if ((w_t && !w_t_d) || (w_s && !w_s_d)) return RELGNN_EINVAL;
     assemble_by_target_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, perm_t_d, col_t_d, perm_t,
-                                                                            col_t, inv_perm_t);
+                                                                            col_t, inv_perm_t, w_t_d, src_t, w_t);
     assemble_by_source_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, perm_s_d, frow_s_d,
-                                                                            pos_t_of_s_d, perm_s, frow_s, tgt_s, pos_t_of_s);
+                                                                            pos_t_of_s_d, perm_s, frow_s, tgt_s, pos_t_of_s,
+                                                                            w_s_d, w_s);
   }
   return launch_status();
 }

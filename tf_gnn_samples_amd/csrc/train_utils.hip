@@ -69,8 +69,19 @@ __global__ __launch_bounds__(64) void mt_l2norm_final_kernel(const double* __res
 
 // grid (chunks, tensors): g' = g * clip / max(||g||, clip)  (tf.clip_by_norm), then TF1 Adam:
 //   m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr_t * m / (sqrt(v) + eps),  lr_t = lr sqrt(1-b2^t)/(1-b1^t)
+// state[0] = number of Adam steps taken so far (as a float: exact up to 2^24), state[1] = lr_t of the step being taken.
+// One thread: t += 1; lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t).  Keeps the step count ON THE DEVICE so that a captured
+// hipGraph of the training step advances it on every replay (a host scalar would be frozen into the graph).
+__global__ void adam_step_size_kernel(float* __restrict__ state, float lr, float b1, float b2) {
+  const float t = state[0] + 1.f;
+  state[0] = t;
+  state[1] = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+}
+
 __global__ __launch_bounds__(256) void mt_adam_clip_kernel(MtArgs a, const float* __restrict__ norms, float clip,
-                                                           float lr_t, float b1, float b2, float eps) {
+                                                           float lr_t, const float* __restrict__ d_lr_t, float b1, float b2,
+                                                           float eps) {
+  if (d_lr_t) lr_t = d_lr_t[0];
   const int t = blockIdx.y;
   const long long n = a.n[t];
   const long long chunk = 4096;
@@ -191,9 +202,32 @@ int relgnn_mt_l2norm(const float* const* h_grads, const int64_t* h_sizes, int32_
   return launch_status();
 }
 
+int relgnn_adam_step_size(float* d_state, float lr, float beta1, float beta2, void* stream) {
+  if (!d_state) return RELGNN_EINVAL;
+  adam_step_size_kernel<<<1, 1, 0, as_stream(stream)>>>(d_state, lr, beta1, beta2);
+  return launch_status();
+}
+
+static int mt_adam_clip_impl(float* const* h_params, const float* const* h_grads, float* const* h_m, float* const* h_v,
+                             const int64_t* h_sizes, int32_t n, const float* norms, float clip, float lr_t,
+                             const float* d_lr_t, float beta1, float beta2, float eps, void* stream);
+
 int relgnn_mt_adam_clip(float* const* h_params, const float* const* h_grads, float* const* h_m, float* const* h_v,
                         const int64_t* h_sizes, int32_t n, const float* norms, float clip, float lr_t, float beta1,
                         float beta2, float eps, void* stream) {
+  return mt_adam_clip_impl(h_params, h_grads, h_m, h_v, h_sizes, n, norms, clip, lr_t, nullptr, beta1, beta2, eps, stream);
+}
+
+int relgnn_mt_adam_clip_devlr(float* const* h_params, const float* const* h_grads, float* const* h_m, float* const* h_v,
+                              const int64_t* h_sizes, int32_t n, const float* norms, float clip, const float* d_lr_t,
+                              float beta1, float beta2, float eps, void* stream) {
+  if (!d_lr_t) return RELGNN_EINVAL;
+  return mt_adam_clip_impl(h_params, h_grads, h_m, h_v, h_sizes, n, norms, clip, 0.f, d_lr_t, beta1, beta2, eps, stream);
+}
+
+static int mt_adam_clip_impl(float* const* h_params, const float* const* h_grads, float* const* h_m, float* const* h_v,
+                             const int64_t* h_sizes, int32_t n, const float* norms, float clip, float lr_t,
+                             const float* d_lr_t, float beta1, float beta2, float eps, void* stream) {
   if (n < 0 || n > RELGNN_MT_MAX) return RELGNN_EINVAL;
   if (n == 0) return RELGNN_OK;
   if (!h_params || !h_grads || !h_m || !h_v || !h_sizes || (clip > 0.f && !norms)) return RELGNN_EINVAL;
@@ -206,7 +240,7 @@ int relgnn_mt_adam_clip(float* const* h_params, const float* const* h_grads, flo
   }
   if (maxn == 0) return RELGNN_OK;
   dim3 grid((unsigned)((maxn + 4095) / 4096), (unsigned)n);
-  mt_adam_clip_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, norms, clip, lr_t, beta1, beta2, eps);
+  mt_adam_clip_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, norms, clip, lr_t, d_lr_t, beta1, beta2, eps);
   return launch_status();
 }
 

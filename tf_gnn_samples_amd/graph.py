@@ -121,7 +121,7 @@ class RelGraph:
         h_cnt = (ctypes.c_int64 * L)(*self.edge_counts)
         _lib.check(lib.relgnn_relational_keys_all(h_adj, h_cnt, L, V, _lib.ptr(key_t), _lib.ptr(key_s), _lib.ptr(node_t),
                                                   _lib.ptr(node_s), _lib.ptr(err), st), "relgnn_relational_keys_all")
-        self.key_by_target, self.key_by_source = key_t, key_s
+        self._key_t, self._key_s = key_t, key_s
 
         S = V * L
         ws_bytes = lib.relgnn_relational_plan_workspace_bytes(M, V)
@@ -171,14 +171,10 @@ class RelGraph:
         self.edge_counts = [int(a.shape[0]) for a in adj]
         self.M = M = sum(self.edge_counts)
         self.device = dev = rowptr_t.device
-        key_t, key_s, node_t, node_s = _i32(M, dev), _i32(M, dev), _i32(M, dev), _i32(M, dev)
+        # the per-message keys (tgt*L+l, src*L+l in type-major order) are only read by the pair / materialised-message
+        # paths: computed on first use (relgnn_relational_keys_all), not per batch
+        self._key_t = self._key_s = None
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-        h_adj = (ctypes.c_void_p * L)(*[_lib.ptr(a) if a.shape[0] else None for a in adj])
-        h_cnt = (ctypes.c_int64 * L)(*self.edge_counts)
-        _lib.check(lib.relgnn_relational_keys_all(h_adj, h_cnt, L, V, _lib.ptr(key_t), _lib.ptr(key_s), _lib.ptr(node_t),
-                                                  _lib.ptr(node_s), _lib.ptr(err), _lib.current_stream()),
-                   "relgnn_relational_keys_all")
-        self.key_by_target, self.key_by_source = key_t, key_s
         self.rowptr_t, self.perm_t, self.col_t, self.inv_perm_t = rowptr_t, perm_t, col_t, inv_perm_t
         self.rowptr_s, self.perm_s, self.frow_s, self.tgt_s, self.pos_t_of_s = rowptr_s, perm_s, frow_s, tgt_s, pos_t_of_s
         self._src_t = None
@@ -187,6 +183,42 @@ class RelGraph:
         self._err_flag = err
         self._checked = True
         return self
+
+    def _ensure_keys(self):
+        if self._key_t is None:
+            lib = _lib.load_library()
+            L, M, dev = self.L, self.M, self.device
+            key_t, key_s, node_t, node_s = _i32(M, dev), _i32(M, dev), _i32(M, dev), _i32(M, dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            h_adj = (ctypes.c_void_p * L)(*[_lib.ptr(a) if a.shape[0] else None for a in self.adjacency_lists])
+            h_cnt = (ctypes.c_int64 * L)(*self.edge_counts)
+            _lib.check(lib.relgnn_relational_keys_all(h_adj, h_cnt, L, self.V, _lib.ptr(key_t), _lib.ptr(key_s),
+                                                      _lib.ptr(node_t), _lib.ptr(node_s), _lib.ptr(err),
+                                                      _lib.current_stream()), "relgnn_relational_keys_all")
+            self._key_t, self._key_s = key_t, key_s
+
+    @property
+    def key_by_target(self):
+        """tgt*L + l of every message in the reference's type-major order (gnns/rgcn.py:78,108)."""
+        self._ensure_keys()
+        return self._key_t
+
+    @property
+    def key_by_source(self):
+        self._ensure_keys()
+        return self._key_s
+
+    def preset_degree_scale(self, type_to_num_incoming_edges: torch.Tensor, src_t, w_t, w_s):
+        """Arrays the producer of a from_arrays() graph already holds (tasks/resident.py copies them from fold-level
+        arrays inside relgnn_plan_assemble): the source node per by-target position and the per-message
+        1/(in-degree + 1e-7) scales for THIS degree table, in by-target and by-source order."""
+        t = type_to_num_incoming_edges
+        self._src_t = src_t
+        self._scales[(t.data_ptr(), t._version, tuple(t.shape))] = (t, w_t)
+        plan = self.plan_transformed(w_t)
+        plan._w_bwd[_lib.AGG_SUM] = w_s
+        self._plans[("w_s", w_t.data_ptr())] = (w_t, w_s)
+        self._preset = (src_t, w_t, w_s)
 
     # ---- bucketing on a side stream (input pipeline) --------------------------------------------
     ready_event = None
@@ -209,10 +241,11 @@ class RelGraph:
             return self
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        for t in (self.key_by_target, self.key_by_source, self.rowptr_t, self.perm_t, self.col_t, self.inv_perm_t,
+        for t in (self._key_t, self._key_s, self.rowptr_t, self.perm_t, self.col_t, self.inv_perm_t,
                   self.rowptr_s, self.perm_s, self.frow_s, self.tgt_s, self.pos_t_of_s, self._err_flag,
-                  *self.adjacency_lists):
-            t.record_stream(cur)
+                  *self.adjacency_lists, *getattr(self, "_preset", ())):
+            if t is not None:
+                t.record_stream(cur)
         return self
 
     def check(self):
@@ -248,7 +281,8 @@ class RelGraph:
         tt = t.to(torch.float32).contiguous()
         w = torch.empty(self.M, dtype=torch.float32, device=self.device)
         lib = _lib.load_library()
-        _lib.check(lib.relgnn_degree_scale(_lib.ptr(tt), _lib.ptr(self.rowptr_t), self.L, self.V, 1e-7,
+        if self.M > 0:           # an edge-free batch has no message to scale
+            _lib.check(lib.relgnn_degree_scale(_lib.ptr(tt), _lib.ptr(self.rowptr_t), self.L, self.V, 1e-7,
                                            _lib.ptr(w), _lib.current_stream()), "relgnn_degree_scale")
         self._scales[key] = (t, w)  # keep `t` alive so the data_ptr key cannot be recycled
         while len(self._scales) > 4:

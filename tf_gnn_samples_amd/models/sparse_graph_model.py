@@ -53,10 +53,14 @@ class TFStyleOptimizer:
         return self.name == 'adam' and len(self.params) > 0 and all(p.is_cuda for p in self.params)
 
     @torch.no_grad()
-    def clip_and_step(self, lr_scale: float = 1.0):
+    def clip_and_step(self, lr_scale: float = 1.0, device_step_count: bool = False):
         """clip_by_norm per variable + update.  Adam on the GPU: two fused multi-tensor HIP launches
-        (relgnn_mt_l2norm, relgnn_mt_adam_clip) instead of ~30 elementwise kernels."""
+        (relgnn_mt_l2norm, relgnn_mt_adam_clip) instead of ~30 elementwise kernels.
+        device_step_count=True (hipGraph capture): the step count and lr_t live in device memory
+        (relgnn_adam_step_size / relgnn_mt_adam_clip_devlr); the caller keeps self.t in step."""
         if not self._fused_adam_available():
+            if device_step_count:
+                raise RuntimeError("a captured training step needs the fused device-side Adam update")
             self.clip_gradients()
             self.step(lr_scale)
             return
@@ -67,9 +71,14 @@ class TFStyleOptimizer:
         idx = [i for i, p in enumerate(self.params) if p.grad is not None]
         if not idx:
             return
-        self.t += 1
         b1, b2, eps = 0.9, 0.999, 1e-8
-        lr_t = self.lr * lr_scale * (1 - b2 ** self.t) ** 0.5 / (1 - b1 ** self.t)
+        dev_state = None
+        if device_step_count:
+            dev_state = self._device_state()
+            _lib.check(lib.relgnn_adam_step_size(_lib.ptr(dev_state), self.lr * lr_scale, b1, b2, st), "relgnn_adam_step_size")
+        else:
+            self.t += 1
+            lr_t = self.lr * lr_scale * (1 - b2 ** self.t) ** 0.5 / (1 - b1 ** self.t)
         for c0 in range(0, len(idx), _lib.MT_MAX):
             chunk = idx[c0:c0 + _lib.MT_MAX]
             n = len(chunk)
@@ -85,8 +94,23 @@ class TFStyleOptimizer:
             ws_bytes = lib.relgnn_mt_l2norm_workspace_bytes()
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=norms.device)
             _lib.check(lib.relgnn_mt_l2norm(h_g, h_n, n, _lib.ptr(norms), _lib.ptr(ws), ws_bytes, st), "relgnn_mt_l2norm")
-            _lib.check(lib.relgnn_mt_adam_clip(h_p, h_g, h_m, h_v, h_n, n, _lib.ptr(norms), float(self.clip), lr_t,
-                                               b1, b2, eps, st), "relgnn_mt_adam_clip")
+            if dev_state is not None:
+                _lib.check(lib.relgnn_mt_adam_clip_devlr(h_p, h_g, h_m, h_v, h_n, n, _lib.ptr(norms), float(self.clip),
+                                                         dev_state[1:].data_ptr(), b1, b2, eps, st), "relgnn_mt_adam_clip_devlr")
+            else:
+                _lib.check(lib.relgnn_mt_adam_clip(h_p, h_g, h_m, h_v, h_n, n, _lib.ptr(norms), float(self.clip), lr_t,
+                                                   b1, b2, eps, st), "relgnn_mt_adam_clip")
+
+    def _device_state(self):
+        """[steps taken, lr_t] in device memory, seeded from the host step count."""
+        if getattr(self, "_dev_state", None) is None:
+            self._dev_state = torch.tensor([float(self.t), 0.0], dtype=torch.float32, device=self.params[0].device)
+        return self._dev_state
+
+    def sync_device_step_count(self):
+        """Call before switching to device-side counting (the host count may have advanced since the last time)."""
+        if getattr(self, "_dev_state", None) is not None:
+            self._dev_state[0] = float(self.t)
 
     @torch.no_grad()
     def clip_gradients(self):
@@ -175,6 +199,19 @@ class TFStyleOptimizer:
             self.t = max(0, int(round(math.log(float(weights["beta1_power:0"])) / math.log(0.9))) - 1)
             used.update(k for k in ("beta1_power:0", "beta2_power:0") if k in weights)
         return used
+
+
+class CapturedTrainStep:
+    """A training step recorded as a hipGraph on one fixed batch (Sparse_Graph_Model.capture_train_step)."""
+
+    def __init__(self, model, graph, metrics, batch):
+        self.model, self.graph, self.metrics, self.batch = model, graph, metrics, batch
+
+    def replay(self) -> Dict[str, torch.Tensor]:
+        """One more training step: a single graph launch.  The returned tensors are overwritten by the next replay."""
+        self.graph.replay()
+        self.model.optimizer.t += 1
+        return self.metrics
 
 
 class Sparse_Graph_Model(ABC):
@@ -365,7 +402,34 @@ class Sparse_Graph_Model(ABC):
             batch.type_to_num_incoming_edges, keep)
         return self.task.compute_task_metrics(final, batch, self.variables.scope(self._task_scope))
 
-    def train_step(self, batch: DeviceBatch, grad_hook=None) -> Dict[str, torch.Tensor]:
+    def capture_train_step(self, batch: DeviceBatch, warmup_steps: int = 3):
+        """One full training step on a FIXED batch as a hipGraph (forward, backward, clip, Adam: ~150 launches replayed
+        with one host call).  For workloads whose step is host-enqueue bound (C3: 153 k messages per batch) and whose
+        batch shapes repeat.  Runs `warmup_steps` real steps first (allocator / plan caches), then captures; returns a
+        CapturedTrainStep whose replay() performs exactly one more step and returns the (static) metric tensors."""
+        from ..graph import as_rel_graph as _as_graph
+        if self.device.type != "cuda" or self.optimizer.name != 'adam':
+            raise RuntimeError("capture_train_step needs a GPU model trained with Adam")
+        batch.wait_ready()
+        if getattr(batch, "graph", None) is None:           # the bucketing is part of the fixed batch, not of the step
+            batch.graph = _as_graph(batch.adjacency_lists, batch.num_nodes, validate=True)
+        opt = self.optimizer
+        opt.sync_device_step_count()
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup_steps):
+                self.train_step(batch, device_step_count=True)
+                opt.t += 1
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad()
+        with torch.cuda.graph(graph):
+            metrics = self.train_step(batch, device_step_count=True)
+        return CapturedTrainStep(self, graph, {k: v for k, v in metrics.items() if torch.is_tensor(v)}, batch)
+
+    def train_step(self, batch: DeviceBatch, grad_hook=None, device_step_count: bool = False) -> Dict[str, torch.Tensor]:
         """forward + backward + per-variable clip + optimizer update == one sess.run with train_step (:287-293)."""
         self.optimizer.zero_grad()
         metrics = self.forward_batch(batch, training=True)
@@ -379,7 +443,7 @@ class Sparse_Graph_Model(ABC):
         lr_n = self.params.get('lr_for_num_graphs_per_batch')
         if lr_n is not None:
             lr_scale = float(batch.num_graphs) / float(lr_n)
-        self.optimizer.clip_and_step(lr_scale)
+        self.optimizer.clip_and_step(lr_scale, device_step_count=device_step_count)
         return metrics
 
     def _batches(self, data, data_fold: DataFold):

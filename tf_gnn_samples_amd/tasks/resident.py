@@ -64,6 +64,10 @@ class ResidentDataset:
         g = RelGraph(union, N, validate=True)                                    # node-id range check, once
         self.plan_d = dict(rowptr_t=g.rowptr_t, perm_t=g.perm_t, col_t=g.col_t, rowptr_s=g.rowptr_s, perm_s=g.perm_s,
                            frow_s=g.frow_s, pos_t_of_s=g.pos_t_of_s)
+        # per-message 1/(in-degree + 1e-7) of the whole fold, by-target and by-source order: graph properties, copied
+        # per batch by relgnn_plan_assemble instead of being recomputed (relgnn_degree_scale + two gathers per batch)
+        self.w_t_d = g.degree_scale(self.deg_d) if M > 0 else torch.zeros(0, device=dev)
+        self.w_s_d = g.w_by_source(self.w_t_d) if M > 0 else torch.zeros(0, device=dev)
         # operands of relgnn_batch_gather: the fold's adjacency as ONE type-major [M_fold, 2] list, payload rows as
         # 4-byte elements (anything else is gathered with index_select)
         self.adj_flat_d = torch.cat(self.adj_d).contiguous() if L else torch.zeros((0, 2), dtype=torch.int32, device=dev)
@@ -153,6 +157,9 @@ class ResidentDataset:
         i32 = lambda n: torch.empty(int(n), dtype=torch.int32, device=dev)
         rowptr_t, perm_t, col_t, inv_t = i32(S + 1), i32(M), i32(M), i32(M)
         rowptr_s, perm_s, frow_s, tgt_s, pos = i32(S + 1), i32(M), i32(M), i32(M), i32(M)
+        src_t = i32(M)
+        w_t = torch.empty(M, dtype=torch.float32, device=dev)
+        w_s = torch.empty(M, dtype=torch.float32, device=dev)
         d = self.plan_d
         _lib.check(lib.relgnn_plan_assemble(
             _lib.ptr(ids_d), K, L, G, _lib.ptr(node_off_bd), _lib.ptr(msg_off_bd), _lib.ptr(edge_off_bd), _lib.ptr(type_off_bd),
@@ -160,9 +167,11 @@ class ResidentDataset:
             _lib.ptr(d["rowptr_t"]), _lib.ptr(d["perm_t"]), _lib.ptr(d["col_t"]), _lib.ptr(d["rowptr_s"]),
             _lib.ptr(d["perm_s"]), _lib.ptr(d["frow_s"]), _lib.ptr(d["pos_t_of_s"]),
             _lib.ptr(rowptr_t), _lib.ptr(perm_t), _lib.ptr(col_t), _lib.ptr(inv_t), _lib.ptr(rowptr_s), _lib.ptr(perm_s),
-            _lib.ptr(frow_s), _lib.ptr(tgt_s), _lib.ptr(pos), st), "relgnn_plan_assemble")
+            _lib.ptr(frow_s), _lib.ptr(tgt_s), _lib.ptr(pos), _lib.ptr(self.w_t_d), _lib.ptr(self.w_s_d), _lib.ptr(src_t),
+            _lib.ptr(w_t), _lib.ptr(w_s), st), "relgnn_plan_assemble")
         graph = RelGraph.from_arrays(adj, V, rowptr_t=rowptr_t, perm_t=perm_t, col_t=col_t, inv_perm_t=inv_t,
                                      rowptr_s=rowptr_s, perm_s=perm_s, frow_s=frow_s, tgt_s=tgt_s, pos_t_of_s=pos)
+        graph.preset_degree_scale(deg, src_t, w_t, w_s)
         batch = DeviceBatch.from_tensors(
             num_graphs=K, num_nodes=V, num_edges=M, initial_node_features=payload[self.features], adjacency_lists=adj,
             type_to_num_incoming_edges=deg, graph_nodes_list=n2g,
