@@ -28,6 +28,9 @@ for name, layout, a, b, lib in (
         ("fwd  [V,256]@[256,256]", D.GEMM_NN, r(V, 256), r(256, 256), lambda a, b: a @ b),
         ("dX   [V,768]@[256,768]^T", D.GEMM_NT, r(V, 768), r(256, 768), lambda a, b: a @ b.t()),
         ("dX   [V,256]@[256,256]^T", D.GEMM_NT, r(V, 256), r(256, 256), lambda a, b: a @ b.t()),
+        ("fwd  [V,768]@[768,256]  (aggregate-first)", D.GEMM_NN, r(V, 768), r(768, 256), lambda a, b: a @ b),
+        ("dX   [V,256]@[768,256]^T (aggregate-first dA)", D.GEMM_NT, r(V, 256), r(768, 256), lambda a, b: a @ b.t()),
+        ("dW   [V,768]^T@[V,256]  (aggregate-first)", D.GEMM_TN, r(V, 768), r(V, 256), None),
         ("dW   [V,256]^T@[V,768]", D.GEMM_TN, r(V, 256), r(V, 768), None),
         ("dW   [V,256]^T@[V,256]", D.GEMM_TN, r(V, 256), r(V, 256), None)):
     M, N, K = (a.shape[0], b.shape[1], a.shape[1]) if layout == D.GEMM_NN else \
@@ -40,7 +43,7 @@ for name, layout, a, b, lib in (
         libt = t(lambda: D.matmul_tn_splitk(a, b))
         single = t(lambda: a.t() @ b)
         D._OWN_GEMM = True
-        print("%-28s own %7.1f us %6.1f TF | lib split-K %7.1f us %6.1f TF | lib single %7.1f us" % (name, own, flop / own / 1e6, libt, flop / libt / 1e6, single))
+        print("%-48s own %7.1f us %6.1f TF | lib split-K %7.1f us %6.1f TF | lib single %7.1f us" % (name, own, flop / own / 1e6, libt, flop / libt / 1e6, single))
     else:
         libt = t(lambda: lib(a, b))
-        print("%-28s own %7.1f us %6.1f TF | lib %7.1f us %6.1f TF" % (name, own, flop / own / 1e6, libt, flop / libt / 1e6))
+        print("%-48s own %7.1f us %6.1f TF | lib %7.1f us %6.1f TF" % (name, own, flop / own / 1e6, libt, flop / libt / 1e6))

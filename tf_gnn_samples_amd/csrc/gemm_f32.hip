@@ -150,20 +150,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     if (more) gload(kbeg + (t + 1) * BK);              // in flight while this tile is multiplied
     const float* ta = lds + (t & 1) * (A_FLOATS + B_FLOATS);
     const float* tb = ta + A_FLOATS;
+    // Software pipeline over the four 4-k-pair groups of the tile: the LDS reads of group j4+1 are issued (into their OWN
+    // registers) before the 16 MFMAs of group j4.  Left to itself the compiler re-used one register pair for every B
+    // fragment, so each ds_read had to wait until the previous MFMAs had consumed their operands and every group of four
+    // MFMAs started with an exposed LDS round trip (92 TFLOP/s at any K).
+    float fa[2][TM][4], fb[2][TN][4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) fetch4<A_KM, BM>(fa[0][a], ta, wm + 32 * a, 0, lane);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fetch4<B_KM, BN>(fb[0][b], tb, wn + 32 * b, 0, lane);
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
-      float fa[TM][4], fb[TN][4];
+      const int cur = j4 & 1, nxt = cur ^ 1;
+      if (j4 < 3) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a) fetch4<A_KM, BM>(fa[a], ta, wm + 32 * a, j4, lane);
+        for (int a = 0; a < TM; ++a) fetch4<A_KM, BM>(fa[nxt][a], ta, wm + 32 * a, j4 + 1, lane);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) fetch4<B_KM, BN>(fb[b], tb, wn + 32 * b, j4, lane);
+        for (int b = 0; b < TN; ++b) fetch4<B_KM, BN>(fb[nxt][b], tb, wn + 32 * b, j4 + 1, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // keep the prefetch above the MFMA block
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][jj], fb[b][jj], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][jj], fb[cur][b][jj], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) lstore((t + 1) & 1);
     __syncthreads();
