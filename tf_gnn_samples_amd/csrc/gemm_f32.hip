@@ -35,6 +35,14 @@ struct RmTile { static constexpr int floats = ROWS * RM_STRIDE; };
 template <int COLS>  // KM operand tile: element (x, k) at k * COLS + x
 struct KmTile { static constexpr int floats = BK * COLS; };
 
+// Workgroup rendezvous on LDS contents only: global loads issued before it stay in flight across it (__syncthreads()
+// would also drain vmcnt).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- global -> registers (one k-tile of one operand; 256 threads) ---------------------------------------------------
 // RM: X rows x 32 k.  float4 f = tid + 256 p: row = f / 8, c4 = f % 8.
 // GUARD = false: the whole tile is inside the operand (wave-uniform decision by the caller): no per-lane branches.
@@ -139,47 +147,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     if constexpr (B_KM) store_km<BN>(tb, rb, tid); else store_rm<BN>(tb, rb, tid);
   };
 
+  // One k-tile = four groups of 4 k-pairs (16 MFMAs per wave and group at TM = TN = 2).  The loop keeps the matrix pipe
+  // fed without a serial segment: everything that is not an MFMA is issued at the head of a group and completes under that
+  // group's MFMAs, and the only rendezvous per k-tile sits between groups 2 and 3:
+  //   group 0 | fragments of group 1 <- LDS;  tile t+1 (in registers since the previous iteration) -> the other LDS buffer
+  //   group 1 | fragments of group 2 <- LDS;  global loads of tile t+2 -> registers
+  //   group 2 | fragments of group 3 <- LDS
+  //   -- wait for own LDS traffic, s_barrier: tile t+1 is complete in LDS, nobody reads tile t from LDS any more --
+  //   group 3 | fragments of group 0 of tile t+1 <- LDS
+  // Measured by ablation on random operands: k-loop with MFMAs only 109-119 TFLOP/s (the sustained
+  // clock under fp32 MFMA load, not 2.4 GHz, sets that ceiling), + LDS traffic 96-105, + global loads 87-92.
   const int ntiles = (kend - kbeg + BK - 1) / BK;
+  float fa[2][TM][4], fb[2][TN][4];
+  auto frags = [&](int buf, int tile, int group) {
+    const float* ta = lds + (tile & 1) * (A_FLOATS + B_FLOATS);
+    const float* tb = ta + A_FLOATS;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) fetch4<A_KM, BM>(fa[buf][a], ta, wm + 32 * a, group, lane);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fetch4<B_KM, BN>(fb[buf][b], tb, wn + 32 * b, group, lane);
+  };
+  auto mfma_group = [&](int buf) {
+    __builtin_amdgcn_sched_barrier(0);            // the group's loads / stores stay above its MFMA block
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][a][jj], fb[buf][b][jj], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   if (ntiles > 0) {
     gload(kbeg);
     lstore(0);
-    __syncthreads();
+    if (ntiles > 1) gload(kbeg + BK);
+    lds_barrier();
+    frags(0, 0, 0);
   }
   for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) gload(kbeg + (t + 1) * BK);              // in flight while this tile is multiplied
-    const float* ta = lds + (t & 1) * (A_FLOATS + B_FLOATS);
-    const float* tb = ta + A_FLOATS;
-    // Software pipeline over the four 4-k-pair groups of the tile: the LDS reads of group j4+1 are issued (into their OWN
-    // registers) before the 16 MFMAs of group j4.  Left to itself the compiler re-used one register pair for every B
-    // fragment, so each ds_read had to wait until the previous MFMAs had consumed their operands and every group of four
-    // MFMAs started with an exposed LDS round trip (92 TFLOP/s at any K).
-    float fa[2][TM][4], fb[2][TN][4];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) fetch4<A_KM, BM>(fa[0][a], ta, wm + 32 * a, 0, lane);
-#pragma unroll
-    for (int b = 0; b < TN; ++b) fetch4<B_KM, BN>(fb[0][b], tb, wn + 32 * b, 0, lane);
-#pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-      const int cur = j4 & 1, nxt = cur ^ 1;
-      if (j4 < 3) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) fetch4<A_KM, BM>(fa[nxt][a], ta, wm + 32 * a, j4 + 1, lane);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) fetch4<B_KM, BN>(fb[nxt][b], tb, wn + 32 * b, j4 + 1, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);          // keep the prefetch above the MFMA block
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][jj], fb[cur][b][jj], acc[a][b], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more) lstore((t + 1) & 1);
-    __syncthreads();
+    frags(1, t, 1);
+    if (t + 1 < ntiles) lstore((t + 1) & 1);
+    mfma_group(0);
+    frags(0, t, 2);
+    if (t + 2 < ntiles) gload(kbeg + (t + 2) * BK);
+    mfma_group(1);
+    frags(1, t, 3);
+    mfma_group(0);
+    lds_barrier();
+    if (t + 1 < ntiles) frags(0, t + 1, 0);
+    mfma_group(1);
   }
 
   // C layout of v_mfma_f32_32x32x2: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -237,7 +254,7 @@ int launch(int act, const float* A, int64_t lda, const float* B, int64_t ldb, fl
   return launch_status();
 }
 
-// tile choice: largest tile whose grid still fills the 256 CUs about twice (2 workgroups are resident per CU)
+// tile choice: largest tile whose grid still fills the 256 CUs about twice (2-3 workgroups are resident per CU)
 template <bool A_KM, bool B_KM>
 int dispatch(int act, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
              int splits, int k_chunk, const float* bias, hipStream_t st) {
