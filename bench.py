@@ -382,6 +382,7 @@ def main():
 
     from tf_gnn_samples_amd.graph import check_pending_graph_errors, clear_graph_cache
     from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.models.sparse_graph_model import MetricsReadback
     from tf_gnn_samples_amd.tasks import DataFold
     task, fold, gen_params = build_local_fold(rank, world)
     params = RGCN_Model.default_params()
@@ -404,18 +405,20 @@ def main():
 
     def fetch(pending):
         m, b = pending
-        state["loss"] = float(m['loss'])          # the host sync of sess.run's fetch (:293), one step late
-        float(m['f1_score'])
+        m = m.get()                               # the host sync of sess.run's fetch (:293), one step late: waits for the
+        state["loss"] = m['loss']                 # D2H copy enqueued right behind THAT step (models.MetricsReadback)
+        m['f1_score']
         state["fetched"] += 1
 
     def one_step():
         batch = state["upcoming"]
         hook = (lambda ps: reducer(float(batch.num_nodes))) if reducer is not None else None
         m = model.train_step(batch, grad_hook=hook)
+        readback = MetricsReadback(m)             # async D2H of this step's metrics into pinned memory
         state["upcoming"] = next(stream)          # assembly + bucketing of the next batch, enqueued behind this step
         if state["pending"] is not None:
             fetch(state["pending"])
-        state["pending"] = ({k: (v.detach() if torch.is_tensor(v) else v) for k, v in m.items()}, batch)
+        state["pending"] = (readback, batch)
         state["edges"] += batch.num_edges
         state["nodes"] += batch.num_nodes
         state["graphs"] += batch.num_graphs

@@ -597,6 +597,11 @@ int relgnn_batch_pack(int32_t num_types, int64_t n_graphs, const int64_t* h_grap
  * Optional (NULL to skip), fused into the same passes: src_t [M] = source NODE per by-target position; w_t / w_s [M] =
  * the per-message scales of the batch in by-target / by-source order, copied from the dataset-level arrays w_t_d / w_s_d
  * (1/(in-degree + 1e-7), gnns/rgcn.py:100-104, is a property of the graph, not of the batch).
+ * LEAN call: perm_t, col_t, inv_perm_t, perm_s, frow_s, pos_t_of_s all NULL (all six or none).  Then only the row
+ * pointers, src_t, tgt_s and the scales are produced — everything the fused gather kernels of the sum / mean / sqrt_n
+ * layers read — in two passes that move 16 bytes per message; the six arrays (permutations to and from the reference's
+ * type-major message order, the scattered inverse, (node, type) rows: what the pair / attention / materialised-message
+ * paths read) can be produced later by a second, full call with the same tables.
  */
 /*
  * The batch's TENSORS from the fold's flat device arrays, same packing rules as relgnn_batch_pack (replaces the numpy
@@ -607,6 +612,8 @@ int relgnn_batch_pack(int32_t num_types, int64_t n_graphs, const int64_t* h_grap
  *                               of 4-byte elements (h_payload_cols: HOST array)
  *   deg_d [L, N] -> deg_b [L, V];  adj_d [M_fold, 2] type-major, graph-local ids -> adj_b [M, 2] type-major
  *   node_to_graph [V] int32
+ * adj_b may be NULL: the batch's adjacency lists are then not produced (a caller that hands the bucketing, not the lists,
+ * to the layers asks for them only when something reads them).
  */
 int relgnn_batch_gather(const int64_t* ids, int32_t num_batch_graphs, int32_t num_edge_types, int64_t num_dataset_graphs,
                         const int64_t* node_off_b, const int64_t* edge_off_b, const int64_t* type_off_b,

@@ -78,11 +78,15 @@ def test_resident_batches_and_plans_are_bit_identical(gpu_device, L):
     resident = ResidentDataset(store, gpu_device)
     host = NativeBatcher(store, gpu_device, bucket=False)
     for ids in ([0], [5, 2, 2, 17], list(range(30)), [3], [29, 0, 3, 4]):          # order, repeats, an edge-free graph
-        a = resident.assemble(np.array(ids))
         b = host.pack(np.array(ids))
-        _same_batch(a, b)
-        _same_plan(a.graph, b.adjacency_lists, b.num_nodes)
-        _same_scales(a)
+        for lean in (True, False):
+            a = resident.assemble(np.array(ids), lean=lean)
+            assert (a.graph.__dict__.get("_complete") is not None) == lean      # lean: permutation arrays deferred
+            assert torch.equal(a.graph.src_t, torch.cat([x[:, 0] for x in b.adjacency_lists])[a.graph.perm_t.long()]) \
+                if a.graph.M else True
+            _same_batch(a, b)
+            _same_plan(a.graph, b.adjacency_lists, b.num_nodes)
+            _same_scales(a)
     got = [x.num_graphs for x in resident.iterate(np.arange(30), 200)]
     want = [x.num_graphs for x in host.iterate(np.arange(30), 200)]
     assert got == want and sum(got) == 30
@@ -114,3 +118,36 @@ def test_resident_qm9_with_per_graph_targets_and_training(gpu_device):
         loss, res, n, *_ = model._run_epoch("valid", data[:64], DataFold.VALIDATION, quiet=True)
         outs.append((loss, n, [r['abs_err_task0'] for r in res]))
     assert outs[0] == outs[1]
+
+
+def test_lean_batches_stay_lean_through_an_rgcn_step_and_train_identically(gpu_device):
+    """The default (lean) assembly defers the adjacency lists and the six permutation-type arrays of the bucketing; the
+    RGCN sum path must never ask for them, and must train bit-identically to the fully assembled batch."""
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
+    from tf_gnn_samples_amd.tasks.resident import ResidentDataset
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(6, 1, seed=2, mean_nodes=200, std_nodes=40, min_nodes=80, max_nodes=300, fwd_edges_per_node=5.0)
+    store = task.make_graph_store(task._loaded_data[DataFold.TRAIN])
+    resident = ResidentDataset(store, gpu_device, constants={})
+    ids = np.array([4, 1, 5])
+    results = []
+    for lean in (True, False):
+        params = RGCN_Model.default_params()
+        params.update(hidden_size=64, graph_num_layers=2, graph_layer_input_dropout_keep_prob=1.0, random_seed=1)
+        model = RGCN_Model(params, task, device=str(gpu_device))
+        batch = task._finish_native_batch(resident.assemble(ids, lean=lean))
+        losses = [float(model.train_step(batch)['loss'].detach()) for _ in range(3)]
+        if lean:
+            assert batch.graph.__dict__.get("_complete") is not None, "the RGCN step read a deferred array"
+            assert callable(batch._adjacency), "the RGCN step read the adjacency lists"
+        results.append((losses, {n: model.variables[n].detach().clone() for n in model.variables.names()}))
+    assert results[0][0] == results[1][0]
+    for n, v in results[0][1].items():
+        assert torch.equal(v, results[1][1][n]), n
+    # and the deferred pieces, once read, are the real ones
+    lean_batch, full_batch = resident.assemble(ids), resident.assemble(ids, lean=False)
+    for x, y in zip(lean_batch.adjacency_lists, full_batch.adjacency_lists):
+        assert torch.equal(x, y)
+    for name in ("perm_t", "col_t", "inv_perm_t", "perm_s", "frow_s", "pos_t_of_s"):
+        assert torch.equal(getattr(lean_batch.graph, name), getattr(full_batch.graph, name)), name

@@ -42,6 +42,10 @@ __device__ __forceinline__ int32_t translate_message(const BatchTables& t, int32
   return (int32_t)(t.type_off_b[l] + t.edge_off_b[(int64_t)l * (t.K + 1) + k] + e);
 }
 
+// FULL = false ("lean"): only what the fused gather kernels read per message — the source / target NODE and the scale.
+// The permutations, the inverse permutation (a scattered 4-byte write per message) and the (node, type) rows are what the
+// pair / attention / materialised-message paths need; a caller that passes NULL for them gets them later by calling again.
+template <bool FULL>
 __global__ __launch_bounds__(256) void assemble_by_target_kernel(
     BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ col_d,
     int32_t* __restrict__ perm_b, int32_t* __restrict__ col_b, int32_t* __restrict__ inv_b,
@@ -50,18 +54,22 @@ __global__ __launch_bounds__(256) void assemble_by_target_kernel(
     const int k = upper_slot(t.msg_off_b, t.K, p);
     const int64_t g = t.ids[k];
     const int64_t pd = t.msg_off_d[g] + (p - t.msg_off_b[k]);
-    const int32_t c = col_d[pd];
-    const int l = c % t.L;
-    const int64_t src = c / t.L - t.node_off_d[g] + t.node_off_b[k];
-    col_b[p] = (int32_t)(src * t.L + l);
+    const uint32_t c = (uint32_t)col_d[pd];
+    const uint32_t cn = c / (uint32_t)t.L;
+    const int64_t src = (int64_t)cn - t.node_off_d[g] + t.node_off_b[k];
     if (src_b) src_b[p] = (int32_t)src;            // source NODE per by-target position (row of the state table)
     if (w_t_b) w_t_b[p] = w_t_d[pd];                // per-message scale: a property of the graph, not of the batch
-    const int32_t mb = translate_message(t, perm_d[pd], l, k, g);
-    perm_b[p] = mb;
-    inv_b[mb] = (int32_t)p;
+    if constexpr (FULL) {
+      const int l = (int)(c - cn * (uint32_t)t.L);
+      col_b[p] = (int32_t)(src * t.L + l);
+      const int32_t mb = translate_message(t, perm_d[pd], l, k, g);
+      perm_b[p] = mb;
+      inv_b[mb] = (int32_t)p;
+    }
   }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(256) void assemble_by_source_kernel(
     BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ frow_d,
     const int32_t* __restrict__ pos_d, int32_t* __restrict__ perm_b, int32_t* __restrict__ frow_b,
@@ -70,14 +78,17 @@ __global__ __launch_bounds__(256) void assemble_by_source_kernel(
     const int k = upper_slot(t.msg_off_b, t.K, q);
     const int64_t g = t.ids[k];
     const int64_t qd = t.msg_off_d[g] + (q - t.msg_off_b[k]);
-    const int32_t f = frow_d[qd];
-    const int l = f % t.L;
-    const int64_t tgt = f / t.L - t.node_off_d[g] + t.node_off_b[k];
-    frow_b[q] = (int32_t)(tgt * t.L + l);
+    const uint32_t f = (uint32_t)frow_d[qd];
+    const uint32_t fn = f / (uint32_t)t.L;
+    const int64_t tgt = (int64_t)fn - t.node_off_d[g] + t.node_off_b[k];
     tgt_b[q] = (int32_t)tgt;
-    perm_b[q] = translate_message(t, perm_d[qd], l, k, g);
-    pos_b[q] = (int32_t)((int64_t)pos_d[qd] - t.msg_off_d[g] + t.msg_off_b[k]);
     if (w_s_b) w_s_b[q] = w_s_d[qd];
+    if constexpr (FULL) {
+      const int l = (int)(f - fn * (uint32_t)t.L);
+      frow_b[q] = (int32_t)(tgt * t.L + l);
+      perm_b[q] = translate_message(t, perm_d[qd], l, k, g);
+      pos_b[q] = (int32_t)((int64_t)pos_d[qd] - t.msg_off_d[g] + t.msg_off_b[k]);
+    }
   }
 }
 
@@ -105,15 +116,18 @@ __global__ __launch_bounds__(256) void assemble_rowptr_kernel(
 // Nodes of a graph are contiguous in the fold and in the batch: every copy below is K contiguous segment copies, found
 // per element by a binary search over the K+1 batch offsets (K <= a few hundred; the tables sit in L1/L2).
 
-// dst[v, :] = src[node_d(v), :]   rows of `cols` 4-byte elements
+// dst[v, :] = src[node_d(v), :]   rows of `cols` 4-byte elements.  A slot's rows are contiguous on both sides: the flat
+// element index is searched in the slot table directly (no per-element division).
 __global__ __launch_bounds__(256) void gather_node_rows_kernel(BatchTables t, int64_t V, int32_t cols,
                                                                const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
   const int64_t total = V * cols;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t v = i / cols;
-    const int k = upper_slot(t.node_off_b, t.K, v);
-    const int64_t vd = v - t.node_off_b[k] + t.node_off_d[t.ids[k]];
-    dst[i] = src[vd * cols + (i - v * cols)];
+    int lo = 0, hi = t.K;                // invariant: node_off_b[lo] * cols <= i < node_off_b[hi] * cols
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (t.node_off_b[mid] * cols <= i) lo = mid; else hi = mid;
+    }
+    dst[i] = src[(t.node_off_d[t.ids[lo]] - t.node_off_b[lo]) * cols + i];
   }
 }
 
@@ -174,8 +188,8 @@ int relgnn_batch_gather(const int64_t* ids, int32_t num_batch_graphs, int32_t nu
     if (!deg_d || !deg_b || !node_to_graph) return RELGNN_EINVAL;
     gather_degree_kernel<<<flat_grid(num_nodes, 256), 256, 0, st>>>(t, num_nodes, num_dataset_nodes, deg_d, deg_b, node_to_graph);
   }
-  if (num_messages > 0) {
-    if (!adj_d || !adj_b) return RELGNN_EINVAL;
+  if (num_messages > 0 && adj_b) {               // adj_b == NULL: the caller does not want the adjacency lists (yet)
+    if (!adj_d) return RELGNN_EINVAL;
     gather_adjacency_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, (const int2*)adj_d, (int2*)adj_b);
   }
   return launch_status();
@@ -210,15 +224,25 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
   assemble_rowptr_kernel<<<flat_grid(buckets + 1, 256), 256, 0, st>>>(t, buckets, num_messages, rowptr_t_d, rowptr_s_d,
                                                                       rowptr_t, rowptr_s);
   if (num_messages > 0) {
-    if (!perm_t_d || !col_t_d || !perm_s_d || !frow_s_d || !pos_t_of_s_d || !perm_t || !col_t || !inv_perm_t || !perm_s ||
-        !frow_s || !tgt_s || !pos_t_of_s)
+    // the six index arrays of the pair / attention / materialised-message paths are all-or-nothing
+    const bool full = perm_t || col_t || inv_perm_t || perm_s || frow_s || pos_t_of_s;
+    if (full && (!perm_t || !col_t || !inv_perm_t || !perm_s || !frow_s || !pos_t_of_s || !perm_t_d || !perm_s_d || !pos_t_of_s_d))
       return RELGNN_EINVAL;
+    if (!col_t_d || !frow_s_d || !tgt_s) return RELGNN_EINVAL;
+    if (!full && !src_t) return RELGNN_EINVAL;      // a lean call that produces nothing by target
     if ((w_t && !w_t_d) || (w_s && !w_s_d)) return RELGNN_EINVAL;
-    assemble_by_target_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, perm_t_d, col_t_d, perm_t,
-                                                                            col_t, inv_perm_t, w_t_d, src_t, w_t);
-    assemble_by_source_kernel<<<flat_grid(num_messages, 256), 256, 0, st>>>(t, num_messages, perm_s_d, frow_s_d,
-                                                                            pos_t_of_s_d, perm_s, frow_s, tgt_s, pos_t_of_s,
-                                                                            w_s_d, w_s);
+    const dim3 grid = flat_grid(num_messages, 256);
+    if (full) {
+      assemble_by_target_kernel<true><<<grid, 256, 0, st>>>(t, num_messages, perm_t_d, col_t_d, perm_t, col_t, inv_perm_t,
+                                                            w_t_d, src_t, w_t);
+      assemble_by_source_kernel<true><<<grid, 256, 0, st>>>(t, num_messages, perm_s_d, frow_s_d, pos_t_of_s_d, perm_s, frow_s,
+                                                            tgt_s, pos_t_of_s, w_s_d, w_s);
+    } else {
+      assemble_by_target_kernel<false><<<grid, 256, 0, st>>>(t, num_messages, nullptr, col_t_d, nullptr, nullptr, nullptr,
+                                                             w_t_d, src_t, w_t);
+      assemble_by_source_kernel<false><<<grid, 256, 0, st>>>(t, num_messages, nullptr, frow_s_d, nullptr, nullptr, nullptr,
+                                                             tgt_s, nullptr, w_s_d, w_s);
+    }
   }
   return launch_status();
 }

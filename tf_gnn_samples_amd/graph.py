@@ -35,11 +35,24 @@ class GatherReducePlan:
 
     def __init__(self, *, rowptr, stride, col, w, num_out, num_rows_x, rowptr_b, stride_b, col_b,
                  pos_b, num_messages):
-        self.rowptr, self.stride, self.col, self.w = rowptr, int(stride), col, w
+        # `col` / `pos_b` may be zero-argument callables: resolved on first read (arrays a lean RelGraph has deferred)
+        self.rowptr, self.stride, self._col, self.w = rowptr, int(stride), col, w
         self.num_out, self.num_rows_x = int(num_out), int(num_rows_x)
-        self.rowptr_b, self.stride_b, self.col_b, self.pos_b = rowptr_b, int(stride_b), col_b, pos_b
+        self.rowptr_b, self.stride_b, self.col_b, self._pos_b = rowptr_b, int(stride_b), col_b, pos_b
         self.num_messages = int(num_messages)
         self._w_bwd = {}
+
+    @property
+    def col(self):
+        if callable(self._col):
+            self._col = self._col()
+        return self._col
+
+    @property
+    def pos_b(self):
+        if callable(self._pos_b):
+            self._pos_b = self._pos_b()
+        return self._pos_b
 
     def w_bwd(self, mode: int):
         """Per-message weights in the TRANSPOSED order for the gradient of sum/mean/sqrt_n:
@@ -156,33 +169,63 @@ class RelGraph:
             if len(_PENDING_CHECKS) > 4096:
                 check_pending_graph_errors()
 
+    # index arrays / adjacency lists a producer may leave out (tasks/resident.py lean assembly) and fill on first use
+    _LAZY_ARRAYS = ("perm_t", "col_t", "inv_perm_t", "perm_s", "frow_s", "pos_t_of_s")
+
     @classmethod
-    def from_arrays(cls, adjacency_lists, num_nodes: int, *, rowptr_t, perm_t, col_t, inv_perm_t, rowptr_s, perm_s,
-                    frow_s, tgt_s, pos_t_of_s) -> "RelGraph":
+    def from_arrays(cls, adjacency_lists, num_nodes: int, *, rowptr_t, rowptr_s, tgt_s, perm_t=None, col_t=None,
+                    inv_perm_t=None, perm_s=None, frow_s=None, pos_t_of_s=None, edge_counts=None, complete=None,
+                    device=None) -> "RelGraph":
         """A RelGraph whose bucketing was produced elsewhere (tasks/resident.py: slices of a fold-level bucketing
         re-based by relgnn_plan_assemble).  The arrays must be what __init__ would compute; the node-id range check is
-        the producer's job."""
-        lib = _lib.load_library()
+        the producer's job.
+        Lean form: the six _LAZY_ARRAYS (and `adjacency_lists`, then give `edge_counts`) may be None when `complete` is a
+        callable returning a dict with them ({"adjacency_lists": [...], "perm_t": ..., ...}); it runs on the first read
+        of any of them (the sum / mean / sqrt_n layers of the RGCN / GGNN path never do)."""
         self = cls.__new__(cls)
-        adj = [a if a.dtype == torch.int32 else a.to(torch.int32) for a in adjacency_lists]
-        self.adjacency_lists = adj
-        self.L = L = len(adj)
+        lazy = {k: v for k, v in dict(perm_t=perm_t, col_t=col_t, inv_perm_t=inv_perm_t, perm_s=perm_s, frow_s=frow_s,
+                                      pos_t_of_s=pos_t_of_s).items()}
+        missing = [k for k, v in lazy.items() if v is None]
+        if (missing or adjacency_lists is None) and complete is None:
+            raise ValueError("from_arrays: %s missing and no `complete` callable" % (missing or "adjacency_lists"))
+        if adjacency_lists is not None:
+            adj = [a if a.dtype == torch.int32 else a.to(torch.int32) for a in adjacency_lists]
+            self.adjacency_lists = adj
+            edge_counts = [int(a.shape[0]) for a in adj]
+        elif edge_counts is None:
+            raise ValueError("from_arrays: edge_counts is required when adjacency_lists is deferred")
+        self.L = L = len(edge_counts)
         self.V = V = int(num_nodes)
-        self.edge_counts = [int(a.shape[0]) for a in adj]
+        self.edge_counts = [int(e) for e in edge_counts]
         self.M = M = sum(self.edge_counts)
         self.device = dev = rowptr_t.device
         # the per-message keys (tgt*L+l, src*L+l in type-major order) are only read by the pair / materialised-message
         # paths: computed on first use (relgnn_relational_keys_all), not per batch
         self._key_t = self._key_s = None
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.rowptr_t, self.perm_t, self.col_t, self.inv_perm_t = rowptr_t, perm_t, col_t, inv_perm_t
-        self.rowptr_s, self.perm_s, self.frow_s, self.tgt_s, self.pos_t_of_s = rowptr_s, perm_s, frow_s, tgt_s, pos_t_of_s
+        self.rowptr_t, self.rowptr_s, self.tgt_s = rowptr_t, rowptr_s, tgt_s
+        for k, v in lazy.items():
+            if v is not None:
+                setattr(self, k, v)
+        self._complete = complete
         self._src_t = None
         self._plans = {}
         self._scales = OrderedDict()
         self._err_flag = err
         self._checked = True
         return self
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: a deferred array of a lean from_arrays() graph
+        if name in RelGraph._LAZY_ARRAYS or name == "adjacency_lists":
+            complete = self.__dict__.get("_complete")
+            if complete is not None:
+                self.__dict__["_complete"] = None
+                for k, v in complete().items():
+                    self.__dict__.setdefault(k, v)
+                if name in self.__dict__:
+                    return self.__dict__[name]
+        raise AttributeError("%s has no attribute %r" % (type(self).__name__, name))
 
     def _ensure_keys(self):
         if self._key_t is None:
@@ -241,9 +284,9 @@ class RelGraph:
             return self
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        for t in (self._key_t, self._key_s, self.rowptr_t, self.perm_t, self.col_t, self.inv_perm_t,
-                  self.rowptr_s, self.perm_s, self.frow_s, self.tgt_s, self.pos_t_of_s, self._err_flag,
-                  *self.adjacency_lists, *getattr(self, "_preset", ())):
+        d = self.__dict__                     # (deferred arrays of a lean graph are not touched: they do not exist yet)
+        for t in (self._key_t, self._key_s, self.rowptr_t, self.rowptr_s, self.tgt_s, self._err_flag,
+                  *[d.get(k) for k in RelGraph._LAZY_ARRAYS], *d.get("adjacency_lists", ()), *d.get("_preset", ())):
             if t is not None:
                 t.record_stream(cur)
         return self
@@ -347,9 +390,9 @@ class RelGraph:
         key = ("T", None if w is None else w.data_ptr())
         if key not in self._plans:
             self._plans[key] = (w, GatherReducePlan(
-                rowptr=self.rowptr_t, stride=self.L, col=self.col_t, w=w, num_out=self.V,
+                rowptr=self.rowptr_t, stride=self.L, col=lambda: self.col_t, w=w, num_out=self.V,
                 num_rows_x=self.V * self.L, rowptr_b=self.rowptr_s, stride_b=1, col_b=self.tgt_s,
-                pos_b=self.pos_t_of_s, num_messages=self.M))
+                pos_b=lambda: self.pos_t_of_s, num_messages=self.M))
         return self._plans[key][1]
 
     def plan_untransformed(self, w: Optional[torch.Tensor] = None) -> GatherReducePlan:
@@ -359,7 +402,7 @@ class RelGraph:
             self._plans[key] = (w, GatherReducePlan(
                 rowptr=self.rowptr_t, stride=self.L, col=self.src_t, w=w, num_out=self.V,
                 num_rows_x=self.V, rowptr_b=self.rowptr_s, stride_b=self.L, col_b=self.tgt_s,
-                pos_b=self.pos_t_of_s, num_messages=self.M))
+                pos_b=lambda: self.pos_t_of_s, num_messages=self.M))
         return self._plans[key][1]
 
 

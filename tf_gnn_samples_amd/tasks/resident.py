@@ -93,7 +93,12 @@ class ResidentDataset:
         return buf, k
 
     # ---- one batch ----------------------------------------------------------------------------
-    def assemble(self, graph_ids: Sequence[int]) -> DeviceBatch:
+    def assemble(self, graph_ids: Sequence[int], lean: bool = True) -> DeviceBatch:
+        """One batch from graph ids.  lean (default): only what every layer's fused gather kernels read is produced now —
+        payload rows, degree tables, graph slot per node, both row-pointer arrays, source / target node and
+        1/(in-degree + 1e-7) scale per bucketed message (16 bytes per message).  The batch's adjacency lists and the six
+        permutation-type arrays of the bucketing (RelGraph._LAZY_ARRAYS) are gathered on their first read, from the same
+        offset tables (the RGCN / GGNN sum paths never read them).  lean=False produces everything at once."""
         import ctypes
         lib = _lib.load_library()
         st = _lib.current_stream()
@@ -122,6 +127,8 @@ class ResidentDataset:
         self._stage_done[slot] = ev
         o = np.cumsum([0] + sizes)
         ids_d, node_off_bd, msg_off_bd, type_off_bd, edge_off_bd = (tab[o[i]:o[i + 1]] for i in range(5))
+        type_off = [int(x) for x in type_off_b]
+        i32 = lambda n: torch.empty(int(n), dtype=torch.int32, device=dev)
 
         # ---- tensors of the batch: one C call, a handful of gather kernels (packing rules of relgnn_batch_pack) ----
         names = self.store.payload_names
@@ -133,17 +140,24 @@ class ResidentDataset:
             payload[names[i]] = out_fast[-1]
         deg = torch.empty((L, V), dtype=torch.float32, device=dev)
         n2g = torch.empty(V, dtype=torch.int32, device=dev)
-        adj_flat = torch.empty((M, 2), dtype=torch.int32, device=dev)
         nf = len(self._fast)
         arr = ctypes.c_void_p * max(nf, 1)
-        _lib.check(lib.relgnn_batch_gather(
-            _lib.ptr(ids_d), K, L, G, _lib.ptr(node_off_bd), _lib.ptr(edge_off_bd), _lib.ptr(type_off_bd),
-            _lib.ptr(self.node_off_d), _lib.ptr(self.edge_off_d), _lib.ptr(self.type_off_d), V, M, self._num_nodes_fold, nf,
-            arr(*[self.payload_d[i].data_ptr() for i in self._fast]), (ctypes.c_int32 * max(nf, 1))(*self._fast_cols),
-            arr(*[t.data_ptr() for t in out_fast]), _lib.ptr(self.deg_d), _lib.ptr(deg), _lib.ptr(self.adj_flat_d),
-            _lib.ptr(adj_flat), _lib.ptr(n2g), st), "relgnn_batch_gather")
-        type_off = [int(x) for x in type_off_b]
-        adj = [adj_flat[type_off[l]:type_off[l + 1]] for l in range(L)]
+
+        def gather(n_payloads, with_node_tables, adj_flat):
+            _lib.check(lib.relgnn_batch_gather(
+                _lib.ptr(ids_d), K, L, G, _lib.ptr(node_off_bd), _lib.ptr(edge_off_bd), _lib.ptr(type_off_bd),
+                _lib.ptr(self.node_off_d), _lib.ptr(self.edge_off_d), _lib.ptr(self.type_off_d), V, M, self._num_nodes_fold,
+                n_payloads, arr(*[self.payload_d[i].data_ptr() for i in self._fast]),
+                (ctypes.c_int32 * max(nf, 1))(*self._fast_cols), arr(*[t.data_ptr() for t in out_fast]),
+                _lib.ptr(self.deg_d), _lib.ptr(deg) if with_node_tables else None, _lib.ptr(self.adj_flat_d),
+                _lib.ptr(adj_flat), _lib.ptr(n2g) if with_node_tables else None, _lib.current_stream()),
+                "relgnn_batch_gather")
+
+        def split_types(adj_flat):
+            return [adj_flat[type_off[l]:type_off[l + 1]] for l in range(L)]
+
+        adj_flat = None if lean else torch.empty((M, 2), dtype=torch.int32, device=dev)
+        gather(nf, True, adj_flat)
         if len(self._fast) < len(names):          # payloads that are not 4-byte rows
             node_idx = (torch.arange(V, device=dev) - node_off_bd[n2g.long()] + self.node_off_d[ids_d[n2g.long()]])
             for i, name in enumerate(names):
@@ -154,26 +168,52 @@ class ResidentDataset:
 
         # ---- bucketing: re-based slices of the fold's arrays ----
         S = V * L
-        i32 = lambda n: torch.empty(int(n), dtype=torch.int32, device=dev)
-        rowptr_t, perm_t, col_t, inv_t = i32(S + 1), i32(M), i32(M), i32(M)
-        rowptr_s, perm_s, frow_s, tgt_s, pos = i32(S + 1), i32(M), i32(M), i32(M), i32(M)
-        src_t = i32(M)
+        rowptr_t, rowptr_s, tgt_s, src_t = i32(S + 1), i32(S + 1), i32(M), i32(M)
         w_t = torch.empty(M, dtype=torch.float32, device=dev)
         w_s = torch.empty(M, dtype=torch.float32, device=dev)
         d = self.plan_d
-        _lib.check(lib.relgnn_plan_assemble(
-            _lib.ptr(ids_d), K, L, G, _lib.ptr(node_off_bd), _lib.ptr(msg_off_bd), _lib.ptr(edge_off_bd), _lib.ptr(type_off_bd),
-            _lib.ptr(self.node_off_d), _lib.ptr(self.msg_off_d), _lib.ptr(self.edge_off_d), _lib.ptr(self.type_off_d), V, M,
-            _lib.ptr(d["rowptr_t"]), _lib.ptr(d["perm_t"]), _lib.ptr(d["col_t"]), _lib.ptr(d["rowptr_s"]),
-            _lib.ptr(d["perm_s"]), _lib.ptr(d["frow_s"]), _lib.ptr(d["pos_t_of_s"]),
-            _lib.ptr(rowptr_t), _lib.ptr(perm_t), _lib.ptr(col_t), _lib.ptr(inv_t), _lib.ptr(rowptr_s), _lib.ptr(perm_s),
-            _lib.ptr(frow_s), _lib.ptr(tgt_s), _lib.ptr(pos), _lib.ptr(self.w_t_d), _lib.ptr(self.w_s_d), _lib.ptr(src_t),
-            _lib.ptr(w_t), _lib.ptr(w_s), st), "relgnn_plan_assemble")
-        graph = RelGraph.from_arrays(adj, V, rowptr_t=rowptr_t, perm_t=perm_t, col_t=col_t, inv_perm_t=inv_t,
-                                     rowptr_s=rowptr_s, perm_s=perm_s, frow_s=frow_s, tgt_s=tgt_s, pos_t_of_s=pos)
+
+        def plan(full):
+            """full=False: row pointers, src_t, tgt_s, scales.  full=True: additionally the six permutation-type arrays
+            (the lean outputs are rewritten with the same values)."""
+            six = {k: (i32(M) if full else None) for k in RelGraph._LAZY_ARRAYS}
+            _lib.check(lib.relgnn_plan_assemble(
+                _lib.ptr(ids_d), K, L, G, _lib.ptr(node_off_bd), _lib.ptr(msg_off_bd), _lib.ptr(edge_off_bd),
+                _lib.ptr(type_off_bd), _lib.ptr(self.node_off_d), _lib.ptr(self.msg_off_d), _lib.ptr(self.edge_off_d),
+                _lib.ptr(self.type_off_d), V, M,
+                _lib.ptr(d["rowptr_t"]), _lib.ptr(d["perm_t"]), _lib.ptr(d["col_t"]), _lib.ptr(d["rowptr_s"]),
+                _lib.ptr(d["perm_s"]), _lib.ptr(d["frow_s"]), _lib.ptr(d["pos_t_of_s"]),
+                _lib.ptr(rowptr_t), _lib.ptr(six["perm_t"]), _lib.ptr(six["col_t"]), _lib.ptr(six["inv_perm_t"]),
+                _lib.ptr(rowptr_s), _lib.ptr(six["perm_s"]), _lib.ptr(six["frow_s"]), _lib.ptr(tgt_s),
+                _lib.ptr(six["pos_t_of_s"]), _lib.ptr(self.w_t_d), _lib.ptr(self.w_s_d), _lib.ptr(src_t), _lib.ptr(w_t),
+                _lib.ptr(w_s), _lib.current_stream()), "relgnn_plan_assemble")
+            return six
+
+        state = {"adj": None if lean else split_types(adj_flat)}
+
+        def adjacency():
+            """the batch's adjacency lists (tasks/ppi_task.py:228), gathered when first read"""
+            if state["adj"] is None:
+                tab.record_stream(torch.cuda.current_stream(dev))        # `tab` was allocated on the assembling stream
+                flat = torch.empty((M, 2), dtype=torch.int32, device=dev)
+                gather(0, False, flat)
+                state["adj"] = split_types(flat)
+            return state["adj"]
+
+        def complete():
+            tab.record_stream(torch.cuda.current_stream(dev))
+            return {"adjacency_lists": adjacency(), **plan(True)}
+
+        six = plan(not lean)
+        if lean:
+            graph = RelGraph.from_arrays(None, V, rowptr_t=rowptr_t, rowptr_s=rowptr_s, tgt_s=tgt_s,
+                                         edge_counts=[type_off[l + 1] - type_off[l] for l in range(L)], complete=complete)
+        else:
+            graph = RelGraph.from_arrays(state["adj"], V, rowptr_t=rowptr_t, rowptr_s=rowptr_s, tgt_s=tgt_s, **six)
         graph.preset_degree_scale(deg, src_t, w_t, w_s)
         batch = DeviceBatch.from_tensors(
-            num_graphs=K, num_nodes=V, num_edges=M, initial_node_features=payload[self.features], adjacency_lists=adj,
+            num_graphs=K, num_nodes=V, num_edges=M, initial_node_features=payload[self.features],
+            adjacency_lists=adjacency if lean else state["adj"],
             type_to_num_incoming_edges=deg, graph_nodes_list=n2g,
             extra={**{k: v for k, v in payload.items() if k != self.features}, **self.constants})
         batch.graph = graph

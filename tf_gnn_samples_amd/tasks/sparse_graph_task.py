@@ -56,11 +56,23 @@ class DeviceBatch:
         self = cls.__new__(cls)
         self.num_graphs, self.num_nodes, self.num_edges = int(num_graphs), int(num_nodes), int(num_edges)
         self.initial_node_features = initial_node_features
-        self.adjacency_lists = list(adjacency_lists)
+        # a zero-argument callable defers the lists (tasks/resident.py: the layers get the batch's bucketing, the lists are
+        # gathered only if something reads them)
+        self._adjacency = adjacency_lists if callable(adjacency_lists) else list(adjacency_lists)
         self.type_to_num_incoming_edges = type_to_num_incoming_edges
         self.graph_nodes_list = graph_nodes_list
         self.extra = dict(extra or {})
         return self
+
+    @property
+    def adjacency_lists(self):
+        if callable(self._adjacency):
+            self._adjacency = list(self._adjacency())
+        return self._adjacency
+
+    @adjacency_lists.setter
+    def adjacency_lists(self, value):
+        self._adjacency = value
 
     ready_event = None
 
@@ -74,7 +86,8 @@ class DeviceBatch:
         cur = torch.cuda.current_stream(self.initial_node_features.device)
         cur.wait_event(ev)
         tensors = [self.initial_node_features, self.type_to_num_incoming_edges, self.graph_nodes_list,
-                   *self.adjacency_lists, *[v for v in self.extra.values() if torch.is_tensor(v)]]
+                   *([] if callable(self._adjacency) else self._adjacency),
+                   *[v for v in self.extra.values() if torch.is_tensor(v)]]
         for t in tensors:
             if t is not None and t.is_cuda:
                 t.record_stream(cur)
