@@ -401,12 +401,15 @@ def main():
                 yield b
 
     stream = batch_stream()
-    state = {"upcoming": next(stream), "pending": None, "edges": 0, "nodes": 0, "graphs": 0, "loss": 0.0, "fetched": 0}
+    state = {"upcoming": next(stream), "pending": None, "edges": 0, "nodes": 0, "graphs": 0, "loss": 0.0, "fetched": 0,
+             "host_wait": 0.0}
 
     def fetch(pending):
         m, b = pending
+        t_wait = time.perf_counter()
         m = m.get()                               # the host sync of sess.run's fetch (:293), one step late: waits for the
-        state["loss"] = m['loss']                 # D2H copy enqueued right behind THAT step (models.MetricsReadback)
+        state["host_wait"] += time.perf_counter() - t_wait   # D2H copy enqueued right behind THAT step (MetricsReadback)
+        state["loss"] = m['loss']
         m['f1_score']
         state["fetched"] += 1
 
@@ -429,7 +432,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    state.update(edges=0, nodes=0, graphs=0)
+    state.update(edges=0, nodes=0, graphs=0, host_wait=0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -483,6 +486,9 @@ def main():
         "gradient_allreduce_bytes": reducer.nbytes if reducer is not None else 0,
         "gemm_autotuned": False,
         "final_loss": state["loss"],
+        # time rank 0's host spent blocked on the (one step late) metrics copy: ~0 = the host is the bottleneck,
+        # large = the GPU is
+        "host_blocked_on_gpu_ms_per_step": state["host_wait"] / args.steps * 1e3,
     }
 
     # ---- secondary figures (rank 0, single GPU): same-batch step, forward only, transfers ---------------------------

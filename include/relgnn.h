@@ -654,6 +654,22 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
 int relgnn_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                     float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t k_splits, void* stream);
 
+/*
+ * The same three products as PLAIN LIBRARY GEMMs (hipBLASLt), for the layers that are not fused: what torch.mm runs, minus
+ * the per-call solution lookup.  Every batch of a shuffled epoch has its own node count, so every call is a shape the
+ * library has not seen, and its heuristic costs ~70 us of host time per new shape (21 calls per C2 training step: the
+ * host, not the GPU, bounded the step).  The lookup is done once per (layout, N, K, batch, M / 4096, bias, accumulate) and
+ * the solution is reused for every M of that bucket.
+ *   batch > 1: strided batched product, operand / result z at A + z*stride_a, B + z*stride_b, C + z*stride_c (elements)
+ *   bias (NN-style epilogue, length N, batch == 1 only) is added to every row;  accumulate != 0: C += product
+ *   workspace: caller-allocated device scratch handed to the library (may be NULL with workspace_bytes 0)
+ * Not re-entrant across streams for ONE process-wide handle: calls are serialised by a mutex (one rank per process).
+ */
+int relgnn_blaslt_gemm_f32(int32_t layout, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                           float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t batch, int64_t stride_a,
+                           int64_t stride_b, int64_t stride_c, int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                           void* stream);
+
 /* ========================================================================== *
  * 11. Dynamic per-target convolution kernels  (gnns/rgdcn.py:126-160)
  * ========================================================================== */

@@ -1,0 +1,6 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r02w
+timeout 600 python -m pytest tests/test_gpu_lib_gemm.py tests/test_gpu_gemm.py tests/test_gpu_layers.py -q -x 2>&1 | tail -8
+python scripts/exp_matmul_host_cost.py 2>&1 | grep -v amdgpu.ids | head -6
+timeout 600 python bench.py --steps 60 --warmup 12 --no-roofline --no-cpu-baseline 2>gpurun_out/r02w/bench.err | tee gpurun_out/r02w/bench.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['host_blocked_on_gpu_ms_per_step'], d['value'], d['same_batch'])"

@@ -1,0 +1,76 @@
+"""relgnn_blaslt_gemm_f32 (csrc/blaslt_gemm.hip): the library GEMM with a cached solution must compute what torch.mm computes
+for every layout, for node counts that share a cache bucket, with bias, accumulate and the strided-batched split-K form."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(gen, *shape):
+    return torch.rand(shape, device=gen.device, generator=gen) * 2 - 1
+
+
+def _close(got, want, K):
+    # fp32 products summed in a library-chosen order: compare against float64, tolerance ~ sqrt(K) ulps of the magnitude
+    err = (got.double() - want).abs().max().item()
+    assert err <= 2e-6 * max(1.0, float(np.sqrt(K))) * max(1.0, want.abs().max().item()), err
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_layouts_and_bucket_reuse(gpu_device, layout):
+    from tf_gnn_samples_amd import dense as D
+    gen = torch.Generator(device=gpu_device).manual_seed(layout)
+    for V in (4099, 4100, 4611, 7000, 37, 1):                 # several node counts per 4096-row bucket, tiny ones
+        for (n_in, n_out) in ((256, 768), (50, 256), (121, 256), (768, 256)):
+            if layout == D.GEMM_NN:
+                a, b = _rand(gen, V, n_in), _rand(gen, n_in, n_out)
+                want = a.double() @ b.double()
+            elif layout == D.GEMM_NT:
+                a, b = _rand(gen, V, n_in), _rand(gen, n_out, n_in)
+                want = a.double() @ b.double().t()
+            else:
+                a, b = _rand(gen, V, n_in), _rand(gen, V, n_out)
+                want = a.double().t() @ b.double()
+            got = D.lib_gemm(layout, a, b)
+            assert got.shape == want.shape
+            _close(got, want, a.shape[1] if layout != D.GEMM_TN else V)
+
+
+def test_bias_accumulate_and_row_strided_operands(gpu_device):
+    from tf_gnn_samples_amd import dense as D
+    gen = torch.Generator(device=gpu_device).manual_seed(7)
+    a, b, bias = _rand(gen, 5000, 256), _rand(gen, 256, 121), _rand(gen, 121)
+    _close(D.lib_gemm(D.GEMM_NN, a, b, bias), a.double() @ b.double() + bias.double(), 256)
+    out = _rand(gen, 5000, 121)
+    want = out.double() + a.double() @ b.double()
+    _close(D.lib_gemm(D.GEMM_NN, a, b, out=out, accumulate=True), want, 256)
+    wide = _rand(gen, 5000, 768)
+    view = wide[:, 256:512]                                     # rows dense, row stride 768
+    _close(D.lib_gemm(D.GEMM_NN, view, b), view.double() @ b.double(), 256)
+    _close(D.lib_gemm(D.GEMM_TN, view, a), view.double().t() @ a.double(), 5000)
+
+
+@pytest.mark.parametrize("V", [36411, 30011, 5000, 700])
+def test_split_k_weight_gradient(gpu_device, V):
+    from tf_gnn_samples_amd import dense as D
+    gen = torch.Generator(device=gpu_device).manual_seed(V)
+    for M, N in ((768, 256), (256, 256), (256, 121), (50, 256)):
+        a, b = _rand(gen, V, M), _rand(gen, V, N)
+        _close(D.matmul_tn_splitk(a, b), a.double().t() @ b.double(), V)
+
+
+def test_dense_autograd_matches_torch(gpu_device):
+    from tf_gnn_samples_amd.dense import dense
+    gen = torch.Generator(device=gpu_device).manual_seed(3)
+    x, k, bias = _rand(gen, 9001, 256), _rand(gen, 256, 121), _rand(gen, 121)
+    xs = [t.clone().requires_grad_(True) for t in (x, k, bias)]
+    ys = [t.clone().requires_grad_(True) for t in (x, k, bias)]
+    out = dense(*xs)
+    ref = torch.addmm(ys[2], ys[0], ys[1])
+    g = _rand(gen, *out.shape)
+    out.backward(g)
+    ref.backward(g)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-4)
+    for got, want in zip(xs, ys):
+        assert torch.allclose(got.grad, want.grad, rtol=1e-4, atol=2e-3), (got.grad - want.grad).abs().max()

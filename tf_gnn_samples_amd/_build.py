@@ -64,7 +64,9 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         if p.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
     tmp = LIB_PATH.with_suffix(".so.tmp")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs)]
+    # hipBLASLt: the plain library GEMMs of csrc/blaslt_gemm.hip (in a process that has imported torch the already loaded
+    # copy with the same SONAME is the one that gets used)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs), "-lhipblaslt"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))

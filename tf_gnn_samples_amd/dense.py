@@ -15,7 +15,56 @@ import torch
 # every shape it supports.  Default: the library (hipBLASLt through torch) — measured on MI355X at the C2 shapes
 # (scripts/bench_gemm.py, K = 256): library default solutions 100-119 TFLOP/s, own kernel 77-92 TFLOP/s.
 _OWN_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "mfma"
+# RELGNN_GEMM=torch: library GEMMs through torch.mm (a hipBLASLt solution lookup per call: ~70 us of host time for every
+# node count not seen before, i.e. for every batch of a shuffled epoch).  Default "lib": the same library through
+# relgnn_blaslt_gemm_f32 (csrc/blaslt_gemm.hip), which caches the solution per (layout, N, K, V / 4096).
+_CACHED_LIB_GEMM = os.environ.get("RELGNN_GEMM", "lib") != "torch"
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
+_WORKSPACE = {}
+
+
+def _lib_rows_ok(t: torch.Tensor) -> bool:
+    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] > 0 and t.shape[1] > 0
+
+
+def _workspace(device):
+    ws = _WORKSPACE.get(device)
+    if ws is None:
+        ws = _WORKSPACE[device] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    return ws
+
+
+def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, out: torch.Tensor = None,
+             accumulate: bool = False) -> torch.Tensor:
+    """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
+    Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU)."""
+    if not (_CACHED_LIB_GEMM and _lib_rows_ok(a) and _lib_rows_ok(b) and (bias is None or (bias.is_cuda and bias.is_contiguous()
+                                                                                          and bias.dtype == torch.float32))):
+        if layout == GEMM_NN:
+            res = torch.addmm(bias, a, b) if bias is not None else a @ b
+        elif layout == GEMM_NT:
+            res = a @ b.t()
+        else:
+            res = a.t() @ b
+        if out is None:
+            return res
+        return out.add_(res) if accumulate else out.copy_(res)
+    from . import _lib
+    lib = _lib.load_library()
+    if layout == GEMM_NN:
+        M, K, N = a.shape[0], a.shape[1], b.shape[1]
+    elif layout == GEMM_NT:
+        M, K, N = a.shape[0], a.shape[1], b.shape[0]
+    else:
+        K, M, N = a.shape[0], a.shape[1], b.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ws = _workspace(a.device)
+    _lib.check(lib.relgnn_blaslt_gemm_f32(layout, _lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
+                                          b.stride(0), _lib.ptr(bias), _lib.ptr(out, rows_strided=True), out.stride(0), M, N, K,
+                                          1, 0, 0, 0, 1 if accumulate else 0, _lib.ptr(ws), ws.numel(),
+                                          _lib.current_stream()), "relgnn_blaslt_gemm_f32")
+    return out
 
 
 def _rows_ok(t: torch.Tensor) -> bool:
@@ -98,9 +147,24 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     N = b.shape[1]
     S = _split_count(V, M, N)
     if S <= 1:
-        return torch.mm(a.t(), b)
+        return lib_gemm(GEMM_TN, a, b)
     c = V // S
     head = c * S
+    # (outputs narrower than one 64-wide tile — the [50, 256] gradient of the input projection — keep torch.bmm: hipBLASLt's
+    # strided-batched pick for them measured 148 us against 52 us, scripts/exp_cached_gemm_quality.py)
+    if _CACHED_LIB_GEMM and min(M, N) >= 64 and _lib_rows_ok(a) and _lib_rows_ok(b) and a.is_contiguous() and b.is_contiguous():
+        # one strided-batched library call: chunk z = rows [z*c, (z+1)*c) of both operands
+        from . import _lib
+        lib = _lib.load_library()
+        parts = torch.empty((S, M, N), dtype=torch.float32, device=a.device)
+        ws = _workspace(a.device)
+        _lib.check(lib.relgnn_blaslt_gemm_f32(GEMM_TN, _lib.ptr(a), M, _lib.ptr(b), N, None, _lib.ptr(parts), N, M, N, c, S,
+                                              c * M, c * N, M * N, 0, _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                   "relgnn_blaslt_gemm_f32")
+        out = parts.sum(0)
+        if head < V:
+            lib_gemm(GEMM_TN, a[head:], b[head:], out=out, accumulate=True)   # the < c leftover rows
+        return out
     out = torch.bmm(a[:head].view(S, c, M).transpose(1, 2), b[:head].view(S, c, N)).sum(0)
     if head < V:
         out.addmm_(a[head:].t(), b[head:])       # the < c leftover rows, accumulated in place
@@ -130,9 +194,7 @@ class _DenseFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         if own_gemm_supported(GEMM_NN, x, kernel) and (bias is None or bias.is_contiguous()):
             return own_gemm(GEMM_NN, x, kernel, bias)
-        if bias is not None:
-            return torch.addmm(bias, x, kernel)
-        return x @ kernel
+        return lib_gemm(GEMM_NN, x, kernel, bias)
 
     @staticmethod
     def backward(ctx, g):
@@ -140,7 +202,7 @@ class _DenseFn(torch.autograd.Function):
         g = g.contiguous()
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = own_gemm(GEMM_NT, g, kernel) if own_gemm_supported(GEMM_NT, g, kernel) else g @ kernel.t()
+            gx = own_gemm(GEMM_NT, g, kernel) if own_gemm_supported(GEMM_NT, g, kernel) else lib_gemm(GEMM_NT, g, kernel)
         gk = matmul_tn_splitk(x.contiguous(), g) if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:

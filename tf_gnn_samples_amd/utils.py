@@ -153,7 +153,8 @@ class _FusedGRU(torch.autograd.Function):
         z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
         _lib.check(lib.relgnn_gru_gates_fwd(_lib.ptr(xk), _lib.ptr(rec), _lib.ptr(h), V, u, _lib.ptr(z), _lib.ptr(r),
                                             _lib.ptr(rh), st), "relgnn_gru_gates_fwd")
-        q = rh @ u_h
+        from .dense import GEMM_NN, lib_gemm
+        q = lib_gemm(GEMM_NN, rh, u_h)
         hh, out = torch.empty_like(h), torch.empty_like(h)
         _lib.check(lib.relgnn_gru_out_fwd(_lib.ptr(xk), _lib.ptr(q), _lib.ptr(z), _lib.ptr(h), V, u, act, _lib.ptr(hh),
                                           _lib.ptr(out), st), "relgnn_gru_out_fwd")
@@ -174,7 +175,8 @@ class _FusedGRU(torch.autograd.Function):
         gq, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
         _lib.check(lib.relgnn_gru_out_bwd(_lib.ptr(gout), _lib.ptr(z), _lib.ptr(h), _lib.ptr(hh), V, u, ctx.act,
                                           _lib.ptr(gxk), _lib.ptr(gq), _lib.ptr(gz), _lib.ptr(gh), st), "relgnn_gru_out_bwd")
-        grh = gq @ u_h.t()
+        from .dense import GEMM_NT, lib_gemm
+        grh = lib_gemm(GEMM_NT, gq, u_h)
         gu_h = matmul_tn_splitk(rh, gq) if ctx.needs_input_grad[3] else None
         _lib.check(lib.relgnn_gru_gates_bwd(_lib.ptr(grh), _lib.ptr(gz), _lib.ptr(z), _lib.ptr(r), _lib.ptr(h), V, u,
                                             _lib.ptr(gxk), _lib.ptr(gh), st), "relgnn_gru_gates_bwd")
