@@ -670,6 +670,19 @@ int relgnn_blaslt_gemm_f32(int32_t layout, const float* A, int64_t lda, const fl
                            int64_t stride_b, int64_t stride_c, int32_t accumulate, void* workspace, int64_t workspace_bytes,
                            void* stream);
 
+/*
+ * Weight gradient of a node-side Dense layer: C[M, N] (+)= A[K, M]^T @ B[K, N], K = the node dimension (3e4 .. 1e6), M, N
+ * small (the MatMul gradient TF derives for models/sparse_graph_model.py:165-172,194-200, tasks/ppi_task.py:176-179,
+ * gnns/rgcn.py:70-74).  Streaming kernel: every wave owns one 64 x 64 output tile for one chunk of rows and feeds
+ * v_mfma_f32_32x32x2_f32 straight from global memory (the reduction index is the row of both row-major operands, which is
+ * the MFMA operand layout): no LDS, no barriers; partial products per chunk go to `workspace`
+ * (relgnn_gemm_tn_stream_workspace_bytes) and are summed in chunk order (deterministic).  Exact fp32.  Any M, N, lda >= M,
+ * ldb >= N; 8-byte loads when a row stride is even and its base 8-byte aligned, 4-byte loads otherwise.
+ */
+int64_t relgnn_gemm_tn_stream_workspace_bytes(int32_t M, int32_t N, int64_t K);
+int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                              int64_t K, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ========================================================================== *
  * 11. Dynamic per-target convolution kernels  (gnns/rgdcn.py:126-160)
  * ========================================================================== */

@@ -74,3 +74,19 @@ def test_dense_autograd_matches_torch(gpu_device):
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-4)
     for got, want in zip(xs, ys):
         assert torch.allclose(got.grad, want.grad, rtol=1e-4, atol=2e-3), (got.grad - want.grad).abs().max()
+
+
+@pytest.mark.parametrize("V", [36411, 4099, 130, 17, 2, 1])
+def test_streaming_weight_gradient_kernel(gpu_device, V):
+    """relgnn_gemm_tn_stream_f32: every output shape class (full tiles, ragged M / N, odd row strides -> 4-byte loads,
+    row-strided views), chunk tails (odd V, V smaller than one unrolled step), bit-reproducible."""
+    from tf_gnn_samples_amd import dense as D
+    gen = torch.Generator(device=gpu_device).manual_seed(V)
+    for M, N in ((256, 256), (256, 121), (50, 256), (121, 50), (128, 128), (1, 1), (65, 63), (768, 256)):
+        a, b = _rand(gen, V, M), _rand(gen, V, N)
+        got = D.tn_stream_gemm(a, b)
+        _close(got, a.double().t() @ b.double(), V)
+        assert torch.equal(got, D.tn_stream_gemm(a, b))
+    wide = _rand(gen, V, 512)
+    a, b = wide[:, 3:131], wide[:, 256:512]            # odd base offset -> scalar loads; even -> 8-byte loads
+    _close(D.tn_stream_gemm(a, b), a.double().t() @ b.double(), V)

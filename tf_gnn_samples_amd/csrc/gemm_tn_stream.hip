@@ -1,0 +1,242 @@
+// Weight gradients of the node-side Dense layers:  dW[M, N] = X[V, M]^T @ G[V, N]   (the MatMul gradient TF derives for
+// every Keras Dense of the path: models/sparse_graph_model.py:165-172,194-200, tasks/ppi_task.py:176-179, gnns/rgcn.py:70-74).
+//
+// Shape: the reduction runs over the NODE dimension (V ~ 3e4 .. 1e6) and the output is tiny (50..768 x 121..256), so the
+// product is a stream over two tall operands with 32-64 flops per byte.  A tiled LDS GEMM is the wrong tool: split over V
+// to fill the chip, each workgroup sees a K of a few hundred rows and spends its time in prologue, barriers and epilogue
+// (hipBLASLt strided-batched + sum: 147 us for [36 k, 256]^T @ [36 k, 256] = 33 TFLOP/s; relgnn_gemm_f32 TN: 100 us).
+//
+// Here every WAVE owns one 64 x 64 output tile for one chunk of rows and needs neither LDS nor barriers: both operands are
+// row-major with the reduction index as the ROW, which is exactly the operand layout of v_mfma_f32_32x32x2_f32 (lane l
+// supplies element [k = l >> 5][x = l & 31]).  A lane loads TWO adjacent columns of its row (one 8-byte load per operand
+// and k-pair), which feeds 2 x 2 MFMA tiles whose rows / columns interleave (tile j covers x = 2 i + j); the loads of the
+// next 8 k-pairs are in flight under the MFMAs of the current ones (register ring, vmcnt-counted).  The 4 waves of a
+// workgroup take 4 neighbouring column tiles of the same row chunk, so the A rows they share hit in L1.
+// Partial products go to a caller-provided workspace [chunks, M, N]; a second kernel sums them in chunk order
+// (deterministic, no atomics).  Exact fp32 (f32 operands, f32 accumulate).
+#include "common.h"
+
+#include <algorithm>
+
+using namespace relgnn;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kDepth = 8;   // k-pairs in flight per wave
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Per-lane column state of one operand: the two adjacent columns x, x + 1 this lane feeds, as load offsets that are always
+// inside the row plus two 0/1 factors — the k-loop has no lane branches (rows past the chunk likewise: the row pointer is
+// clamped to the chunk's last row and the pair multiplied by 0 when it is consumed).
+struct Cols {
+  int off0, off1;        // column offsets actually loaded (clamped into [0, X))
+  float on0, on1;        // 1.f where the column exists
+};
+__device__ __forceinline__ Cols make_cols(int x, int X) {
+  Cols c;
+  c.on0 = x < X ? 1.f : 0.f;
+  c.on1 = x + 1 < X ? 1.f : 0.f;
+  c.off0 = min(x, X - 1);
+  c.off1 = min(x + 1, X - 1);
+  return c;
+}
+
+// One ring slot = the two columns of one row.  The loads are issued as inline assembly and waited for with an explicit
+// s_waitcnt: left to the compiler, loads that stay in flight across the loop back-edge are drained with vmcnt(0) at the loop
+// head (its wait-count analysis merges the back-edge conservatively), which exposes the full memory latency once per
+// iteration.  VEC: one 8-byte load (row stride even, base 8-byte aligned); otherwise two 4-byte loads.
+template <bool VEC> struct Slot;
+template <> struct Slot<true> { f32x2 v; };
+template <> struct Slot<false> { float x, y; };
+
+__device__ __forceinline__ void issue(Slot<true>& s, const float* row, const Cols& c) {
+  const float* p = row + (c.on0 != 0.f ? c.off0 : 0);      // even offset; x + 1 is inside the row's storage when x exists
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(s.v) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue(Slot<false>& s, const float* row, const Cols& c) {
+  const float* p0 = row + c.off0;
+  const float* p1 = row + c.off1;
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(s.x) : "v"(p0) : "memory");
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(s.y) : "v"(p1) : "memory");
+}
+// wait until at most N vector-memory loads are outstanding; the slots are operands so that their uses stay behind the wait
+template <int N>
+__device__ __forceinline__ void wait_for(Slot<true>& a, Slot<true>& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a.v), "+v"(b.v) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void wait_for(Slot<true>& a, Slot<false>& b) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a.v), "+v"(b.x), "+v"(b.y) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void wait_for(Slot<false>& a, Slot<true>& b) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a.x), "+v"(a.y), "+v"(b.v) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void wait_for(Slot<false>& a, Slot<false>& b) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y) : "n"(N)); }
+__device__ __forceinline__ float first(const Slot<true>& s) { return s.v.x; }
+__device__ __forceinline__ float second(const Slot<true>& s) { return s.v.y; }
+__device__ __forceinline__ float first(const Slot<false>& s) { return s.x; }
+__device__ __forceinline__ float second(const Slot<false>& s) { return s.y; }
+
+template <bool VEC_A, bool VEC_B>
+__global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                             int64_t ldb, int64_t K, int32_t M, int32_t N, int64_t chunk_rows,
+                                                             float* __restrict__ partial, int32_t tiles_n, int32_t tiles) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (tile >= tiles) return;                                   // whole wave
+  const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
+  const int64_t k_begin = (int64_t)blockIdx.x * chunk_rows, k_end = min(K, k_begin + chunk_rows);
+  const Cols ca = make_cols(m0 + 2 * (lane & 31), M), cb = make_cols(n0 + 2 * (lane & 31), N);
+  const int rows = (int)(k_end - k_begin);                     // <= chunk_rows < 2^31
+  const int half = lane >> 5;                                  // this lane's row inside a k-pair
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // per-lane row pointers, advanced by two rows per k-pair and clamped to the chunk's last row
+  const float* pa = A + (k_begin + min(half, rows - 1)) * lda;
+  const float* pb = B + (k_begin + min(half, rows - 1)) * ldb;
+  const float* pa_last = A + (k_end - 1) * lda;
+  const float* pb_last = B + (k_end - 1) * ldb;
+  const int64_t step_a = 2 * lda, step_b = 2 * ldb;
+  auto advance = [&]() {
+    pa = pa + step_a < pa_last ? pa + step_a : pa_last;
+    pb = pb + step_b < pb_last ? pb + step_b : pb_last;
+  };
+
+  constexpr int kLoadsPerPair = (VEC_A ? 1 : 2) + (VEC_B ? 1 : 2);
+  Slot<VEC_A> ra[kDepth];
+  Slot<VEC_B> rb[kDepth];
+#pragma unroll
+  for (int u = 0; u < kDepth; ++u) {
+    issue(ra[u], pa, ca);
+    issue(rb[u], pb, cb);
+    advance();
+  }
+  for (int r0 = 0; r0 < rows; r0 += 2 * kDepth) {
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u) {
+      // the OLDEST pair in flight is slot u; everything issued after it may stay in flight
+      wait_for<kLoadsPerPair * (kDepth - 1)>(ra[u], rb[u]);
+      const float live = r0 + 2 * u + half < rows ? 1.f : 0.f;
+      const float a0 = first(ra[u]) * (live * ca.on0), a1 = second(ra[u]) * (live * ca.on1);
+      const float b0 = first(rb[u]) * cb.on0, b1 = second(rb[u]) * cb.on1;
+      issue(ra[u], pa, ca);                                    // refill the slot with the pair kDepth ahead
+      issue(rb[u], pb, cb);
+      advance();
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the refills past the end (clamped, never used)
+
+  // (a masked element is multiplied by 0: it is a REAL element of the matrix — clamped address — so it is finite whenever
+  // the matrix is.)
+  // C layout of v_mfma_f32_32x32x2: column index c = lane & 31, row index i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  // tile (a, b) holds output rows m0 + 2 i + a and columns n0 + 2 c + b.
+  float* out = partial + (int64_t)blockIdx.x * M * N;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + a;
+      const int n = n0 + 2 * (lane & 31);
+      if (m < M) {
+        if (n < N) out[(int64_t)m * N + n] = acc[a][0][r];
+        if (n + 1 < N) out[(int64_t)m * N + n + 1] = acc[a][1][r];
+      }
+    }
+}
+
+// C[m, n] (+)= sum over chunks.  256 threads = 64 outputs x 4 chunk groups: group g sums chunks g, g + 4, ... (independent
+// loads in flight instead of one long dependent chain per output), the four group sums are added in group order through
+// LDS — a fixed order, so the result is deterministic.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int64_t mn, int32_t chunks, int32_t N,
+                                                           float* __restrict__ C, int64_t ldc, int32_t accumulate) {
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < mn) {
+    int c = g;
+    for (; c + 4 < chunks; c += 8) {
+      s0 += partial[(int64_t)c * mn + i];
+      s1 += partial[(int64_t)(c + 4) * mn + i];
+    }
+    if (c < chunks) s0 += partial[(int64_t)c * mn + i];
+  }
+  part[g][o] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && i < mn) {
+    const float s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    float* dst = C + (i / N) * ldc + (i % N);
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+struct Plan {
+  int32_t tiles_m, tiles_n, tiles, chunks;
+  int64_t chunk_rows;
+};
+
+Plan make_plan(int32_t M, int32_t N, int64_t K) {
+  Plan p;
+  p.tiles_m = (M + 63) / 64;
+  p.tiles_n = (N + 63) / 64;
+  p.tiles = p.tiles_m * p.tiles_n;
+  // ~2 waves per SIMD over the 256 CUs, at least 64 rows per chunk, chunk length a multiple of the unrolled step
+  int64_t chunks = (2048 + p.tiles - 1) / p.tiles;
+  chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, (K + 63) / 64));
+  int64_t rows = (K + chunks - 1) / chunks;
+  rows = (rows + 2 * kDepth - 1) / (2 * kDepth) * (2 * kDepth);
+  p.chunk_rows = rows;
+  p.chunks = (int32_t)((K + rows - 1) / rows);
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t relgnn_gemm_tn_stream_workspace_bytes(int32_t M, int32_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const Plan p = make_plan(M, N, K);
+  return (int64_t)p.chunks * M * N * 4;
+}
+
+int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                              int64_t K, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || lda < M || ldb < N || ldc < N) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!C) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (K == 0) {
+    if (!accumulate && hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, st) != hipSuccess) return RELGNN_EHIP;
+    return RELGNN_OK;
+  }
+  if (!A || !B || !workspace) return RELGNN_EINVAL;
+  if (K >= ((int64_t)1 << 40)) return RELGNN_EUNSUPPORTED;
+  const Plan p = make_plan(M, N, K);
+  if (workspace_bytes < (int64_t)p.chunks * M * N * 4) return RELGNN_EINVAL;
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid((unsigned)p.chunks, (unsigned)((p.tiles + 3) / 4));
+  const bool va = (reinterpret_cast<uintptr_t>(A) % 8 == 0) && lda % 2 == 0;
+  const bool vb = (reinterpret_cast<uintptr_t>(B) % 8 == 0) && ldb % 2 == 0;
+#define RELGNN_TN_LAUNCH(VA, VB) \
+  gemm_tn_stream_kernel<VA, VB><<<grid, 256, 0, st>>>(A, lda, B, ldb, K, M, N, p.chunk_rows, partial, p.tiles_n, p.tiles)
+  if (va && vb) RELGNN_TN_LAUNCH(true, true);
+  else if (va) RELGNN_TN_LAUNCH(true, false);
+  else if (vb) RELGNN_TN_LAUNCH(false, true);
+  else RELGNN_TN_LAUNCH(false, false);
+#undef RELGNN_TN_LAUNCH
+  const int64_t mn = (int64_t)M * N;
+  sum_partials_kernel<<<(unsigned)((mn + 63) / 64), 256, 0, st>>>(partial, mn, p.chunks, N, C, ldc, accumulate);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@ _OWN_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "mfma"
 # node count not seen before, i.e. for every batch of a shuffled epoch).  Default "lib": the same library through
 # relgnn_blaslt_gemm_f32 (csrc/blaslt_gemm.hip), which caches the solution per (layout, N, K, V / 4096).
 _CACHED_LIB_GEMM = os.environ.get("RELGNN_GEMM", "lib") != "torch"
+_STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 _WORKSPACE = {}
 
@@ -139,12 +140,32 @@ def _split_count(V: int, M: int, N: int) -> int:
     return int(max(1, min(want, V // 512, 64)))
 
 
+def tn_stream_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T @ b for a [V, M], b [V, N] through the streaming weight-gradient kernel (csrc/gemm_tn_stream.hip)."""
+    from . import _lib
+    lib = _lib.load_library()
+    V, M = a.shape
+    N = b.shape[1]
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    nbytes = lib.relgnn_gemm_tn_stream_workspace_bytes(M, N, V)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_gemm_tn_stream_f32(_lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
+                                             b.stride(0), _lib.ptr(out), N, M, N, V, 0, _lib.ptr(ws), nbytes,
+                                             _lib.current_stream()), "relgnn_gemm_tn_stream_f32")
+    return out
+
+
 def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T @ b for a [V, M], b [V, N] (both row-major), reduction over V split into S chunks."""
     if own_gemm_supported(GEMM_TN, a, b):
         return own_gemm(GEMM_TN, a, b)
     V, M = a.shape
     N = b.shape[1]
+    # small outputs (every Dense of the path except the stacked per-type transforms): the streaming kernel — measured at
+    # V = 36 k: [256 x 256] 69 us vs 171 us for the library's strided-batched split-K, [256 x 121] 48 vs 114, [50 x 256]
+    # 41 vs 57, [128 x 128] 39 vs 56; the library wins for [768 x 256] (131 vs 223) and for V ~ 1e6 (scripts/exp_tn_stream.py)
+    if _STREAM_TN and M * N <= 256 * 256 and 0 < V <= (1 << 18) and _lib_rows_ok(a) and _lib_rows_ok(b):
+        return tn_stream_gemm(a, b)
     S = _split_count(V, M, N)
     if S <= 1:
         return lib_gemm(GEMM_TN, a, b)
