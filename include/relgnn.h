@@ -662,10 +662,11 @@ int relgnn_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t lda, co
  * the solution is reused for every M of that bucket.
  *   batch > 1: strided batched product, operand / result z at A + z*stride_a, B + z*stride_b, C + z*stride_c (elements)
  *   bias (NN-style epilogue, length N, batch == 1 only) is added to every row;  accumulate != 0: C += product
+ *   act: RELGNN_ACT_LINEAR or RELGNN_ACT_RELU (the library's ReLU epilogue, after the bias; batch == 1, no accumulate)
  *   workspace: caller-allocated device scratch handed to the library (may be NULL with workspace_bytes 0)
  * Not re-entrant across streams for ONE process-wide handle: calls are serialised by a mutex (one rank per process).
  */
-int relgnn_blaslt_gemm_f32(int32_t layout, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                            float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t batch, int64_t stride_a,
                            int64_t stride_b, int64_t stride_c, int32_t accumulate, void* workspace, int64_t workspace_bytes,
                            void* stream);

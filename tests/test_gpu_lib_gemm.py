@@ -42,6 +42,8 @@ def test_bias_accumulate_and_row_strided_operands(gpu_device):
     gen = torch.Generator(device=gpu_device).manual_seed(7)
     a, b, bias = _rand(gen, 5000, 256), _rand(gen, 256, 121), _rand(gen, 121)
     _close(D.lib_gemm(D.GEMM_NN, a, b, bias), a.double() @ b.double() + bias.double(), 256)
+    _close(D.lib_gemm(D.GEMM_NN, a, b, relu=True), (a.double() @ b.double()).clamp_(min=0), 256)
+    _close(D.lib_gemm(D.GEMM_NN, a, b, bias, relu=True), (a.double() @ b.double() + bias.double()).clamp_(min=0), 256)
     out = _rand(gen, 5000, 121)
     want = out.double() + a.double() @ b.double()
     _close(D.lib_gemm(D.GEMM_NN, a, b, out=out, accumulate=True), want, 256)

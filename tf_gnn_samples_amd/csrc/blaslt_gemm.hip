@@ -20,16 +20,16 @@ using namespace relgnn;
 namespace {
 
 struct Key {
-  int32_t layout, n, k, batch, m_bucket, bias, beta1;
+  int32_t layout, n, k, batch, m_bucket, bias, beta1, act;
   bool operator==(const Key& o) const {
     return layout == o.layout && n == o.n && k == o.k && batch == o.batch && m_bucket == o.m_bucket && bias == o.bias &&
-           beta1 == o.beta1;
+           beta1 == o.beta1 && act == o.act;
   }
 };
 struct KeyHash {
   size_t operator()(const Key& k) const {
     uint64_t h = 1469598103934665603ull;
-    for (int32_t v : {k.layout, k.n, k.k, k.batch, k.m_bucket, k.bias, k.beta1}) h = (h ^ (uint32_t)v) * 1099511628211ull;
+    for (int32_t v : {k.layout, k.n, k.k, k.batch, k.m_bucket, k.bias, k.beta1, k.act}) h = (h ^ (uint32_t)v) * 1099511628211ull;
     return (size_t)h;
   }
 };
@@ -67,7 +67,7 @@ struct Desc {
 
 extern "C" {
 
-int relgnn_blaslt_gemm_f32(int32_t layout, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                            float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t batch, int64_t stride_a,
                            int64_t stride_b, int64_t stride_c, int32_t accumulate, void* workspace, int64_t workspace_bytes,
                            void* stream) {
@@ -76,6 +76,8 @@ int relgnn_blaslt_gemm_f32(int32_t layout, const float* A, int64_t lda, const fl
   if (M == 0 || N == 0) return RELGNN_OK;
   if (!A || !B || !C || K == 0) return RELGNN_EINVAL;
   if (bias && (batch > 1 || accumulate)) return RELGNN_EINVAL;
+  if (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU) return RELGNN_EUNSUPPORTED;   // the library's epilogues: none / ReLU
+  if (act != RELGNN_ACT_LINEAR && (batch > 1 || accumulate)) return RELGNN_EINVAL;
   State& s = state();
   std::lock_guard<std::mutex> lock(s.mu);
   if (!s.handle && hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) return RELGNN_EHIP;
@@ -91,10 +93,11 @@ int relgnn_blaslt_gemm_f32(int32_t layout, const float* A, int64_t lda, const fl
   int32_t opa = (int32_t)op_first, opb = (int32_t)op_second;
   hipblasLtMatmulDescSetAttribute(desc.d, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa));
   hipblasLtMatmulDescSetAttribute(desc.d, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb));
-  if (bias) {
-    hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+  if (bias || act == RELGNN_ACT_RELU) {
+    hipblasLtEpilogue_t ep = bias ? (act == RELGNN_ACT_RELU ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS)
+                                  : HIPBLASLT_EPILOGUE_RELU;
     hipblasLtMatmulDescSetAttribute(desc.d, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep));
-    hipblasLtMatmulDescSetAttribute(desc.d, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    if (bias) hipblasLtMatmulDescSetAttribute(desc.d, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
   }
   Layout first, second, out;
   const bool ok = (layout == RELGNN_GEMM_NT ? first.make(K, N, ldb, batch, stride_b) : first.make(N, K, ldb, batch, stride_b)) &&
@@ -102,7 +105,7 @@ int relgnn_blaslt_gemm_f32(int32_t layout, const float* A, int64_t lda, const fl
                   out.make(N, M, ldc, batch, stride_c);
   if (!ok) return RELGNN_EHIP;
 
-  const Key key{layout, N, K, batch, M >> 12, bias ? 1 : 0, accumulate ? 1 : 0};
+  const Key key{layout, N, K, batch, M >> 12, bias ? 1 : 0, accumulate ? 1 : 0, act};
   auto it = s.algos.find(key);
   if (it == s.algos.end()) {
     if (!s.pref && hipblasLtMatmulPreferenceCreate(&s.pref) != HIPBLAS_STATUS_SUCCESS) return RELGNN_EHIP;

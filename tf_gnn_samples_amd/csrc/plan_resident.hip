@@ -116,18 +116,17 @@ __global__ __launch_bounds__(256) void assemble_rowptr_kernel(
 // Nodes of a graph are contiguous in the fold and in the batch: every copy below is K contiguous segment copies, found
 // per element by a binary search over the K+1 batch offsets (K <= a few hundred; the tables sit in L1/L2).
 
-// dst[v, :] = src[node_d(v), :]   rows of `cols` 4-byte elements.  A slot's rows are contiguous on both sides: the flat
-// element index is searched in the slot table directly (no per-element division).
+// dst[v, :] = src[node_d(v), :]   rows of `cols` 4-byte elements.  One wave per row (4 rows per block): the slot search runs
+// once per row, the row itself is a coalesced copy — no per-element search or division.
 __global__ __launch_bounds__(256) void gather_node_rows_kernel(BatchTables t, int64_t V, int32_t cols,
                                                                const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
-  const int64_t total = V * cols;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int lo = 0, hi = t.K;                // invariant: node_off_b[lo] * cols <= i < node_off_b[hi] * cols
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (t.node_off_b[mid] * cols <= i) lo = mid; else hi = mid;
-    }
-    dst[i] = src[(t.node_off_d[t.ids[lo]] - t.node_off_b[lo]) * cols + i];
+  const int lane = threadIdx.x & 63;
+  for (int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); v < V; v += (int64_t)gridDim.x * 4) {
+    const int k = upper_slot(t.node_off_b, t.K, v);
+    const int64_t vd = v - t.node_off_b[k] + t.node_off_d[t.ids[k]];
+    const uint32_t* __restrict__ s = src + vd * cols;
+    uint32_t* __restrict__ d = dst + v * cols;
+    for (int c = lane; c < cols; c += 64) d[c] = s[c];
   }
 }
 
@@ -181,7 +180,7 @@ int relgnn_batch_gather(const int64_t* ids, int32_t num_batch_graphs, int32_t nu
   for (int p = 0; p < n_payloads; ++p) {
     if (h_payload_cols[p] <= 0) continue;
     if (!h_payload_d[p] || !h_payload_b[p]) return RELGNN_EINVAL;
-    gather_node_rows_kernel<<<flat_grid(num_nodes * h_payload_cols[p], 256), 256, 0, st>>>(
+    gather_node_rows_kernel<<<flat_grid(num_nodes * 64, 256), 256, 0, st>>>(
         t, num_nodes, h_payload_cols[p], (const uint32_t*)h_payload_d[p], (uint32_t*)h_payload_b[p]);
   }
   if (deg_b || node_to_graph) {

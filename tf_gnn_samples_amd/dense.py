@@ -36,7 +36,7 @@ def _workspace(device):
 
 
 def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, out: torch.Tensor = None,
-             accumulate: bool = False) -> torch.Tensor:
+             accumulate: bool = False, relu: bool = False) -> torch.Tensor:
     """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
     Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU)."""
     if not (_CACHED_LIB_GEMM and _lib_rows_ok(a) and _lib_rows_ok(b) and (bias is None or (bias.is_cuda and bias.is_contiguous()
@@ -47,6 +47,8 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
             res = a @ b.t()
         else:
             res = a.t() @ b
+        if relu:
+            res = res.relu_()
         if out is None:
             return res
         return out.add_(res) if accumulate else out.copy_(res)
@@ -61,7 +63,8 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ws = _workspace(a.device)
-    _lib.check(lib.relgnn_blaslt_gemm_f32(layout, _lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
+    _lib.check(lib.relgnn_blaslt_gemm_f32(layout, _lib.ACT_RELU if relu else _lib.ACT_LINEAR,
+                                          _lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
                                           b.stride(0), _lib.ptr(bias), _lib.ptr(out, rows_strided=True), out.stride(0), M, N, K,
                                           1, 0, 0, 0, 1 if accumulate else 0, _lib.ptr(ws), ws.numel(),
                                           _lib.current_stream()), "relgnn_blaslt_gemm_f32")
@@ -179,7 +182,7 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         lib = _lib.load_library()
         parts = torch.empty((S, M, N), dtype=torch.float32, device=a.device)
         ws = _workspace(a.device)
-        _lib.check(lib.relgnn_blaslt_gemm_f32(GEMM_TN, _lib.ptr(a), M, _lib.ptr(b), N, None, _lib.ptr(parts), N, M, N, c, S,
+        _lib.check(lib.relgnn_blaslt_gemm_f32(GEMM_TN, _lib.ACT_LINEAR, _lib.ptr(a), M, _lib.ptr(b), N, None, _lib.ptr(parts), N, M, N, c, S,
                                               c * M, c * N, M * N, 0, _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                    "relgnn_blaslt_gemm_f32")
         out = parts.sum(0)

@@ -218,12 +218,14 @@ class MetricsReadback:
         self._event = self._slot = None
         if dev:
             device = dev[0][1].device
-            packed = torch.stack([v.reshape(()).to(torch.float64) for _, v in dev])
-            ring = MetricsReadback._ring.setdefault((device, len(dev)), [])
+            # one small kernel when the metrics share a dtype (the usual case: fp32 scalars), converted only if they differ
+            dtype = dev[0][1].dtype if all(v.dtype == dev[0][1].dtype for _, v in dev) else torch.float64
+            packed = torch.stack([v.reshape(()) if v.dtype == dtype else v.reshape(()).to(dtype) for _, v in dev])
+            ring = MetricsReadback._ring.setdefault((device, len(dev), dtype), [])
             # a pinned slot is taken until its reader has consumed it (get()) or dropped it
             slot = next((b for b in ring if not b[1]), None)
             if slot is None:
-                slot = [torch.empty(len(dev), dtype=torch.float64).pin_memory(), False]
+                slot = [torch.empty(len(dev), dtype=dtype).pin_memory(), False]
                 ring.append(slot)
             slot[1] = True
             slot[0].copy_(packed, non_blocking=True)

@@ -695,11 +695,12 @@ class _AggregateThenTransform(torch.autograd.Function):
         L, d_in, d_out = W.shape
         V = graph.V
         agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L).view(V, L * d_in)
-        out = lib_gemm(GEMM_NN, agg, W.view(L * d_in, d_out))
         f = _mode_factor(graph, mode)
+        fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the library GEMM's epilogue
+        out = lib_gemm(GEMM_NN, agg, W.view(L * d_in, d_out), relu=fused_relu)
         if f is not None:
             out.mul_(f.unsqueeze(1))
-        if act == _lib.ACT_RELU:
+        if act == _lib.ACT_RELU and not fused_relu:
             out.relu_()
         elif act == _lib.ACT_TANH:
             out.tanh_()
