@@ -19,7 +19,7 @@ HBM when the timed region starts (tasks/resident.py); nothing is cached across s
   no collective, ONE RCCL all-reduce of the flat gradient per step.
 
 Prints ONE JSON line on rank 0 with `roofline` (the gather/segment-reduce kernel, timed live with HIP events on the
-launch stream at three working-set sizes, HBM bytes from live rocprofv3 PMC passes) and `cpu_baseline` (the
+launch stream at four working-set sizes, HBM bytes from live rocprofv3 PMC passes) and `cpu_baseline` (the
 reference-order CPU restatement timed on this box's host cores on a bounded sample of the same batch).
 """
 import argparse
@@ -218,7 +218,11 @@ def roofline_section(device, iters, with_pmc):
         "c2_note": "at the C2 size the same kernel runs %.1f GB/s algorithmic = %.2f of the %.0f GB/s aggregate-L2 peak: "
                    "the 99 MB table lives in L2 + Infinity Cache, HBM only moves the compulsory bytes (%.0f GB/s cold)"
                    % (c2["algorithmic_GBps_warm"], c2["frac_of_l2_peak_algorithmic_warm"], R.L2_PEAK_GBS,
-                      c2["compulsory_GBps_cold"]),
+                      c2["compulsory_GBps_cold"])
+                   + "".join("; in the order the RGCN layer runs since round 2 (c2h: rows of the [V, 256] state table into the "
+                             "V*L buckets) %.1f GB/s = %.2f of the L2 peak" % (h["algorithmic_GBps_warm"],
+                                                                                 h["frac_of_l2_peak_algorithmic_warm"])
+                             for h in sizes if h["workload"] == "c2h"),
         "sizes": sizes,
     }
     return roof

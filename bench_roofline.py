@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Roofline measurement of the dominant kernel (gather + 1/deg scale + segment-sum + ReLU of one RGCN
-layer forward, csrc/seg_reduce.hip) at three working-set sizes, imported by bench.py and runnable on its own
+layer forward, csrc/seg_reduce.hip) at four working-set sizes, imported by bench.py and runnable on its own
 (the rocprofv3 passes of bench.py and scripts/gpu_profile_r02.sh launch exactly this file).
 
-Why three sizes: the kernel gathers one D-float row per MESSAGE (M*(4D+8) + V*4D + 4(VL+1)
+Why four sizes: the kernel gathers one D-float row per MESSAGE (M*(4D+8) + V*4D + 4(VL+1)
 algorithmic bytes per launch), but every source row is gathered ~28 times (the mean out-degree), so whether those
 bytes cross HBM depends on whether the gathered table stays in the 4 MiB-per-XCD L2 / 256 MiB Infinity Cache:
 
