@@ -124,3 +124,25 @@ def test_layer_norm_constant_rows_and_determinism(gpu_device):
         ya = layer_norm(xa, ga, ba); ya.square().sum().backward()
         outs.append((ya.detach(), xa.grad, ga.grad, ba.grad))
     assert all(torch.equal(p, q) for p, q in zip(*outs))
+
+
+def test_metrics_readback_is_asynchronous_and_ordered(gpu_device):
+    """MetricsReadback: the values are the ones the metrics held when the read-back was created (the copy is enqueued right
+    behind the step), several may be in flight at once without sharing a pinned slot, get() is idempotent, mixed dtypes."""
+    from tf_gnn_samples_amd.models.sparse_graph_model import MetricsReadback
+    x = torch.zeros((), device=gpu_device)
+    cnt = torch.zeros((), dtype=torch.int64, device=gpu_device)
+    pending = []
+    for i in range(6):
+        x.add_(1.25)
+        cnt.add_(3)
+        pending.append(MetricsReadback({"loss": x, "count": cnt, "step": i, "half": x * 0.5}))
+    for i, rb in enumerate(pending):
+        want = {"loss": 1.25 * (i + 1), "count": 3.0 * (i + 1), "step": i, "half": 0.625 * (i + 1)}
+        assert rb.get() == want
+        assert rb.get() == want
+    assert MetricsReadback({}).get() == {}
+    slots = sum(len(v) for v in MetricsReadback._ring.values())
+    more = [MetricsReadback({"loss": x}) for _ in range(3)]
+    [m.get() for m in more]
+    assert sum(len(v) for v in MetricsReadback._ring.values()) <= slots + 3       # slots are recycled after get()
