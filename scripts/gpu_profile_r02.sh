@@ -3,8 +3,9 @@
 #  (1) the bench line (its roofline section runs the live PMC passes itself)
 #  (2) kernel trace + stats of the bench command's timed loop
 #  (3) kernel trace + stats of the roofline workload alone (HBM-bound 'giant' size): the seg_reduce average duration the
-#      bench line's roofline.avg_kernel_ms must agree with
-#  (4) PMC passes of the three roofline workloads written out as a CSV (same passes bench.py runs live)
+#      bench line's roofline.avg_kernel_ms must agree with (--cold-only: every launch of that process runs the bench line's
+#      cold protocol)
+#  (4) PMC passes of the four roofline workloads written out as a CSV (same passes bench.py runs live)
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -16,7 +17,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bench -o bench -- \
     python $R/bench.py --steps 40 --warmup 10 --no-roofline --no-extras --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_giant -o giant -- \
-    python $R/bench_roofline.py --only giant --iters 20 > $O/roofline_giant.jsonl 2> $O/roofline_giant.err
+    python $R/bench_roofline.py --only giant --iters 20 --cold-only > $O/roofline_giant.jsonl 2> $O/roofline_giant.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -o c2 -- \
     python $R/bench_roofline.py --only c2 --iters 40 > $O/roofline_c2.jsonl 2> $O/roofline_c2.err
 cd $R
