@@ -172,7 +172,7 @@ def measure(names, iters, device, cold_only=False):
     out = []
     for n in names:
         wl = build_workload(n, device)
-        it = iters if n != "giant" else max(3, iters // 4)
+        it = iters if n != "giant" else max(8, iters // 2)
         res = summarize(wl, *time_workload(wl, it, device, cold_only))
         if cold_only:
             res["protocol"] = "cold only: warm_* fields repeat the cold figures"
