@@ -700,8 +700,9 @@ class _AggregateThenTransform(torch.autograd.Function):
         out = lib_gemm(GEMM_NN, agg, W.view(L * d_in, d_out), relu=fused_relu)
         if f is not None:
             out.mul_(f.unsqueeze(1))
-        if act == _lib.ACT_RELU and not fused_relu:
-            out.relu_()
+        if act == _lib.ACT_RELU:
+            if not fused_relu:
+                out.relu_()
         elif act == _lib.ACT_TANH:
             out.tanh_()
         elif act != _lib.ACT_LINEAR:
