@@ -68,10 +68,12 @@ def test_sigmoid_ce_stats_and_gradient(gpu_device):
     z = (rng.random((V, N)) < 0.3).astype(np.float32)
     xd = torch.as_tensor(x, device=gpu_device).requires_grad_(True)
     zd = torch.as_tensor(z, device=gpu_device)
-    stats = _SigmoidCEStats.apply(xd, zd)
-    (stats[0] / V).backward()
+    mean_loss, total_loss, f1, counts = _SigmoidCEStats.apply(xd, zd, 1.0 / V)
+    mean_loss.backward()
+    stats = [float(total_loss), *[float(c) for c in counts], float(f1)]
     ref = OM.sigmoid_cross_entropy_with_logits(x.astype(np.float64), z.astype(np.float64))
     assert abs(float(stats[0]) - ref.sum()) < 1e-5 * ref.sum()
+    assert abs(float(mean_loss) - ref.sum() / V) < 1e-5 * ref.sum() / V
     pred = np.round(1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.int32)
     zi = z.astype(np.int32)
     tp, fp, fn = np.count_nonzero(pred * zi), np.count_nonzero(pred * (zi - 1)), np.count_nonzero((pred - 1) * zi)
@@ -81,6 +83,11 @@ def test_sigmoid_ce_stats_and_gradient(gpu_device):
     assert abs(float(stats[4]) - float(micro_f1(xd.detach(), zd))) < 1e-6
     gref = (1.0 / (1.0 + np.exp(-x.astype(np.float64))) - z) / V
     assert np.abs(xd.grad.cpu().numpy() - gref).max() < 1e-7
+    # the summed loss is differentiable too (DP scales it by the global node count), and both at once
+    xd2 = torch.as_tensor(x, device=gpu_device).requires_grad_(True)
+    m2, t2, _, _ = _SigmoidCEStats.apply(xd2, zd, 1.0 / V)
+    (t2 * (0.5 / V) + m2 * 0.5).backward()
+    assert np.abs(xd2.grad.cpu().numpy() - gref).max() < 1e-7
 
 
 @pytest.mark.parametrize("rows,D", [(1, 64), (7, 128), (5000, 128), (3001, 256), (513, 320), (257, 1000), (100, 32), (64, 6)])

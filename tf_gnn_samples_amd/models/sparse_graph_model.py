@@ -483,6 +483,8 @@ class Sparse_Graph_Model(ABC):
             metrics = self.train_step(batch, device_step_count=True)
         return CapturedTrainStep(self, graph, {k: v for k, v in metrics.items() if torch.is_tensor(v)}, batch)
 
+    _backward_seed: Dict[Any, torch.Tensor] = {}
+
     def train_step(self, batch: DeviceBatch, grad_hook=None, device_step_count: bool = False) -> Dict[str, torch.Tensor]:
         """forward + backward + per-variable clip + optimizer update == one sess.run with train_step (:287-293)."""
         self.optimizer.zero_grad()
@@ -490,7 +492,11 @@ class Sparse_Graph_Model(ABC):
         # one process drives one GPU: running the backward on the calling thread instead of the autograd engine's
         # device thread saves the hand-off per node (host enqueue 1.56 -> 1.29 ms per C2 step) and a busy CPU thread
         with torch.autograd.set_multithreading_enabled(False):
-            metrics['loss'].backward()
+            loss = metrics['loss']
+            one = self._backward_seed.get((loss.device, loss.dtype, loss.shape))
+            if one is None:       # (loss.backward() would fill a fresh ones_like every step)
+                one = self._backward_seed[(loss.device, loss.dtype, loss.shape)] = torch.ones_like(loss)
+            loss.backward(gradient=one)
         if grad_hook is not None:  # data-parallel gradient all-reduce goes here (before clipping)
             grad_hook(self.optimizer.params)
         lr_scale = 1.0

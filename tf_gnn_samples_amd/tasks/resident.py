@@ -220,10 +220,18 @@ class ResidentDataset:
         return batch
 
     def iterate(self, graph_ids: Sequence[int], max_nodes_per_batch: int) -> Iterator[DeviceBatch]:
-        """Batches of one epoch.  Each batch is assembled on a SIDE stream: the training loop asks for batch i+1 right
-        after it has enqueued step i, so the gather / re-basing kernels (bandwidth-light) run under step i's GEMMs
-        instead of behind them.  The consumer's stream waits for the batch's event (DeviceBatch.wait_ready /
-        RelGraph.wait_ready) before its first kernel touches the tensors."""
+        """Batches of one epoch (the training loop asks for batch i+1 right after it has enqueued step i).  With
+        RELGNN_ASSEMBLE_STREAM=side each batch is assembled on a side stream under step i's kernels and the consumer's
+        stream waits for the batch's event (DeviceBatch.wait_ready / RelGraph.wait_ready) before its first kernel touches
+        the tensors."""
+        import os
+        # Default: assemble on the CALLER's stream.  The lean assembly is ~85 us of streaming kernels; run on a side stream
+        # under the previous step they stretched whichever GEMM they met from 113 to 229 us (kernel timeline,
+        # scripts/gpu_step_timeline.sh) — 2.38 vs 2.44 ms per step in one A/B.  RELGNN_ASSEMBLE_STREAM=side keeps the overlap.
+        if os.environ.get("RELGNN_ASSEMBLE_STREAM", "main") != "side":
+            for ids in self.store.split_batches(graph_ids, max_nodes_per_batch):
+                yield self.assemble(ids)
+            return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         for ids in self.store.split_batches(graph_ids, max_nodes_per_batch):
