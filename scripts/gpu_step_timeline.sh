@@ -2,8 +2,9 @@
 # Ordered kernel timeline of ONE steady-state training step of bench.py (which op costs what, in program order).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/timeline; rm -rf $O; mkdir -p $O; cd /tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o bench -- \
-    python $R/bench.py --steps 30 --warmup 10 --no-roofline --no-extras --no-cpu-baseline > $O/bench.json 2> $O/err.txt
+# usage: gpu_step_timeline.sh [command ...]   (default: the bench loop); a step ends with the Adam kernel
+if [ $# -gt 0 ]; then CMD="$*"; else CMD="python $R/bench.py --steps 30 --warmup 10 --no-roofline --no-extras --no-cpu-baseline"; fi
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o bench -- $CMD > $O/bench.json 2> $O/err.txt
 cd $R
 python - <<'PY'
 import csv, glob, os
@@ -11,8 +12,10 @@ O = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/timeline"
 f = glob.glob(O + "/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # a step boundary = the Adam kernel; take the step between the 20th and 21st occurrence
-idx = [i for i, r in enumerate(rows) if "mt_adam_clip_kernel" in r["Kernel_Name"]]
-a, b = idx[24], idx[25]
+# a step ends with the LAST optimizer kernel of a run of them (large models take several multi-tensor launches)
+idx = [i for i, r in enumerate(rows[:-1]) if "mt_adam_clip" in r["Kernel_Name"] and "mt_" not in rows[i + 1]["Kernel_Name"]]
+k = min(24, len(idx) - 2)
+a, b = idx[k], idx[k + 1]
 t0 = int(rows[a]["End_Timestamp"])
 out = []
 for r in rows[a + 1:b + 1]:

@@ -92,3 +92,6 @@ def test_streaming_weight_gradient_kernel(gpu_device, V):
     wide = _rand(gen, V, 512)
     a, b = wide[:, 3:131], wide[:, 256:512]            # odd base offset -> scalar loads; even -> 8-byte loads
     _close(D.tn_stream_gemm(a, b), a.double().t() @ b.double(), V)
+    acc = _rand(gen, 128, 256)
+    want = acc.double() + a.double().t() @ b.double()
+    _close(D.tn_stream_gemm(a, b, out=acc), want, V)    # accumulate into an existing product

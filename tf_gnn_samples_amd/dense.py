@@ -143,18 +143,21 @@ def _split_count(V: int, M: int, N: int) -> int:
     return int(max(1, min(want, V // 512, 64)))
 
 
-def tn_stream_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T @ b for a [V, M], b [V, N] through the streaming weight-gradient kernel (csrc/gemm_tn_stream.hip)."""
+def tn_stream_gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """a^T @ b for a [V, M], b [V, N] through the streaming weight-gradient kernel (csrc/gemm_tn_stream.hip);
+    with `out` (contiguous [M, N]): out += a^T @ b."""
     from . import _lib
     lib = _lib.load_library()
     V, M = a.shape
     N = b.shape[1]
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     nbytes = lib.relgnn_gemm_tn_stream_workspace_bytes(M, N, V)
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=a.device)
     _lib.check(lib.relgnn_gemm_tn_stream_f32(_lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
-                                             b.stride(0), _lib.ptr(out), N, M, N, V, 0, _lib.ptr(ws), nbytes,
-                                             _lib.current_stream()), "relgnn_gemm_tn_stream_f32")
+                                             b.stride(0), _lib.ptr(out), N, M, N, V, 1 if accumulate else 0, _lib.ptr(ws),
+                                             nbytes, _lib.current_stream()), "relgnn_gemm_tn_stream_f32")
     return out
 
 
@@ -187,7 +190,12 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
                    "relgnn_blaslt_gemm_f32")
         out = parts.sum(0)
         if head < V:
-            lib_gemm(GEMM_TN, a[head:], b[head:], out=out, accumulate=True)   # the < c leftover rows
+            # the < c leftover rows: a few (often < 64) rows against a wide output — the library's pick for that shape took
+            # 191 us at [16, 128]^T @ [16, 640] (C3 timeline); the streaming kernel accumulates them in ~15 us
+            if _STREAM_TN:
+                tn_stream_gemm(a[head:], b[head:], out=out)
+            else:
+                lib_gemm(GEMM_TN, a[head:], b[head:], out=out, accumulate=True)
         return out
     out = torch.bmm(a[:head].view(S, c, M).transpose(1, 2), b[:head].view(S, c, N)).sum(0)
     if head < V:
