@@ -22,6 +22,7 @@ _CACHED_LIB_GEMM = os.environ.get("RELGNN_GEMM", "lib") != "torch"
 _STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 _WORKSPACE = {}
+_WARNED_UNSUPPORTED = False
 
 
 def _lib_rows_ok(t: torch.Tensor) -> bool:
@@ -63,11 +64,26 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ws = _workspace(a.device)
-    _lib.check(lib.relgnn_blaslt_gemm_f32(layout, _lib.ACT_RELU if relu else _lib.ACT_LINEAR,
-                                          _lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
-                                          b.stride(0), _lib.ptr(bias), _lib.ptr(out, rows_strided=True), out.stride(0), M, N, K,
-                                          1, 0, 0, 0, 1 if accumulate else 0, _lib.ptr(ws), ws.numel(),
-                                          _lib.current_stream()), "relgnn_blaslt_gemm_f32")
+    code = lib.relgnn_blaslt_gemm_f32(layout, _lib.ACT_RELU if relu else _lib.ACT_LINEAR,
+                                      _lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
+                                      b.stride(0), _lib.ptr(bias), _lib.ptr(out, rows_strided=True), out.stride(0), M, N, K,
+                                      1, 0, 0, 0, 1 if accumulate else 0, _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    if code == _lib.EUNSUPPORTED:
+        # the library has no solution for this problem through the direct interface (never seen on the shapes of the
+        # path): same library through torch, said once — still the GPU, still fp32
+        global _WARNED_UNSUPPORTED
+        if not _WARNED_UNSUPPORTED:
+            _WARNED_UNSUPPORTED = True
+            import warnings
+            warnings.warn("relgnn_blaslt_gemm_f32: no hipBLASLt solution for layout %d, M=%d N=%d K=%d; using torch.mm "
+                          "for such shapes" % (layout, M, N, K))
+        res = (a @ b) if layout == GEMM_NN else (a @ b.t()) if layout == GEMM_NT else (a.t() @ b)
+        if bias is not None:
+            res = res + bias
+        if relu:
+            res = res.relu_()
+        return out.add_(res) if accumulate else out.copy_(res)
+    _lib.check(code, "relgnn_blaslt_gemm_f32")
     return out
 
 
