@@ -292,12 +292,54 @@ class RelGraph:
         return self
 
     def check(self):
-        """Host sync: raise if the device-side validation saw a node id outside [0, V)."""
+        """Host sync: raise if the device-side validation saw a node id outside [0, V); the same round trip reads the
+        longest bucket and splits long ones (split_long_segments)."""
         if not self._checked:
             self._checked = True
-            if int(self._err_flag.item()) != 0:
+            longest = self._longest_buckets()
+            flags = torch.cat([self._err_flag.to(torch.int64).reshape(1), longest]).tolist()
+            if flags[0] != 0:
                 # TF-CPU raises InvalidArgumentError for out-of-range gather / segment ids.
                 raise ValueError("adjacency list holds a node id outside [0, %d)" % self.V)
+            self._attach_split_plans(flags[1:])
+
+    # ---- hubs: buckets too long for one wave -----------------------------------------------------
+    def _bucketings(self):
+        return ((self.rowptr_t, 1), (self.rowptr_t, self.L), (self.rowptr_s, 1), (self.rowptr_s, self.L))
+
+    def _longest_buckets(self) -> torch.Tensor:
+        """longest bucket of the four bucketings the kernels use: (target, type), target, (source, type), source"""
+        if self.M == 0:
+            return torch.zeros(4, dtype=torch.int64, device=self.device)
+        out = []
+        for rp, stride in self._bucketings():
+            b = rp[0::stride]
+            out.append((b[1:] - b[:-1]).max().to(torch.int64).reshape(1))
+        return torch.cat(out)
+
+    def _attach_split_plans(self, longest, threshold: int = None) -> bool:
+        from . import ops
+        threshold = ops.LONG_SEGMENT if threshold is None else threshold
+        any_long = False
+        for (rp, stride), n in zip(self._bucketings(), longest):
+            if n > threshold:
+                plans = getattr(rp, "_relgnn_split", None)
+                if plans is None:
+                    plans = rp._relgnn_split = {}
+                if stride not in plans:
+                    plans[stride] = ops.SplitPlan(rp, stride, self.V * self.L // stride, threshold)
+                any_long = True
+        self.has_long_buckets = any_long
+        return any_long
+
+    has_long_buckets = False
+
+    def split_long_segments(self, threshold: int = None) -> bool:
+        """One host round trip: find buckets longer than `threshold` messages (default ops.LONG_SEGMENT) and route the
+        gather / reduce launches that walk them through chunked virtual rows (ops.SplitPlan).  Called by check() for
+        validated graphs and by tasks/resident.py for batches of a fold that is known to hold such hubs; graphs built
+        with validate="deferred" keep one wave per bucket (PPI-, QM9- and VarMisuse-shaped data: longest bucket < 2 k)."""
+        return self._attach_split_plans(self._longest_buckets().tolist(), threshold)
 
     # ---- derived index arrays -----------------------------------------------------------
     @property

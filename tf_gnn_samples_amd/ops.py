@@ -50,7 +50,55 @@ def _check_f32(x: torch.Tensor, what: str):
         raise ValueError("%s must be float32, got %s" % (what, x.dtype))
 
 
+# ---- long buckets -----------------------------------------------------------------------------------------------------
+# The gather kernel gives ONE wave to a bucket and folds its messages in order: a hub with 1e5 incoming edges keeps one
+# wave busy for milliseconds while the rest of the chip has long finished.  A graph that knows it has such buckets
+# (RelGraph.split_long_segments: the lengths are read back once, where the graph is validated anyway) attaches a
+# SplitPlan to the row-pointer tensor; _seg_reduce_raw then runs two launches of the SAME kernel: chunks of at most
+# LONG_SEGMENT messages as virtual rows, then the virtual rows of a bucket combined in chunk order (deterministic; the
+# fp32 summation order of a hub differs from the sequential fold by the chunking only).
+LONG_SEGMENT = 4096
+
+
+class SplitPlan:
+    def __init__(self, rowptr: torch.Tensor, stride: int, num_out: int, chunk: int = LONG_SEGMENT):
+        dev = rowptr.device
+        bounds = rowptr[0:num_out * stride + 1:stride].long()                     # [num_out + 1]
+        starts, ends = bounds[:-1], bounds[1:]
+        self.lengths = ends - starts
+        chunks = torch.clamp((self.lengths + chunk - 1) // chunk, min=1)
+        off = torch.zeros(num_out + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.cumsum(chunks, 0)
+        self.num_virtual = int(off[-1])                                            # host sync, once per plan
+        seg_of = torch.repeat_interleave(torch.arange(num_out, device=dev), chunks)
+        first = starts[seg_of] + (torch.arange(self.num_virtual, device=dev) - off[seg_of]) * chunk
+        self.virtual_rowptr = torch.cat([first, bounds[-1:]]).to(torch.int32).contiguous()
+        self.combine_rowptr = off.to(torch.int32).contiguous()
+        self.iota = torch.arange(self.num_virtual, dtype=torch.int32, device=dev)
+
+
+_ACT_BY_ID = {_lib.ACT_TANH: torch.tanh, _lib.ACT_RELU: torch.relu,
+              _lib.ACT_LEAKY_RELU: lambda x: torch.nn.functional.leaky_relu(x, 0.2),
+              _lib.ACT_ELU: torch.nn.functional.elu, _lib.ACT_SELU: torch.selu,
+              _lib.ACT_GELU: lambda x: torch.nn.functional.gelu(x, approximate="none")}
+
+
+def _seg_reduce_split(mode, X, sp: SplitPlan, col, w, num_out, act):
+    first = _lib.AGG_MAX if mode == _lib.AGG_MAX else _lib.AGG_SUM
+    parts = _seg_reduce_raw(first, X, sp.virtual_rowptr, 1, col, w, sp.num_virtual)
+    out = _seg_reduce_raw(first, parts, sp.combine_rowptr, 1, sp.iota, None, num_out)
+    if mode in (_lib.AGG_MEAN, _lib.AGG_SQRT_N):
+        n = sp.lengths.clamp(min=1).to(torch.float32).unsqueeze(1)
+        out = out / (n if mode == _lib.AGG_MEAN else torch.sqrt(n))
+    if act != _lib.ACT_LINEAR:
+        out = _ACT_BY_ID[act](out)
+    return out
+
+
 def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEAR):
+    split = getattr(rowptr, "_relgnn_split", None)
+    if split is not None and stride in split:
+        return _seg_reduce_split(mode, X, split[stride], col, w, num_out, act)
     lib = _lib.load_library()
     D = X.shape[1]
     out = torch.empty((num_out, D), dtype=torch.float32, device=X.device)

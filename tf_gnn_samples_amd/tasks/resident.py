@@ -62,6 +62,7 @@ class ResidentDataset:
             shift = torch.repeat_interleave(self.node_off_d[:-1], counts).to(torch.int32)
             union.append((self.adj_d[l] + shift.unsqueeze(1)).contiguous())
         g = RelGraph(union, N, validate=True)                                    # node-id range check, once
+        self._has_hubs = g.has_long_buckets          # a bucket of the fold too long for one wave: split per batch too
         self.plan_d = dict(rowptr_t=g.rowptr_t, perm_t=g.perm_t, col_t=g.col_t, rowptr_s=g.rowptr_s, perm_s=g.perm_s,
                            frow_s=g.frow_s, pos_t_of_s=g.pos_t_of_s)
         # per-message 1/(in-degree + 1e-7) of the whole fold, by-target and by-source order: graph properties, copied
@@ -211,6 +212,8 @@ class ResidentDataset:
         else:
             graph = RelGraph.from_arrays(state["adj"], V, rowptr_t=rowptr_t, rowptr_s=rowptr_s, tgt_s=tgt_s, **six)
         graph.preset_degree_scale(deg, src_t, w_t, w_s)
+        if self._has_hubs:
+            graph.split_long_segments()
         batch = DeviceBatch.from_tensors(
             num_graphs=K, num_nodes=V, num_edges=M, initial_node_features=payload[self.features],
             adjacency_lists=adjacency if lean else state["adj"],
