@@ -1,18 +1,20 @@
 """Node-side dense layers (Keras `Dense` of the reference: y = x @ kernel (+ bias), kernel [in, out]).
 
-These are plain library GEMMs (hipBLASLt through torch) and NOT part of the gather/segment hot path, but
-their WEIGHT-GRADIENT GEMM  dW = x^T @ g  reduces over the node dimension (K = V ~ 3e4..1e6, output only
-in x out ~ 256 x 768): a single GEMM call leaves most of the 256 CUs idle (12 output tiles) and measured
-400 us for [256 x 32k] @ [32k x 768] on MI355X.  Splitting the node dimension into S chunks, running one
-batched GEMM and summing the S partial products (split-K) brings it to ~130 us (13.6 GFLOP at ~105 TFLOP/s
-fp32).  The bias gradient (column sums over V rows) is a GEMV instead of a strided reduction.
+Forward and input-gradient products are plain library GEMMs (hipBLASLt, called through relgnn_blaslt_gemm_f32 so that the
+library's solution is cached per shape class instead of being looked up for every new node count: lib_gemm).  The
+WEIGHT-GRADIENT GEMM  dW = x^T @ g  reduces over the node dimension (K = V ~ 3e4..1e6, output only in x out <= 256 x 768):
+a single library call leaves most of the 256 CUs idle (12 output tiles) and measured 400 us for [256 x 32k] @ [32k x 768] on
+MI355X.  Outputs up to 256 x 256 go through the streaming MFMA kernel (relgnn_gemm_tn_stream_f32: 69 us at 256 x 256);
+the [768 x 256] ones split the node dimension into S chunks, run one strided-batched library GEMM and sum the S partial
+products (split-K, ~130 us = 13.6 GFLOP at ~105 TFLOP/s fp32).  The bias gradient (column sums over V rows) is a two-stage
+HIP reduction.
 """
 import os
 
 import torch
 
 # RELGNN_GEMM=mfma routes the node-side GEMMs through the hand-written exact-fp32 MFMA kernel (csrc/gemm_f32.hip) for
-# every shape it supports.  Default: the library (hipBLASLt through torch) — measured on MI355X at the C2 shapes
+# every shape it supports.  Default: the library (hipBLASLt, cached solutions) — measured on MI355X at the C2 shapes
 # (scripts/bench_gemm.py, K = 256): library default solutions 100-119 TFLOP/s, own kernel 77-92 TFLOP/s.
 _OWN_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "mfma"
 # RELGNN_GEMM=torch: library GEMMs through torch.mm (a hipBLASLt solution lookup per call: ~70 us of host time for every

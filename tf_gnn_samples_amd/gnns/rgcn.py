@@ -6,7 +6,7 @@ Same signature, keyword names, defaults and message order as the reference.  Wha
 is WHERE the work happens:
   * the per-edge Dense (rgcn.py:96-98, an [E_l, D] x [D, D] MatMul on gathered rows) becomes ONE
     node-side GEMM  H [V, D] @ [W_0 | ... | W_{L-1}]  — identical per-row dot products, 1/degree
-    of the flops (hipBLASLt through torch.mm);
+    of the flops (library GEMM, dense.lib_gemm);
   * gather (rgcn.py:87-89), degree scale (:100-104), concat (:108), segment reduction
     (:109-112) and activation (:114) are ONE HIP kernel (csrc/seg_reduce.hip) over the
     (target, type)-bucketed CSR built once per batch.

@@ -13,8 +13,8 @@ device.  A batch is then a list of graph ids, and
     and relgnn_plan_assemble re-bases the per-graph slices of those arrays (include/relgnn.h section 10) —
     three streaming kernels instead of two radix sorts per batch, bit-identical arrays.
 
-Nothing crosses PCIe per batch except the K-entry offset tables.  (bench.py's headline step does NOT use this: there
-every step pays for its own bucketing; the whole-epoch figure does.)
+Nothing crosses PCIe per batch except the K-entry offset tables.  This is the input pipeline of bench.py's headline
+(distinct batches of a shuffled epoch); its `same_batch` figure instead re-buckets one resident batch per step.
 """
 from typing import Iterator, Optional, Sequence
 

@@ -8,7 +8,7 @@ error behaviour) on PyTorch-ROCm tensors.
   micro_f1                  utils/utils.py:61-74
   SMALL_NUMBER, BIG_NUMBER  utils/utils.py:6-7
 
-Node-wise GEMMs (Dense, GRU) are hipBLASLt through PyTorch-ROCm; the elementwise halves of the GRU cell and the layer
+Node-wise GEMMs (Dense, GRU) are library GEMMs (hipBLASLt, dense.lib_gemm); the elementwise halves of the GRU cell and the layer
 normalisation are HIP kernels of librelgnn (csrc/gru.hip, csrc/layer_norm.hip).
 """
 import math
