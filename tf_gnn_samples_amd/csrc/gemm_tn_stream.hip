@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 using namespace relgnn;
 
@@ -51,15 +52,19 @@ template <bool VEC> struct Slot;
 template <> struct Slot<true> { f32x2 v; };
 template <> struct Slot<false> { float x, y; };
 
+// The destination is a READ-WRITE operand ("+v"): the load lands asynchronously, so the slot must stay in ONE physical
+// register from the issue to the wait — with a write-only operand the allocator is free to give the load a fresh register
+// and copy it into place before the data has arrived.  A value still needed from the slot (the pair just consumed) is
+// thereby copied out by the compiler before the load is issued.
 __device__ __forceinline__ void issue(Slot<true>& s, const float* row, const Cols& c) {
   const float* p = row + (c.on0 != 0.f ? c.off0 : 0);      // even offset; x + 1 is inside the row's storage when x exists
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(s.v) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(s.v) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void issue(Slot<false>& s, const float* row, const Cols& c) {
   const float* p0 = row + c.off0;
   const float* p1 = row + c.off1;
-  asm volatile("global_load_dword %0, %1, off" : "=&v"(s.x) : "v"(p0) : "memory");
-  asm volatile("global_load_dword %0, %1, off" : "=&v"(s.y) : "v"(p1) : "memory");
+  asm volatile("global_load_dword %0, %1, off" : "+v"(s.x) : "v"(p0) : "memory");
+  asm volatile("global_load_dword %0, %1, off" : "+v"(s.y) : "v"(p1) : "memory");
 }
 // wait until at most N vector-memory loads are outstanding; the slots are operands so that their uses stay behind the wait
 template <int N>
@@ -70,10 +75,15 @@ template <int N>
 __device__ __forceinline__ void wait_for(Slot<false>& a, Slot<true>& b) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a.x), "+v"(a.y), "+v"(b.v) : "n"(N)); }
 template <int N>
 __device__ __forceinline__ void wait_for(Slot<false>& a, Slot<false>& b) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y) : "n"(N)); }
-__device__ __forceinline__ float first(const Slot<true>& s) { return s.v.x; }
-__device__ __forceinline__ float second(const Slot<true>& s) { return s.v.y; }
-__device__ __forceinline__ float first(const Slot<false>& s) { return s.x; }
-__device__ __forceinline__ float second(const Slot<false>& s) { return s.y; }
+// Copy a landed pair OUT of its slot with explicit moves, so that the slot's old value is dead when the refill is issued
+// into it: otherwise the allocator keeps the old value where it is, gives the (asynchronous) refill a fresh register and
+// moves it back into place right away — before the data has arrived.
+__device__ __forceinline__ void take(const Slot<true>& s, float& x, float& y) {
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(x), "=&v"(y) : "v"(s.v.x), "v"(s.v.y));
+}
+__device__ __forceinline__ void take(const Slot<false>& s, float& x, float& y) {
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(x), "=&v"(y) : "v"(s.x), "v"(s.y));
+}
 
 template <bool VEC_A, bool VEC_B>
 __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
@@ -108,31 +118,49 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
   };
 
   constexpr int kLoadsPerPair = (VEC_A ? 1 : 2) + (VEC_B ? 1 : 2);
-  Slot<VEC_A> ra[kDepth];
-  Slot<VEC_B> rb[kDepth];
+  Slot<VEC_A> ra[kDepth] = {};
+  Slot<VEC_B> rb[kDepth] = {};
 #pragma unroll
   for (int u = 0; u < kDepth; ++u) {
     issue(ra[u], pa, ca);
     issue(rb[u], pb, cb);
     advance();
   }
-  for (int r0 = 0; r0 < rows; r0 += 2 * kDepth) {
+  // One ring step: consume the OLDEST pair in flight (slot u; everything issued after it may stay in flight), refill its
+  // slot with the pair kDepth ahead.  LEAN: the pair and its refill lie wholly inside the chunk and the tile is interior,
+  // so there is nothing to clamp or mask — 2 pointer adds, 2 loads, 1 wait and 4 MFMAs per k-pair (the masked form issues
+  // ~14 instructions per MFMA and kept the matrix pipe 50 % busy, profiles/r02_c_tn_stream_pmc.txt).
+  auto ring_pass = [&](int r0, auto lean_tag) {
+    constexpr bool LEAN = decltype(lean_tag)::value;
 #pragma unroll
     for (int u = 0; u < kDepth; ++u) {
-      // the OLDEST pair in flight is slot u; everything issued after it may stay in flight
       wait_for<kLoadsPerPair * (kDepth - 1)>(ra[u], rb[u]);
-      const float live = r0 + 2 * u + half < rows ? 1.f : 0.f;
-      const float a0 = first(ra[u]) * (live * ca.on0), a1 = second(ra[u]) * (live * ca.on1);
-      const float b0 = first(rb[u]) * cb.on0, b1 = second(rb[u]) * cb.on1;
-      issue(ra[u], pa, ca);                                    // refill the slot with the pair kDepth ahead
+      float a0, a1, b0, b1;
+      take(ra[u], a0, a1);
+      take(rb[u], b0, b1);
+      if constexpr (!LEAN) {
+        const float live = r0 + 2 * u + half < rows ? 1.f : 0.f;
+        a0 *= live * ca.on0; a1 *= live * ca.on1;
+        b0 *= cb.on0; b1 *= cb.on1;
+      }
+      issue(ra[u], pa, ca);
       issue(rb[u], pb, cb);
-      advance();
+      if constexpr (LEAN) { pa += step_a; pb += step_b; } else advance();
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-  }
+  };
+  // rows the lean passes may cover: every pair consumed AND every pair refilled (kDepth pairs later) has both rows in the
+  // chunk.  Edge tiles (columns to mask) take the masked form throughout.
+  const bool interior = m0 + 64 <= M && n0 + 64 <= N;
+  const int lean_rows = interior ? ((rows / 2 - kDepth) / kDepth) * (2 * kDepth) : 0;
+  int r0 = 0;
+  for (; r0 < lean_rows; r0 += 2 * kDepth) ring_pass(r0, std::true_type{});
+  pa = pa < pa_last ? pa : pa_last;      // the lean passes advance unclamped: the next refill may be the pair past the end
+  pb = pb < pb_last ? pb : pb_last;
+  for (; r0 < rows; r0 += 2 * kDepth) ring_pass(r0, std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the refills past the end (clamped, never used)
 
   // (a masked element is multiplied by 0: it is a REAL element of the matrix — clamped address — so it is finite whenever
