@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 using namespace relgnn;
@@ -217,8 +218,11 @@ Plan make_plan(int32_t M, int32_t N, int64_t K) {
   p.tiles_m = (M + 63) / 64;
   p.tiles_n = (N + 63) / 64;
   p.tiles = p.tiles_m * p.tiles_n;
-  // ~2 waves per SIMD over the 256 CUs, at least 64 rows per chunk, chunk length a multiple of the unrolled step
-  int64_t chunks = (2048 + p.tiles - 1) / p.tiles;
+  // at least 64 rows per chunk, chunk length a multiple of the unrolled step
+  // one wave per SIMD, one round of workgroups (256 CUs x 4): measured at [36 k, 256]^T @ [36 k, 256 | 121 | 50-row]:
+  // 512 waves 94 / 65 / 39 us, 768: 70 / 50 / 33, 1024: 59 / 43 / 33, 1280: 84 / 59 / 41, 2048: 64 / 49 / 41, 4096: 73 / 64 / 49
+  static const int64_t waves = [] { const char* e = getenv("RELGNN_TN_WAVES"); return e ? (int64_t)atoi(e) : (int64_t)1024; }();
+  int64_t chunks = (waves + p.tiles - 1) / p.tiles;
   chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, (K + 63) / 64));
   int64_t rows = (K + chunks - 1) / chunks;
   rows = (rows + 2 * kDepth - 1) / (2 * kDepth) * (2 * kDepth);
