@@ -193,6 +193,8 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     S = _split_count(V, M, N)
     if S <= 1:
         return lib_gemm(GEMM_TN, a, b)
+    if not (a.is_contiguous() and b.is_contiguous()):      # the chunked forms below view the operands as [S, c, .]
+        a, b = a.contiguous(), b.contiguous()
     c = V // S
     head = c * S
     # (outputs narrower than one 64-wide tile — the [50, 256] gradient of the input projection — keep torch.bmm: hipBLASLt's
@@ -232,7 +234,7 @@ def column_sum(g: torch.Tensor) -> torch.Tensor:
     out = torch.empty(N, dtype=torch.float32, device=g.device)
     nbytes = lib.relgnn_column_sum_workspace_bytes(V, N)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device)
-    _lib.check(lib.relgnn_column_sum(_lib.ptr(g), V, N, g.stride(0), _lib.ptr(out), _lib.ptr(ws), nbytes,
+    _lib.check(lib.relgnn_column_sum(_lib.ptr(g, rows_strided=True), V, N, g.stride(0), _lib.ptr(out), _lib.ptr(ws), nbytes,
                                      _lib.current_stream()), "relgnn_column_sum")
     return out
 
@@ -249,11 +251,13 @@ class _DenseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, kernel = ctx.saved_tensors
-        g = g.contiguous()
-        gx = None
+        if g.dim() != 2 or g.stride(1) != 1 or not g.is_cuda:
+            g = g.contiguous()             # (a row-strided gradient, e.g. a column block of the GRU's gate gradients, is
+        gx = None                          # read in place: every consumer below takes a leading dimension)
         if ctx.needs_input_grad[0]:
             gx = own_gemm(GEMM_NT, g, kernel) if own_gemm_supported(GEMM_NT, g, kernel) else lib_gemm(GEMM_NT, g, kernel)
-        gk = matmul_tn_splitk(x.contiguous(), g) if ctx.needs_input_grad[1] else None
+        gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), g) \
+            if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = column_sum(g)
