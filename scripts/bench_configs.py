@@ -94,11 +94,11 @@ if "C3" in which:
         p = cls.default_params(); p.update(hidden_size=128, graph_num_layers=6, graph_rnn_cell="GRU", message_aggregation_function=agg)
         run("C3 GGNN/QM9 GRU %s D=128 6 layers" % agg, quiet_model(cls, p, task), batch, mb)
 
-if any(w in which for w in ("C4", "RGIN", "MLP0", "MLP1", "FILM", "RGDCN")):
+if any(w in which for w in ("C2", "C4", "RGIN", "MLP0", "MLP1", "FILM", "RGDCN")):
     task = PPI_Task(PPI_Task.default_params()); task.load_synthetic(16, 1, seed=0)
     mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
     batch = DeviceBatch(mb, dev)
-    for key, mname in (("C4", "RGAT"), ("RGIN", "RGIN"), ("MLP0", "GNN-Edge-MLP0"), ("MLP1", "GNN-Edge-MLP1"),
+    for key, mname in (("C2", "RGCN"), ("C4", "RGAT"), ("RGIN", "RGIN"), ("MLP0", "GNN-Edge-MLP0"), ("MLP1", "GNN-Edge-MLP1"),
                        ("FILM", "GNN-FiLM"), ("RGDCN", "RGDCN")):
         if key in which:
             cls, extra = name_to_model_class(mname)
