@@ -25,6 +25,9 @@ import torch
 from . import _lib
 
 
+_ZERO_FLAGS = {}
+
+
 def _i32(n, device):
     return torch.empty(int(n), dtype=torch.int32, device=device)
 
@@ -202,7 +205,9 @@ class RelGraph:
         # the per-message keys (tgt*L+l, src*L+l in type-major order) are only read by the pair / materialised-message
         # paths: computed on first use (relgnn_relational_keys_all), not per batch
         self._key_t = self._key_s = None
-        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        err = _ZERO_FLAGS.get(dev)            # never written for a graph whose producer validated it: one shared word
+        if err is None:
+            err = _ZERO_FLAGS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rowptr_t, self.rowptr_s, self.tgt_s = rowptr_t, rowptr_s, tgt_s
         for k, v in lazy.items():
             if v is not None:

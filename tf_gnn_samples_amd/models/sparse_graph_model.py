@@ -407,7 +407,7 @@ class Sparse_Graph_Model(ABC):
             cur_node_representations = apply_activation(activation_fn, dense(initial_node_features, w["dense/kernel"]))
         else:
             cur_node_representations = initial_node_features
-        last_residual_representations = torch.zeros_like(cur_node_representations)
+        last_residual_representations = None          # (the reference's zeros_like is overwritten at layer 0 before any use)
         for layer_idx in range(p['graph_num_layers']):
             self._layer_weights = w.scope('gnn_layer_%i' % layer_idx)
             if dropout_keep_prob < 1.0:

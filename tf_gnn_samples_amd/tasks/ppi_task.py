@@ -35,6 +35,7 @@ class _SigmoidCEStats(torch.autograd.Function):
                                                _lib.ptr(ws), nbytes, _lib.current_stream()), "relgnn_sigmoid_ce_stats")
         ctx.save_for_backward(logits, labels)
         ctx.inv_n = inv_n
+        ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None, not as a zero tensor
         total, f1 = stats[0], stats[4]
         counts = stats[1:4]                                   # true_pos, false_pos, false_neg
         ctx.mark_non_differentiable(f1, counts)
@@ -50,6 +51,8 @@ class _SigmoidCEStats(torch.autograd.Function):
             gscale = g_mean * ctx.inv_n
         if g_total is not None:
             gscale = g_total if gscale is None else gscale + g_total
+        if gscale is None:
+            return None, None, None
         gscale = gscale.reshape(1).to(torch.float32).contiguous()
         gl = torch.empty_like(logits)
         _lib.check(lib.relgnn_sigmoid_ce_bwd(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), _lib.ptr(gscale),
