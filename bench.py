@@ -565,7 +565,7 @@ def main():
             result["same_batch"] = {"error": repr(e)}
     del model, reducer
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline:          # (at N > 1 the other ranks wait at the final barrier meanwhile)
         try:
             result["roofline"] = roofline_section(device, args.kernel_iters, not args.no_pmc)
         except Exception as e:
