@@ -14,10 +14,13 @@ sys.stdout = so
 data = task._loaded_data[DataFold.TRAIN]
 marks = []
 t0 = time.time()
-for ep in range(150):
+EPOCHS = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+for ep in range(EPOCHS):
     loss, res, n, *_ = model._run_epoch("e", data, DataFold.TRAIN, quiet=True)
-    if ep % 30 == 0 or ep == 149:
+    if ep % max(EPOCHS // 5, 1) == 0 or ep == EPOCHS - 1:
         torch.cuda.synchronize()
         marks.append((ep, len(res), round(loss, 4), torch.cuda.memory_allocated() >> 20, torch.cuda.memory_reserved() >> 20))
 print("epochs/steps per epoch/loss/allocated MiB/reserved MiB:", marks, "wall %.1f s" % (time.time() - t0))
-assert marks[-1][3] <= marks[1][3] * 1.2 + 16, "device memory grows"
+# `allocated` at a sampling point depends on which batches are in flight (they differ in size); what must not grow is the
+# allocator's reservation once the first epochs have seen every batch shape
+assert marks[-1][4] <= marks[2][4] * 1.1 + 16, "device memory grows"

@@ -431,15 +431,30 @@ class RelGraph:
         return self._plans["tgt_t"]
 
     # ---- plans ----------------------------------------------------------------------------
+    def _deferred(self, name: str):
+        """A zero-argument getter of one of this graph's (possibly lazily produced) arrays for a plan's deferred fields.
+        Holds the graph WEAKLY: the plan lives in self._plans, and a strong reference back would make graph <-> plan a
+        cycle that only the cyclic collector frees — every batch's index arrays (tens of MB at C2) would then outlive
+        the step until a full collection happens to run."""
+        import weakref
+        ref = weakref.ref(self)
+
+        def get():
+            g = ref()
+            if g is None:
+                raise RuntimeError("the RelGraph of this plan is gone")
+            return getattr(g, name)
+        return get
+
     def plan_transformed(self, w: Optional[torch.Tensor] = None) -> GatherReducePlan:
         """Messages gathered from a per-(node, type) table T [V*L, D] (row = src*L + l), reduced
         over ALL edge types into the target node.  w: optional by-target per-message weights."""
         key = ("T", None if w is None else w.data_ptr())
         if key not in self._plans:
             self._plans[key] = (w, GatherReducePlan(
-                rowptr=self.rowptr_t, stride=self.L, col=lambda: self.col_t, w=w, num_out=self.V,
+                rowptr=self.rowptr_t, stride=self.L, col=self._deferred("col_t"), w=w, num_out=self.V,
                 num_rows_x=self.V * self.L, rowptr_b=self.rowptr_s, stride_b=1, col_b=self.tgt_s,
-                pos_b=lambda: self.pos_t_of_s, num_messages=self.M))
+                pos_b=self._deferred("pos_t_of_s"), num_messages=self.M))
         return self._plans[key][1]
 
     def plan_untransformed(self, w: Optional[torch.Tensor] = None) -> GatherReducePlan:
@@ -449,7 +464,7 @@ class RelGraph:
             self._plans[key] = (w, GatherReducePlan(
                 rowptr=self.rowptr_t, stride=self.L, col=self.src_t, w=w, num_out=self.V,
                 num_rows_x=self.V, rowptr_b=self.rowptr_s, stride_b=self.L, col_b=self.tgt_s,
-                pos_b=lambda: self.pos_t_of_s, num_messages=self.M))
+                pos_b=self._deferred("pos_t_of_s"), num_messages=self.M))
         return self._plans[key][1]
 
 
