@@ -515,6 +515,8 @@ def main():
         # time rank 0's host spent blocked on the (one step late) metrics copy: ~0 = the host is the bottleneck,
         # large = the GPU is
         "host_blocked_on_gpu_ms_per_step": state["host_wait"] / args.steps * 1e3,
+        # rank 0's peak device memory over fold + model + timed loop (a batch's arrays must die with the step)
+        "peak_device_bytes": int(torch.cuda.max_memory_allocated(device)),
     }
 
     # ---- secondary figures (rank 0, single GPU): same-batch step, forward only, transfers ---------------------------
