@@ -95,3 +95,26 @@ def test_streaming_weight_gradient_kernel(gpu_device, V):
     acc = _rand(gen, 128, 256)
     want = acc.double() + a.double().t() @ b.double()
     _close(D.tn_stream_gemm(a, b, out=acc), want, V)    # accumulate into an existing product
+
+
+def test_streaming_kernel_random_shapes(gpu_device):
+    """Seeded sweep over node counts, output shapes and row strides (aligned / odd, views into wider storage): the kernel's
+    load ring is hand-scheduled assembly, so every combination of its four load variants, of lean and masked passes and of
+    chunk tails is compared with float64."""
+    from tf_gnn_samples_amd import dense as D
+    rng = np.random.default_rng(1234)
+    gen = torch.Generator(device=gpu_device).manual_seed(99)
+    for case in range(48):
+        V = int(rng.choice([1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 500, 1023, 1024, 1025, 4097, 20011, 65537]))
+        M = int(rng.choice([1, 2, 31, 32, 50, 63, 64, 65, 121, 128, 200, 256]))
+        N = int(rng.choice([1, 3, 32, 50, 64, 100, 121, 128, 129, 255, 256]))
+        pad_a, pad_b = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        off_a, off_b = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        wa = _rand(gen, V, off_a + M + pad_a)
+        wb = _rand(gen, V, off_b + N + pad_b)
+        a, b = wa[:, off_a:off_a + M], wb[:, off_b:off_b + N]
+        got = D.tn_stream_gemm(a, b)
+        want = a.double().t() @ b.double()
+        err = (got.double() - want).abs().max().item()
+        tol = 2e-6 * max(1.0, float(np.sqrt(V))) * max(1.0, want.abs().max().item())
+        assert got.shape == (M, N) and err <= tol, (case, V, M, N, off_a, pad_a, off_b, pad_b, err, tol)
