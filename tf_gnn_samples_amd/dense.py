@@ -4,7 +4,7 @@ Forward and input-gradient products are plain library GEMMs (hipBLASLt, called t
 library's solution is cached per shape class instead of being looked up for every new node count: lib_gemm).  The
 WEIGHT-GRADIENT GEMM  dW = x^T @ g  reduces over the node dimension (K = V ~ 3e4..1e6, output only in x out <= 256 x 768):
 a single library call leaves most of the 256 CUs idle (12 output tiles) and measured 400 us for [256 x 32k] @ [32k x 768] on
-MI355X.  Outputs up to 256 x 256 go through the streaming MFMA kernel (relgnn_gemm_tn_stream_f32: 69 us at 256 x 256);
+MI355X.  Outputs up to 256 x 256 go through the streaming MFMA kernel (relgnn_gemm_tn_stream_f32: 59 us at 256 x 256);
 the [768 x 256] ones split the node dimension into S chunks, run one strided-batched library GEMM and sum the S partial
 products (split-K, ~130 us = 13.6 GFLOP at ~105 TFLOP/s fp32).  The bias gradient (column sums over V rows) is a two-stage
 HIP reduction.
@@ -186,8 +186,8 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     V, M = a.shape
     N = b.shape[1]
     # small outputs (every Dense of the path except the stacked per-type transforms): the streaming kernel — measured at
-    # V = 36 k: [256 x 256] 69 us vs 171 us for the library's strided-batched split-K, [256 x 121] 48 vs 114, [50 x 256]
-    # 41 vs 57, [128 x 128] 39 vs 56; the library wins for [768 x 256] (131 vs 223) and for V ~ 1e6 (scripts/exp_tn_stream.py)
+    # V = 36 k: [256 x 256] 59 us vs 171 us for the library's strided-batched split-K, [256 x 121] 43 vs 114, [50 x 256]
+    # 33 vs 57, [128 x 128] 30 vs 56; the library wins for [768 x 256] (131 vs 223) and for V ~ 1e6 (scripts/exp_tn_stream.py)
     if _STREAM_TN and M * N <= 256 * 256 and 0 < V <= (1 << 18) and _lib_rows_ok(a) and _lib_rows_ok(b):
         return tn_stream_gemm(a, b)
     S = _split_count(V, M, N)
