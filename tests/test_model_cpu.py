@@ -186,3 +186,22 @@ def test_metrics_readback_on_host_values():
     rb = MetricsReadback({"loss": torch.tensor(1.5), "f1": torch.tensor(0.25, dtype=torch.float64), "n": 7})
     assert rb.get() == {"loss": 1.5, "f1": 0.25, "n": 7}
     assert rb.get() == {"loss": 1.5, "f1": 0.25, "n": 7}
+
+
+def test_split_plan_virtual_rows_cpu():
+    """ops.SplitPlan is pure index arithmetic: chunked virtual rows of long buckets, checked without a GPU."""
+    import torch
+    from tf_gnn_samples_amd.ops import SplitPlan
+    rowptr = torch.tensor([0, 0, 5, 5, 10005, 10006, 10006], dtype=torch.int32)
+    sp = SplitPlan(rowptr, 1, 6, chunk=4096)
+    assert sp.num_virtual == 8
+    assert sp.virtual_rowptr.tolist() == [0, 0, 5, 5, 4101, 8197, 10005, 10006, 10006]
+    assert sp.combine_rowptr.tolist() == [0, 1, 2, 3, 6, 7, 8]
+    assert sp.lengths.tolist() == [0, 5, 0, 10000, 1, 0]
+    merged = SplitPlan(rowptr, 2, 3, chunk=4096)
+    assert merged.virtual_rowptr.tolist() == [0, 5, 4101, 8197, 10005, 10006]
+    assert merged.combine_rowptr.tolist() == [0, 1, 4, 5]
+    # every message belongs to exactly one virtual row, in order
+    v = sp.virtual_rowptr
+    assert (v[1:] >= v[:-1]).all() and v[0] == 0 and v[-1] == rowptr[-1]
+    assert int((v[1:] - v[:-1]).max()) <= 4096
