@@ -50,22 +50,34 @@ __global__ __launch_bounds__(256) void assemble_by_target_kernel(
     BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ col_d,
     int32_t* __restrict__ perm_b, int32_t* __restrict__ col_b, int32_t* __restrict__ inv_b,
     const float* __restrict__ w_t_d, int32_t* __restrict__ src_b, float* __restrict__ w_t_b) {
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < M; p += (int64_t)gridDim.x * blockDim.x) {
-    const int k = upper_slot(t.msg_off_b, t.K, p);
-    const int64_t g = t.ids[k];
-    const int64_t pd = t.msg_off_d[g] + (p - t.msg_off_b[k]);
-    const uint32_t c = (uint32_t)col_d[pd];
-    const uint32_t cn = c / (uint32_t)t.L;
-    const int64_t src = (int64_t)cn - t.node_off_d[g] + t.node_off_b[k];
-    if (src_b) src_b[p] = (int32_t)src;            // source NODE per by-target position (row of the state table)
-    if (w_t_b) w_t_b[p] = w_t_d[pd];                // per-message scale: a property of the graph, not of the batch
-    if constexpr (FULL) {
-      const int l = (int)(c - cn * (uint32_t)t.L);
-      col_b[p] = (int32_t)(src * t.L + l);
-      const int32_t mb = translate_message(t, perm_d[pd], l, k, g);
-      perm_b[p] = mb;
-      inv_b[mb] = (int32_t)p;
+  // positions of one slot are contiguous: the slot of a block's first position is searched once per block (thread 0) and
+  // walked forward per element, instead of a binary search per message
+  __shared__ int first_slot;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < M; base += (int64_t)gridDim.x * 1024) {
+    if (threadIdx.x == 0) first_slot = upper_slot(t.msg_off_b, t.K, base);
+    __syncthreads();
+    int k = first_slot;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t p = base + threadIdx.x + 256 * e;
+      if (p >= M) break;
+      while (p >= t.msg_off_b[k + 1]) ++k;
+      const int64_t g = t.ids[k];
+      const int64_t pd = t.msg_off_d[g] + (p - t.msg_off_b[k]);
+      const uint32_t c = (uint32_t)col_d[pd];
+      const uint32_t cn = c / (uint32_t)t.L;
+      const int64_t src = (int64_t)cn - t.node_off_d[g] + t.node_off_b[k];
+      if (src_b) src_b[p] = (int32_t)src;            // source NODE per by-target position (row of the state table)
+      if (w_t_b) w_t_b[p] = w_t_d[pd];                // per-message scale: a property of the graph, not of the batch
+      if constexpr (FULL) {
+        const int l = (int)(c - cn * (uint32_t)t.L);
+        col_b[p] = (int32_t)(src * t.L + l);
+        const int32_t mb = translate_message(t, perm_d[pd], l, k, g);
+        perm_b[p] = mb;
+        inv_b[mb] = (int32_t)p;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -74,21 +86,31 @@ __global__ __launch_bounds__(256) void assemble_by_source_kernel(
     BatchTables t, int64_t M, const int32_t* __restrict__ perm_d, const int32_t* __restrict__ frow_d,
     const int32_t* __restrict__ pos_d, int32_t* __restrict__ perm_b, int32_t* __restrict__ frow_b,
     int32_t* __restrict__ tgt_b, int32_t* __restrict__ pos_b, const float* __restrict__ w_s_d, float* __restrict__ w_s_b) {
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < M; q += (int64_t)gridDim.x * blockDim.x) {
-    const int k = upper_slot(t.msg_off_b, t.K, q);
-    const int64_t g = t.ids[k];
-    const int64_t qd = t.msg_off_d[g] + (q - t.msg_off_b[k]);
-    const uint32_t f = (uint32_t)frow_d[qd];
-    const uint32_t fn = f / (uint32_t)t.L;
-    const int64_t tgt = (int64_t)fn - t.node_off_d[g] + t.node_off_b[k];
-    tgt_b[q] = (int32_t)tgt;
-    if (w_s_b) w_s_b[q] = w_s_d[qd];
-    if constexpr (FULL) {
-      const int l = (int)(f - fn * (uint32_t)t.L);
-      frow_b[q] = (int32_t)(tgt * t.L + l);
-      perm_b[q] = translate_message(t, perm_d[qd], l, k, g);
-      pos_b[q] = (int32_t)((int64_t)pos_d[qd] - t.msg_off_d[g] + t.msg_off_b[k]);
+  __shared__ int first_slot;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < M; base += (int64_t)gridDim.x * 1024) {
+    if (threadIdx.x == 0) first_slot = upper_slot(t.msg_off_b, t.K, base);
+    __syncthreads();
+    int k = first_slot;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t q = base + threadIdx.x + 256 * e;
+      if (q >= M) break;
+      while (q >= t.msg_off_b[k + 1]) ++k;
+      const int64_t g = t.ids[k];
+      const int64_t qd = t.msg_off_d[g] + (q - t.msg_off_b[k]);
+      const uint32_t f = (uint32_t)frow_d[qd];
+      const uint32_t fn = f / (uint32_t)t.L;
+      const int64_t tgt = (int64_t)fn - t.node_off_d[g] + t.node_off_b[k];
+      tgt_b[q] = (int32_t)tgt;
+      if (w_s_b) w_s_b[q] = w_s_d[qd];
+      if constexpr (FULL) {
+        const int l = (int)(f - fn * (uint32_t)t.L);
+        frow_b[q] = (int32_t)(tgt * t.L + l);
+        perm_b[q] = translate_message(t, perm_d[qd], l, k, g);
+        pos_b[q] = (int32_t)((int64_t)pos_d[qd] - t.msg_off_d[g] + t.msg_off_b[k]);
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -116,17 +138,33 @@ __global__ __launch_bounds__(256) void assemble_rowptr_kernel(
 // Nodes of a graph are contiguous in the fold and in the batch: every copy below is K contiguous segment copies, found
 // per element by a binary search over the K+1 batch offsets (K <= a few hundred; the tables sit in L1/L2).
 
-// dst[v, :] = src[node_d(v), :]   rows of `cols` 4-byte elements.  One wave per row (4 rows per block): the slot search runs
-// once per row, the row itself is a coalesced copy — no per-element search or division.
+// dst[v, :] = src[node_d(v), :]   rows of `cols` 4-byte elements.  A slot's rows are contiguous on both sides, so the copy
+// is flat per slot: every thread takes 4 consecutive elements of the batch's flat payload, the slot of the block's first
+// element is searched once per block and walked forward from there (a block of 1024 elements rarely crosses a slot).
 __global__ __launch_bounds__(256) void gather_node_rows_kernel(BatchTables t, int64_t V, int32_t cols,
                                                                const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
-  const int lane = threadIdx.x & 63;
-  for (int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); v < V; v += (int64_t)gridDim.x * 4) {
-    const int k = upper_slot(t.node_off_b, t.K, v);
-    const int64_t vd = v - t.node_off_b[k] + t.node_off_d[t.ids[k]];
-    const uint32_t* __restrict__ s = src + vd * cols;
-    uint32_t* __restrict__ d = dst + v * cols;
-    for (int c = lane; c < cols; c += 64) d[c] = s[c];
+  __shared__ int first_slot;
+  const int64_t total = V * cols;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < total; base += (int64_t)gridDim.x * 1024) {
+    if (threadIdx.x == 0) {
+      int lo = 0, hi = t.K;              // invariant: node_off_b[lo] * cols <= base < node_off_b[hi] * cols
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.node_off_b[mid] * cols <= base) lo = mid; else hi = mid;
+      }
+      first_slot = lo;
+    }
+    __syncthreads();
+    int k = first_slot;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = base + threadIdx.x + 256 * e;      // 256 consecutive elements per pass: coalesced
+      if (i < total) {
+        while (i >= t.node_off_b[k + 1] * cols) ++k;
+        dst[i] = src[(t.node_off_d[t.ids[k]] - t.node_off_b[k]) * cols + i];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -180,7 +218,7 @@ int relgnn_batch_gather(const int64_t* ids, int32_t num_batch_graphs, int32_t nu
   for (int p = 0; p < n_payloads; ++p) {
     if (h_payload_cols[p] <= 0) continue;
     if (!h_payload_d[p] || !h_payload_b[p]) return RELGNN_EINVAL;
-    gather_node_rows_kernel<<<flat_grid(num_nodes * 64, 256), 256, 0, st>>>(
+    gather_node_rows_kernel<<<flat_grid((num_nodes * h_payload_cols[p] + 3) / 4, 256), 256, 0, st>>>(
         t, num_nodes, h_payload_cols[p], (const uint32_t*)h_payload_d[p], (uint32_t*)h_payload_b[p]);
   }
   if (deg_b || node_to_graph) {
@@ -230,7 +268,7 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
     if (!col_t_d || !frow_s_d || !tgt_s) return RELGNN_EINVAL;
     if (!full && !src_t) return RELGNN_EINVAL;      // a lean call that produces nothing by target
     if ((w_t && !w_t_d) || (w_s && !w_s_d)) return RELGNN_EINVAL;
-    const dim3 grid = flat_grid(num_messages, 256);
+    const dim3 grid = flat_grid((num_messages + 3) / 4, 256);
     if (full) {
       assemble_by_target_kernel<true><<<grid, 256, 0, st>>>(t, num_messages, perm_t_d, col_t_d, perm_t, col_t, inv_perm_t,
                                                             w_t_d, src_t, w_t);
