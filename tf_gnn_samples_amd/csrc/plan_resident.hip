@@ -57,16 +57,21 @@ __global__ __launch_bounds__(256) void assemble_by_target_kernel(
     if (threadIdx.x == 0) first_slot = upper_slot(t.msg_off_b, t.K, base);
     __syncthreads();
     int k = first_slot;
+    int64_t g = t.ids[k], slot_end = t.msg_off_b[k + 1];                        // per-slot constants stay in registers
+    int64_t msg_delta = t.msg_off_d[g] - t.msg_off_b[k], node_delta = t.node_off_b[k] - t.node_off_d[g];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t p = base + threadIdx.x + 256 * e;
       if (p >= M) break;
-      while (p >= t.msg_off_b[k + 1]) ++k;
-      const int64_t g = t.ids[k];
-      const int64_t pd = t.msg_off_d[g] + (p - t.msg_off_b[k]);
+      if (p >= slot_end) {
+        do { ++k; } while (p >= t.msg_off_b[k + 1]);
+        g = t.ids[k]; slot_end = t.msg_off_b[k + 1];
+        msg_delta = t.msg_off_d[g] - t.msg_off_b[k]; node_delta = t.node_off_b[k] - t.node_off_d[g];
+      }
+      const int64_t pd = p + msg_delta;
       const uint32_t c = (uint32_t)col_d[pd];
       const uint32_t cn = c / (uint32_t)t.L;
-      const int64_t src = (int64_t)cn - t.node_off_d[g] + t.node_off_b[k];
+      const int64_t src = (int64_t)cn + node_delta;
       if (src_b) src_b[p] = (int32_t)src;            // source NODE per by-target position (row of the state table)
       if (w_t_b) w_t_b[p] = w_t_d[pd];                // per-message scale: a property of the graph, not of the batch
       if constexpr (FULL) {
@@ -91,23 +96,28 @@ __global__ __launch_bounds__(256) void assemble_by_source_kernel(
     if (threadIdx.x == 0) first_slot = upper_slot(t.msg_off_b, t.K, base);
     __syncthreads();
     int k = first_slot;
+    int64_t g = t.ids[k], slot_end = t.msg_off_b[k + 1];
+    int64_t msg_delta = t.msg_off_d[g] - t.msg_off_b[k], node_delta = t.node_off_b[k] - t.node_off_d[g];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t q = base + threadIdx.x + 256 * e;
       if (q >= M) break;
-      while (q >= t.msg_off_b[k + 1]) ++k;
-      const int64_t g = t.ids[k];
-      const int64_t qd = t.msg_off_d[g] + (q - t.msg_off_b[k]);
+      if (q >= slot_end) {
+        do { ++k; } while (q >= t.msg_off_b[k + 1]);
+        g = t.ids[k]; slot_end = t.msg_off_b[k + 1];
+        msg_delta = t.msg_off_d[g] - t.msg_off_b[k]; node_delta = t.node_off_b[k] - t.node_off_d[g];
+      }
+      const int64_t qd = q + msg_delta;
       const uint32_t f = (uint32_t)frow_d[qd];
       const uint32_t fn = f / (uint32_t)t.L;
-      const int64_t tgt = (int64_t)fn - t.node_off_d[g] + t.node_off_b[k];
+      const int64_t tgt = (int64_t)fn + node_delta;
       tgt_b[q] = (int32_t)tgt;
       if (w_s_b) w_s_b[q] = w_s_d[qd];
       if constexpr (FULL) {
         const int l = (int)(f - fn * (uint32_t)t.L);
         frow_b[q] = (int32_t)(tgt * t.L + l);
         perm_b[q] = translate_message(t, perm_d[qd], l, k, g);
-        pos_b[q] = (int32_t)((int64_t)pos_d[qd] - t.msg_off_d[g] + t.msg_off_b[k]);
+        pos_b[q] = (int32_t)((int64_t)pos_d[qd] - msg_delta);
       }
     }
     __syncthreads();
@@ -156,12 +166,18 @@ __global__ __launch_bounds__(256) void gather_node_rows_kernel(BatchTables t, in
     }
     __syncthreads();
     int k = first_slot;
+    int64_t slot_end = t.node_off_b[k + 1] * cols;                               // per-slot constants stay in registers
+    int64_t delta = (t.node_off_d[t.ids[k]] - t.node_off_b[k]) * cols;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t i = base + threadIdx.x + 256 * e;      // 256 consecutive elements per pass: coalesced
       if (i < total) {
-        while (i >= t.node_off_b[k + 1] * cols) ++k;
-        dst[i] = src[(t.node_off_d[t.ids[k]] - t.node_off_b[k]) * cols + i];
+        if (i >= slot_end) {
+          do { ++k; } while (i >= t.node_off_b[k + 1] * cols);
+          slot_end = t.node_off_b[k + 1] * cols;
+          delta = (t.node_off_d[t.ids[k]] - t.node_off_b[k]) * cols;
+        }
+        dst[i] = src[delta + i];
       }
     }
     __syncthreads();
