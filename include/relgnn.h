@@ -683,6 +683,13 @@ int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t 
 int64_t relgnn_gemm_tn_stream_workspace_bytes(int32_t M, int32_t N, int64_t K);
 int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
                               int64_t K, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/*
+ * The closing pass of a split-K weight gradient: C[M, N] = sum over `num_slabs` partial products slabs[z] (each [M, N],
+ * contiguous, summed in slab order) + At[R, M]^T @ Bt[R, N] for the R rows (R < one chunk, typically < 64) that the equal
+ * chunks left over.  One launch instead of a sum, a second product and an accumulate.
+ */
+int relgnn_sum_slabs_tail_f32(const float* slabs, int32_t num_slabs, int32_t M, int32_t N, const float* At, int64_t lda,
+                              const float* Bt, int64_t ldb, int32_t R, float* C, void* stream);
 
 /* ========================================================================== *
  * 11. Dynamic per-target convolution kernels  (gnns/rgdcn.py:126-160)

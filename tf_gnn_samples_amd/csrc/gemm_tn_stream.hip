@@ -208,6 +208,28 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   }
 }
 
+// C[m, n] = sum_z slabs[z][m][n] (slab order) + sum_{r < R} At[r][m] * Bt[r][n]: the reduction of a split-K weight gradient
+// whose chunks left R < 64 rows over (V = S * c + R), folded into the pass that sums the partial products anyway
+// (library strided-batched GEMM + torch.sum + a second product for the leftover rows were three launches).
+__global__ __launch_bounds__(256) void sum_slabs_tail_kernel(const float* __restrict__ slabs, int32_t S, int64_t mn, int32_t N,
+                                                             const float* __restrict__ At, int64_t lda,
+                                                             const float* __restrict__ Bt, int64_t ldb, int32_t R,
+                                                             float* __restrict__ C) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= mn) return;
+  float s0 = 0.f, s1 = 0.f;
+  int z = 0;
+  for (; z + 1 < S; z += 2) {
+    s0 += slabs[(int64_t)z * mn + i];
+    s1 += slabs[(int64_t)(z + 1) * mn + i];
+  }
+  if (z < S) s0 += slabs[(int64_t)z * mn + i];
+  float s = s0 + s1;
+  const int64_t m = i / N, n = i - m * N;
+  for (int r = 0; r < R; ++r) s = fmaf(At[(int64_t)r * lda + m], Bt[(int64_t)r * ldb + n], s);
+  C[i] = s;
+}
+
 struct Plan {
   int32_t tiles_m, tiles_n, tiles, chunks;
   int64_t chunk_rows;
@@ -268,6 +290,16 @@ int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64
 #undef RELGNN_TN_LAUNCH
   const int64_t mn = (int64_t)M * N;
   sum_partials_kernel<<<(unsigned)((mn + 63) / 64), 256, 0, st>>>(partial, mn, p.chunks, N, C, ldc, accumulate);
+  return launch_status();
+}
+
+int relgnn_sum_slabs_tail_f32(const float* slabs, int32_t num_slabs, int32_t M, int32_t N, const float* At, int64_t lda,
+                              const float* Bt, int64_t ldb, int32_t R, float* C, void* stream) {
+  if (num_slabs < 0 || M < 0 || N < 0 || R < 0) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!C || (num_slabs > 0 && !slabs) || (R > 0 && (!At || !Bt || lda < M || ldb < N))) return RELGNN_EINVAL;
+  const int64_t mn = (int64_t)M * N;
+  sum_slabs_tail_kernel<<<(unsigned)((mn + 255) / 256), 256, 0, as_stream(stream)>>>(slabs, num_slabs, mn, N, At, lda, Bt, ldb, R, C);
   return launch_status();
 }
 

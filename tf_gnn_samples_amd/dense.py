@@ -208,14 +208,14 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         _lib.check(lib.relgnn_blaslt_gemm_f32(GEMM_TN, _lib.ACT_LINEAR, _lib.ptr(a), M, _lib.ptr(b), N, None, _lib.ptr(parts), N, M, N, c, S,
                                               c * M, c * N, M * N, 0, _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                    "relgnn_blaslt_gemm_f32")
-        out = parts.sum(0)
-        if head < V:
-            # the < c leftover rows: a few (often < 64) rows against a wide output — the library's pick for that shape took
-            # 191 us at [16, 128]^T @ [16, 640] (C3 timeline); the streaming kernel accumulates them in ~15 us
-            if _STREAM_TN:
-                tn_stream_gemm(a[head:], b[head:], out=out)
-            else:
-                lib_gemm(GEMM_TN, a[head:], b[head:], out=out, accumulate=True)
+        # the partial products are summed in slab order and the < S leftover rows (V = S * c + R) are multiplied in by the
+        # same pass (relgnn_sum_slabs_tail_f32): torch.sum + a second product + an accumulate were three launches, and the
+        # library's pick for a [16, 128]^T @ [16, 640] leftover took 191 us (C3 timeline)
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        R = V - head
+        _lib.check(lib.relgnn_sum_slabs_tail_f32(_lib.ptr(parts), S, M, N, _lib.ptr(a[head:]) if R else None, M,
+                                                 _lib.ptr(b[head:]) if R else None, N, R, _lib.ptr(out),
+                                                 _lib.current_stream()), "relgnn_sum_slabs_tail_f32")
         return out
     out = torch.bmm(a[:head].view(S, c, M).transpose(1, 2), b[:head].view(S, c, N)).sum(0)
     if head < V:
