@@ -14,8 +14,19 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict
   const int64_t chunk = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
   float acc = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + rg; r < r1; r += 4) acc += X[r * ld + c];
+  if (c < cols) {
+    // four independent loads in flight per thread (the one-load-per-iteration form was latency-bound: 19.5 us for [36 k, 121])
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t r = r0 + rg;
+    for (; r + 12 < r1; r += 16) {
+      a0 += X[r * ld + c];
+      a1 += X[(r + 4) * ld + c];
+      a2 += X[(r + 8) * ld + c];
+      a3 += X[(r + 12) * ld + c];
+    }
+    for (; r < r1; r += 4) a0 += X[r * ld + c];
+    acc = (a0 + a1) + (a2 + a3);
+  }
   red[rg][cx] = acc;
   __syncthreads();
   if (rg == 0 && c < cols) partial[(int64_t)blockIdx.x * cols + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
@@ -27,7 +38,7 @@ extern "C" {
 
 size_t relgnn_column_sum_workspace_bytes(int64_t rows, int32_t cols) {
   (void)rows;
-  return (size_t)128 * (size_t)(cols > 0 ? cols : 1) * sizeof(float);
+  return (size_t)512 * (size_t)(cols > 0 ? cols : 1) * sizeof(float);
 }
 
 int relgnn_column_sum(const float* X, int64_t rows, int32_t cols, int64_t ld, float* out, void* workspace,
@@ -42,7 +53,7 @@ int relgnn_column_sum(const float* X, int64_t rows, int32_t cols, int64_t ld, fl
   }
   if (!X || !workspace) return RELGNN_EINVAL;
   if (workspace_bytes < relgnn_column_sum_workspace_bytes(rows, cols)) return RELGNN_ENOSPC;
-  const unsigned nblk = (unsigned)((rows + 255) / 256 < 128 ? (rows + 255) / 256 : 128);
+  const unsigned nblk = (unsigned)((rows + 63) / 64 < 512 ? (rows + 63) / 64 : 512);
   dim3 grid(nblk, (unsigned)((cols + 63) / 64));
   float* partial = static_cast<float*>(workspace);
   column_sum_kernel<<<grid, 256, 0, st>>>(X, rows, cols, ld, partial);
