@@ -461,14 +461,16 @@ def test_rgdcn_model_trains(gpu_device):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize("D", [128, 256])
 @pytest.mark.parametrize("layer", ["film", "edge_mlp0"])
-def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer):
+def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer, D):
     """The by-source backward has two implementations: gather-reduce of per-message gradients emitted by the by-target
-    pass (default) and the pass that re-gathers the per-bucket rows per message (RELGNN_EDGE_BWD_REGATHER=1,
-    relgnn_film_bwd_msg / relgnn_pair_bwd_p).  Same gradients from both."""
+    pass and the pass that re-gathers the per-bucket rows per message (relgnn_film_bwd_msg / relgnn_pair_bwd_p);
+    ops._FusedEdgeMessages picks by geometry, RELGNN_EDGE_BWD=emit|regather forces one.  Same gradients from both, for
+    the lane-group kernels (D = 128) and the wave kernels (D = 256, both MU variants)."""
     from tf_gnn_samples_amd.gnns import sparse_gnn_edge_mlp_layer, sparse_gnn_film_layer
     rng, adj, deg = _graph(21)
-    V, L, D = 150, 3, 128
+    V, L = 150, 3
     h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
     if layer == "film":
         w = dict(rgcn_weights(rng, L, D, D), **LN(D))
@@ -480,11 +482,8 @@ def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer):
         fn = lambda x, ww, a, d: sparse_gnn_edge_mlp_layer(x, a, d, D, 1, "elu", "sum", True, True, 0, weights=ww)
     adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
     grads = []
-    for flag in (None, "1"):
-        if flag is None:
-            monkeypatch.delenv("RELGNN_EDGE_BWD_REGATHER", raising=False)
-        else:
-            monkeypatch.setenv("RELGNN_EDGE_BWD_REGATHER", flag)
+    for flag in ("emit", "regather"):
+        monkeypatch.setenv("RELGNN_EDGE_BWD", flag)
         hd = torch.as_tensor(h, device=gpu_device).requires_grad_(True)
         wd = {k: torch.as_tensor(v, device=gpu_device).requires_grad_(True) for k, v in w.items()}
         out = fn(hd, wd, adj_d, deg_d)

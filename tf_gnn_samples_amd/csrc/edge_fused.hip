@@ -12,6 +12,8 @@
 // Lanes run across features (float4 per lane).  G lanes per node: 64 (D > 128) or 32/16/8,
 // NCH float4 chunks per lane (D <= 1024).  Bound: HBM / Infinity-Cache bandwidth;
 // algorithmic bytes: M*(4D+8) + S_nonempty*rowbytes + V*4D.
+#include <type_traits>
+
 #include "common.h"
 
 using namespace relgnn;
@@ -24,37 +26,38 @@ constexpr int PU = 4;  // messages in flight per lane group
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 
-// The activation id is a wave-uniform RUNTIME value (one uniform branch per message; the kernels are
-// memory-bound) so that the kernel count stays at geometry x kind instead of x 7 activations.
+// The activation id is a wave-uniform RUNTIME value (one uniform branch per message) so that the kernel count stays at
+// geometry x kind instead of x 7 activations.  Evaluated once per message and feature, so the v_exp / v_rcp based
+// variants of common.h: with the library erff the GELU kernels were ALU-bound (Edge-MLP0 forward 681 us vs 249 us with ReLU).
 template <int ACT>
 __device__ __forceinline__ float4 act4_t(float4 x) {
-  return make_float4(act_fwd<ACT>(x.x), act_fwd<ACT>(x.y), act_fwd<ACT>(x.z), act_fwd<ACT>(x.w));
+  return make_float4(act_fwd_fast<ACT>(x.x), act_fwd_fast<ACT>(x.y), act_fwd_fast<ACT>(x.z), act_fwd_fast<ACT>(x.w));
 }
 template <int ACT>
 __device__ __forceinline__ float4 actg4_t(float4 x) {
-  return make_float4(act_grad<ACT>(x.x), act_grad<ACT>(x.y), act_grad<ACT>(x.z), act_grad<ACT>(x.w));
+  return make_float4(act_grad_fast<ACT>(x.x), act_grad_fast<ACT>(x.y), act_grad_fast<ACT>(x.z), act_grad_fast<ACT>(x.w));
 }
-__device__ __forceinline__ float4 act4(int act, float4 x) {
+// Runs f(integral_constant<ACT>) for the runtime activation id: ONE wave-uniform switch per batch of messages, the
+// batch's loop nest is then straight-line code of that activation (a switch per message and float4 put seven inlined
+// activations between any two loads of the unrolled loop).
+template <class F>
+__device__ __forceinline__ void with_act(int act, F&& f) {
   switch (act) {
-    case RELGNN_ACT_TANH: return act4_t<RELGNN_ACT_TANH>(x);
-    case RELGNN_ACT_RELU: return act4_t<RELGNN_ACT_RELU>(x);
-    case RELGNN_ACT_LEAKY_RELU: return act4_t<RELGNN_ACT_LEAKY_RELU>(x);
-    case RELGNN_ACT_ELU: return act4_t<RELGNN_ACT_ELU>(x);
-    case RELGNN_ACT_SELU: return act4_t<RELGNN_ACT_SELU>(x);
-    case RELGNN_ACT_GELU: return act4_t<RELGNN_ACT_GELU>(x);
-    default: return x;
+    case RELGNN_ACT_TANH: f(std::integral_constant<int, RELGNN_ACT_TANH>{}); break;
+    case RELGNN_ACT_RELU: f(std::integral_constant<int, RELGNN_ACT_RELU>{}); break;
+    case RELGNN_ACT_LEAKY_RELU: f(std::integral_constant<int, RELGNN_ACT_LEAKY_RELU>{}); break;
+    case RELGNN_ACT_ELU: f(std::integral_constant<int, RELGNN_ACT_ELU>{}); break;
+    case RELGNN_ACT_SELU: f(std::integral_constant<int, RELGNN_ACT_SELU>{}); break;
+    case RELGNN_ACT_GELU: f(std::integral_constant<int, RELGNN_ACT_GELU>{}); break;
+    default: f(std::integral_constant<int, RELGNN_ACT_LINEAR>{}); break;
   }
 }
+// per-call form (one switch per float4): the lane-group by-target backward keeps it — hoisting the switch there costs
+// 12 VGPRs (96 -> 108), i.e. one resident wave per SIMD, and 20 % of the kernel at the C5 shape (675 -> 810 us)
 __device__ __forceinline__ float4 actg4(int act, float4 x) {
-  switch (act) {
-    case RELGNN_ACT_TANH: return actg4_t<RELGNN_ACT_TANH>(x);
-    case RELGNN_ACT_RELU: return actg4_t<RELGNN_ACT_RELU>(x);
-    case RELGNN_ACT_LEAKY_RELU: return actg4_t<RELGNN_ACT_LEAKY_RELU>(x);
-    case RELGNN_ACT_ELU: return actg4_t<RELGNN_ACT_ELU>(x);
-    case RELGNN_ACT_SELU: return actg4_t<RELGNN_ACT_SELU>(x);
-    case RELGNN_ACT_GELU: return actg4_t<RELGNN_ACT_GELU>(x);
-    default: return make_float4(1.f, 1.f, 1.f, 1.f);
-  }
+  float4 r;
+  with_act(act, [&](auto a_tag) { r = actg4_t<decltype(a_tag)::value>(x); });
+  return r;
 }
 __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -133,15 +136,18 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(
         for (int u = 0; u < PU; ++u)
 #pragma unroll
           for (int c = 0; c < NCH; ++c) t[u][c] = T[(int64_t)r[u] * ldt4 + cc[c]];
+        with_act(act, [&](auto a_tag) {
+          constexpr int ACT = decltype(a_tag)::value;
 #pragma unroll
-        for (int u = 0; u < PU; ++u)
-          if (p + u < e) {
+          for (int u = 0; u < PU; ++u)
+            if (p + u < e) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              const float4 m = act4(act, pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
-              acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
+              for (int c = 0; c < NCH; ++c) {
+                const float4 m = act4_t<ACT>(pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+                acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
+              }
             }
-          }
+        });
       }
     }
     b = e;
@@ -292,16 +298,19 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_kernel(
         rb[u][c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
         g[u][c] = gagg[(int64_t)tg[u] * ldg4 + cc[c]];
       }
+    with_act(act, [&](auto a_tag) {
+      constexpr int ACT = decltype(a_tag)::value;
 #pragma unroll
-    for (int u = 0; u < PU; ++u)
-      if (q + u < e) {
+      for (int u = 0; u < PU; ++u)
+        if (q + u < e) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const float4 gp = g[u][c] * actg4(act, pre_act<KIND>(ww[u], t[c], ra[u][c], rb[u][c]));
-          if constexpr (KIND == KIND_FILM) acc[c] = acc[c] + ww[u] * (ra[u][c] * gp);
-          else acc[c] = acc[c] + ww[u] * gp;
+          for (int c = 0; c < NCH; ++c) {
+            const float4 gp = g[u][c] * actg4_t<ACT>(pre_act<KIND>(ww[u], t[c], ra[u][c], rb[u][c]));
+            if constexpr (KIND == KIND_FILM) acc[c] = acc[c] + ww[u] * (ra[u][c] * gp);
+            else acc[c] = acc[c] + ww[u] * gp;
+          }
         }
-      }
+    });
   }
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -373,15 +382,18 @@ __global__ __launch_bounds__(256) void edge_fwd_wave_kernel(
               for (int c = 0; c < NCH; ++c) t[u][c] = row[cc[c]];
             }
           }
+          with_act(act, [&](auto a_tag) {
+            constexpr int ACT = decltype(a_tag)::value;
 #pragma unroll
-          for (int u = 0; u < WU; ++u)
-            if (u < rem) {
+            for (int u = 0; u < WU; ++u)
+              if (u < rem) {
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                const float4 m = act4(act, pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
-                acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
+                for (int c = 0; c < NCH; ++c) {
+                  const float4 m = act4_t<ACT>(pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+                  acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
+                }
               }
-            }
+          });
         }
       }
     }
@@ -453,22 +465,25 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
               for (int c = 0; c < NCH; ++c) t[u][c] = row[cc[c]];
             }
           }
+          with_act(act, [&](auto a_tag) {
+            constexpr int ACT = decltype(a_tag)::value;
 #pragma unroll
-          for (int u = 0; u < WU; ++u)
-            if (u < rem) {
+            for (int u = 0; u < WU; ++u)
+              if (u < rem) {
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                const float4 gp = g[c] * actg4(act, pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
-                if constexpr (KIND == KIND_FILM) {
-                  s1[c] = s1[c] + gp * (ww[u] * t[u][c]);
-                  s2[c] = s2[c] + gp;
-                } else {
-                  s1[c] = s1[c] + ww[u] * gp;
+                for (int c = 0; c < NCH; ++c) {
+                  const float4 gp = g[c] * actg4_t<ACT>(pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+                  if constexpr (KIND == KIND_FILM) {
+                    s1[c] = s1[c] + gp * (ww[u] * t[u][c]);
+                    s2[c] = s2[c] + gp;
+                  } else {
+                    s1[c] = s1[c] + ww[u] * gp;
+                  }
+                  if (dmsg && on[c])
+                    dmsg[(int64_t)(p + k + u) * D4 + lane + 64 * c] = (KIND == KIND_FILM) ? ww[u] * (ra[c] * gp) : ww[u] * gp;
                 }
-                if (dmsg && on[c])
-                  dmsg[(int64_t)(p + k + u) * D4 + lane + 64 * c] = (KIND == KIND_FILM) ? ww[u] * (ra[c] * gp) : ww[u] * gp;
               }
-            }
+          });
         }
       }
     }
@@ -487,14 +502,13 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
 }
 
 // by-(source,type) rows: one wave per row r of T; per message the bucket row A[frow] and the target's gagg row
-// are gathered (scalar bases), 4 messages (8..12 row loads) in flight.
-template <int NCH, int KIND>
+// are gathered (scalar bases), MU messages (2-3 row loads each) in flight.
+template <int NCH, int KIND, int MU>
 __global__ __launch_bounds__(256) void edge_bwd_msgs_wave_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr_b, int64_t n_rows, const int32_t* __restrict__ tgt_b,
     const int32_t* __restrict__ frow_b, const float* __restrict__ w_b, const float4* __restrict__ gagg,
     int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int32_t act, int64_t nlb, const int32_t* __restrict__ trow) {
-  constexpr int MU = 4;
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
@@ -541,16 +555,19 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_wave_kernel(
           }
         }
       }
+      with_act(act, [&](auto a_tag) {
+        constexpr int ACT = decltype(a_tag)::value;
 #pragma unroll
-      for (int u = 0; u < MU; ++u)
-        if (u < rem) {
+        for (int u = 0; u < MU; ++u)
+          if (u < rem) {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const float4 gp = g[u][c] * actg4(act, pre_act<KIND>(ww[u], t[c], ra[u][c], rb[u][c]));
-            if constexpr (KIND == KIND_FILM) acc[c] = acc[c] + ww[u] * (ra[u][c] * gp);
-            else acc[c] = acc[c] + ww[u] * gp;
+            for (int c = 0; c < NCH; ++c) {
+              const float4 gp = g[u][c] * actg4_t<ACT>(pre_act<KIND>(ww[u], t[c], ra[u][c], rb[u][c]));
+              if constexpr (KIND == KIND_FILM) acc[c] = acc[c] + ww[u] * (ra[u][c] * gp);
+              else acc[c] = acc[c] + ww[u] * gp;
+            }
           }
-        }
+      });
     }
   }
 #pragma unroll
@@ -571,15 +588,18 @@ __global__ __launch_bounds__(256) void pair_materialize_kernel(int32_t act,
     const int32_t* __restrict__ row_src, const int32_t* __restrict__ row_tgt, int64_t M,
     const float4* __restrict__ ghidden, float4* __restrict__ out, int64_t ldo4) {
   const int64_t total = M * D4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / D4;
-    const int c = (int)(i - m * D4);
-    float4 pre = P[(int64_t)row_src[m] * ldp4 + c];
-    if (Q) pre = pre + Q[(int64_t)row_tgt[m] * ldq4 + c];
-    if constexpr (GRAD) out[m * ldo4 + c] = ghidden[m * ldo4 + c] * actg4(act, pre);
-    else out[m * ldo4 + c] = act4(act, pre);
-  }
+  with_act(act, [&](auto a_tag) {
+    constexpr int ACT = decltype(a_tag)::value;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t m = i / D4;
+      const int c = (int)(i - m * D4);
+      float4 pre = P[(int64_t)row_src[m] * ldp4 + c];
+      if (Q) pre = pre + Q[(int64_t)row_tgt[m] * ldq4 + c];
+      if constexpr (GRAD) out[m * ldo4 + c] = ghidden[m * ldo4 + c] * actg4_t<ACT>(pre);
+      else out[m * ldo4 + c] = act4_t<ACT>(pre);
+    }
+  });
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
@@ -685,10 +705,22 @@ int launch_bwd_msgs(int32_t act, const float* T, int64_t ldt, const float* A, in
   if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
   if (geo.G == 64 && n_rows * (lda / 4) < ((int64_t)1 << 32) && n_rows * (ldg / 4) < ((int64_t)1 << 32)) {
     const int64_t wnlb = (n_rows + 3) / 4;
+    // messages in flight per wave: RELGNN_EDGE_MSGS_MU = 4 (default) | 8.  Measured at the C2 shape: 8 does not pay —
+    // the extra registers cost as many resident waves as the unroll adds loads (FiLM 7.51 vs 7.52 ms per step,
+    // pair messages 9.02 vs 8.77 ms).
+    static const int mu_env = [] { const char* e = getenv("RELGNN_EDGE_MSGS_MU"); return e ? atoi(e) : 0; }();
+    const int mu = mu_env == 8 ? 8 : 4;
 #define EDGE_MSGS_WAVE(NN)                                                                                          \
-  edge_bwd_msgs_wave_kernel<NN, KIND><<<padded_grid(wnlb), 256, 0, st>>>(                                            \
-      (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,             \
-      (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, wnlb, trow)
+  do {                                                                                                              \
+    if (mu == 8)                                                                                                    \
+      edge_bwd_msgs_wave_kernel<NN, KIND, 8><<<padded_grid(wnlb), 256, 0, st>>>(                                     \
+          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,         \
+          (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, wnlb, trow);                                     \
+    else                                                                                                            \
+      edge_bwd_msgs_wave_kernel<NN, KIND, 4><<<padded_grid(wnlb), 256, 0, st>>>(                                     \
+          (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr_b, n_rows, tgt_b, frow_b, w_b,         \
+          (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, act, wnlb, trow);                                     \
+  } while (0)
     if (geo.NCH == 1) EDGE_MSGS_WAVE(1); else if (geo.NCH == 2) EDGE_MSGS_WAVE(2); else EDGE_MSGS_WAVE(4);
 #undef EDGE_MSGS_WAVE
     return launch_status();

@@ -46,6 +46,19 @@ __device__ __forceinline__ float act_apply(int act, float x) {
   }
 }
 
+// per-MESSAGE activation (Edge-MLP messages): the v_exp / v_rcp based variants of common.h
+__device__ __forceinline__ float msg_act_apply(int act, float x) {
+  switch (act) {
+    case RELGNN_ACT_TANH: return act_fwd_fast<RELGNN_ACT_TANH>(x);
+    case RELGNN_ACT_RELU: return act_fwd_fast<RELGNN_ACT_RELU>(x);
+    case RELGNN_ACT_LEAKY_RELU: return act_fwd_fast<RELGNN_ACT_LEAKY_RELU>(x);
+    case RELGNN_ACT_ELU: return act_fwd_fast<RELGNN_ACT_ELU>(x);
+    case RELGNN_ACT_SELU: return act_fwd_fast<RELGNN_ACT_SELU>(x);
+    case RELGNN_ACT_GELU: return act_fwd_fast<RELGNN_ACT_GELU>(x);
+    default: return x;
+  }
+}
+
 template <bool IS_MAX, bool MSGACT = false>
 __device__ __forceinline__ void combine(float4& acc, float w, const float4& v, int msg_act = RELGNN_ACT_LINEAR) {
   // product and add are rounded separately (file is built with -ffp-contract=off):
@@ -53,8 +66,8 @@ __device__ __forceinline__ void combine(float4& acc, float w, const float4& v, i
   float4 m = make_float4(w * v.x, w * v.y, w * v.z, w * v.w);
   if constexpr (MSGACT) {  // activation applied to every message BEFORE the reduction (separate instantiation:
                            // the default kernel must not pay for the extra argument / branch — measured +42 %)
-    m.x = act_apply(msg_act, m.x); m.y = act_apply(msg_act, m.y);
-    m.z = act_apply(msg_act, m.z); m.w = act_apply(msg_act, m.w);
+    m.x = msg_act_apply(msg_act, m.x); m.y = msg_act_apply(msg_act, m.y);
+    m.z = msg_act_apply(msg_act, m.z); m.w = msg_act_apply(msg_act, m.w);
   }
   if constexpr (IS_MAX) {
     acc.x = fmaxf(acc.x, m.x); acc.y = fmaxf(acc.y, m.y);
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256) void seg_reduce_scalar_kernel(
   for (int d = lane; d < D; d += 64) {
     float acc = IS_MAX ? -FLT_MAX : 0.f;
     for (int p = beg; p < end; ++p) {
-      float m = act_apply(msg_act, (w ? w[p] : 1.f) * X[(int64_t)col[p] * ldx + d]);
+      float m = msg_act_apply(msg_act, (w ? w[p] : 1.f) * X[(int64_t)col[p] * ldx + d]);
       acc = IS_MAX ? fmaxf(acc, m) : acc + m;
     }
     float nrm = (float)max(end - beg, 1);
@@ -343,8 +356,8 @@ __global__ __launch_bounds__(256) void msg_act_bwd_kernel(int32_t act, const flo
     switch (act) {
 #define RELGNN_CASE(A)                                                                                             \
   case A:                                                                                                         \
-    r = make_float4(wm * act_grad<A>(wm * x.x) * g.x, wm * act_grad<A>(wm * x.y) * g.y, wm * act_grad<A>(wm * x.z) * g.z, \
-                    wm * act_grad<A>(wm * x.w) * g.w);                                                             \
+    r = make_float4(wm * act_grad_fast<A>(wm * x.x) * g.x, wm * act_grad_fast<A>(wm * x.y) * g.y,                   \
+                    wm * act_grad_fast<A>(wm * x.z) * g.z, wm * act_grad_fast<A>(wm * x.w) * g.w);              \
     break;
       RELGNN_CASE(RELGNN_ACT_TANH) RELGNN_CASE(RELGNN_ACT_RELU) RELGNN_CASE(RELGNN_ACT_LEAKY_RELU)
       RELGNN_CASE(RELGNN_ACT_ELU) RELGNN_CASE(RELGNN_ACT_SELU) RELGNN_CASE(RELGNN_ACT_GELU)

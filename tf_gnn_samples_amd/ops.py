@@ -305,10 +305,17 @@ class _FusedEdgeMessages(torch.autograd.Function):
             # compact tables: every real row is written by the kernels; the few padding rows are not and feed the
             # batched weight-gradient GEMM (against all-zero inputs, but 0 * NaN garbage would still poison it)
             gA.index_fill_(0, pairs.tgt.pad_rows, 0.0)
-        # Pass A (by target) also emits every message's gradient w.r.t. its gathered row; gT is then one plain
-        # gather-reduce of those rows over the by-source buckets.  (The alternative pass B re-gathers the per-bucket
-        # row -- 8D bytes for FiLM -- once per MESSAGE in by-source order: RELGNN_EDGE_BWD_REGATHER=1 keeps it.)
-        emit = os.environ.get("RELGNN_EDGE_BWD_REGATHER") is None
+        # Two ways to the gradient of the gathered rows (RELGNN_EDGE_BWD=emit|regather overrides the choice):
+        #  emit:     pass A (by target) also writes every message's gradient w.r.t. its gathered row ([M, D]); gT is then
+        #            one plain gather-reduce of those rows over the by-source buckets;
+        #  regather: pass B walks the by-source buckets and re-gathers the per-bucket row (8D bytes for FiLM) and the
+        #            target's gradient row once per MESSAGE, recomputing the pre-activation: nothing [M, D] is written.
+        # Measured on MI355X (scripts/bench_configs.py): the wave kernels (D > 128) on dense tables win with regather
+        # (FiLM on the C2 batch: 833 + 426 us -> 330 + 536 us per layer, step 9.06 -> 7.66 ms); the lane-group kernels on
+        # compact pair tables (C5: D = 128, 23 types) with emit (47.4 vs 52.9 ms).
+        choice = os.environ.get("RELGNN_EDGE_BWD") or ("emit" if os.environ.get("RELGNN_EDGE_BWD_REGATHER") is None
+                                                       and (pairs is not None or D <= 128) else "regather")
+        emit = choice == "emit"
         dmsg = torch.empty((graph.M, D), dtype=torch.float32, device=T.device) if emit else None
         if kind == "film":
             col = graph.col_t if pairs is None else pairs.col_t
