@@ -267,3 +267,38 @@ class _DenseFn(torch.autograd.Function):
 def dense(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
     """x @ kernel (+ bias) with a split-K weight gradient."""
     return _DenseFn.apply(x, kernel, bias)
+
+
+class _DenseReluFn(torch.autograd.Function):
+    """relu(x @ kernel (+ bias)): the ReLU rides in the library GEMM's epilogue (one kernel instead of GEMM + clamp), the
+    backward masks the incoming gradient by the saved OUTPUT (relgnn_act_bwd_from_output) and continues as _DenseFn."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        y = lib_gemm(GEMM_NN, x, kernel, bias, relu=True)
+        ctx.save_for_backward(x, kernel, y)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x, kernel, y = ctx.saved_tensors
+        g = g.contiguous()
+        gm = torch.empty_like(g)
+        _lib.check(_lib.load_library().relgnn_act_bwd_from_output(_lib.ACT_RELU, _lib.ptr(y), _lib.ptr(g), g.numel(),
+                                                                  _lib.ptr(gm), _lib.current_stream()),
+                   "relgnn_act_bwd_from_output")
+        gx = lib_gemm(GEMM_NT, gm, kernel) if ctx.needs_input_grad[0] else None
+        gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), gm) \
+            if ctx.needs_input_grad[1] else None
+        gb = column_sum(gm) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gk, gb
+
+
+def dense_relu(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
+    """relu(dense(x, kernel, bias)) as one GEMM with a ReLU epilogue (CUDA fp32 operands; anything else takes the two-step
+    route)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _CACHED_LIB_GEMM):
+        return torch.relu(dense(x, kernel, bias))
+    return _DenseReluFn.apply(x, kernel, bias)

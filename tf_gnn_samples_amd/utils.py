@@ -17,7 +17,7 @@ from typing import Callable, List, Mapping, Optional, Union
 import torch
 
 from . import ops
-from .dense import dense
+from .dense import dense, dense_relu
 
 BIG_NUMBER = 1e7
 SMALL_NUMBER = 1e-7
@@ -321,10 +321,12 @@ class MLP(object):
                 res["%s/%s/bias" % (name, lname)] = ((dims[i + 1],), "zeros")
         return res
 
-    def _dense(self, i, x):
+    def _dense(self, i, x, fused_relu: bool = False):
         lname = self.layer_names(len(self.hidden_layer_sizes) + 1)[i]
         k = self.weights["%s/%s/kernel" % (self.name, lname)]
         b = self.weights["%s/%s/bias" % (self.name, lname)] if self.use_biases else None
+        if fused_relu:
+            return dense_relu(x, k, b)
         return dense(x, k, b)
 
     def __call__(self, input: torch.Tensor) -> torch.Tensor:
@@ -333,5 +335,8 @@ class MLP(object):
         for i in range(n_hidden):
             if self.dropout_rate > 0.0 and self.training:
                 activations = torch.nn.functional.dropout(activations, self.dropout_rate, True)
-            activations = apply_activation(self.activation_fun, self._dense(i, activations))
+            if self.activation_fun is torch.relu:        # the default: ReLU in the GEMM's epilogue
+                activations = self._dense(i, activations, fused_relu=True)
+            else:
+                activations = apply_activation(self.activation_fun, self._dense(i, activations))
         return self._dense(n_hidden, activations)
