@@ -491,13 +491,16 @@ int relgnn_mt_adam_clip_devlr(float* const* h_params, const float* const* h_grad
  * PPI output head in one pass (tasks/ppi_task.py:181-191 + utils/utils.py:61-74):
  *   stats[0] = sum_i sigmoid_cross_entropy_with_logits(logits_i, labels_i)
  *   stats[1..3] = true_pos, false_pos, false_neg of round(sigmoid(logits)) vs int(labels);  stats[4] = micro-F1
- * and the loss gradient  glogits = gscale[0] * (sigmoid(logits) - labels).  n = number of elements.
+ *   stats[5] = mean_scale * stats[0]   (the task's loss: mean_scale = 1 / num_nodes, ppi_task.py:189)
+ * and the loss gradient  glogits = (g_mean[0] * mean_scale + g_total[0]) * (sigmoid(logits) - labels), g_mean / g_total =
+ * device scalars holding the incoming gradients of stats[5] / stats[0] (either may be NULL = 0, not both).
+ * n = number of elements; stats has 6 floats.
  */
 size_t relgnn_sigmoid_ce_stats_workspace_bytes(void);
-int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n, float* stats,
+int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n, float mean_scale, float* stats,
                             void* workspace, size_t workspace_bytes, void* stream);
-int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* gscale,
-                          float* glogits, void* stream);
+int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* g_mean, float mean_scale,
+                          const float* g_total, float* glogits, void* stream);
 
 /* ========================================================================== *
  * 8. GRU cell elementwise halves (node-side; gnns/ggnn.py:92 via utils/utils.py:15-16)

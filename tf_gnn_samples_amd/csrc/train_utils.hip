@@ -108,32 +108,51 @@ __global__ __launch_bounds__(256) void mt_adam_clip_kernel(MtArgs a, const float
 }
 
 // ---- PPI head: sigmoid cross-entropy sum + micro-F1 counts -------------------------------------
-// stats = {sum of losses, true_pos, false_pos, false_neg, micro-F1}
+// stats = {sum of losses, true_pos, false_pos, false_neg, micro-F1, mean_scale * sum of losses}
+struct CeAcc {
+  double loss;
+  int tp, fp, fn;
+};
+
+__device__ __forceinline__ void ce_element(float x, float z, CeAcc& a) {
+  // tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
+  const float e = expf(-fabsf(x));
+  a.loss += (double)(fmaxf(x, 0.f) - x * z + log1pf(e));
+  // round(sigmoid(x)) with round-half-even == (1 / (1 + exp(-x)) > 0.5).  For x <= 0, exp(-x) >= 1 makes the quotient
+  // <= 0.5 in every rounding; for x > 0, exp(-x) is the e above — one exponential serves the loss and the prediction.
+  const bool pred = x > 0.f && (1.f / (1.f + e)) > 0.5f;
+  const int zi = (int)z;
+  a.tp += (pred && zi != 0) ? 1 : 0;
+  a.fp += (pred && zi != 1) ? 1 : 0;
+  a.fn += (!pred && zi != 0) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(1024) void sigmoid_ce_stats_kernel(const float* __restrict__ logits,
                                                                 const float* __restrict__ labels, long long n,
                                                                 double* __restrict__ partial) {
   __shared__ double red[16];
-  double loss = 0.0, tp = 0.0, fp = 0.0, fn = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float x = logits[i], z = labels[i];
-    // tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
-    loss += (double)(fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))));
-    const bool pred = (1.f / (1.f + expf(-x))) > 0.5f;  // round(sigmoid(x)) with round-half-even
-    const int zi = (int)z;
-    tp += (pred && zi != 0) ? 1.0 : 0.0;
-    fp += (pred && zi != 1) ? 1.0 : 0.0;
-    fn += (!pred && zi != 0) ? 1.0 : 0.0;
+  CeAcc a = {0.0, 0, 0, 0};
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+  // 16-byte loads over the aligned body (both arrays are whole allocations), scalar tail
+  const bool vec = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(labels)) & 15) == 0;
+  const long long n4 = vec ? n / 4 : 0;
+  const float4* x4 = reinterpret_cast<const float4*>(logits);
+  const float4* z4 = reinterpret_cast<const float4*>(labels);
+  for (long long i = tid; i < n4; i += nth) {
+    const float4 x = x4[i], z = z4[i];
+    ce_element(x.x, z.x, a); ce_element(x.y, z.y, a); ce_element(x.z, z.z, a); ce_element(x.w, z.w, a);
   }
+  for (long long i = 4 * n4 + tid; i < n; i += nth) ce_element(logits[i], labels[i], a);
   double s;
-  s = block_sum_1024(loss, red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = s;
-  s = block_sum_1024(tp, red);   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = s;
-  s = block_sum_1024(fp, red);   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = s;
-  s = block_sum_1024(fn, red);   if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = s;
+  s = block_sum_1024(a.loss, red);       if (threadIdx.x == 0) partial[blockIdx.x * 4 + 0] = s;
+  s = block_sum_1024((double)a.tp, red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 1] = s;
+  s = block_sum_1024((double)a.fp, red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 2] = s;
+  s = block_sum_1024((double)a.fn, red); if (threadIdx.x == 0) partial[blockIdx.x * 4 + 3] = s;
 }
 
 // 256 threads: thread b holds the four partial sums of block b; fixed-shape tree reduction
 __global__ __launch_bounds__(256) void sigmoid_ce_stats_final_kernel(const double* __restrict__ partial, int nblk,
-                                                                     float* __restrict__ stats) {
+                                                                     float mean_scale, float* __restrict__ stats) {
   __shared__ double red[4][4];
   __shared__ double tot[4];
   const int b = threadIdx.x;
@@ -162,14 +181,18 @@ __global__ __launch_bounds__(256) void sigmoid_ce_stats_final_kernel(const doubl
     const double precision = tot[1] / (tot[1] + tot[2]);
     const double recall = tot[1] / (tot[1] + tot[3]);
     stats[4] = (float)((2.0 * precision * recall) / (precision + recall));
+    stats[5] = (float)tot[0] * mean_scale;      // float32 product, as tf.reduce_sum(...) / num_nodes would round it
   }
 }
 
-// glogits = gscale[0] * (sigmoid(x) - z)
+// glogits = gs * (sigmoid(x) - z),  gs = g_mean[0] * mean_scale + g_total[0]  (either pointer may be null)
 __global__ __launch_bounds__(256) void sigmoid_ce_bwd_kernel(const float* __restrict__ logits,
                                                              const float* __restrict__ labels, long long n,
-                                                             const float* __restrict__ gscale, float* __restrict__ gl) {
-  const float gs = gscale[0];
+                                                             const float* __restrict__ g_mean, float mean_scale,
+                                                             const float* __restrict__ g_total, float* __restrict__ gl) {
+  float gs = 0.f;
+  if (g_mean) gs = g_mean[0] * mean_scale;
+  if (g_total) gs = g_mean ? gs + g_total[0] : g_total[0];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float x = logits[i];
     gl[i] = gs * (1.f / (1.f + expf(-x)) - labels[i]);
@@ -246,8 +269,8 @@ static int mt_adam_clip_impl(float* const* h_params, const float* const* h_grads
 
 size_t relgnn_sigmoid_ce_stats_workspace_bytes(void) { return (size_t)kStatsBlocks * 4 * sizeof(double); }
 
-int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n, float* stats, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n, float mean_scale, float* stats,
+                            void* workspace, size_t workspace_bytes, void* stream) {
   if (n < 0 || !stats) return RELGNN_EINVAL;
   if (!workspace || workspace_bytes < relgnn_sigmoid_ce_stats_workspace_bytes()) return RELGNN_ENOSPC;
   if (n > 0 && (!logits || !labels)) return RELGNN_EINVAL;
@@ -256,16 +279,17 @@ int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n,
   if (nblk < 1) nblk = 1;
   if (nblk > kStatsBlocks) nblk = kStatsBlocks;
   sigmoid_ce_stats_kernel<<<nblk, 1024, 0, st>>>(logits, labels, n, static_cast<double*>(workspace));
-  sigmoid_ce_stats_final_kernel<<<1, 256, 0, st>>>(static_cast<const double*>(workspace), nblk, stats);
+  sigmoid_ce_stats_final_kernel<<<1, 256, 0, st>>>(static_cast<const double*>(workspace), nblk, mean_scale, stats);
   return launch_status();
 }
 
-int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* gscale, float* glogits,
-                          void* stream) {
+int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* g_mean, float mean_scale,
+                          const float* g_total, float* glogits, void* stream) {
   if (n < 0) return RELGNN_EINVAL;
   if (n == 0) return RELGNN_OK;
-  if (!logits || !labels || !gscale || !glogits) return RELGNN_EINVAL;
-  sigmoid_ce_bwd_kernel<<<flat_grid(n, 256), 256, 0, as_stream(stream)>>>(logits, labels, n, gscale, glogits);
+  if (!logits || !labels || (!g_mean && !g_total) || !glogits) return RELGNN_EINVAL;
+  sigmoid_ce_bwd_kernel<<<flat_grid(n, 256), 256, 0, as_stream(stream)>>>(logits, labels, n, g_mean, mean_scale, g_total,
+                                                                          glogits);
   return launch_status();
 }
 

@@ -28,35 +28,34 @@ class _SigmoidCEStats(torch.autograd.Function):
         from .. import _lib
         lib = _lib.load_library()
         logits, labels = logits.contiguous(), labels.contiguous()
-        stats = torch.empty(5, dtype=torch.float32, device=logits.device)
+        stats = torch.empty(6, dtype=torch.float32, device=logits.device)
         nbytes = lib.relgnn_sigmoid_ce_stats_workspace_bytes()
         ws = torch.empty(nbytes // 8, dtype=torch.float64, device=logits.device)
-        _lib.check(lib.relgnn_sigmoid_ce_stats(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), _lib.ptr(stats),
-                                               _lib.ptr(ws), nbytes, _lib.current_stream()), "relgnn_sigmoid_ce_stats")
+        _lib.check(lib.relgnn_sigmoid_ce_stats(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), float(inv_n),
+                                               _lib.ptr(stats), _lib.ptr(ws), nbytes, _lib.current_stream()),
+                   "relgnn_sigmoid_ce_stats")
         ctx.save_for_backward(logits, labels)
-        ctx.inv_n = inv_n
+        ctx.inv_n = float(inv_n)
         ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None, not as a zero tensor
-        total, f1 = stats[0], stats[4]
+        mean, total, f1 = stats[5], stats[0], stats[4]        # (the mean is the kernel's own float32 product)
         counts = stats[1:4]                                   # true_pos, false_pos, false_neg
         ctx.mark_non_differentiable(f1, counts)
-        return total * inv_n, total, f1, counts
+        return mean, total, f1, counts
 
     @staticmethod
     def backward(ctx, g_mean, g_total, g_f1, g_counts):
         from .. import _lib
         lib = _lib.load_library()
         logits, labels = ctx.saved_tensors
-        gscale = None
-        if g_mean is not None:
-            gscale = g_mean * ctx.inv_n
-        if g_total is not None:
-            gscale = g_total if gscale is None else gscale + g_total
-        if gscale is None:
+        if g_mean is None and g_total is None:
             return None, None, None
-        gscale = gscale.reshape(1).to(torch.float32).contiguous()
+
+        def scalar(g):                            # the incoming gradients stay on the device: the kernel reads them
+            return None if g is None else g.reshape(1).to(torch.float32).contiguous()
+        g_mean, g_total = scalar(g_mean), scalar(g_total)
         gl = torch.empty_like(logits)
-        _lib.check(lib.relgnn_sigmoid_ce_bwd(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), _lib.ptr(gscale),
-                                             _lib.ptr(gl), _lib.current_stream()), "relgnn_sigmoid_ce_bwd")
+        _lib.check(lib.relgnn_sigmoid_ce_bwd(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), _lib.ptr(g_mean), ctx.inv_n,
+                                             _lib.ptr(g_total), _lib.ptr(gl), _lib.current_stream()), "relgnn_sigmoid_ce_bwd")
         return gl, None, None
 
 
