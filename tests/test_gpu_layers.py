@@ -462,7 +462,7 @@ def test_rgdcn_model_trains(gpu_device):
 
 
 @pytest.mark.parametrize("D", [128, 256])
-@pytest.mark.parametrize("layer", ["film", "edge_mlp0"])
+@pytest.mark.parametrize("layer", ["film", "edge_mlp0", "edge_mlp1"])
 def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer, D):
     """The by-source backward has two implementations: gather-reduce of per-message gradients emitted by the by-target
     pass and the pass that re-gathers the per-bucket rows per message (relgnn_film_bwd_msg / relgnn_pair_bwd_p);
@@ -477,9 +477,13 @@ def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer, 
         for l in range(L):
             w["Edge_%i_FiLM_Computations/kernel" % l] = glorot(rng, (D, 2 * D))
         fn = lambda x, ww, a, d: sparse_gnn_film_layer(x, a, d, D, 1, "tanh", "mean", True, weights=ww)
-    else:
+    elif layer == "edge_mlp0":
         w = dict({"Edge_%i_MLP/dense/kernel" % l: glorot(rng, (2 * D, D)) for l in range(L)}, **LN(D))
         fn = lambda x, ww, a, d: sparse_gnn_edge_mlp_layer(x, a, d, D, 1, "elu", "sum", True, True, 0, weights=ww)
+    else:   # one hidden layer: the first Dense's pre-activation gradient (ops._PairMaterialize) has the same two routes
+        w = dict({"Edge_%i_MLP/dense/kernel" % l: glorot(rng, (2 * D, D)) for l in range(L)}, **LN(D))
+        w.update({"Edge_%i_MLP/dense_1/kernel" % l: glorot(rng, (D, D)) for l in range(L)})
+        fn = lambda x, ww, a, d: sparse_gnn_edge_mlp_layer(x, a, d, D, 1, "gelu", "sum", True, True, 1, weights=ww)
     adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
     grads = []
     for flag in ("emit", "regather"):
