@@ -101,7 +101,9 @@ def build_local_fold(rank, world):
     graphs = task._loaded_data[DataFold.TRAIN]
     edge_counts = [sum(len(a) for a in g.adjacency_lists) for g in graphs]
     shard = shard_graphs_by_edges(edge_counts, world)[rank]
-    return task, [graphs[i] for i in shard], gen
+    local = [graphs[i] for i in shard]
+    task._loaded_data[DataFold.TRAIN] = local      # the other ranks' graphs (1.3 GB of host memory at 8 ranks) die here
+    return task, local, gen
 
 
 def build_local_batch(rank, world, device):
