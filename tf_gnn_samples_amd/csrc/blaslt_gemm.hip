@@ -11,7 +11,6 @@
 #include "common.h"
 
 #include <hipblaslt/hipblaslt.h>
-#include <cmath>
 
 #include <cstdio>
 #include <cstdlib>
@@ -111,11 +110,12 @@ int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t 
   const float alpha = 1.f, beta = accumulate ? 1.f : 0.f;
   hipStream_t st_ = as_stream(stream);
   // (in the weight-gradient layout K is the node dimension — per-batch, like M in the other two: bucketed as well)
-  // The per-batch dimension (M; K in the weight-gradient layout) enters the key as round(log2(.)): the batches of one
-  // training run (C2: 28 k .. 40 k nodes) then share one class, which every layer meets in the first step.
-  const auto size_class = [](int32_t v) { return v <= 0 ? 0 : (int32_t)lroundf(log2f((float)v) * 1.0f); };
-  const Key key{layout, N, layout == RELGNN_GEMM_TN ? size_class(K) : K, batch, layout == RELGNN_GEMM_TN ? M : size_class(M),
-                bias ? 1 : 0, accumulate ? 1 : 0, act};
+  // The per-batch dimension (M; K in the weight-gradient layout) enters the key in buckets of 4096 (256) rows.  Coarser
+  // classes were measured and are worse: with ONE class for the 28 k .. 40 k nodes of the C2 batches (round(log2 M)) the
+  // pick for the first batch's M (MT256x144x32) served every batch, where the heuristic asked per 4096-row bucket also
+  // returns MT256x112x32 / MT256x32x64 / MT256x160x32 — the library GEMMs of 50 steps took 71.2 ms instead of 60.6 ms
+  // (+0.21 ms per step; the macro tile interacts with M through the number of tile rows per CU).
+  const Key key{layout, N, layout == RELGNN_GEMM_TN ? (K >> 8) : K, batch, M >> 12, bias ? 1 : 0, accumulate ? 1 : 0, act};
   auto it = s.algos.find(key);
   if (it == s.algos.end()) {
     if (!s.pref && hipblasLtMatmulPreferenceCreate(&s.pref) != HIPBLAS_STATUS_SUCCESS) return RELGNN_EHIP;
@@ -128,11 +128,12 @@ int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t 
     // what is cached by default.  RELGNN_GEMM_TUNE=n (n >= 2) MEASURES the first n candidates instead — each run on the
     // caller's operands, timed with events on the caller's stream, the fastest kept for the class.  Measured on the C2
     // shapes the first guess is within 2-5 % of the best except for the 121-column head (53 -> 32 us); a class costs ~4 ms
-    // to measure.  With the size classes above every class of a run is met (and measured) in its first steps: C2 bench,
-    // A/B in one call, 80 timed steps after 16 warm-up steps: 2.369 / 2.366 ms untuned, 2.316 / 2.330 ms with n = 8,
-    // 2.324 ms with n = 16 (-1.8 %).  Still opt-in: which candidate wins a close race depends on timing noise, and with it
-    // the summation order of a split product — the default keeps results bit-identical from run to run.  Never done for
-    // accumulating calls (the timing runs would add into C) nor while the stream is being captured into a graph.
+    // to measure, which a long training run amortises and a 100-step benchmark does not (2.91 vs 2.63 ms per step with the
+    // measurements inside the run), hence opt-in.  (With coarse round(log2) size classes, so that every class is measured in
+    // the warm-up steps, n = 8 gave 2.32 ms against 2.37 ms for the first guess of the same coarse classes — and the first
+    // guess per 4096-row bucket gives that 2.30-2.32 ms without measuring anything.)  The winner of a close race, and with
+    // it a split product's summation order, would also depend on timing noise.  Never done for accumulating calls (the
+    // timing runs would add into C) nor while the stream is being captured into a graph.
     static const int want = [] { const char* e = getenv("RELGNN_GEMM_TUNE"); return e ? atoi(e) : 1; }();
     constexpr int kMax = 16;
     hipblasLtMatmulHeuristicResult_t res[kMax];
