@@ -115,7 +115,9 @@ int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t 
   // pick for the first batch's M (MT256x144x32) served every batch, where the heuristic asked per 4096-row bucket also
   // returns MT256x112x32 / MT256x32x64 / MT256x160x32 — the library GEMMs of 50 steps took 71.2 ms instead of 60.6 ms
   // (+0.21 ms per step; the macro tile interacts with M through the number of tile rows per CU).
-  const Key key{layout, N, layout == RELGNN_GEMM_TN ? (K >> 8) : K, batch, M >> 12, bias ? 1 : 0, accumulate ? 1 : 0, act};
+  static const int m_shift = [] { const char* e = getenv("RELGNN_GEMM_BUCKET_SHIFT"); return e ? atoi(e) : 12; }();
+  const Key key{layout, N, layout == RELGNN_GEMM_TN ? (K >> (m_shift > 4 ? m_shift - 4 : 0)) : K, batch, M >> m_shift, bias ? 1 : 0,
+                accumulate ? 1 : 0, act};
   auto it = s.algos.find(key);
   if (it == s.algos.end()) {
     if (!s.pref && hipblasLtMatmulPreferenceCreate(&s.pref) != HIPBLAS_STATUS_SUCCESS) return RELGNN_EHIP;
