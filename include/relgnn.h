@@ -377,9 +377,13 @@ int relgnn_rgat_bwd_msg(int32_t D, int32_t num_heads, const int32_t* rowptr_b, i
  *                        softmax passes read 4K bytes per message and never touch the gathered rows
  *   relgnn_headw_reduce  out[s, head h] = sum_{p in segment s} W[(wpos ? wpos[p] : p), h] * X[col[p], head h]
  *                        = rgat.py:131-136 with W = alpha (forward), and the gradient w.r.t. T on the transposed plan
- *                        (X = gout, col = tgt_b, wpos = pos_b)
+ *                        (X = gout, col = tgt_b, wpos = pos_b).  Z / zsum (both or neither): a second [*, K] table indexed
+ *                        like W; zsum[s, k] = sum over the segment of Z[(wpos ? wpos[p] : p), k] — the by-source sum of dz
+ *                        (gradient of the per-source score table) rides along in the backward's gather
  *   relgnn_rgat_dz       dz[p,k] as in relgnn_rgat_bwd_logits (needs D <= 256 and D/num_heads/4 a power of two);
- *                        gs_tgt / gs_src are then plain relgnn_seg_reduce_fwd calls over dz [M, K]
+ *                        gs_tgt (optional, num_edge_types * num_heads <= 64, else RELGNN_EUNSUPPORTED): [V*L, K] sums of dz
+ *                        over the (target, type) buckets, written by the same pass; without it gs_tgt / gs_src are plain
+ *                        relgnn_seg_reduce_fwd calls over dz [M, K]
  */
 int relgnn_rgat_alpha(const float* s_src, const float* s_tgt, int32_t num_heads, const int32_t* rowptr,
                       int32_t num_nodes, int32_t num_edge_types, const int32_t* col, float slope,
@@ -387,11 +391,11 @@ int relgnn_rgat_alpha(const float* s_src, const float* s_tgt, int32_t num_heads,
 int relgnn_headw_reduce(const float* X, int64_t num_rows_x, int64_t ldx, int32_t D, int32_t num_heads,
                         const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
                         const int32_t* col, const float* W, const int32_t* wpos, float* out, int64_t ldo,
-                        void* stream);
+                        const float* Z, float* zsum, void* stream);
 int relgnn_rgat_dz(const float* T, int64_t num_rows_t, int64_t ldt, int32_t D, int32_t num_heads,
                    const float* s_src, const float* s_tgt, const int32_t* rowptr, int32_t num_nodes,
                    int32_t num_edge_types, const int32_t* col, float slope, const float* alpha,
-                   const float* out, const float* gout, int64_t ldo, float* dz, void* stream);
+                   const float* out, const float* gout, int64_t ldo, float* dz, float* gs_tgt, void* stream);
 
 /*
  * Attention-logit tables and their gradients (gnns/rgat.py:103-115: the [E, K, 2*Dh] concat + einsum with

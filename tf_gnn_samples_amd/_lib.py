@@ -57,8 +57,8 @@ _SIGNATURES = {
     "relgnn_rgat_bwd_logits": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_rgat_bwd_msg": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_rgat_alpha": (ctypes.c_int, [_ptr, _ptr, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr]),
-    "relgnn_headw_reduce": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr]),
-    "relgnn_rgat_dz": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
+    "relgnn_headw_reduce": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
+    "relgnn_rgat_dz": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_pair_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
     "relgnn_pair_bwd_q": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_pair_bwd_p": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),

@@ -23,6 +23,18 @@ __device__ __forceinline__ float wave_sum(float x) {
   for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
   return x;
 }
+// wave total in every lane: four DPP adds inside each 16-lane row, then the four row totals through SGPRs
+__device__ __forceinline__ float wave_total_dpp(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+  return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 template <int CTRL>
@@ -110,7 +122,8 @@ template <int NCH, int K>
 __global__ __launch_bounds__(256) void headw_reduce_kernel(
     const float4* __restrict__ X, int64_t ldx4, int32_t D4, int32_t Dh4, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col, const float* __restrict__ W,
-    const int32_t* __restrict__ wpos, float4* __restrict__ out, int64_t ldo4, int64_t nlb) {
+    const int32_t* __restrict__ wpos, float4* __restrict__ out, int64_t ldo4, int64_t nlb,
+    const float* __restrict__ Z, float* __restrict__ zsum) {
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
@@ -118,6 +131,12 @@ __global__ __launch_bounds__(256) void headw_reduce_kernel(
   if (s >= num_segments) return;
   const int beg = __builtin_amdgcn_readfirstlane(rowptr[s * stride]);
   const int end = __builtin_amdgcn_readfirstlane(rowptr[(s + 1) * stride]);
+  // Z (optional): a second [*, K] per-message table indexed like W; zsum[s, :] = its sum over the segment's messages.
+  // Rides along because the RGAT backward needs exactly that sum of dz over the same by-source buckets (rgat.py:103-110,
+  // gradient of the per-source score table): as a separate gather-reduce it cost 60 us per layer at the C2 shape.
+  float zs[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) zs[k] = 0.f;
   float4 acc[NCH];
   bool on[NCH];
   uint32_t cc[NCH];
@@ -138,6 +157,10 @@ __global__ __launch_bounds__(256) void headw_reduce_kernel(
     float my_w[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) my_w[k] = ok ? W[wrow * K + k] : 0.f;
+    if (Z) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) zs[k] += ok ? Z[wrow * K + k] : 0.f;
+    }
     int k0 = 0;
     for (; k0 + kU <= n; k0 += kU) {
       float4 v[kU][NCH];
@@ -188,6 +211,15 @@ __global__ __launch_bounds__(256) void headw_reduce_kernel(
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
     if (on[c]) out[s * ldo4 + lane + 64 * c] = acc[c];
+  if (Z) {
+    float tot = 0.f;      // lane k keeps the total of column k
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float t = wave_total_dpp(zs[k]);
+      tot = (lane == k) ? t : tot;
+    }
+    if (lane < K) zsum[s * K + lane] = tot;
+  }
 }
 
 // ---- dz: one wave per target, lanes across features ---------------------------------------------
@@ -200,7 +232,7 @@ __global__ __launch_bounds__(256) void rgat_dz_kernel(
     const float4* __restrict__ T, int64_t ldt4, int32_t D4, int32_t Dh4, const float* __restrict__ s_src,
     const float* __restrict__ s_tgt, const int32_t* __restrict__ rowptr, int32_t V, int32_t L,
     const int32_t* __restrict__ col, float slope, const float* __restrict__ alpha, const float4* __restrict__ out,
-    const float4* __restrict__ gout, int64_t ldo4, float* __restrict__ dz, int64_t nlb) {
+    const float4* __restrict__ gout, int64_t ldo4, float* __restrict__ dz, int64_t nlb, float* __restrict__ gs_tgt) {
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
@@ -208,7 +240,14 @@ __global__ __launch_bounds__(256) void rgat_dz_kernel(
   if (v >= V) return;
   const int beg = __builtin_amdgcn_readfirstlane(rowptr[v * L]);
   const int end = __builtin_amdgcn_readfirstlane(rowptr[(v + 1) * L]);
-  if (beg == end) return;
+  // gs_tgt (optional, L * K <= 64): gs_tgt[(v, l), k] = sum of dz[p, k] over the messages of bucket (v, l) — the gradient
+  // of the per-(target, type) score table (rgat.py:103-110).  dz is in registers here, lane j keeps the running total of
+  // (l, k) = (j / K, j % K); as a separate gather-reduce over dz it cost 70 us per layer at the C2 shape.
+  float bucket_total = 0.f;
+  if (beg == end) {
+    if (gs_tgt && lane < L * K) gs_tgt[(int64_t)v * L * K + lane] = 0.f;
+    return;
+  }
   const bool on = lane < D4;
   const uint32_t cc = (uint32_t)min(lane, D4 - 1);
   const int head = (int)cc / Dh4;
@@ -233,8 +272,8 @@ __global__ __launch_bounds__(256) void rgat_dz_kernel(
     const int my_col = ok ? col[idx] : 0;
     // this lane's message: logits derivative factors and alpha, K heads
     float my_a[K], my_d[K], my_dz[K];
+    int l = 0;
     if (ok) {
-      int l = 0;
       for (int j = 1; j < L; ++j) l += (idx >= rowptr[v * L + j]) ? 1 : 0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -274,11 +313,26 @@ __global__ __launch_bounds__(256) void rgat_dz_kernel(
         my_dz[h] = (lane == k0) ? val : my_dz[h];
       }
     }
+    float val[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) val[k] = ok ? my_a[k] * my_dz[k] * my_d[k] : 0.f;
     if (ok) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) dz[(int64_t)idx * K + k] = my_a[k] * my_dz[k] * my_d[k];
+      for (int k = 0; k < K; ++k) dz[(int64_t)idx * K + k] = val[k];
+    }
+    if (gs_tgt) {
+      // the chunk's messages are in bucket order: types l_lo .. l_hi, each a contiguous lane range
+      const int l_lo = __builtin_amdgcn_readlane(l, 0), l_hi = __builtin_amdgcn_readlane(l, n - 1);
+      for (int t = l_lo; t <= l_hi; ++t) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float tot = wave_total_dpp((ok && l == t) ? val[k] : 0.f);
+          bucket_total = (lane == t * K + k) ? bucket_total + tot : bucket_total;
+        }
+      }
     }
   }
+  if (gs_tgt && lane < L * K) gs_tgt[(int64_t)v * L * K + lane] = bucket_total;
 }
 
 inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
@@ -312,10 +366,11 @@ int relgnn_rgat_alpha(const float* s_src, const float* s_tgt, int32_t num_heads,
 
 int relgnn_headw_reduce(const float* X, int64_t num_rows_x, int64_t ldx, int32_t D, int32_t num_heads,
                         const int32_t* rowptr, int64_t num_segments, int32_t seg_stride, const int32_t* col,
-                        const float* W, const int32_t* wpos, float* out, int64_t ldo, void* stream) {
+                        const float* W, const int32_t* wpos, float* out, int64_t ldo, const float* Z, float* zsum,
+                        void* stream) {
   if (D < 0 || num_segments < 0 || seg_stride <= 0 || num_heads <= 0 || num_rows_x < 0) return RELGNN_EINVAL;
   if (num_segments == 0 || D == 0) return RELGNN_OK;
-  if (!rowptr || !out || !W) return RELGNN_EINVAL;
+  if (!rowptr || !out || !W || ((Z == nullptr) != (zsum == nullptr))) return RELGNN_EINVAL;
   if (D % num_heads != 0 || (D / num_heads) % 4 != 0 || D > 1024 || !vec_ok(X, ldx) || !vec_ok(out, ldo) ||
       num_rows_x * (ldx / 4) >= ((int64_t)1 << 32))
     return RELGNN_EUNSUPPORTED;
@@ -326,7 +381,7 @@ int relgnn_headw_reduce(const float* X, int64_t num_rows_x, int64_t ldx, int32_t
 #define HEADW_LAUNCH(NN, KK)                                                                                       \
   headw_reduce_kernel<NN, KK><<<padded_grid(nlb), 256, 0, st>>>((const float4*)X, ldx / 4, D4, Dh4, rowptr,        \
                                                                  num_segments, seg_stride, col, W, wpos, (float4*)out, \
-                                                                 ldo / 4, nlb)
+                                                                 ldo / 4, nlb, Z, zsum)
   RGAT_DISPATCH_K(num_heads, KK, {
     if (nch == 1) HEADW_LAUNCH(1, KK);
     else if (nch == 2) HEADW_LAUNCH(2, KK);
@@ -339,8 +394,9 @@ int relgnn_headw_reduce(const float* X, int64_t num_rows_x, int64_t ldx, int32_t
 int relgnn_rgat_dz(const float* T, int64_t num_rows_t, int64_t ldt, int32_t D, int32_t num_heads, const float* s_src,
                    const float* s_tgt, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
                    const int32_t* col, float slope, const float* alpha, const float* out, const float* gout,
-                   int64_t ldo, float* dz, void* stream) {
+                   int64_t ldo, float* dz, float* gs_tgt, void* stream) {
   if (D < 0 || num_nodes < 0 || num_edge_types <= 0 || num_heads <= 0) return RELGNN_EINVAL;
+  if (gs_tgt && (int64_t)num_edge_types * num_heads > 64) return RELGNN_EUNSUPPORTED;
   if (num_nodes == 0 || D == 0) return RELGNN_OK;
   if (!rowptr || !out || !gout || !s_src || !s_tgt || !alpha || !dz) return RELGNN_EINVAL;
   const int D4 = D / 4;
@@ -352,7 +408,7 @@ int relgnn_rgat_dz(const float* T, int64_t num_rows_t, int64_t ldt, int32_t D, i
   const int64_t nlb = ((int64_t)num_nodes + 3) / 4;
   RGAT_DISPATCH_K(num_heads, KK, (rgat_dz_kernel<KK><<<padded_grid(nlb), 256, 0, as_stream(stream)>>>(
                                      (const float4*)T, ldt / 4, D4, Dh4, s_src, s_tgt, rowptr, num_nodes, num_edge_types,
-                                     col, slope, alpha, (const float4*)out, (const float4*)gout, ldo / 4, dz, nlb)));
+                                     col, slope, alpha, (const float4*)out, (const float4*)gout, ldo / 4, dz, nlb, gs_tgt)));
   return launch_status();
 }
 

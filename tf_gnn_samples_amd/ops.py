@@ -546,7 +546,7 @@ class _RgatAttention(torch.autograd.Function):
             _lib.check(lib.relgnn_rgat_alpha(_lib.ptr(s_src), _lib.ptr(s_tgt), num_heads, _lib.ptr(graph.rowptr_t), V, L,
                                              _lib.ptr(graph.col_t), slope, _lib.ptr(alpha), st), "relgnn_rgat_alpha")
             _lib.check(lib.relgnn_headw_reduce(_lib.ptr(T), V * L, D, D, num_heads, _lib.ptr(graph.rowptr_t), V, L,
-                                               _lib.ptr(graph.col_t), _lib.ptr(alpha), None, _lib.ptr(out), D, st),
+                                               _lib.ptr(graph.col_t), _lib.ptr(alpha), None, _lib.ptr(out), D, None, None, st),
                        "relgnn_headw_reduce")
         else:
             _lib.check(lib.relgnn_rgat_fwd(_lib.ptr(T), D, D, num_heads, _lib.ptr(s_src), _lib.ptr(s_tgt),
@@ -566,11 +566,18 @@ class _RgatAttention(torch.autograd.Function):
         D = T.shape[1]
         gout = gout.contiguous()
         dz = torch.empty((M, K), dtype=torch.float32, device=T.device)
+        # the two score-table gradients are sums of dz over the (target, type) and the (source, type) buckets: the dz
+        # pass keeps the first in registers and the by-source gather of the gT pass carries the second along
+        # (RELGNN_RGAT_FUSED_SUMS=0: two separate gather-reduces over dz, 70 + 60 us per layer at the C2 shape)
+        fuse = os.environ.get("RELGNN_RGAT_FUSED_SUMS", "1") != "0"
         if ctx.fast and _rgat_dz_fast_ok(D, K):
+            fuse_t = fuse and L * K <= 64
+            gs_tgt = torch.empty((V * L, K), dtype=torch.float32, device=T.device) if fuse_t else None
             _lib.check(lib.relgnn_rgat_dz(_lib.ptr(T), V * L, D, D, K, _lib.ptr(s_src), _lib.ptr(s_tgt),
                                           _lib.ptr(graph.rowptr_t), V, L, _lib.ptr(graph.col_t), slope, _lib.ptr(alpha),
-                                          _lib.ptr(out), _lib.ptr(gout), D, _lib.ptr(dz), st), "relgnn_rgat_dz")
-            gs_tgt = _seg_reduce_raw(_lib.AGG_SUM, dz, graph.rowptr_t, 1, graph.iota, None, V * L)
+                                          _lib.ptr(out), _lib.ptr(gout), D, _lib.ptr(dz), _lib.ptr(gs_tgt), st), "relgnn_rgat_dz")
+            if not fuse_t:
+                gs_tgt = _seg_reduce_raw(_lib.AGG_SUM, dz, graph.rowptr_t, 1, graph.iota, None, V * L)
         else:
             gs_tgt = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
             _lib.check(lib.relgnn_rgat_bwd_logits(_lib.ptr(T), D, D, K, _lib.ptr(s_src), _lib.ptr(s_tgt),
@@ -579,10 +586,13 @@ class _RgatAttention(torch.autograd.Function):
                                                   _lib.ptr(gs_tgt), st), "relgnn_rgat_bwd_logits")
         if ctx.fast:
             gT = torch.empty_like(T)
+            gs_src = torch.empty((V * L, K), dtype=torch.float32, device=T.device) if fuse else None
             _lib.check(lib.relgnn_headw_reduce(_lib.ptr(gout), V, D, D, K, _lib.ptr(graph.rowptr_s), V * L, 1,
                                                _lib.ptr(graph.tgt_s), _lib.ptr(alpha), _lib.ptr(graph.pos_t_of_s),
-                                               _lib.ptr(gT), D, st), "relgnn_headw_reduce")
-            gs_src = _seg_reduce_raw(_lib.AGG_SUM, dz, graph.rowptr_s, 1, graph.pos_t_of_s, None, V * L)
+                                               _lib.ptr(gT), D, _lib.ptr(dz) if fuse else None, _lib.ptr(gs_src), st),
+                       "relgnn_headw_reduce")
+            if not fuse:
+                gs_src = _seg_reduce_raw(_lib.AGG_SUM, dz, graph.rowptr_s, 1, graph.pos_t_of_s, None, V * L)
         else:
             gT = torch.empty_like(T)
             gs_src = torch.empty((V * L, K), dtype=torch.float32, device=T.device)
