@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void rgat_alpha_kernel(const float* __restrict
 }
 
 // ---- per-head weighted gather-reduce --------------------------------------------------------------
-template <int NCH, int K>
+template <int NCH, int K, bool HAS_Z>
 __global__ __launch_bounds__(256) void headw_reduce_kernel(
     const float4* __restrict__ X, int64_t ldx4, int32_t D4, int32_t Dh4, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col, const float* __restrict__ W,
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void headw_reduce_kernel(
     float my_w[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) my_w[k] = ok ? W[wrow * K + k] : 0.f;
-    if (Z) {
+    if constexpr (HAS_Z) {
 #pragma unroll
       for (int k = 0; k < K; ++k) zs[k] += ok ? Z[wrow * K + k] : 0.f;
     }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void headw_reduce_kernel(
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
     if (on[c]) out[s * ldo4 + lane + 64 * c] = acc[c];
-  if (Z) {
+  if constexpr (HAS_Z) {
     float tot = 0.f;      // lane k keeps the total of column k
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -265,6 +265,13 @@ __global__ __launch_bounds__(256) void rgat_dz_kernel(
   };
   const float cdot = head_sum(on ? dot4(go, out[v * ldo4 + cc]) : 0.f);
   const uint32_t ld = (uint32_t)ldt4;
+  // The per-head values of a message live in the lanes of that head; the per-message factors (alpha, lrelu') live one
+  // message per lane.  The transposition goes through LDS: the first lane of every head stores its value at
+  // [message][head] (one ds_write with K active lanes per message), after the chunk every lane loads its message's K
+  // values (K readlane + K select per message before: 241 us per launch at the C2 shape).
+  __shared__ float stage_all[4][64 * K];
+  float* stage = stage_all[threadIdx.x >> 6];
+  const bool leader = on && ((int)cc % Dh4) == 0;
   for (int p = beg; p < end; p += 64) {
     const int n = min(64, end - p);
     const int idx = p + lane;
@@ -295,23 +302,19 @@ __global__ __launch_bounds__(256) void rgat_dz_kernel(
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const float dal = head_sum(on ? dot4(go, t[u]) : 0.f) - cdot;   // (dalpha - <gout,out>) of my head
-        // hand the value of head h to the lane that owns message k0+u
-#pragma unroll
-        for (int h = 0; h < K; ++h) {
-          const float val = rl(dal, h * Dh4);                           // any lane of head h holds it
-          my_dz[h] = (lane == k0 + u) ? val : my_dz[h];
-        }
+        if (leader) stage[(k0 + u) * K + head] = dal;                   // message-major, read back one message per lane
       }
     }
     for (; k0 < n; ++k0) {
       const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k0);
       const float4 t = T[(size_t)(r * ld) + cc];
       const float dal = head_sum(on ? dot4(go, t) : 0.f) - cdot;
+      if (leader) stage[k0 * K + head] = dal;
+    }
+    // same wave, LDS operations complete in issue order: lane i now reads the K values the head leaders wrote for message i
+    if (ok) {
 #pragma unroll
-      for (int h = 0; h < K; ++h) {
-        const float val = rl(dal, h * Dh4);
-        my_dz[h] = (lane == k0) ? val : my_dz[h];
-      }
+      for (int k = 0; k < K; ++k) my_dz[k] = stage[lane * K + k];
     }
     float val[K];
 #pragma unroll
@@ -379,9 +382,14 @@ int relgnn_headw_reduce(const float* X, int64_t num_rows_x, int64_t ldx, int32_t
   const int nch = D4 <= 64 ? 1 : (D4 <= 128 ? 2 : 4);
   hipStream_t st = as_stream(stream);
 #define HEADW_LAUNCH(NN, KK)                                                                                       \
-  headw_reduce_kernel<NN, KK><<<padded_grid(nlb), 256, 0, st>>>((const float4*)X, ldx / 4, D4, Dh4, rowptr,        \
-                                                                 num_segments, seg_stride, col, W, wpos, (float4*)out, \
-                                                                 ldo / 4, nlb, Z, zsum)
+  do {                                                                                                             \
+    if (Z)                                                                                                         \
+      headw_reduce_kernel<NN, KK, true><<<padded_grid(nlb), 256, 0, st>>>(                                          \
+          (const float4*)X, ldx / 4, D4, Dh4, rowptr, num_segments, seg_stride, col, W, wpos, (float4*)out, ldo / 4, nlb, Z, zsum); \
+    else                                                                                                           \
+      headw_reduce_kernel<NN, KK, false><<<padded_grid(nlb), 256, 0, st>>>(                                         \
+          (const float4*)X, ldx / 4, D4, Dh4, rowptr, num_segments, seg_stride, col, W, wpos, (float4*)out, ldo / 4, nlb, Z, zsum); \
+  } while (0)
   RGAT_DISPATCH_K(num_heads, KK, {
     if (nch == 1) HEADW_LAUNCH(1, KK);
     else if (nch == 2) HEADW_LAUNCH(2, KK);
