@@ -321,7 +321,7 @@ int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* 
                          int32_t D, const int32_t* rowptr, int32_t num_nodes,
                          int32_t num_edge_types, const int32_t* col, const float* w,
                          const float* gagg, int64_t ldg, float* gfilm, int64_t ldgf,
-                         const int32_t* bucket_row, float* dmsg, void* stream);
+                         const int32_t* bucket_row, float* dmsg, void* sign_mask, void* stream);
 /* dmsg (nullable, [num_messages, D] contiguous, by-target order): pass A also writes every message's gradient
  * w.r.t. its gathered row, dmsg[p] = w[p] * gamma * g_p (pair kernels: w[p] * g_p).  gT is then ONE plain
  * gather-reduce of dmsg over the by-source buckets (relgnn_seg_reduce_fwd with col = by-target position of each
@@ -334,6 +334,17 @@ int relgnn_film_bwd_msg(int32_t act, const float* T, int64_t ldt, const float* f
                         const int32_t* tgt_b, const int32_t* frow_b, const float* w_b,
                         const float* gagg, int64_t ldg, float* gT, int64_t ldgt,
                         const int32_t* bucket_row_b, void* stream);
+/* sign_mask (nullable; [num_messages, 4] 64-bit words, by-target order; dense tables, 128 < D <= 256 only, else
+ * RELGNN_EUNSUPPORTED): pass A also writes the sign of every message's pre-activation, one bit per feature (word j, bit i =
+ * feature 4*i + j).  For the piecewise-linear activations (linear, ReLU, leaky ReLU) that is all pass B needs of a message:
+ * relgnn_film_bwd_msg_masked = pass B without re-gathering beta and without the pre-activation,
+ *   gT[r,:] = sum_q w_b[q] * gamma[frow_b[q],:] * gagg[tgt_b[q],:] * (bit ? 1 : negative slope),  bit from
+ *   sign_mask[pos_b[q]] (pos_b[q] = by-target position of by-source message q).  2 KiB instead of 3 KiB gathered per
+ * message at D = 256. */
+int relgnn_film_bwd_msg_masked(int32_t act, const float* film, int64_t ldf, int32_t D, const int32_t* rowptr_b,
+                               int64_t num_rows_t, const int32_t* tgt_b, const int32_t* frow_b, const float* w_b,
+                               const int32_t* pos_b, const void* sign_mask, const float* gagg, int64_t ldg, float* gT,
+                               int64_t ldgt, void* stream);
 
 /* ========================================================================== *
  * 4. RGAT segmented-softmax attention  (gnns/rgat.py:86-138)

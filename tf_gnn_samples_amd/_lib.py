@@ -51,7 +51,8 @@ _SIGNATURES = {
     "relgnn_agg_transform_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr,
                                                 _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
-    "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr]),
+    "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr]),
+    "relgnn_film_bwd_msg_masked": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_film_bwd_msg": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_rgat_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_rgat_bwd_logits": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i32, _c_i32, _ptr, _c_f32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr]),

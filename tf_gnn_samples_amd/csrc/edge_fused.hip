@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
     const float4* __restrict__ T, int64_t ldt4, const float4* __restrict__ A, int64_t lda4, int32_t D4,
     const int32_t* __restrict__ rowptr, int32_t V, int32_t L, const int32_t* __restrict__ col,
     const float* __restrict__ w, const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gA,
-    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow, float4* __restrict__ dmsg) {
+    int64_t ldga4, int32_t act, int64_t nlb, const int32_t* __restrict__ brow, float4* __restrict__ dmsg,
+    unsigned long long* __restrict__ smask) {
   const int64_t lb = xcd_logical_block(nlb);
   if (lb < 0) return;
   const int lane = threadIdx.x & 63;
@@ -472,7 +473,8 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
               if (u < rem) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                  const float4 gp = g[c] * actg4_t<ACT>(pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+                  const float4 pre = pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]);
+                  const float4 gp = g[c] * actg4_t<ACT>(pre);
                   if constexpr (KIND == KIND_FILM) {
                     s1[c] = s1[c] + gp * (ww[u] * t[u][c]);
                     s2[c] = s2[c] + gp;
@@ -481,6 +483,16 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_wave_kernel(
                   }
                   if (dmsg && on[c])
                     dmsg[(int64_t)(p + k + u) * D4 + lane + 64 * c] = (KIND == KIND_FILM) ? ww[u] * (ra[c] * gp) : ww[u] * gp;
+                  if constexpr (NCH == 1) {
+                    // sign of the pre-activation, one bit per feature: word j = ballot over the lanes of component j.
+                    // All the by-source pass needs of this message when the activation is piecewise linear.
+                    if (smask) {
+                      const unsigned long long b0 = __ballot(pre.x > 0.f), b1 = __ballot(pre.y > 0.f);
+                      const unsigned long long b2 = __ballot(pre.z > 0.f), b3 = __ballot(pre.w > 0.f);
+                      const unsigned long long word = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+                      if (lane < 4) smask[(int64_t)(p + k + u) * 4 + lane] = word;
+                    }
+                  }
                 }
               }
           });
@@ -575,6 +587,71 @@ __global__ __launch_bounds__(256) void edge_bwd_msgs_wave_kernel(
     if (on[c]) gT[tr * ldgt4 + lane + 64 * c] = acc[c];
 }
 
+// by-(source,type) rows for PIECEWISE-LINEAR activations (linear / ReLU / leaky ReLU), D <= 256: the derivative of a
+// message is one bit per feature, written by the by-target pass (smask, by-target order; pos_b[q] = by-target position of
+// by-source message q).  Per message this pass gathers gamma (FiLM; nothing for PAIR), the target's gradient row and 32
+// bytes of mask — not beta, not the pre-activation: 2 KiB instead of 3 KiB per message for FiLM at D = 256 (the
+// recomputing pass moves 3.2 GB per launch at the C2 shape and runs at the memory system's 6 TB/s).
+template <int KIND>
+__global__ __launch_bounds__(256) void edge_bwd_msgs_mask_wave_kernel(
+    const float4* __restrict__ A, int64_t lda4, int32_t D4, const int32_t* __restrict__ rowptr_b, int64_t n_rows,
+    const int32_t* __restrict__ tgt_b, const int32_t* __restrict__ frow_b, const float* __restrict__ w_b,
+    const int32_t* __restrict__ pos_b, const unsigned long long* __restrict__ smask, float neg_slope,
+    const float4* __restrict__ gagg, int64_t ldg4, float4* __restrict__ gT, int64_t ldgt4, int64_t nlb) {
+  constexpr int MU = 8;
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = lb * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int b = __builtin_amdgcn_readfirstlane(rowptr_b[r]);
+  const int e = __builtin_amdgcn_readfirstlane(rowptr_b[r + 1]);
+  const bool on = lane < D4;
+  const uint32_t cc = (uint32_t)min(lane, D4 - 1);
+  float4 acc = f4(0.f);
+  const uint32_t lda = (uint32_t)lda4, ldg = (uint32_t)ldg4;
+  for (int q = b; q < e; q += 64) {
+    const int n = min(64, e - q);
+    const int my_fr = (KIND == KIND_FILM && lane < n) ? frow_b[q + lane] : 0;
+    const int my_tg = (lane < n) ? tgt_b[q + lane] : 0;
+    const int my_pos = (lane < n) ? pos_b[q + lane] : 0;
+    const float my_w = (w_b && lane < n) ? w_b[q + lane] : 1.f;
+    for (int k = 0; k < n; k += MU) {
+      const int rem = n - k;
+      float4 ra[MU], g[MU];
+      unsigned long long m[MU][4];      // wave-uniform addresses: scalar loads into SGPRs
+      float ww[MU];
+#pragma unroll
+      for (int u = 0; u < MU; ++u) {
+        const int ku = k + min(u, rem - 1);
+        const uint32_t fr = (uint32_t)__builtin_amdgcn_readlane(my_fr, ku);
+        const uint32_t tg = (uint32_t)__builtin_amdgcn_readlane(my_tg, ku);
+        const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane(my_pos, ku);
+        ww[u] = rlf(my_w, ku);
+        if (u < rem) {
+          ra[u] = (KIND == KIND_FILM) ? A[(size_t)(fr * lda) + cc] : f4(1.f);
+          g[u] = gagg[(size_t)(tg * ldg) + cc];
+          const unsigned long long* mw = smask + (size_t)ps * 4;   // the same 32 bytes for every lane
+          m[u][0] = mw[0]; m[u][1] = mw[1]; m[u][2] = mw[2]; m[u][3] = mw[3];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+        if (u < rem) {
+          float4 d;
+          d.x = ((m[u][0] >> lane) & 1ull) ? 1.f : neg_slope;
+          d.y = ((m[u][1] >> lane) & 1ull) ? 1.f : neg_slope;
+          d.z = ((m[u][2] >> lane) & 1ull) ? 1.f : neg_slope;
+          d.w = ((m[u][3] >> lane) & 1ull) ? 1.f : neg_slope;
+          const float4 gp = g[u] * d;
+          if constexpr (KIND == KIND_FILM) acc = acc + ww[u] * (ra[u] * gp);
+          else acc = acc + ww[u] * gp;
+        }
+    }
+  }
+  if (on) gT[r * ldgt4 + lane] = acc;
+}
+
 // -----------------------------------------------------------------------------------------
 // materialise per-message hidden states in the ORIGINAL type-major message order:
 //   hidden[m] = act( P[row_src[m]] + Q[row_tgt[m]] )     (rows = node*L + type)
@@ -666,7 +743,7 @@ template <int KIND>
 int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, int64_t lda, int32_t D,
                     const int32_t* rowptr, int32_t V, int32_t L, const int32_t* col, const float* w,
                     const float* gagg, int64_t ldg, float* gA, int64_t ldga, hipStream_t st,
-                    const int32_t* brow = nullptr, float* dmsg = nullptr) {
+                    const int32_t* brow = nullptr, float* dmsg = nullptr, unsigned long long* smask = nullptr) {
   Geo geo;
   if (!pick_geo(D, &geo) || !vec_ok(T, ldt) || !vec_ok(A, lda) || !vec_ok(gagg, ldg) || !vec_ok(gA, ldga) ||
       !aligned16(dmsg))
@@ -679,11 +756,13 @@ int launch_bwd_rows(int32_t act, const float* T, int64_t ldt, const float* A, in
 #define EDGE_ROWS_WAVE(NN)                                                                                          \
   edge_bwd_rows_wave_kernel<NN, KIND><<<padded_grid(wnlb), 256, 0, st>>>(                                            \
       (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4, \
-      (float4*)gA, ldga / 4, act, wnlb, brow, (float4*)dmsg)
+      (float4*)gA, ldga / 4, act, wnlb, brow, (float4*)dmsg, smask)
+    if (smask && geo.NCH != 1) return RELGNN_EUNSUPPORTED;
     if (geo.NCH == 1) EDGE_ROWS_WAVE(1); else if (geo.NCH == 2) EDGE_ROWS_WAVE(2); else EDGE_ROWS_WAVE(4);
 #undef EDGE_ROWS_WAVE
     return launch_status();
   }
+  if (smask) return RELGNN_EUNSUPPORTED;      // sign masks: wave kernels with one float4 per lane only (128 < D <= 256)
   RELGNN_DISPATCH_GEO(geo, GG, NN, {
     edge_bwd_rows_kernel<GG, NN, KIND><<<grid, 256, 0, st>>>(
         (const float4*)T, ldt / 4, (const float4*)A, lda / 4, D / 4, rowptr, V, L, col, w, (const float4*)gagg, ldg / 4,
@@ -753,11 +832,35 @@ int relgnn_film_fwd(int32_t mode, int32_t act, const float* T, int64_t ldt, cons
 int relgnn_film_bwd_film(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,
                          int32_t D, const int32_t* rowptr, int32_t num_nodes, int32_t num_edge_types,
                          const int32_t* col, const float* w, const float* gagg, int64_t ldg, float* gfilm,
-                         int64_t ldgf, const int32_t* bucket_row, float* dmsg, void* stream) {
+                         int64_t ldgf, const int32_t* bucket_row, float* dmsg, void* sign_mask, void* stream) {
   if (bad_common(D, num_nodes, num_edge_types) || ldf < 2 * D || ldgf < 2 * D) return RELGNN_EINVAL;
   if (num_nodes == 0 || D == 0) return RELGNN_OK;
   if (!rowptr || !gagg || !gfilm) return RELGNN_EINVAL;
-  return launch_bwd_rows<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gfilm, ldgf, as_stream(stream), bucket_row, dmsg);
+  if (sign_mask && (!aligned16(sign_mask) || bucket_row)) return RELGNN_EUNSUPPORTED;
+  return launch_bwd_rows<KIND_FILM>(act, T, ldt, film, ldf, D, rowptr, num_nodes, num_edge_types, col, w, gagg, ldg, gfilm, ldgf, as_stream(stream), bucket_row, dmsg,
+                                    static_cast<unsigned long long*>(sign_mask));
+}
+
+int relgnn_film_bwd_msg_masked(int32_t act, const float* film, int64_t ldf, int32_t D, const int32_t* rowptr_b,
+                               int64_t num_rows_t, const int32_t* tgt_b, const int32_t* frow_b, const float* w_b,
+                               const int32_t* pos_b, const void* sign_mask, const float* gagg, int64_t ldg, float* gT,
+                               int64_t ldgt, void* stream) {
+  if (D < 0 || num_rows_t < 0 || ldf < 2 * D) return RELGNN_EINVAL;
+  if (num_rows_t == 0 || D == 0) return RELGNN_OK;
+  if (!rowptr_b || !film || !gT || !gagg || !tgt_b || !frow_b || !pos_b || !sign_mask) return RELGNN_EINVAL;
+  float neg_slope;
+  if (act == RELGNN_ACT_LINEAR) neg_slope = 1.f;
+  else if (act == RELGNN_ACT_RELU) neg_slope = 0.f;
+  else if (act == RELGNN_ACT_LEAKY_RELU) neg_slope = 0.2f;
+  else return RELGNN_EUNSUPPORTED;
+  if (D % 4 != 0 || D > 256 || !vec_ok(film, ldf) || !vec_ok(gagg, ldg) || !vec_ok(gT, ldgt) || !aligned16(sign_mask) ||
+      num_rows_t * (ldf / 4) >= ((int64_t)1 << 32) || num_rows_t * (ldg / 4) >= ((int64_t)1 << 32))
+    return RELGNN_EUNSUPPORTED;
+  const int64_t wnlb = (num_rows_t + 3) / 4;
+  edge_bwd_msgs_mask_wave_kernel<KIND_FILM><<<padded_grid(wnlb), 256, 0, as_stream(stream)>>>(
+      (const float4*)film, ldf / 4, D / 4, rowptr_b, num_rows_t, tgt_b, frow_b, w_b, pos_b,
+      static_cast<const unsigned long long*>(sign_mask), neg_slope, (const float4*)gagg, ldg / 4, (float4*)gT, ldgt / 4, wnlb);
+  return launch_status();
 }
 
 int relgnn_film_bwd_msg(int32_t act, const float* T, int64_t ldt, const float* film, int64_t ldf,

@@ -317,12 +317,21 @@ class _FusedEdgeMessages(torch.autograd.Function):
                                                        and (pairs is not None or D <= 128) else "regather")
         emit = choice == "emit"
         dmsg = torch.empty((graph.M, D), dtype=torch.float32, device=T.device) if emit else None
+        # RELGNN_EDGE_SIGN_MASK=1 (opt-in; regather + piecewise-linear activation + wave kernels with one float4 per lane):
+        # pass A leaves one sign bit per feature and message, pass B then gathers gamma and the target's gradient row only.
+        # Measured on the C2 batch: pass B 536 -> 419 us, but the four ballots + the mask store cost pass A 330 -> 402 us and
+        # the step does not get faster (7.31 / 7.27 ms without, 7.43 / 7.41 ms with, one A/B call) -> off by default.
+        smask = None
+        if (not emit and kind == "film" and pairs is None and act in (_lib.ACT_LINEAR, _lib.ACT_RELU, _lib.ACT_LEAKY_RELU)
+                and 128 < D <= 256 and L <= 63 and V * L * (D // 4) < 2 ** 32 and graph.M > 0
+                and os.environ.get("RELGNN_EDGE_SIGN_MASK", "0") == "1"):
+            smask = torch.empty((graph.M, 4), dtype=torch.int64, device=T.device)
         if kind == "film":
             col = graph.col_t if pairs is None else pairs.col_t
             brow_t = None if pairs is None else pairs.tgt.bucket_row
             _lib.check(lib.relgnn_film_bwd_film(act, _lib.ptr(T), D, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_t),
                                                 V, L, _lib.ptr(col), _lib.ptr(w), _lib.ptr(gagg), D,
-                                                _lib.ptr(gA), A.shape[1], _lib.ptr(brow_t), _lib.ptr(dmsg), st),
+                                                _lib.ptr(gA), A.shape[1], _lib.ptr(brow_t), _lib.ptr(dmsg), _lib.ptr(smask), st),
                        "relgnn_film_bwd_film")
         else:
             _lib.check(lib.relgnn_pair_bwd_q(act, _lib.ptr(T), D, _lib.ptr(A), D, D, _lib.ptr(graph.rowptr_t), V, L,
@@ -334,6 +343,13 @@ class _FusedEdgeMessages(torch.autograd.Function):
             else:
                 rowptr_c, _, pos_c = pairs._messages_by_source_row()
                 gT = _seg_reduce_raw(_lib.AGG_SUM, dmsg, rowptr_c, 1, pos_c, None, pairs.P_s)   # padding rows: zero
+        elif smask is not None:
+            gT = torch.empty_like(T)
+            _lib.check(lib.relgnn_film_bwd_msg_masked(act, _lib.ptr(A), A.shape[1], D, _lib.ptr(graph.rowptr_s), V * L,
+                                                      _lib.ptr(graph.tgt_s), _lib.ptr(graph.frow_s),
+                                                      _lib.ptr(graph.w_by_source(w)), _lib.ptr(graph.pos_t_of_s),
+                                                      _lib.ptr(smask), _lib.ptr(gagg), D, _lib.ptr(gT), D, st),
+                       "relgnn_film_bwd_msg_masked")
         elif kind == "film":
             gT = torch.empty_like(T)
             if pairs is not None:
