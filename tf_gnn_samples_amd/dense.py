@@ -28,13 +28,20 @@ _WARNED_UNSUPPORTED = False
 
 
 def _lib_rows_ok(t: torch.Tensor) -> bool:
-    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] > 0 and t.shape[1] > 0
+    # row-dense: unit column stride AND rows that do not overlap (an expand()-backed gradient, e.g. from dense(x, W).sum(0),
+    # arrives with strides (0, 1): every C entry point below would read it with ld = 0)
+    return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] > 0
+            and t.shape[1] > 0 and (t.stride(0) >= t.shape[1] or t.shape[0] == 1))
 
 
 def _workspace(device):
-    ws = _WORKSPACE.get(device)
+    """hipBLASLt scratch (split-K / stream-K solutions write partial products there), one buffer per (device, stream):
+    GEMMs issued on different streams may run concurrently and must not share it.  The library checks the size it is handed
+    against the solution's need on every call (a cached solution that wants more fails and is re-queried, blaslt_gemm.hip)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = _WORKSPACE[device] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        ws = _WORKSPACE[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -91,6 +98,7 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
 
 def _rows_ok(t: torch.Tensor) -> bool:
     return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+            and (t.stride(0) >= t.shape[1] or t.shape[0] == 1)
             and t.data_ptr() % 16 == 0 and t.shape[0] < 2 ** 31 and t.shape[1] < 2 ** 31)
 
 
@@ -251,9 +259,10 @@ class _DenseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, kernel = ctx.saved_tensors
-        if g.dim() != 2 or g.stride(1) != 1 or not g.is_cuda:
+        if g.dim() != 2 or g.stride(1) != 1 or not g.is_cuda or (g.stride(0) < g.shape[1] and g.shape[0] != 1):
             g = g.contiguous()             # (a row-strided gradient, e.g. a column block of the GRU's gate gradients, is
-        gx = None                          # read in place: every consumer below takes a leading dimension)
+        gx = None                          # read in place: every consumer below takes a leading dimension; an expanded one,
+                                           # strides (0, 1), is materialised)
         if ctx.needs_input_grad[0]:
             gx = own_gemm(GEMM_NT, g, kernel) if own_gemm_supported(GEMM_NT, g, kernel) else lib_gemm(GEMM_NT, g, kernel)
         gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), g) \

@@ -436,6 +436,9 @@ class RelGraph:
         Holds the graph WEAKLY: the plan lives in self._plans, and a strong reference back would make graph <-> plan a
         cycle that only the cyclic collector frees — every batch's index arrays (tens of MB at C2) would then outlive
         the step until a full collection happens to run."""
+        have = self.__dict__.get(name)
+        if have is not None:                  # already materialised (every graph but a lean from_arrays() one): hand the
+            return have                       # tensor over, so that a plan used in backward does not need the graph alive
         import weakref
         ref = weakref.ref(self)
 

@@ -195,10 +195,27 @@ class TFStyleOptimizer:
                     t.copy_(torch.as_tensor(np.asarray(weights[key]), dtype=torch.float32))
                     used.add(key)
         if self.name == 'adam' and "beta1_power:0" in weights:
-            import math
-            self.t = max(0, int(round(math.log(float(weights["beta1_power:0"])) / math.log(0.9))) - 1)
+            self.t = self._steps_from_beta_powers(weights.get("beta1_power:0"), weights.get("beta2_power:0"))
             used.update(k for k in ("beta1_power:0", "beta2_power:0") if k in weights)
         return used
+
+    @staticmethod
+    def _steps_from_beta_powers(beta1_power, beta2_power) -> int:
+        """Step count t from TF's float32 scalars beta1_power = 0.9^(t+1), beta2_power = 0.999^(t+1).  0.9^(t+1) leaves the
+        normal float32 range after ~830 steps and is exactly 0.0 after ~985, so it identifies t only for short runs; past
+        that 0.999^(t+1) does (normal up to ~8.7e4 steps); when both have underflowed every bias correction is 1 to fp32
+        precision and any large t reproduces the update rule."""
+        import math
+        tiny = float(np.finfo(np.float32).tiny)
+        for power, beta in ((beta1_power, 0.9), (beta2_power, 0.999)):
+            if power is None:
+                continue
+            p = float(np.asarray(power).reshape(-1)[0])
+            if math.isfinite(p) and tiny <= p < 1.0:
+                return max(0, int(round(math.log(p) / math.log(beta))) - 1)
+            if p >= 1.0:
+                return 0
+        return 10 ** 6
 
 
 class MetricsReadback:
@@ -260,11 +277,20 @@ class CapturedTrainStep:
 
     def __init__(self, model, graph, metrics, batch):
         self.model, self.graph, self.metrics, self.batch = model, graph, metrics, batch
+        self._expected_t = model.optimizer.t
 
     def replay(self) -> Dict[str, torch.Tensor]:
-        """One more training step: a single graph launch.  The returned tensors are overwritten by the next replay."""
+        """One more training step: a single graph launch.  The returned tensors are overwritten by the next replay.
+        The graph reads the Adam step count from device memory; if the host count moved since the last replay (an eager
+        train_step(), load_weights()), the device copy is re-seeded first, so lr_t never comes from a stale count.
+        (lr_t of a replayed step is computed in float32 on the device, of an eager step in double on the host: the two
+        agree to ~1e-7 relative, not bit for bit.)"""
+        opt = self.model.optimizer
+        if opt.t != self._expected_t:
+            opt.sync_device_step_count()
         self.graph.replay()
-        self.model.optimizer.t += 1
+        opt.t += 1
+        self._expected_t = opt.t
         return self.metrics
 
 
