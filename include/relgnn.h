@@ -221,6 +221,22 @@ int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int6
                           int64_t ldo, void* stream);
 
 /*
+ * relgnn_seg_reduce_acc64_fwd — the same gather + scale + segment SUM (sum / mean / sqrt_n; not max), with each
+ * bucket accumulated in float64 (w * x is exact there) and rounded to float32 once.
+ *
+ * For bucket sums that FEED A GEMM — the aggregate-then-transform evaluation of gnns/rgcn.py:84-114
+ * (out = sum_l A_l W_l with A_l[v] = sum_{(u,v) in A_l} 1/(c_{l,v}+1e-7) h_u): the reference never forms A_l, so there
+ * is no reference summation order to reproduce; what counts against the 1e-5 budget is how much rounding the
+ * aggregation adds in front of the K = L*D dot products.  relgnn_seg_reduce_fwd (sequential float32, the order of
+ * tf.unsorted_segment_sum on the reference's message tensor) stays the kernel wherever the reduced values ARE the
+ * reference's segment sums.  Rows of 132 .. 1024 floats, 16-byte aligned (RELGNN_EUNSUPPORTED otherwise).
+ */
+int relgnn_seg_reduce_acc64_fwd(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                                const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                                const int32_t* col, const float* w, int32_t act, float* out,
+                                int64_t ldo, void* stream);
+
+/*
  * Per-MESSAGE activation before the reduction (gnns/gnn_edge_mlp.py:104-116, rgin.py:127-133: scale, activation,
  * segment reduce on the materialised message tensor) without an elementwise pass over [M, D]:
  *   relgnn_seg_reduce_msgact_fwd : out[s,:] = finalize_mode( REDUCE_p msg_act( w[p] * X[col[p],:] ) )

@@ -256,3 +256,34 @@ def sparse_rgdcn_layer(h, adj, deg, num_channels=8, channel_dim=16, num_timestep
             outs.append(act(agg(torch.cat(per_type, 0), tgts, V)))
         cur = torch.cat(outs, 1)
     return cur
+
+
+def sparse_rgcn_layer_lean(h, adj, deg, state_dim, num_timesteps=1, activation_function="tanh",
+                           message_aggregation_function="sum", normalize_by_num_incoming=True, *, weights):
+    """BASELINE-size variant of sparse_rgcn_layer above for REFERENCE GRADIENTS in float64 (sum aggregation, source-only
+    inputs): the same function, evaluated as  act(sum_l A_l (h W_l))  with A_l the sparse [V, V] matrix holding
+    1/(c_{l,v} + 1e-7) at (v, u) for every edge (u, v) of type l (duplicates summed).  Op for op the chain above keeps two
+    [M, D] float64 tensors per layer alive for autograd (7.6 GB per layer at the C2 batch); this one keeps [V, D] tensors.
+    In float64 the association of the sums is immaterial at the 1e-12 level (tests/test_oracle_crosscheck_cpu.py checks it
+    against the op-for-op path); the 1/(c + 1e-7) scale is evaluated in float32 like the reference's and then widened, so
+    that both sides multiply by the same number."""
+    if _KINDS.get(message_aggregation_function) != "sum":
+        raise ValueError("sparse_rgcn_layer_lean: sum aggregation only")
+    act = activation(activation_function)
+    V = h.shape[0]
+    mats = []
+    for l, a in enumerate(adj):
+        a = a.long()
+        if normalize_by_num_incoming:
+            scale = (1.0 / (deg[l].to(torch.float32)[a[:, 1]] + torch.tensor(SMALL_NUMBER, dtype=torch.float32))).to(h.dtype)
+        else:
+            scale = torch.ones(a.shape[0], dtype=h.dtype)
+        mats.append(torch.sparse_coo_tensor(torch.stack([a[:, 1], a[:, 0]]), scale, (V, V)).coalesce().to_sparse_csr())
+    cur = h
+    for _ in range(num_timesteps):
+        total = None
+        for l, A in enumerate(mats):
+            part = torch.sparse.mm(A, cur @ weights["Edge_%i_Weight/kernel" % l])
+            total = part if total is None else total + part
+        cur = act(total)
+    return cur

@@ -78,6 +78,79 @@ def test_c2_full_batch_rgcn_model_forward(gpu_device, c2):
     assert_parity(final, ref, strict_abs=True, what="C2 full batch RGCN_Model forward (3 layers + dense)")
 
 
+def test_c2_full_batch_rgcn_layer_against_the_op_for_op_oracle(gpu_device, c2):
+    """One layer on the full C2 batch against the oracle in the REFERENCE's op order (gnns/rgcn.py:84-112: gather the source
+    rows of every edge, per-edge [E_l, D] @ [D, D], scale, concat, sequential segment sum — 2 GB of messages, ~30 s of host
+    time) — not the node-side evaluation order the other C2 cases use.  The two oracle orders must agree BIT FOR BIT at this
+    size too (a row of a matrix product does not depend on which other rows are in the batch; tests/test_oracle.py pins the
+    same on small graphs), which is what lets the chained / whole-model cases use the cheap one."""
+    from tf_gnn_samples_amd.gnns import sparse_rgcn_layer
+    _, mb = c2
+    fd = mb.feed_dict
+    rng = np.random.default_rng(0)
+    D = 256
+    adj, deg = fd["adjacency_lists"], fd["type_to_num_incoming_edges"].astype(np.float32)
+    h = (rng.random((mb.num_nodes, D), dtype=np.float32) * 2 - 1)
+    w = rgcn_weights(rng, 3, D, D)
+    ref = G.sparse_rgcn_layer(h, adj, deg, D, 1, "ReLU", "sum", weights=w, node_side_transform=False)
+    cheap = G.sparse_rgcn_layer(h, adj, deg, D, 1, "ReLU", "sum", weights=w, node_side_transform=True)
+    assert np.array_equal(ref, cheap), "the oracle's node-side order deviates from the op-for-op order at full size"
+    out = sparse_rgcn_layer(_dev(h, gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), D, 1, "ReLU", "sum",
+                            weights=_dev(w, gpu_device))
+    assert_parity(out, ref, strict_abs=True, what="C2 full batch rgcn layer vs op-for-op oracle (per-edge matmul order)")
+
+
+def test_c2_full_batch_model_gradients(gpu_device, c2):
+    """d loss / d (every variable) and d loss / d (input features) of the 3-layer RGCN + PPI head on the FULL C2 batch:
+    the HIP path's backward (by-source gather-reduce, GEMMs with the stacked kernels, streaming / split-K weight
+    gradients, fused loss) against float64 autograd through the torch mirror of the driver (oracle/torch_model.py) with
+    the layer evaluated as sparse products (oracle/torch_ref.py:sparse_rgcn_layer_lean, pinned to the op-for-op mirror
+    in tests/test_oracle_crosscheck_cpu.py)."""
+    from oracle import torch_model as TM
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DeviceBatch
+    task, mb = c2
+    p = RGCN_Model.default_params()
+    p.update(hidden_size=256, graph_num_layers=3, graph_activation_function="ReLU", message_aggregation_function="sum",
+             graph_layer_input_dropout_keep_prob=1.0)
+    model = RGCN_Model(p, task, device=str(gpu_device))
+    batch = DeviceBatch(mb, gpu_device)
+    batch.wait_ready()
+    x_hip = batch.initial_node_features.detach().clone().requires_grad_(True)
+    batch.initial_node_features = x_hip
+    model.optimizer.zero_grad()
+    metrics = model.forward_batch(batch, training=True)
+    metrics['loss'].backward()
+    torch.cuda.synchronize()
+
+    names = list(model.variables.names())
+    W = {n[len("graph_model/"):]: model.variables[n].detach().cpu().double().requires_grad_(True)
+         for n in names if n.startswith("graph_model/")}
+    head = {n: model.variables[n].detach().cpu().double().requires_grad_(True) for n in names if not n.startswith("graph_model/")}
+    fd = mb.feed_dict
+    adj = [torch.as_tensor(a) for a in fd['adjacency_lists']]
+    deg = torch.as_tensor(fd['type_to_num_incoming_edges'].astype(np.float32))
+    x = torch.as_tensor(fd['initial_node_features']).double().requires_grad_(True)
+    final = TM.graph_propagation(x, adj, deg, p, W, TM.rgcn_apply(p, lean=True))
+    kernel = next(v for k, v in head.items() if k.endswith("kernel"))
+    bias = next(v for k, v in head.items() if k.endswith("bias"))
+    loss = TM.ppi_loss(final, torch.as_tensor(fd['target_labels']).double(), kernel, bias)
+    loss.backward()
+    assert abs(float(metrics['loss']) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+
+    worst_rel = 0.0
+    for n in names:
+        ref = (W[n[len("graph_model/"):]] if n.startswith("graph_model/") else head[n]).grad.numpy()
+        got = model.variables[n].grad
+        assert got is not None, n
+        a, r = assert_parity(got, ref, strict_abs=True, what="C2 full batch d loss / d %s" % n)
+        worst_rel = max(worst_rel, r)
+    a, r = assert_parity(x_hip.grad, x.grad.numpy(), strict_abs=True, what="C2 full batch d loss / d initial_node_features")
+    worst_rel = max(worst_rel, r)
+    # fp32 reductions over 32 k nodes / 1.85 M messages against float64: relative to the largest entry of each gradient
+    assert worst_rel < 2e-4, worst_rel
+
+
 def test_c4_rgat_on_the_c2_batch(gpu_device, c2):
     from tf_gnn_samples_amd.gnns import sparse_rgat_layer
     _, mb = c2

@@ -136,3 +136,76 @@ def test_sgd_and_clip_by_norm_against_torch():
     p.grad = torch.as_tensor(g.copy())
     topt.step()
     np.testing.assert_allclose(opt.vars[0], p.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_lean_float64_rgcn_reference_equals_the_op_for_op_mirror(normalize):
+    """oracle/torch_ref.py:sparse_rgcn_layer_lean (sparse products, what the BASELINE-size gradient test differentiates in
+    float64) against the op-for-op mirror sparse_rgcn_layer: values and gradients (h and every kernel).  The lean form
+    evaluates 1/(c + 1e-7) in float32 like the reference and widens it, the mirror evaluates it in the working dtype: at
+    float64 that is a 1e-7 relative difference of the scale, which bounds the tolerance when normalising."""
+    from helpers import degree_table, random_relational_graph, rgcn_weights
+    from oracle import torch_model as TM, torch_ref as R
+    rng = np.random.default_rng(7)
+    V, D = 300, 32
+    adj = random_relational_graph(rng, V, 3, [2000, 300, 1500])
+    deg = degree_table(adj, V)
+    w = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in rgcn_weights(rng, 3, D, D).items()}
+    h = torch.tensor(np.tanh(rng.standard_normal((V, D))), dtype=torch.float64, requires_grad=True)
+    adj_t, deg_t = [torch.as_tensor(a) for a in adj], torch.as_tensor(deg)
+    a = R.sparse_rgcn_layer(h, adj_t, deg_t, D, 2, "ReLU", "sum", normalize, weights=w)
+    b = R.sparse_rgcn_layer_lean(h, adj_t, deg_t, D, 2, "ReLU", "sum", normalize, weights=w)
+    tol = 5e-7 if normalize else 1e-12
+    assert float((a - b).abs().max()) <= tol * max(1.0, float(a.abs().max()))
+    ga = torch.autograd.grad(a.square().sum(), [h] + list(w.values()))
+    gb = torch.autograd.grad(b.square().sum(), [h] + list(w.values()))
+    for x, y in zip(ga, gb):
+        assert float((x - y).abs().max()) <= tol * float(x.abs().max())
+    # the whole-model mirror with either layer: same loss and gradients
+    p = {'hidden_size': D, 'graph_num_layers': 2, 'graph_model_activation_function': 'tanh', 'graph_activation_function': 'ReLU',
+         'message_aggregation_function': 'sum', 'graph_residual_connection_every_num_layers': 2,
+         'graph_num_timesteps_per_layer': 1, 'graph_inter_layer_norm': False, 'graph_dense_between_every_num_gnn_layers': 1}
+    W = {}
+    for layer in range(2):
+        for k, v in rgcn_weights(rng, 3, D, D).items():
+            W["gnn_layer_%i/%s" % (layer, k)] = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+        W["gnn_layer_%i/Dense/kernel" % layer] = torch.tensor(rgcn_weights(rng, 1, D, D)["Edge_0_Weight/kernel"],
+                                                             dtype=torch.float64, requires_grad=True)
+    W["dense/kernel"] = torch.tensor(rng.standard_normal((7, D)) * 0.3, dtype=torch.float64, requires_grad=True)
+    x = torch.tensor(rng.standard_normal((V, 7)), dtype=torch.float64)
+    labels = torch.tensor((rng.random((V, 5)) < 0.4).astype(np.float64))
+    kernel = torch.tensor(rng.standard_normal((D, 5)) * 0.2, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(5, dtype=torch.float64, requires_grad=True)
+    losses, grads = [], []
+    for lean in (False, True):
+        final = TM.graph_propagation(x, adj_t, deg_t, p, W, TM.rgcn_apply(p, lean=lean))
+        loss = TM.ppi_loss(final, labels, kernel, bias)
+        losses.append(float(loss))
+        grads.append(torch.autograd.grad(loss, list(W.values()) + [kernel, bias]))
+    assert abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0])
+    for x_, y_ in zip(*grads):
+        assert float((x_ - y_).abs().max()) <= 1e-6 * max(float(x_.abs().max()), 1e-12)
+
+
+def test_torch_model_mirror_equals_the_numpy_driver():
+    """oracle/torch_model.py (what the gradient tests differentiate) against oracle/model.py (what the forward parity tests
+    compare with), float64, residual connection and inter-layer Dense included."""
+    from helpers import degree_table, random_relational_graph, rgcn_weights
+    from oracle import model as OM, torch_model as TM
+    rng = np.random.default_rng(8)
+    V, D, F = 200, 16, 9
+    adj = random_relational_graph(rng, V, 3, [900, 200, 700])
+    deg = degree_table(adj, V).astype(np.float64)
+    p = {'hidden_size': D, 'graph_num_layers': 4, 'graph_model_activation_function': 'tanh', 'graph_activation_function': 'ReLU',
+         'message_aggregation_function': 'sum', 'graph_residual_connection_every_num_layers': 2,
+         'graph_num_timesteps_per_layer': 1, 'graph_inter_layer_norm': False, 'graph_dense_between_every_num_gnn_layers': 2}
+    W = {"dense/kernel": rng.standard_normal((F, D)) * 0.3}
+    for layer in range(4):
+        for k, v in rgcn_weights(rng, 3, D, D).items():
+            W["gnn_layer_%i/%s" % (layer, k)] = v.astype(np.float64)
+        W["gnn_layer_%i/Dense/kernel" % layer] = rng.standard_normal((D, D)) * 0.2
+    x = rng.standard_normal((V, F))
+    want = OM.graph_propagation(x, adj, deg, p, W, OM.rgcn_apply(p))
+    got = TM.graph_propagation(torch.as_tensor(x), [torch.as_tensor(a) for a in adj], torch.as_tensor(deg), p,
+                               {k: torch.as_tensor(v) for k, v in W.items()}, TM.rgcn_apply(p))
+    np.testing.assert_allclose(got.numpy(), want, rtol=1e-10, atol=1e-12)

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "relgnn_degree_scale": (ctypes.c_int, [_ptr, _ptr, _c_i32, _c_i32, _c_f32, _ptr, _ptr]),
     "relgnn_segment_counts_scale": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_seg_reduce_fwd": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
+    "relgnn_seg_reduce_acc64_fwd": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_seg_reduce_msgact_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
     "relgnn_msg_act_bwd": (ctypes.c_int, [_c_i32, _ptr, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_seg_max_count": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),

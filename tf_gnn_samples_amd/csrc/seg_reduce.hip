@@ -77,6 +77,12 @@ __device__ __forceinline__ void combine(float4& acc, float w, const float4& v, i
   }
 }
 
+__device__ __forceinline__ void combine64(double (&acc)[4], float w, const float4& v) {
+  const double wd = (double)w;           // float * float is exact in float64: one rounding (2^-53) per message
+  acc[0] = fma(wd, (double)v.x, acc[0]); acc[1] = fma(wd, (double)v.y, acc[1]);
+  acc[2] = fma(wd, (double)v.z, acc[2]); acc[3] = fma(wd, (double)v.w, acc[3]);
+}
+
 __device__ __forceinline__ float4 finalize(int mode, int act, float4 a, int n) {
   if (mode == RELGNN_AGG_MEAN) {
     float d = (float)max(n, 1);
@@ -95,7 +101,12 @@ __device__ __forceinline__ float4 finalize(int mode, int act, float4 a, int n) {
 // ---------------------------------------------------------------------------------------
 // One wave per output row.  NCH = float4 chunks per lane (row width up to NCH*256 floats).
 // ---------------------------------------------------------------------------------------
-template <int NCH, bool IS_MAX, bool HAS_W, int UNROLL = kUnroll, bool NT = false, bool XCD = true, bool MSGACT = false>
+// ACC64 (sum-like modes only): the bucket is accumulated in float64 — w * x is exact there and every add rounds at 2^-53 —
+// and rounded to float32 ONCE at the end.  Used where the bucket sums feed a GEMM (aggregate-then-transform: the reference
+// never forms these per-(target, type) sums, so there is no summation order to reproduce; what matters is how little
+// rounding they add in front of the K = L*D dot products).  The kernel is memory-bound: the f64 adds hide under the gather.
+template <int NCH, bool IS_MAX, bool HAS_W, int UNROLL = kUnroll, bool NT = false, bool XCD = true, bool MSGACT = false,
+          bool ACC64 = false>
 __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
     const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
@@ -113,7 +124,9 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
   const int end = __builtin_amdgcn_readfirstlane(rowptr[(s + 1) * stride]);
 
   const int c0 = (col_block0 + (int)blockIdx.y * NCH) * 64 + lane;  // this lane's first float4 column
+  static_assert(!ACC64 || (!IS_MAX && !MSGACT), "float64 accumulation: plain sums only");
   float4 acc[NCH];
+  double accd[ACC64 ? NCH : 1][4];
   bool on[NCH];
   uint32_t cc[NCH];  // column used for LOADS: clamped into the row so that lanes past the
                      // row end read a valid (ignored) address instead of branching
@@ -121,6 +134,7 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
   for (int c = 0; c < NCH; ++c) {
     const float init = IS_MAX ? -FLT_MAX : 0.f;
     acc[c] = make_float4(init, init, init, init);
+    if constexpr (ACC64) accd[c][0] = accd[c][1] = accd[c][2] = accd[c][3] = 0.0;
     on[c] = (c0 + 64 * c) < D4;
     cc[c] = (uint32_t)min(c0 + 64 * c, D4 - 1);
   }
@@ -149,7 +163,10 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) combine<IS_MAX, MSGACT>(acc[c], ww[u], v[u][c], msg_act);
+        for (int c = 0; c < NCH; ++c) {
+          if constexpr (ACC64) combine64(accd[c], ww[u], v[u][c]);
+          else combine<IS_MAX, MSGACT>(acc[c], ww[u], v[u][c], msg_act);
+        }
     }
     for (; k < n; ++k) {
       const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(my_col, k);
@@ -158,9 +175,15 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         float4 v = row[cc[c]];
-        combine<IS_MAX, MSGACT>(acc[c], wk, v, msg_act);
+        if constexpr (ACC64) combine64(accd[c], wk, v);
+        else combine<IS_MAX, MSGACT>(acc[c], wk, v, msg_act);
       }
     }
+  }
+  if constexpr (ACC64) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      acc[c] = make_float4((float)accd[c][0], (float)accd[c][1], (float)accd[c][2], (float)accd[c][3]);
   }
 
   float4* orow = out + s * ldo4 + c0;
@@ -371,11 +394,25 @@ __global__ __launch_bounds__(256) void msg_act_bwd_kernel(int32_t act, const flo
 template <int NCH, bool IS_MAX>
 int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
                 int64_t S, int32_t stride, const int32_t* col, const float* w, int32_t mode,
-                int32_t act, float* out, int64_t ldo, hipStream_t st, int32_t msg_act) {
+                int32_t act, float* out, int64_t ldo, hipStream_t st, int32_t msg_act, bool acc64 = false) {
   const int D4 = D / 4;
   const int64_t nlb = (S + 3) / 4;
   const int col_blocks = (D4 + 64 * NCH - 1) / (64 * NCH);
   dim3 grid((unsigned)(((nlb + 7) / 8) * 8), (unsigned)col_blocks);
+  if constexpr (!IS_MAX) {
+    if (acc64) {
+      if (msg_act != RELGNN_ACT_LINEAR) return RELGNN_EUNSUPPORTED;
+      if (has_w)
+        seg_reduce_wave_kernel<NCH, false, true, kUnroll, false, true, false, true><<<grid, 256, 0, st>>>(
+            reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
+            reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+      else
+        seg_reduce_wave_kernel<NCH, false, false, kUnroll, false, true, false, true><<<grid, 256, 0, st>>>(
+            reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
+            reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+      return launch_status();
+    }
+  }
   if constexpr (NCH == 1 && !IS_MAX) {
     const int var = seg_variant();
     if (var != 0 && has_w) {
@@ -453,9 +490,16 @@ int launch_group(bool has_w, const float* X, int64_t ldx, int32_t D, const int32
 template <bool IS_MAX>
 int dispatch_fwd(const float* X, int64_t num_rows_x, int64_t ldx, int32_t D, const int32_t* rowptr, int64_t S,
                  int32_t stride, const int32_t* col, const float* w, int32_t mode, int32_t act,
-                 float* out, int64_t ldo, hipStream_t st, int32_t msg_act) {
+                 float* out, int64_t ldo, hipStream_t st, int32_t msg_act, bool acc64 = false) {
   const bool vec_ok = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(X) &&
                       aligned16(out) && (num_rows_x * (ldx / 4) < ((int64_t)1 << 32));
+  if (acc64) {        // float64 bucket sums: the one-wave-per-row kernels (rows of 132 .. 1024 floats), plain sums
+    if (IS_MAX || !vec_ok || D / 4 <= 32 || D / 4 > 256) return RELGNN_EUNSUPPORTED;
+    const bool has_w = w != nullptr;
+    if (D / 4 <= 64) return launch_wave<1, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act, true);
+    if (D / 4 <= 128) return launch_wave<2, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act, true);
+    return launch_wave<4, IS_MAX>(has_w, X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, st, msg_act, true);
+  }
   if (!vec_ok) {
     seg_reduce_scalar_kernel<IS_MAX><<<(unsigned)((S + 3) / 4), 256, 0, st>>>(
         X, ldx, D, rowptr, S, stride, col, w, mode, act, out, ldo, msg_act);
@@ -477,7 +521,16 @@ extern "C" {
 
 static int seg_reduce_any(int32_t mode, int32_t msg_act, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
                           const int32_t* rowptr, int64_t num_segments, int32_t seg_stride, const int32_t* col,
-                          const float* w, int32_t act, float* out, int64_t ldo, void* stream);
+                          const float* w, int32_t act, float* out, int64_t ldo, void* stream, bool acc64 = false);
+
+int relgnn_seg_reduce_acc64_fwd(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                                const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                                const int32_t* col, const float* w, int32_t act, float* out, int64_t ldo,
+                                void* stream) {
+  if (mode == RELGNN_AGG_MAX) return RELGNN_EINVAL;
+  return seg_reduce_any(mode, RELGNN_ACT_LINEAR, X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, act,
+                        out, ldo, stream, true);
+}
 
 int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
                           const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
@@ -497,7 +550,7 @@ int relgnn_seg_reduce_msgact_fwd(int32_t mode, int32_t msg_act, const float* X, 
 
 static int seg_reduce_any(int32_t mode, int32_t msg_act, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
                           const int32_t* rowptr, int64_t num_segments, int32_t seg_stride, const int32_t* col,
-                          const float* w, int32_t act, float* out, int64_t ldo, void* stream) {
+                          const float* w, int32_t act, float* out, int64_t ldo, void* stream, bool acc64) {
   if (mode < RELGNN_AGG_SUM || mode > RELGNN_AGG_MAX) return RELGNN_EINVAL;
   if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
   if (D < 0 || num_segments < 0 || seg_stride <= 0 || num_rows_x < 0 || ldx < D || ldo < D)
@@ -509,7 +562,8 @@ static int seg_reduce_any(int32_t mode, int32_t msg_act, const float* X, int64_t
   hipStream_t st = as_stream(stream);
   if (mode == RELGNN_AGG_MAX)
     return dispatch_fwd<true>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st, msg_act);
-  return dispatch_fwd<false>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st, msg_act);
+  return dispatch_fwd<false>(X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, mode, act, out, ldo, st, msg_act,
+                             acc64);
 }
 
 int relgnn_msg_act_bwd(int32_t act, const float* X, int32_t D, const float* w, const int32_t* tgt, const float* gagg,

@@ -95,13 +95,25 @@ def _seg_reduce_split(mode, X, sp: SplitPlan, col, w, num_out, act):
     return out
 
 
-def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEAR):
+def acc64_supported(D: int) -> bool:
+    """Row widths relgnn_seg_reduce_acc64_fwd takes (the one-wave-per-row kernels)."""
+    return D % 4 == 0 and 128 < D <= 1024
+
+
+def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEAR, acc64: bool = False):
+    """acc64: float64 bucket accumulators (relgnn_seg_reduce_acc64_fwd) — for sums that feed a GEMM, never for values that
+    stand for the reference's own segment sums.  Split (hub) plans keep the float32 two-pass route."""
     split = getattr(rowptr, "_relgnn_split", None)
     if split is not None and stride in split:
         return _seg_reduce_split(mode, X, split[stride], col, w, num_out, act)
     lib = _lib.load_library()
     D = X.shape[1]
     out = torch.empty((num_out, D), dtype=torch.float32, device=X.device)
+    if acc64 and mode != _lib.AGG_MAX and acc64_supported(D) and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0:
+        _lib.check(lib.relgnn_seg_reduce_acc64_fwd(
+            mode, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), D, _lib.ptr(rowptr), num_out, stride,
+            _lib.ptr(col), _lib.ptr(w), act, _lib.ptr(out), D, _lib.current_stream()), "relgnn_seg_reduce_acc64_fwd")
+        return out
     _lib.check(lib.relgnn_seg_reduce_fwd(
         mode, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), D, _lib.ptr(rowptr), num_out, stride,
         _lib.ptr(col), _lib.ptr(w), act, _lib.ptr(out), D, _lib.current_stream()),
@@ -774,6 +786,13 @@ def fused_aggregate_transform(H, W, graph, w, aggregation: str, activation: Opti
 
 
 # ---- aggregate, then transform (two kernels, no fusion): gather from the SMALL table -------------------------------------
+def aggregate_acc64() -> bool:
+    """RELGNN_AGG_ACC=f32|f64: accumulator width of the bucket sums that feed the K = L*D GEMM of the aggregate-first order.
+    The reference has no counterpart of these sums (it reduces transformed messages), so their rounding is pure added error
+    against the 1e-5 budget: float64 accumulators take it out (measured at the full C2 batch: profiles/r03_parity_margin.json)."""
+    return os.environ.get("RELGNN_AGG_ACC", "f64") == "f64"
+
+
 class _AggregateThenTransform(torch.autograd.Function):
     """out = act(f_mode(sum_l A_l @ W_l)),  A_l[v] = sum_{p in (v,l)} w_p H[src_p]   (W: [L, Din, Dout]).
 
@@ -790,7 +809,8 @@ class _AggregateThenTransform(torch.autograd.Function):
         H, W = H.contiguous(), W.contiguous()
         L, d_in, d_out = W.shape
         V = graph.V
-        agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L).view(V, L * d_in)
+        agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
+                              acc64=aggregate_acc64()).view(V, L * d_in)
         f = _mode_factor(graph, mode)
         fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the library GEMM's epilogue
         out = lib_gemm(GEMM_NN, agg, W.view(L * d_in, d_out), relu=fused_relu)
@@ -826,7 +846,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
             gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
-                                 plan.num_rows_x).view(V, L * d_out)                   # row u: [dT_0 | .. | dT_{L-1}]
+                                 plan.num_rows_x, acc64=aggregate_acc64()).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
             # (dH = sum_l dT_l @ W_l^T: the stacked [L*Dout, Din] right operand is W_l^T row blocks, 0.8 MB re-laid per step)
             gH = lib_gemm(GEMM_NN, gT, W.permute(0, 2, 1).reshape(L * d_out, d_in))
         if ctx.needs_input_grad[1]:
