@@ -15,9 +15,16 @@ bytes cross HBM depends on whether the gathered table stays in the 4 MiB-per-XCD
   c2h     the same C2 batch in the order the RGCN layer uses since round 2 (aggregate, then transform): rows of the
           [V, 256] node-state table (33 MB; one graph's 2.3 MB slab fits the 4 MiB L2) are gathered into the V*L
           (target, type) buckets; same messages, 3x the output rows.
-  giant   ONE graph with PPI degree statistics and 2^20 nodes: table 3.2 GB, sources uniform over the whole
-          table -> no reuse survives in any cache, every gathered row crosses HBM: algorithmic bytes ARE the HBM
-          bytes.  This is the HBM-bound size the `roofline` object of the bench line is quoted on (frac <= 1).
+  ppi256h the 256-graph union in that same aggregate-first order (table [V, 256] = 0.6 GB).
+  giant   ONE graph with PPI degree statistics and 2^20 nodes: table 3.2 GB.  Forward-type sources are uniform over
+          the table, but the backward type's sources are the forward TARGETS, drawn proportionally to log-normal(0.9)
+          weights: its hottest rows could stay in the 256 MiB Infinity Cache, and FETCH_SIZE counts at the L2's fabric
+          side, Infinity-Cache hits included.  `mall_hit_upper_bound` is the share of all gathers that go to the
+          most-gathered rows that fit 256 MiB (perfect retention of exactly the hottest rows: an upper bound).
+  giant_uniform  the same construction with UNIFORM targets and 2^21 nodes: table 6.4 GB = 25x the Infinity Cache, every
+          row equally likely at every gather -> at most 256 MiB / 6.4 GB = 4 % of the gathers can hit any cache, the
+          algorithmic bytes ARE HBM bytes to within that.  This is the size the `roofline` object of the bench line is
+          quoted on (frac <= 1).
 
 Protocols: `warm` = back-to-back launches on the same table (what a training step sees: the table was just
 written by the GEMM); `cold` = every timed launch is preceded by a 1 GiB streaming write that evicts L2 and
@@ -42,7 +49,8 @@ import torch
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s float4-copy measured)
 HBM_COPY_GBS = 6290.0      # measured float4 copy ceiling of the same guide
 L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth, same guide
-WORKLOADS = ("c2", "c2h", "ppi256", "giant")
+WORKLOADS = ("c2", "c2h", "ppi256", "ppi256h", "giant", "giant_uniform")
+MALL_BYTES = 256 << 20     # Infinity Cache (MI355X_MICROARCH.md)
 HIDDEN = 256
 KERNEL_NAME = "seg_reduce_wave_kernel"
 
@@ -80,16 +88,18 @@ def build_workload(name, device):
     from tf_gnn_samples_amd.graph import RelGraph
     if name in ("c2", "c2h"):
         adj, deg, V = _ppi_union(16, 0, device)
-    elif name == "ppi256":
+    elif name in ("ppi256", "ppi256h"):
         adj, deg, V = _ppi_union(256, 0, device)
     elif name == "giant":
         adj, deg, V = _giant(device)
+    elif name == "giant_uniform":
+        adj, deg, V = _giant(device, log2_nodes=21, sigma=0.0)
     else:
         raise ValueError(name)
     g = RelGraph(adj, V)
     w = g.degree_scale(deg)
     L, M, D = g.L, g.M, HIDDEN
-    if name == "c2h":
+    if name in ("c2h", "ppi256h"):
         from tf_gnn_samples_amd.graph import GatherReducePlan
         plan = GatherReducePlan(rowptr=g.rowptr_t, stride=1, col=g.src_t, w=w, num_out=V * L, num_rows_x=V,
                                 rowptr_b=g.rowptr_s, stride_b=L, col_b=g.frow_s, pos_b=g.pos_t_of_s, num_messages=M)
@@ -100,13 +110,18 @@ def build_workload(name, device):
         unique_rows = int((g.rowptr_s[1:] > g.rowptr_s[:-1]).sum())     # non-empty (source, type) buckets
         table_rows, out_rows = V * L, V
     table_bytes = table_rows * D * 4
+    # share of the gathers that go to the most-gathered rows fitting the Infinity Cache (upper bound on its hit rate)
+    counts = torch.bincount(plan.col.long(), minlength=table_rows)
+    hot = min(table_rows, MALL_BYTES // (D * 4))
+    mall_ub = float(torch.topk(counts, hot).values.sum()) / max(1, M) if hot < table_rows else 1.0
+    del counts
     free = torch.cuda.mem_get_info(device)[0]
     copies = int(max(1, min(4, (free - (6 << 30)) // table_bytes)))
     gen = torch.Generator(device=device).manual_seed(0)
     tables = [torch.rand((table_rows, D), device=device, generator=gen) * 2 - 1 for _ in range(copies)]
     return {
         "name": name, "plan": plan, "tables": tables, "graph": g, "V": V, "L": L, "M": M, "D": D,
-        "unique_rows": unique_rows, "table_bytes": table_bytes,
+        "unique_rows": unique_rows, "table_bytes": table_bytes, "mall_hit_upper_bound": mall_ub,
         # per message one D-float row + (col, w); per node one D-float output row; row pointers
         "algorithmic_bytes": M * (4 * D + 8) + out_rows * 4 * D + 4 * (V * L + 1),
         # what HBM must move at least once: every distinct gathered row, the index/weight streams, rowptr, output
@@ -156,7 +171,9 @@ def summarize(wl, warm_ms, cold_ms, warm_min, cold_min):
     return {
         "workload": wl["name"], "nodes": wl["V"], "edge_types": wl["L"], "messages": wl["M"], "hidden": wl["D"],
         "table_bytes": wl["table_bytes"], "distinct_tables_rotated": len(wl["tables"]),
-        "unique_gathered_rows": wl["unique_rows"],
+        "unique_gathered_rows": wl["unique_rows"], "mall_hit_upper_bound": wl["mall_hit_upper_bound"],
+        # HBM-proper rate if the Infinity Cache kept exactly the hottest rows (it cannot do better): a LOWER bound
+        "hbm_GBps_lower_bound_cold": gbps(alg, cold_ms) * (1.0 - min(1.0, wl["mall_hit_upper_bound"])),
         "algorithmic_bytes": alg, "compulsory_bytes": comp,
         "warm_ms": warm_ms, "cold_ms": cold_ms, "warm_ms_min": warm_min, "cold_ms_min": cold_min,
         "algorithmic_GBps_warm": gbps(alg, warm_ms), "algorithmic_GBps_cold": gbps(alg, cold_ms),
@@ -172,7 +189,7 @@ def measure(names, iters, device, cold_only=False):
     out = []
     for n in names:
         wl = build_workload(n, device)
-        it = iters if n != "giant" else max(8, iters // 2)
+        it = iters if not n.startswith("giant") else max(8, iters // 2)
         res = summarize(wl, *time_workload(wl, it, device, cold_only))
         if cold_only:
             res["protocol"] = "cold only: warm_* fields repeat the cold figures"

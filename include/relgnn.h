@@ -725,6 +725,34 @@ int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64
 int relgnn_sum_slabs_tail_f32(const float* slabs, int32_t num_slabs, int32_t M, int32_t N, const float* At, int64_t lda,
                               const float* Bt, int64_t ldb, int32_t R, float* C, void* stream);
 
+/*
+ * relgnn_panel_gemm_f32 — the same three products on v_mfma_f32_16x16x4_f32 (exact fp32) with direct-to-LDS operand
+ * staging, sized per call so that every CU gets the same number of equal row panels, plus what the node-side Dense
+ * layers of MANY-TYPE graphs need and a library GEMM cannot express without copies:
+ *   a_rows (nullable)  NN / NT: row r of the left operand is A[a_rows[r], :] (a_rows[r] < 0: a row of zeros) — the
+ *                      tf.nn.embedding_lookup of gnns/gnn_film.py:92-93,105 / rgcn.py:87-89 fused into the product;
+ *                      TN: the REDUCTION row k of both operands is (A[a_rows[k], :], B[k, :]) (K <= 1024 per product;
+ *                      with independent batches product z uses a_rows[z*K + k])
+ *   b_select (nullable) rows [p*rows_per_select, (p+1)*rows_per_select) of the output use the right operand
+ *                      B + b_select[p]*b_select_stride: one Edge_%i_Weight / Edge_%i_FiLM_Computations kernel per
+ *                      512-row tile of a compact (node, type) table (gnn_film.py:74-78,92-106); rows_per_select % 128 == 0
+ *   batch > 1          split_k_rows == 0: independent products z at A + z*a_batch_stride, B + z*b_batch_stride,
+ *                      C + z*c_batch_stride (per-tile weight-gradient partials);
+ *                      split_k_rows  > 0: ONE product whose K range is cut into `batch` chunks of split_k_rows rows
+ *                      (% 16 == 0), chunk z writes its partial product to C + z*c_batch_stride (the caller sums the slabs
+ *                      in order: deterministic)
+ *   bias / act         NN-style epilogue (bias of length N, any RELGNN_ACT_*), batch == 1 semantics per product
+ *   zeros              256 zero floats in device memory (the source of padding rows and of the K tail)
+ * Requirements (RELGNN_EUNSUPPORTED otherwise): N % 128 == 0, K % 4 == 0, 16-byte aligned operands and row strides,
+ * TN: M % 4 == 0.  C rows [0, M) x columns [0, N) are written, nothing else.
+ */
+int relgnn_panel_gemm_zeros_floats(void);
+int relgnn_panel_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const float* B,
+                          int64_t ldb, const int32_t* b_select, int32_t rows_per_select, int64_t b_select_stride,
+                          const float* bias, const float* zeros, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                          int32_t batch, int64_t a_batch_stride, int64_t b_batch_stride, int64_t c_batch_stride,
+                          int32_t split_k_rows, void* stream);
+
 /* ========================================================================== *
  * 11. Dynamic per-target convolution kernels  (gnns/rgdcn.py:126-160)
  * ========================================================================== */

@@ -222,3 +222,41 @@ def test_unsorted_segment_dropin_drops_negative_ids(gpu_device, agg):
         assert np.all(np.abs(g[ids >= 0]).sum(1) > 0)
     with pytest.raises(ValueError):
         get_aggregation_function(agg)(x.detach(), torch.as_tensor(np.array([0] * 299 + [25], np.int32), device=gpu_device), 25)
+
+
+@pytest.mark.parametrize("D", [132, 256, 320, 512, 1024])
+@pytest.mark.parametrize("agg", ["sum", "mean", "sqrt_n"])
+def test_float64_bucket_accumulators_round_once(gpu_device, D, agg):
+    """relgnn_seg_reduce_acc64_fwd (the bucket sums that feed the aggregate-first GEMM): w * x is exact in float64 and the
+    bucket is folded in message order in float64, so the result must EQUAL the float64 sequential fold of the exact products
+    rounded to float32 once — bit for bit; narrower rows are refused (the caller then keeps the float32 kernel)."""
+    from tf_gnn_samples_amd import _lib, ops
+    from tf_gnn_samples_amd.graph import RelGraph
+    rng = np.random.default_rng(D + len(agg))
+    V, L = 211, 3
+    adj = random_relational_graph(rng, V, L, [3000, 211, 1500])
+    X = rng.standard_normal((V * L, D)).astype(np.float32)
+    deg = degree_table(adj, V)
+    g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)
+    w = g.degree_scale(torch.as_tensor(deg, device=gpu_device))
+    plan = g.plan_transformed(w)
+    mode = ops.aggregation_mode_id(agg)
+    out = ops._seg_reduce_raw(mode, torch.as_tensor(X, device=gpu_device), plan.rowptr, plan.stride, plan.col, plan.w,
+                              plan.num_out, acc64=True).cpu().numpy()
+    rows = np.concatenate([a[:, 0].astype(np.int64) * L + l for l, a in enumerate(adj)])
+    tg = np.concatenate([a[:, 1] for a in adj]); ty = np.concatenate([np.full(len(a), l) for l, a in enumerate(adj)])
+    w_msg = (np.float32(1.0) / (deg[ty, tg] + np.float32(1e-7))).astype(np.float32)
+    wide = np.zeros((V, D), np.float64)
+    np.add.at(wide, tg, w_msg.astype(np.float64)[:, None] * X[rows].astype(np.float64))     # in-order, exact products
+    want = wide.astype(np.float32)
+    n = np.maximum(np.bincount(tg, minlength=V), 1).astype(np.float32)[:, None]
+    if agg == "mean":
+        want = want / n
+    elif agg == "sqrt_n":
+        want = want / np.sqrt(n)
+    np.testing.assert_array_equal(out, want)
+    narrow = torch.zeros((V * L, 64), device=gpu_device)
+    assert not ops.acc64_supported(64)
+    np.testing.assert_array_equal(
+        ops._seg_reduce_raw(_lib.AGG_SUM, narrow, plan.rowptr, plan.stride, plan.col, plan.w, plan.num_out, acc64=True).cpu().numpy(),
+        np.zeros((V, 64), np.float32))

@@ -86,6 +86,9 @@ _SIGNATURES = {
     "relgnn_layer_norm_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_layer_norm_bwd": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr]),
+    "relgnn_panel_gemm_zeros_floats": (ctypes.c_int, []),
+    "relgnn_panel_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr, _c_i32, _c_i64, _ptr, _ptr, _ptr,
+                                             _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _c_i64, _c_i32, _ptr]),
     "relgnn_blaslt_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32,
                                               _c_i64, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_gemm_tn_stream_workspace_bytes": (_c_i64, [_c_i32, _c_i32, _c_i64]),

@@ -1,0 +1,423 @@
+// Row-panel GEMM on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate, bitwise an fmaf chain;
+// 157 TFLOP/s peak, MI355X_MICROARCH.md) with direct-to-LDS staging (global_load_lds_dwordx4) and a 3-stage LDS ring.
+//
+// Replaces the node-side Dense products of the path wherever the operand shapes allow (K % 4 == 0, N % 128 == 0):
+//   * the stacked per-edge-type transforms  A [V, L*D] @ [L*D, D]  of gnns/rgcn.py:96-98 (aggregate-first order) and their
+//     input gradients;
+//   * the per-(node, type) transforms of many-type graphs  Y[r] = H[node[r]] @ W_type(r)  (gnns/gnn_film.py:92-106,
+//     gnns/rgcn.py, gnns/ggnn.py on VarMisuse-shaped batches): the row GATHER and the per-512-row-tile weight selection
+//     happen in the load addresses — no [P, D] copy of gathered rows, no [tiles, Din, Dout] copy of the weights;
+//   * weight gradients  dW = X^T @ G  as K-split / per-tile partial products (both operands k-major).
+//
+// Geometry.  A workgroup (8 waves) owns ONE panel: up to 16*TMW*WM output rows x NC = 32*WN columns, full K.  The host
+// sizes the panels so that their number is a multiple of the 256 CUs (or, for typed operands, one weight per panel) and
+// every panel carries the same number of 16-row units +-1: the tail that costs a 128 x 128-tiled grid up to 1/3 of its
+// time at M ~ 36 k rows (564 tiles on 512 slots) does not exist.  B (a few hundred KB of weights) is re-streamed from L2
+// by every panel.
+//
+// Wave tile: TMW x 2 MFMA tiles of 16 x 16; the W fragment is the MFMA's A operand and the X fragment its B operand, so
+// that a lane ends up with four CONSECUTIVE output columns of one output row (one dwordx4 store per tile).
+// k-tile = 16.  A k-group permutation (lane group g of the MFMA takes k = 4g + j in step j) makes every lane's four
+// steps one 16-byte LDS read for k-contiguous operands.
+//
+// LDS images (floats), all lane-linear for the DMA (destination = wave-uniform base + 16 B * lane), swizzled through the
+// SOURCE address:
+//   k-contiguous operand ("RM": X [rows, K] or W given as [N, K]): blocks of 16 rows x 16 k = 1 KiB = one DMA instruction;
+//       slot(i, g) = 4 i + (g ^ 2 (i >> 3))   -> conflict-free ds_read_b128 for the 16-lane groups of gfx950
+//   k-major operand ("KM": W [K, N] or X^T): [16 k][W] floats, column n stored at n ^ 16 ((k >> 2) & 1)
+//       -> the two k rows a 32-lane half reads in one ds_read_b32 hit disjoint banks
+// Pipeline per k-tile: wait (own DMA of tile t+1, counted vmcnt) -> s_barrier -> issue DMA of tile t+3 into the stage tile t
+// occupied -> issue the LDS reads of tile t+1's fragments -> MFMAs of tile t.  One barrier per k-tile, DMA two tiles deep,
+// fragment reads one tile ahead of the matrix pipe; the waits are counted by hand (raw s_barrier: __syncthreads() would drain
+// the DMA queue).
+#include "common.h"
+
+using namespace relgnn;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BK = 16;
+constexpr int STAGES = 3;
+constexpr int KIDX_MAX = 1024;          // k-major A with gathered k rows: the row ids of the K range live in LDS
+
+struct PanelArgs {
+  const float* A; int64_t lda; const int32_t* a_rows;
+  const float* B; int64_t ldb; const int32_t* b_select; int32_t rows_per_select; int64_t b_select_stride;
+  const float* bias; const float* zeros;
+  float* C; int64_t ldc;
+  int32_t M, N, K;
+  int64_t a_bs, b_bs, c_bs;            // batch strides (grid.z)
+  int32_t k_chunk;                     // K range of batch z: [z * k_chunk_rows ...) only when split_k (else whole K)
+  int32_t split_k;                     // 1: the batch index splits K (A/B advance along k), C gets one slab per z
+  int32_t act;
+  int32_t units_base, units_rem;       // panel q covers 16-row units [q*base + min(q, rem), +base + (q < rem))
+};
+
+__device__ __forceinline__ float act_rt(int act, float x) {
+  switch (act) {
+    case RELGNN_ACT_TANH: return act_fwd<RELGNN_ACT_TANH>(x);
+    case RELGNN_ACT_RELU: return act_fwd<RELGNN_ACT_RELU>(x);
+    case RELGNN_ACT_LEAKY_RELU: return act_fwd<RELGNN_ACT_LEAKY_RELU>(x);
+    case RELGNN_ACT_ELU: return act_fwd<RELGNN_ACT_ELU>(x);
+    case RELGNN_ACT_SELU: return act_fwd<RELGNN_ACT_SELU>(x);
+    case RELGNN_ACT_GELU: return act_fwd<RELGNN_ACT_GELU>(x);
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
+                                       reinterpret_cast<uintptr_t>(src)),
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// lgkmcnt(0) through the builtin (gfx9 encoding: vmcnt 63 = bits [15:14|3:0], expcnt 7 = bits [6:4], lgkmcnt = bits [11:8]):
+// hipcc's own wait insertion does not see an inline-asm wait and would add a conservative lgkmcnt(0) in front of the MFMA
+// block — after the NEXT tile's fragment reads have been issued, which is exactly the overlap this loop exists for.
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+// WM x WN waves, TMW 16-row tiles per wave.  A_KM: A is given k-major (A[m][k] at A + k*lda + m: the X^T of a weight
+// gradient); B_RM: B is given as [N, K] row-major (k contiguous: the W of an input gradient).
+template <int WM, int WN, int TMW, bool A_KM, bool B_RM>
+__global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
+  constexpr int PR = 16 * TMW * WM;                 // panel rows
+  constexpr int NC = 32 * WN;                       // panel columns
+  constexpr int A_FLOATS = PR * BK, B_FLOATS = NC * BK;
+  constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+  constexpr int PA = A_FLOATS / 256, PB = B_FLOATS / 256, P = PA + PB;     // 1 KiB DMA pieces per stage
+  constexpr int G = (P + 7) / 8;                    // pieces per wave and k-tile (the last ones may be duplicates)
+  static_assert(!A_KM || PR % 32 == 0, "k-major A: the column swizzle needs 32-column multiples");
+  // ONE shared object (a second one makes hipcc wait vmcnt(0) before every fragment read of a DMA pipeline)
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE_FLOATS + (A_KM ? KIDX_MAX : 0)];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int q = blockIdx.x, z = blockIdx.z;
+  const int u0 = q * a.units_base + min(q, a.units_rem);
+  const int nu = a.units_base + (q < a.units_rem ? 1 : 0);
+  const int m0 = u0 * 16;
+  const int rows_here = min(nu * 16, a.M - m0);     // valid rows of this panel
+  const int n0 = blockIdx.y * NC;
+
+  int kbeg = 0, kend = a.K;
+  const float* Ab = a.A;
+  const float* Bb = a.B;
+  float* Cb = a.C + (int64_t)z * a.c_bs;
+  if (a.split_k) {
+    kbeg = z * a.k_chunk;
+    kend = min(a.K, kbeg + a.k_chunk);
+  } else {
+    Ab += (int64_t)z * a.a_bs;
+    Bb += (int64_t)z * a.b_bs;
+  }
+  if (a.b_select) Bb += (int64_t)a.b_select[m0 / a.rows_per_select] * a.b_select_stride;
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
+  // k-major A whose k rows are gathered (dW of a typed transform: A[m][k] = H[a_rows[k]][m]): the row ids of this K range
+  const bool gather_k = A_KM && a.a_rows != nullptr;
+  int* kidx = reinterpret_cast<int*>(lds + STAGES * STAGE_FLOATS);
+  if constexpr (A_KM) {
+    if (gather_k) {
+      // (independent batches: product z reduces over rows a_rows[z*K .. z*K + K); a K split: over a_rows[kbeg .. kend))
+      const int32_t* ids = a.a_rows + (a.split_k ? 0 : (int64_t)z * a.K);
+      for (int i = tid; i < ntiles * BK; i += 512) kidx[i] = (kbeg + i < kend) ? ids[kbeg + i] : -1;
+      __syncthreads();
+    }
+  }
+
+  // ---- DMA sources of this wave's pieces -----------------------------------------------------------------------------
+  const float* src[G];
+  int64_t step[G];
+  int kk[G];                                         // k (inside the tile) of this lane's 16 bytes: for the K tail
+  int piece[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int c = min(wave + 8 * g, P - 1);          // wave-uniform; past the end: a duplicate of the last piece
+    piece[g] = c;
+    const float* s;
+    int64_t st;
+    int k_in;
+    if (c < PA) {
+      if constexpr (A_KM) {
+        const int f = 256 * c + 4 * lane;
+        const int k = f / PR, mp = f % PR;
+        const int m = mp ^ (16 * ((k >> 2) & 1));
+        const bool ok = m < rows_here;
+        // (gathered k rows: `s` is the column part only, the row is looked up per tile in issue())
+        s = ok ? Ab + (gather_k ? 0 : (int64_t)(kbeg + k) * a.lda) + m0 + m : a.zeros + 4 * lane;
+        st = ok ? (gather_k ? 1 : (int64_t)BK * a.lda) : 0;
+        k_in = k;
+      } else {
+        const int i = lane >> 2, gq = (lane & 3) ^ (2 * (i >> 3));
+        const int r = 16 * c + i;
+        int64_t row = -1;
+        if (r < rows_here) row = a.a_rows ? (int64_t)a.a_rows[m0 + r] : (int64_t)(m0 + r);
+        const bool ok = row >= 0;
+        s = ok ? Ab + row * a.lda + kbeg + 4 * gq : a.zeros + 4 * lane;
+        st = ok ? BK : 0;
+        k_in = 4 * gq;
+      }
+    } else {
+      const int cb = c - PA;
+      if constexpr (B_RM) {
+        const int i = lane >> 2, gq = (lane & 3) ^ (2 * (i >> 3));
+        s = Bb + (int64_t)(n0 + 16 * cb + i) * a.ldb + kbeg + 4 * gq;
+        st = BK;
+        k_in = 4 * gq;
+      } else {
+        const int f = 256 * cb + 4 * lane;
+        const int k = f / NC, np = f % NC;
+        const int n = np ^ (16 * ((k >> 2) & 1));
+        s = Bb + (int64_t)(kbeg + k) * a.ldb + n0 + n;
+        st = (int64_t)BK * a.ldb;
+        k_in = k;
+      }
+    }
+    src[g] = s; step[g] = st; kk[g] = k_in;
+  }
+  const float* zsrc = a.zeros + 4 * lane;
+
+  auto issue = [&](int t, int stage) {
+    float* dst = lds + stage * STAGE_FLOATS;
+    const int krem = kend - (kbeg + t * BK);         // >= 1; < 16 only for the K tail
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float* s = (kk[g] < krem) ? src[g] : zsrc;
+      if constexpr (A_KM) {
+        if (gather_k && piece[g] < PA && step[g] != 0) {       // step 0 marks a lane that reads zeros throughout
+          const int row = kidx[t * BK + kk[g]];
+          s = row >= 0 ? src[g] + (int64_t)row * a.lda : zsrc;
+        } else {
+          src[g] += step[g];
+        }
+      } else {
+        src[g] += step[g];
+      }
+      dma16(s, dst + piece[g] * 256);
+    }
+  };
+
+  // ---- fragment addresses ------------------------------------------------------------------------------------------
+  const int li = lane & 15, lg = lane >> 4;
+  const int rm_slot = (4 * li + (lg ^ (2 * (li >> 3)))) * 4;       // float offset inside a 16 x 16 k-contiguous block
+  f32x4 acc[TMW][2];
+#pragma unroll
+  for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct Frags { float x[TMW][4]; float w[2][4]; };
+  auto read_frags = [&](Frags& f, int stage) {
+    const float* sa = lds + stage * STAGE_FLOATS;
+    const float* sb = sa + A_FLOATS;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      if constexpr (B_RM) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (wn * 2 + tn) * 256 + rm_slot);
+        f.w[tn][0] = v[0]; f.w[tn][1] = v[1]; f.w[tn][2] = v[2]; f.w[tn][3] = v[3];
+      } else {
+        const int col = (wn * 32 + tn * 16 + li) ^ (16 * (lg & 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.w[tn][j] = sb[(4 * lg + j) * NC + col];
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm) {
+      if constexpr (A_KM) {
+        const int col = ((wm * TMW + tm) * 16 + li) ^ (16 * (lg & 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.x[tm][j] = sa[(4 * lg + j) * PR + col];
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sa + (wm * TMW + tm) * 256 + rm_slot);
+        f.x[tm][0] = v[0]; f.x[tm][1] = v[1]; f.x[tm][2] = v[2]; f.x[tm][3] = v[3];
+      }
+    }
+  };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[tn][j], f.x[tm][j], acc[tm][tn], 0, 0, 0);
+  };
+
+  // ---- pipeline --------------------------------------------------------------------------------------------------
+  Frags f0, f1;
+  if (ntiles > 0) {
+    issue(0, 0);
+    if (ntiles > 1) { issue(1, 1); wait_vm<G>(); } else { wait_vm<0>(); }
+    __builtin_amdgcn_s_barrier();
+    if (ntiles > 2) issue(2, 2);
+    read_frags(f0, 0);
+  }
+  // iteration t: fragments of tile t are in registers (or on their way: the compiler waits at first use);
+  // DMA in flight: tiles t+1, t+2.
+  auto iteration = [&](int t, Frags& cur, Frags& nxt) {       // t + 1 < ntiles
+    if (t + 2 < ntiles) wait_vm<G>(); else wait_vm<0>();       // my pieces of tile t+1 have landed
+    wait_lgkm0();                                              // my reads of tile t's stage are done
+    __builtin_amdgcn_s_barrier();                              // -> tile t+1 complete for everybody, stage of tile t free
+    if (t + 3 < ntiles) issue(t + 3, t % STAGES);
+    read_frags(nxt, (t + 1) % STAGES);
+    mfmas(cur);
+  };
+  int t = 0;
+  for (; t + 2 < ntiles; t += 2) {
+    iteration(t, f0, f1);
+    iteration(t + 1, f1, f0);
+  }
+  if (t + 1 < ntiles) {            // two tiles left: t, t+1
+    iteration(t, f0, f1);
+    mfmas(f1);
+  } else if (t < ntiles) {         // one tile left
+    mfmas(f0);
+  }
+
+  // ---- epilogue: lane holds C[row = tile row (lane & 15)][4 consecutive columns] --------------------------------------
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int col = n0 + wn * 32 + tn * 16 + 4 * lg;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm) {
+      const int r = (wm * TMW + tm) * 16 + li;
+      if (r < rows_here) {
+        f32x4 v = acc[tm][tn] + bv;
+        if (a.act != RELGNN_ACT_LINEAR) {
+          v[0] = act_rt(a.act, v[0]); v[1] = act_rt(a.act, v[1]); v[2] = act_rt(a.act, v[2]); v[3] = act_rt(a.act, v[3]);
+        }
+        *reinterpret_cast<f32x4*>(Cb + (int64_t)(m0 + r) * a.ldc + col) = v;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TMW, bool A_KM, bool B_RM>
+int launch_cfg(const PanelArgs& a, int num_panels, int batch, hipStream_t st) {
+  constexpr int NC = 32 * WN;
+  dim3 grid((unsigned)num_panels, (unsigned)(a.N / NC), (unsigned)batch);
+  panel_gemm_kernel<WM, WN, TMW, A_KM, B_RM><<<grid, 512, 0, st>>>(a);
+  return launch_status();
+}
+
+// Panel sizing for free row counts: the fewest 16-row units per panel such that the panel count is a multiple of the
+// resident workgroup slots (256 CUs) — every CU then gets the same number of equal panels.
+struct Sizing { int tmw, panels, base, rem; };
+
+Sizing size_panels(int M, int wm, const int* allowed, int n_allowed, int column_chunks, int batch) {
+  const int units = (M + 15) / 16;
+  const int per = 256;                              // workgroup slots filled per round (one 8-wave workgroup per CU)
+  // work items per round are shared by the column chunks and the batch: rows only need per / (chunks * batch) panels
+  int want = per / max(1, column_chunks * batch);
+  if (want < 1) want = 1;
+  Sizing best{0, 0, 0, 0};
+  double best_cost = 1e30;
+  for (int i = 0; i < n_allowed; ++i) {
+    const int cap = allowed[i] * wm;                // units per panel
+    int rounds = (units + want * cap - 1) / (want * cap);
+    if (rounds < 1) rounds = 1;
+    int panels = rounds * want;
+    if (panels > units) panels = units;
+    const int base = units / panels, rem = units % panels;
+    if (base + (rem ? 1 : 0) > cap) continue;
+    // cost ~ rounds x (units the kernel is compiled for): padded MFMA work per workgroup slot
+    const double cost = (double)((panels + want - 1) / want) * cap;
+    if (cost < best_cost) { best_cost = cost; best = Sizing{allowed[i], panels, base, rem}; }
+  }
+  return best;
+}
+
+template <bool A_KM, bool B_RM>
+int dispatch(PanelArgs a, int batch, int force_rows_per_panel, hipStream_t st) {
+  // column geometry: 256-wide panels (8 waves across) when N allows, else 128
+  const bool wide = a.N % 256 == 0;
+  if (!wide && a.N % 128 != 0) return RELGNN_EUNSUPPORTED;
+  const int chunks = a.N / (wide ? 256 : 128);
+  if (force_rows_per_panel > 0) {                   // typed / per-tile operands: fixed 128-row panels
+    if (force_rows_per_panel != 128 || a.M % 16 != 0) return RELGNN_EUNSUPPORTED;
+    const int units = a.M / 16;
+    const int panels = (units + 7) / 8;
+    a.units_base = 8; a.units_rem = 0;
+    if (units % 8 != 0) return RELGNN_EUNSUPPORTED;
+    if (wide) return launch_cfg<1, 8, 8, A_KM, B_RM>(a, panels, batch, st);
+    return launch_cfg<2, 4, 4, A_KM, B_RM>(a, panels, batch, st);
+  }
+  if (wide) {
+    static const int allowed_km[] = {2, 4, 6, 8, 10};
+    static const int allowed_rm[] = {2, 4, 6, 7, 8, 9, 10};
+    const Sizing s = A_KM ? size_panels(a.M, 1, allowed_km, 5, chunks, batch) : size_panels(a.M, 1, allowed_rm, 7, chunks, batch);
+    if (s.tmw == 0) return RELGNN_EUNSUPPORTED;
+    a.units_base = s.base; a.units_rem = s.rem;
+    switch (s.tmw) {
+      case 2: return launch_cfg<1, 8, 2, A_KM, B_RM>(a, s.panels, batch, st);
+      case 4: return launch_cfg<1, 8, 4, A_KM, B_RM>(a, s.panels, batch, st);
+      case 6: return launch_cfg<1, 8, 6, A_KM, B_RM>(a, s.panels, batch, st);
+      case 8: return launch_cfg<1, 8, 8, A_KM, B_RM>(a, s.panels, batch, st);
+      case 10: return launch_cfg<1, 8, 10, A_KM, B_RM>(a, s.panels, batch, st);
+      default: break;
+    }
+    if constexpr (!A_KM) {
+      if (s.tmw == 7) return launch_cfg<1, 8, 7, A_KM, B_RM>(a, s.panels, batch, st);
+      if (s.tmw == 9) return launch_cfg<1, 8, 9, A_KM, B_RM>(a, s.panels, batch, st);
+    }
+    return RELGNN_EUNSUPPORTED;
+  }
+  static const int allowed[] = {1, 2, 3, 4, 5};
+  const Sizing s = size_panels(a.M, 2, allowed, 5, chunks, batch);
+  if (s.tmw == 0) return RELGNN_EUNSUPPORTED;
+  a.units_base = s.base; a.units_rem = s.rem;
+  switch (s.tmw) {
+    case 1: return launch_cfg<2, 4, 1, A_KM, B_RM>(a, s.panels, batch, st);
+    case 2: return launch_cfg<2, 4, 2, A_KM, B_RM>(a, s.panels, batch, st);
+    case 3: return launch_cfg<2, 4, 3, A_KM, B_RM>(a, s.panels, batch, st);
+    case 4: return launch_cfg<2, 4, 4, A_KM, B_RM>(a, s.panels, batch, st);
+    default: return launch_cfg<2, 4, 5, A_KM, B_RM>(a, s.panels, batch, st);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int relgnn_panel_gemm_zeros_floats(void) { return 256; }
+
+int relgnn_panel_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const float* B,
+                          int64_t ldb, const int32_t* b_select, int32_t rows_per_select, int64_t b_select_stride,
+                          const float* bias, const float* zeros, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                          int32_t batch, int64_t a_batch_stride, int64_t b_batch_stride, int64_t c_batch_stride,
+                          int32_t split_k_rows, void* stream) {
+  if (layout < RELGNN_GEMM_NN || layout > RELGNN_GEMM_TN || M < 0 || N < 0 || K < 0 || batch < 1) return RELGNN_EINVAL;
+  if (act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU || split_k_rows < 0) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!A || !B || !C || !zeros) return RELGNN_EINVAL;
+  if (K == 0) return RELGNN_EUNSUPPORTED;
+  if (split_k_rows > 0 && (bias || act != RELGNN_ACT_LINEAR || split_k_rows % BK != 0)) return RELGNN_EINVAL;
+  if (a_rows && layout == RELGNN_GEMM_TN && (split_k_rows > 0 ? split_k_rows : K) > KIDX_MAX) return RELGNN_EUNSUPPORTED;
+  if (b_select && (rows_per_select <= 0 || rows_per_select % 128 != 0)) return RELGNN_EINVAL;
+  if (!aligned16(A) || !aligned16(B) || !aligned16(C) || !aligned16(zeros) || (bias && !aligned16(bias)) || lda % 4 || ldb % 4 ||
+      ldc % 4 || K % 4 || ldc < N)
+    return RELGNN_EUNSUPPORTED;
+  if (layout == RELGNN_GEMM_TN && M % 4 != 0) return RELGNN_EUNSUPPORTED;
+  if (a_batch_stride % 4 || b_batch_stride % 4 || c_batch_stride % 4 || b_select_stride % 4) return RELGNN_EUNSUPPORTED;
+  PanelArgs a{};
+  a.A = A; a.lda = lda; a.a_rows = a_rows; a.B = B; a.ldb = ldb; a.b_select = b_select; a.rows_per_select = rows_per_select;
+  a.b_select_stride = b_select_stride; a.bias = bias; a.zeros = zeros; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.a_bs = a_batch_stride; a.b_bs = b_batch_stride; a.c_bs = c_batch_stride;
+  a.split_k = split_k_rows > 0 ? 1 : 0;
+  a.k_chunk = split_k_rows > 0 ? split_k_rows : K;
+  a.act = act;
+  hipStream_t st = as_stream(stream);
+  const int force = b_select ? 128 : 0;
+  switch (layout) {
+    case RELGNN_GEMM_NN: return dispatch<false, false>(a, batch, force, st);
+    case RELGNN_GEMM_NT: return dispatch<false, true>(a, batch, force, st);
+    default: return dispatch<true, false>(a, batch, force, st);
+  }
+}
+
+}  // extern "C"

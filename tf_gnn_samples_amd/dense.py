@@ -136,6 +136,69 @@ def own_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
     return out.sum(0) if splits > 1 else out
 
 
+_ZEROS = {}
+
+
+def _zeros(device):
+    z = _ZEROS.get(device)
+    if z is None:
+        from . import _lib
+        z = _ZEROS[device] = torch.zeros(int(_lib.load_library().relgnn_panel_gemm_zeros_floats()), dtype=torch.float32,
+                                         device=device)
+    return z
+
+
+def panel_gemm_supported(layout: int, a: torch.Tensor, b: torch.Tensor, n_out: int = None) -> bool:
+    """Shapes relgnn_panel_gemm_f32 takes: fp32 device operands with 16-byte aligned dense rows, N % 128 == 0, K % 4 == 0
+    (TN: M % 4 == 0)."""
+    if not (_rows_ok(a) and _rows_ok(b)):
+        return False
+    if layout == GEMM_NN:
+        K, N = a.shape[1], b.shape[1]
+    elif layout == GEMM_NT:
+        K, N = a.shape[1], b.shape[0]
+    else:
+        K, N = a.shape[0], b.shape[1]
+        if a.shape[1] % 4 != 0:
+            return False
+    if n_out is not None:
+        N = n_out
+    return N % 128 == 0 and K % 4 == 0 and K > 0
+
+
+def panel_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0, *,
+               a_rows: torch.Tensor = None, num_rows: int = None, b_select: torch.Tensor = None, rows_per_select: int = 0,
+               batch: int = 1, strides=(0, 0, 0), split_k_rows: int = 0, dims=None, out: torch.Tensor = None) -> torch.Tensor:
+    """relgnn_panel_gemm_f32 (csrc/panel_gemm.hip).  NN a @ b | NT a @ b^T | TN a^T @ b on the exact-fp32 matrix pipe.
+      a_rows / num_rows : gathered left rows (NN / NT: output row r uses a[a_rows[r]], < 0 = zeros) or gathered reduction
+                          rows of `a` (TN)
+      b_select          : [num_rows / rows_per_select] int32, b is then [num_select, ...] and block p of rows_per_select output
+                          rows multiplies b[b_select[p]]
+      batch / strides   : independent products (element strides of a, b, out) or, with split_k_rows, K chunks -> out [batch, M, N]
+      dims              : (M, N, K) when they do not follow from the operand shapes (batched / typed operands)"""
+    from . import _lib
+    lib = _lib.load_library()
+    if dims is not None:
+        M, N, K = dims
+    elif layout == GEMM_NN:
+        M, K, N = (num_rows if a_rows is not None else a.shape[0]), a.shape[1], b.shape[-1]
+    elif layout == GEMM_NT:
+        M, K, N = (num_rows if a_rows is not None else a.shape[0]), a.shape[1], b.shape[-2]
+    else:
+        K, M, N = (num_rows if a_rows is not None else a.shape[0]), a.shape[1], b.shape[-1]
+    ldb = b.stride(-2)
+    sel_stride = b.stride(0) if b_select is not None else 0
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), dtype=torch.float32, device=a.device)
+    ldc = out.stride(-2)
+    _lib.check(lib.relgnn_panel_gemm_f32(
+        layout, act, a.data_ptr(), a.stride(-2), _lib.ptr(a_rows), b.data_ptr(), ldb, _lib.ptr(b_select), int(rows_per_select),
+        sel_stride, _lib.ptr(bias), _lib.ptr(_zeros(a.device)), out.data_ptr(), ldc, M, N, K, batch, strides[0], strides[1],
+        strides[2] if batch > 1 and strides[2] else (M * ldc if batch > 1 else 0), int(split_k_rows), _lib.current_stream()),
+        "relgnn_panel_gemm_f32")
+    return out
+
+
 def enable_gemm_autotuning(max_tuning_ms_per_solution: int = 30, tune: bool = True) -> bool:
     """PyTorch TunableOp: for every GEMM shape the step uses, time the candidate rocBLAS / hipBLASLt solutions once
     (at first use) and keep the fastest.  Measured on MI355X, config C2: 2.72 -> 2.39 ms per training step (the fp32
