@@ -726,7 +726,7 @@ int relgnn_sum_slabs_tail_f32(const float* slabs, int32_t num_slabs, int32_t M, 
                               const float* Bt, int64_t ldb, int32_t R, float* C, void* stream);
 
 /*
- * relgnn_panel_gemm_f32 — the same three products on v_mfma_f32_16x16x4_f32 (exact fp32) with direct-to-LDS operand
+ * relgnn_panel_gemm_f32 — the same three products on v_mfma_f32_32x32x2_f32 (+ 16x16x4 for a 16-row strip; exact fp32) with direct-to-LDS operand
  * staging, sized per call so that every CU gets the same number of equal row panels, plus what the node-side Dense
  * layers of MANY-TYPE graphs need and a library GEMM cannot express without copies:
  *   a_rows (nullable)  NN / NT: row r of the left operand is A[a_rows[r], :] (a_rows[r] < 0: a row of zeros) — the
@@ -743,7 +743,7 @@ int relgnn_sum_slabs_tail_f32(const float* slabs, int32_t num_slabs, int32_t M, 
  *                      in order: deterministic)
  *   bias / act         NN-style epilogue (bias of length N, any RELGNN_ACT_*), batch == 1 semantics per product
  *   zeros              256 zero floats in device memory (the source of padding rows and of the K tail)
- * Requirements (RELGNN_EUNSUPPORTED otherwise): N % 128 == 0, K % 4 == 0, 16-byte aligned operands and row strides,
+ * Requirements (RELGNN_EUNSUPPORTED otherwise): N % 64 == 0, 16-byte aligned operands and row strides, NN / NT: K % 4 == 0,
  * TN: M % 4 == 0.  C rows [0, M) x columns [0, N) are written, nothing else.
  */
 int relgnn_panel_gemm_zeros_floats(void);

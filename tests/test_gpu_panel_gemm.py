@@ -23,7 +23,9 @@ def _close(got, want, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(36096, 256, 768), (32203, 256, 256), (1000, 128, 128), (17, 256, 64), (4097, 384, 132),
-                                   (300, 768, 256), (50000, 128, 640), (129, 128, 20)])
+                                   (300, 768, 256), (50000, 128, 640), (129, 128, 20), (5000, 64, 128), (40000, 192, 64),
+                                   (28001, 256, 768), (30017, 256, 256), (33333, 256, 768), (38911, 256, 768), (41000, 512, 128),
+                                   (256 * 16 * 3, 256, 64), (256 * 16 * 5 + 1, 256, 64), (256 * 16 * 7 - 3, 256, 64)])
 def test_nn_shapes(gpu_device, M, N, K):
     from tf_gnn_samples_amd.dense import panel_gemm
     gen = torch.Generator(device=gpu_device).manual_seed(M + N + K)
@@ -43,7 +45,8 @@ def test_nn_bias_activation_epilogue(gpu_device, act):
     _close(out, want, 256)
 
 
-@pytest.mark.parametrize("M,N,K", [(36096, 256, 768), (999, 128, 256), (20000, 768, 256), (64, 128, 36)])
+@pytest.mark.parametrize("M,N,K", [(36096, 256, 768), (999, 128, 256), (20000, 768, 256), (64, 128, 36), (3000, 64, 128),
+                                   (33333, 256, 768), (7777, 128, 128)])
 def test_nt_shapes(gpu_device, M, N, K):
     from tf_gnn_samples_amd.dense import panel_gemm
     gen = torch.Generator(device=gpu_device).manual_seed(M + 3 * N + K)
@@ -52,7 +55,8 @@ def test_nt_shapes(gpu_device, M, N, K):
     _close(out, a.double() @ bt.double().t(), K)
 
 
-@pytest.mark.parametrize("K,M,N", [(36096, 768, 256), (5000, 128, 128), (1000, 256, 256), (999 * 4, 128, 384), (700, 64, 128)])
+@pytest.mark.parametrize("K,M,N", [(36096, 768, 256), (32203, 768, 256), (5000, 128, 128), (1000, 256, 256), (999 * 4, 128, 384), (700, 64, 128),
+                                   (2049, 128, 64), (8000, 320, 256)])
 def test_tn_split_k(gpu_device, K, M, N):
     from tf_gnn_samples_amd.dense import panel_gemm
     gen = torch.Generator(device=gpu_device).manual_seed(K + M + N)
@@ -86,7 +90,7 @@ def test_gathered_rows_with_padding_and_typed_weights(gpu_device):
     gen = torch.Generator(device=gpu_device).manual_seed(12)
     V, Din, L, tiles = 5000, 128, 7, 23
     H = _rand(gen, V, Din)
-    for Dout in (128, 256, 384):
+    for Dout in (64, 128, 256, 384):
         W = _rand(gen, L, Din, Dout) * 0.2
         tile_type = torch.randint(0, L, (tiles,), device=gpu_device, generator=gen, dtype=torch.int32)
         node = torch.randint(0, V, (tiles * 512,), device=gpu_device, generator=gen, dtype=torch.int32)
@@ -128,4 +132,6 @@ def test_unsupported_shapes_are_refused(gpu_device):
     with pytest.raises(ValueError):
         panel_gemm(NN, a, b)
     a, b = torch.zeros(10, 64, device=gpu_device), torch.zeros(64, 121, device=gpu_device)
+    assert not panel_gemm_supported(NN, a, b)
+    a, b = torch.zeros(10, 64, device=gpu_device), torch.zeros(64, 96, device=gpu_device)
     assert not panel_gemm_supported(NN, a, b)

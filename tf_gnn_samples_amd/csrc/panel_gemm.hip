@@ -32,11 +32,14 @@
 // the DMA queue).
 #include "common.h"
 
+#include <stdlib.h>
+
 using namespace relgnn;
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
 constexpr int STAGES = 3;
 constexpr int KIDX_MAX = 1024;          // k-major A with gathered k rows: the row ids of the K range live in LDS
@@ -79,17 +82,24 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // block — after the NEXT tile's fragment reads have been issued, which is exactly the overlap this loop exists for.
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
-// WM x WN waves, TMW 16-row tiles per wave.  A_KM: A is given k-major (A[m][k] at A + k*lda + m: the X^T of a weight
-// gradient); B_RM: B is given as [N, K] row-major (k contiguous: the W of an input gradient).
-template <int WM, int WN, int TMW, bool A_KM, bool B_RM>
+// WM x WN waves.  Every wave owns RW = 32*T32 + 16*T16 output rows x 32 columns: T32 tiles of v_mfma_f32_32x32x2_f32 (the
+// shape that sustains ~137 TFLOP/s on this chip; 16x16x4 sustains 113: profiles/r02_c_mfma_rate.txt, r03 ablation) and, for
+// row counts that are an odd multiple of 16, one 16-row strip as two v_mfma_f32_16x16x4_f32 tiles — so that a panel can be
+// any multiple of 16 rows and the panels of a call can be equal to within one 16-row unit.
+// A_KM: A is given k-major (A[m][k] at A + k*lda + m: the X^T of a weight gradient); B_RM: B is given as [N, K] row-major
+// (k contiguous: the W of an input gradient).
+template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM>
 __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
-  constexpr int PR = 16 * TMW * WM;                 // panel rows
+  constexpr int RW = 32 * T32 + 16 * T16;           // rows per wave
+  constexpr int PR = RW * WM;                       // panel rows
   constexpr int NC = 32 * WN;                       // panel columns
   constexpr int A_FLOATS = PR * BK, B_FLOATS = NC * BK;
   constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
   constexpr int PA = A_FLOATS / 256, PB = B_FLOATS / 256, P = PA + PB;     // 1 KiB DMA pieces per stage
   constexpr int G = (P + 7) / 8;                    // pieces per wave and k-tile (the last ones may be duplicates)
-  static_assert(!A_KM || PR % 32 == 0, "k-major A: the column swizzle needs 32-column multiples");
+  constexpr int WPIECES = 2 * T32 + T16;            // A pieces (16-row blocks) per wave-row group
+  static_assert(!A_KM || T16 == 0, "k-major A: 32-row tiles only (the column swizzle needs 32-column multiples)");
+  static_assert(WM * WN == 8, "8 waves");
   // ONE shared object (a second one makes hipcc wait vmcnt(0) before every fragment read of a DMA pipeline)
   __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE_FLOATS + (A_KM ? KIDX_MAX : 0)];
 
@@ -129,6 +139,9 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   }
 
   // ---- DMA sources of this wave's pieces -----------------------------------------------------------------------------
+  // k-contiguous A image: 16-row pieces in panel-row order; rows [32 t, 32 t + 32) of a wave form one 32-row block
+  // (slot(i, kq) = 4 i + (kq ^ ((i >> 3) & 3)), i = row inside the block), the 16-row strip one 16-row block
+  // (slot(i, kq) = 4 i + (kq ^ 2 (i >> 3))): both conflict-free for ds_read_b128 (16-lane groups of gfx950).
   const float* src[G];
   int64_t step[G];
   int kk[G];                                         // k (inside the tile) of this lane's 16 bytes: for the K tail
@@ -151,22 +164,27 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
         st = ok ? (gather_k ? 1 : (int64_t)BK * a.lda) : 0;
         k_in = k;
       } else {
-        const int i = lane >> 2, gq = (lane & 3) ^ (2 * (i >> 3));
-        const int r = 16 * c + i;
+        const int cw = c % WPIECES;                  // piece inside the wave-row group
+        const int i16 = lane >> 2;                   // row inside the 16-row piece
+        int kq;
+        if (T16 && cw == 2 * T32) kq = (lane & 3) ^ (2 * (i16 >> 3));              // the 16-row strip
+        else kq = (lane & 3) ^ ((((cw & 1) * 16 + i16) >> 3) & 3);                 // half of a 32-row block
+        const int r = 16 * c + i16;
         int64_t row = -1;
         if (r < rows_here) row = a.a_rows ? (int64_t)a.a_rows[m0 + r] : (int64_t)(m0 + r);
         const bool ok = row >= 0;
-        s = ok ? Ab + row * a.lda + kbeg + 4 * gq : a.zeros + 4 * lane;
+        s = ok ? Ab + row * a.lda + kbeg + 4 * kq : a.zeros + 4 * lane;
         st = ok ? BK : 0;
-        k_in = 4 * gq;
+        k_in = 4 * kq;
       }
     } else {
       const int cb = c - PA;
-      if constexpr (B_RM) {
-        const int i = lane >> 2, gq = (lane & 3) ^ (2 * (i >> 3));
-        s = Bb + (int64_t)(n0 + 16 * cb + i) * a.ldb + kbeg + 4 * gq;
+      if constexpr (B_RM) {                          // [NC / 32] 32-row blocks of W rows (n)
+        const int i16 = lane >> 2;
+        const int kq = (lane & 3) ^ ((((cb & 1) * 16 + i16) >> 3) & 3);
+        s = Bb + (int64_t)(n0 + 16 * cb + i16) * a.ldb + kbeg + 4 * kq;
         st = BK;
-        k_in = 4 * gq;
+        k_in = 4 * kq;
       } else {
         const int f = 256 * cb + 4 * lane;
         const int k = f / NC, np = f % NC;
@@ -183,9 +201,11 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   auto issue = [&](int t, int stage) {
     float* dst = lds + stage * STAGE_FLOATS;
     const int krem = kend - (kbeg + t * BK);         // >= 1; < 16 only for the K tail
+    const bool tail = krem < BK;                     // uniform: only the last tile of a K range that is not a multiple of 16
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const float* s = (kk[g] < krem) ? src[g] : zsrc;
+      const float* s = src[g];
+      if (tail && kk[g] >= krem) s = zsrc;
       if constexpr (A_KM) {
         if (gather_k && piece[g] < PA && step[g] != 0) {       // step 0 marks a lane that reads zeros throughout
           const int row = kidx[t * BK + kk[g]];
@@ -200,50 +220,94 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
     }
   };
 
-  // ---- fragment addresses ------------------------------------------------------------------------------------------
+  // ---- fragments ---------------------------------------------------------------------------------------------------
+  // 32x32x2: lane (i = lane & 31, h = lane >> 5) supplies k = 8 h + s in step s (s = 0..7: two 16-byte reads of a
+  // k-contiguous row); 16x16x4: lane (i = lane & 15, g = lane >> 4) supplies k = 4 g + j in step j (one 16-byte read).
+  const int i32 = lane & 31, h32 = lane >> 5;
   const int li = lane & 15, lg = lane >> 4;
-  const int rm_slot = (4 * li + (lg ^ (2 * (li >> 3)))) * 4;       // float offset inside a 16 x 16 k-contiguous block
-  f32x4 acc[TMW][2];
+  const int rm32_0 = (4 * i32 + ((2 * h32) ^ ((i32 >> 3) & 3))) * 4;           // float offsets inside a 32-row block
+  const int rm32_1 = (4 * i32 + ((2 * h32 + 1) ^ ((i32 >> 3) & 3))) * 4;
+  const int rm16 = (4 * li + (lg ^ (2 * (li >> 3)))) * 4;                      // inside a 16-row block
+  f32x16 acc32[T32];
+  f32x4 acc16[T16 ? 2 : 1];
 #pragma unroll
-  for (int tm = 0; tm < TMW; ++tm)
+  for (int tm = 0; tm < T32; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 16; ++r) acc32[tm][r] = 0.f;
+  acc16[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (T16) acc16[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  struct Frags { float x[TMW][4]; float w[2][4]; };
+  struct Frags { float x32[T32][8]; float w32[8]; float x16[T16 ? 4 : 1]; float w16[T16 ? 2 : 1][4]; };
   auto read_frags = [&](Frags& f, int stage) {
     const float* sa = lds + stage * STAGE_FLOATS;
     const float* sb = sa + A_FLOATS;
+    if constexpr (B_RM) {
+      const float* blk = sb + wn * 512;              // this wave's 32 W rows (n): one 32-row block
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(blk + rm32_0);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(blk + rm32_1);
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      if constexpr (B_RM) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (wn * 2 + tn) * 256 + rm_slot);
-        f.w[tn][0] = v[0]; f.w[tn][1] = v[1]; f.w[tn][2] = v[2]; f.w[tn][3] = v[3];
-      } else {
-        const int col = (wn * 32 + tn * 16 + li) ^ (16 * (lg & 1));
+      for (int j = 0; j < 4; ++j) { f.w32[j] = v0[j]; f.w32[4 + j] = v1[j]; }
+      if constexpr (T16) {
+        // the same 32 rows seen as two 16-row tiles: rows 16 tn + li, k = 4 lg + j -> slot (row, kq = lg) of the 32-row block
 #pragma unroll
-        for (int j = 0; j < 4; ++j) f.w[tn][j] = sb[(4 * lg + j) * NC + col];
+        for (int tn = 0; tn < 2; ++tn) {
+          const int row = 16 * tn + li;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(blk + (4 * row + (lg ^ ((row >> 3) & 3))) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f.w16[tn][j] = v[j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const int k = 8 * h32 + s2;
+        f.w32[s2] = sb[k * NC + ((wn * 32 + i32) ^ (16 * ((k >> 2) & 1)))];
+      }
+      if constexpr (T16) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f.w16[tn][j] = sb[(4 * lg + j) * NC + ((wn * 32 + tn * 16 + li) ^ (16 * (lg & 1)))];
       }
     }
+    if constexpr (A_KM) {
 #pragma unroll
-    for (int tm = 0; tm < TMW; ++tm) {
-      if constexpr (A_KM) {
-        const int col = ((wm * TMW + tm) * 16 + li) ^ (16 * (lg & 1));
+      for (int tm = 0; tm < T32; ++tm)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) f.x[tm][j] = sa[(4 * lg + j) * PR + col];
-      } else {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sa + (wm * TMW + tm) * 256 + rm_slot);
-        f.x[tm][0] = v[0]; f.x[tm][1] = v[1]; f.x[tm][2] = v[2]; f.x[tm][3] = v[3];
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const int k = 8 * h32 + s2;
+          f.x32[tm][s2] = sa[k * PR + ((wm * RW + tm * 32 + i32) ^ (16 * ((k >> 2) & 1)))];
+        }
+    } else {
+      const float* wa = sa + wm * WPIECES * 256;
+#pragma unroll
+      for (int tm = 0; tm < T32; ++tm) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wa + tm * 512 + rm32_0);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wa + tm * 512 + rm32_1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f.x32[tm][j] = v0[j]; f.x32[tm][4 + j] = v1[j]; }
+      }
+      if constexpr (T16) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wa + T32 * 512 + rm16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.x16[j] = v[j];
       }
     }
   };
   auto mfmas = [&](const Frags& f) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int s2 = 0; s2 < 8; ++s2) {
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TMW; ++tm)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[tn][j], f.x[tm][j], acc[tm][tn], 0, 0, 0);
+      for (int tm = 0; tm < T32; ++tm)
+        acc32[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w32[s2], f.x32[tm][s2], acc32[tm], 0, 0, 0);
+      if constexpr (T16) {
+        if (s2 & 1) {                                // the strip's eight 16x16x4 MFMAs, two after every second k-pair
+          const int j = s2 >> 1;
+          acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w16[0][j], f.x16[j], acc16[0], 0, 0, 0);
+          acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w16[1][j], f.x16[j], acc16[1], 0, 0, 0);
+        }
+      }
+    }
   };
 
   // ---- pipeline --------------------------------------------------------------------------------------------------
@@ -277,39 +341,56 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
     mfmas(f0);
   }
 
-  // ---- epilogue: lane holds C[row = tile row (lane & 15)][4 consecutive columns] --------------------------------------
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  // 32x32 tile: lane holds output row (lane & 31) x columns 8 c + 4 h + {0..3}, c = 0..3 (register r = 4 c + {0..3});
+  // 16x16 tile: output row (lane & 15) x columns 4 (lane >> 4) + {0..3}.  One 16-byte store each.
+  const int colw = n0 + wn * 32;
+  auto finish = [&](f32x4 v, int col) {
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+    if (a.act != RELGNN_ACT_LINEAR) {
+      v[0] = act_rt(a.act, v[0]); v[1] = act_rt(a.act, v[1]); v[2] = act_rt(a.act, v[2]); v[3] = act_rt(a.act, v[3]);
+    }
+    return v;
+  };
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int col = n0 + wn * 32 + tn * 16 + 4 * lg;
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+  for (int tm = 0; tm < T32; ++tm) {
+    const int r = wm * RW + tm * 32 + i32;
+    if (r < rows_here) {
+      float* crow = Cb + (int64_t)(m0 + r) * a.ldc;
 #pragma unroll
-    for (int tm = 0; tm < TMW; ++tm) {
-      const int r = (wm * TMW + tm) * 16 + li;
-      if (r < rows_here) {
-        f32x4 v = acc[tm][tn] + bv;
-        if (a.act != RELGNN_ACT_LINEAR) {
-          v[0] = act_rt(a.act, v[0]); v[1] = act_rt(a.act, v[1]); v[2] = act_rt(a.act, v[2]); v[3] = act_rt(a.act, v[3]);
-        }
-        *reinterpret_cast<f32x4*>(Cb + (int64_t)(m0 + r) * a.ldc + col) = v;
+      for (int c = 0; c < 4; ++c) {
+        const int col = colw + 8 * c + 4 * h32;
+        const f32x4 v = f32x4{acc32[tm][4 * c], acc32[tm][4 * c + 1], acc32[tm][4 * c + 2], acc32[tm][4 * c + 3]};
+        *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
+      }
+    }
+  }
+  if constexpr (T16) {
+    const int r = wm * RW + T32 * 32 + li;
+    if (r < rows_here) {
+      float* crow = Cb + (int64_t)(m0 + r) * a.ldc;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = colw + tn * 16 + 4 * lg;
+        *reinterpret_cast<f32x4*>(crow + col) = finish(acc16[tn], col);
       }
     }
   }
 }
 
-template <int WM, int WN, int TMW, bool A_KM, bool B_RM>
+template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM>
 int launch_cfg(const PanelArgs& a, int num_panels, int batch, hipStream_t st) {
   constexpr int NC = 32 * WN;
   dim3 grid((unsigned)num_panels, (unsigned)(a.N / NC), (unsigned)batch);
-  panel_gemm_kernel<WM, WN, TMW, A_KM, B_RM><<<grid, 512, 0, st>>>(a);
+  panel_gemm_kernel<WM, WN, T32, T16, A_KM, B_RM><<<grid, 512, 0, st>>>(a);
   return launch_status();
 }
 
 // Panel sizing for free row counts: the fewest 16-row units per panel such that the panel count is a multiple of the
 // resident workgroup slots (256 CUs) — every CU then gets the same number of equal panels.
-struct Sizing { int tmw, panels, base, rem; };
+struct Sizing { int cap, panels, base, rem; };
 
-Sizing size_panels(int M, int wm, const int* allowed, int n_allowed, int column_chunks, int batch) {
+Sizing size_panels(int M, const int* caps, int n_caps, int column_chunks, int batch) {
   const int units = (M + 15) / 16;
   const int per = 256;                              // workgroup slots filled per round (one 8-wave workgroup per CU)
   // work items per round are shared by the column chunks and the batch: rows only need per / (chunks * batch) panels
@@ -317,8 +398,8 @@ Sizing size_panels(int M, int wm, const int* allowed, int n_allowed, int column_
   if (want < 1) want = 1;
   Sizing best{0, 0, 0, 0};
   double best_cost = 1e30;
-  for (int i = 0; i < n_allowed; ++i) {
-    const int cap = allowed[i] * wm;                // units per panel
+  for (int i = 0; i < n_caps; ++i) {
+    const int cap = caps[i];                        // 16-row units per panel this configuration is compiled for
     int rounds = (units + want * cap - 1) / (want * cap);
     if (rounds < 1) rounds = 1;
     int panels = rounds * want;
@@ -327,57 +408,80 @@ Sizing size_panels(int M, int wm, const int* allowed, int n_allowed, int column_
     if (base + (rem ? 1 : 0) > cap) continue;
     // cost ~ rounds x (units the kernel is compiled for): padded MFMA work per workgroup slot
     const double cost = (double)((panels + want - 1) / want) * cap;
-    if (cost < best_cost) { best_cost = cost; best = Sizing{allowed[i], panels, base, rem}; }
+    if (cost < best_cost) { best_cost = cost; best = Sizing{cap, panels, base, rem}; }
   }
   return best;
 }
 
 template <bool A_KM, bool B_RM>
 int dispatch(PanelArgs a, int batch, int force_rows_per_panel, hipStream_t st) {
-  // column geometry: 256-wide panels (8 waves across) when N allows, else 128
-  const bool wide = a.N % 256 == 0;
-  if (!wide && a.N % 128 != 0) return RELGNN_EUNSUPPORTED;
-  const int chunks = a.N / (wide ? 256 : 128);
+  // column geometry: 256-wide panels (8 waves across) when N allows, else 128, else 64
+  const int nc = a.N % 256 == 0 ? 256 : (a.N % 128 == 0 ? 128 : (a.N % 64 == 0 ? 64 : 0));
+  if (nc == 0) return RELGNN_EUNSUPPORTED;
+  const int chunks = a.N / nc;
+#define RELGNN_PANEL_CASE(CAP, WM_, WN_, T32_, T16_) \
+  case CAP: return launch_cfg<WM_, WN_, T32_, T16_, A_KM, B_RM>(a, panels, batch, st)
   if (force_rows_per_panel > 0) {                   // typed / per-tile operands: fixed 128-row panels
-    if (force_rows_per_panel != 128 || a.M % 16 != 0) return RELGNN_EUNSUPPORTED;
-    const int units = a.M / 16;
-    const int panels = (units + 7) / 8;
+    if (force_rows_per_panel != 128 || a.M % 128 != 0) return RELGNN_EUNSUPPORTED;
+    const int panels = a.M / 128;
     a.units_base = 8; a.units_rem = 0;
-    if (units % 8 != 0) return RELGNN_EUNSUPPORTED;
-    if (wide) return launch_cfg<1, 8, 8, A_KM, B_RM>(a, panels, batch, st);
-    return launch_cfg<2, 4, 4, A_KM, B_RM>(a, panels, batch, st);
+    if (nc == 256) return launch_cfg<1, 8, 4, 0, A_KM, B_RM>(a, panels, batch, st);
+    if (nc == 128) return launch_cfg<2, 4, 2, 0, A_KM, B_RM>(a, panels, batch, st);
+    return launch_cfg<4, 2, 1, 0, A_KM, B_RM>(a, panels, batch, st);
   }
-  if (wide) {
-    static const int allowed_km[] = {2, 4, 6, 8, 10};
-    static const int allowed_rm[] = {2, 4, 6, 7, 8, 9, 10};
-    const Sizing s = A_KM ? size_panels(a.M, 1, allowed_km, 5, chunks, batch) : size_panels(a.M, 1, allowed_rm, 7, chunks, batch);
-    if (s.tmw == 0) return RELGNN_EUNSUPPORTED;
+  if (nc == 256) {                                  // 1 x 8 waves: panel = 16 * cap rows
+    static const int caps_rm[] = {2, 3, 4, 5, 6, 7, 8, 9, 10};
+    static const int caps_km[] = {2, 4, 6, 8, 10};
+    const Sizing s = A_KM ? size_panels(a.M, caps_km, 5, chunks, batch) : size_panels(a.M, caps_rm, 9, chunks, batch);
+    if (s.cap == 0) return RELGNN_EUNSUPPORTED;
     a.units_base = s.base; a.units_rem = s.rem;
-    switch (s.tmw) {
-      case 2: return launch_cfg<1, 8, 2, A_KM, B_RM>(a, s.panels, batch, st);
-      case 4: return launch_cfg<1, 8, 4, A_KM, B_RM>(a, s.panels, batch, st);
-      case 6: return launch_cfg<1, 8, 6, A_KM, B_RM>(a, s.panels, batch, st);
-      case 8: return launch_cfg<1, 8, 8, A_KM, B_RM>(a, s.panels, batch, st);
-      case 10: return launch_cfg<1, 8, 10, A_KM, B_RM>(a, s.panels, batch, st);
+    const int panels = s.panels;
+    switch (s.cap) {
+      RELGNN_PANEL_CASE(2, 1, 8, 1, 0); RELGNN_PANEL_CASE(4, 1, 8, 2, 0); RELGNN_PANEL_CASE(6, 1, 8, 3, 0);
+      RELGNN_PANEL_CASE(8, 1, 8, 4, 0); RELGNN_PANEL_CASE(10, 1, 8, 5, 0);
       default: break;
     }
     if constexpr (!A_KM) {
-      if (s.tmw == 7) return launch_cfg<1, 8, 7, A_KM, B_RM>(a, s.panels, batch, st);
-      if (s.tmw == 9) return launch_cfg<1, 8, 9, A_KM, B_RM>(a, s.panels, batch, st);
+      switch (s.cap) {
+        RELGNN_PANEL_CASE(3, 1, 8, 1, 1); RELGNN_PANEL_CASE(5, 1, 8, 2, 1); RELGNN_PANEL_CASE(7, 1, 8, 3, 1);
+        RELGNN_PANEL_CASE(9, 1, 8, 4, 1);
+        default: break;
+      }
     }
     return RELGNN_EUNSUPPORTED;
   }
-  static const int allowed[] = {1, 2, 3, 4, 5};
-  const Sizing s = size_panels(a.M, 2, allowed, 5, chunks, batch);
-  if (s.tmw == 0) return RELGNN_EUNSUPPORTED;
-  a.units_base = s.base; a.units_rem = s.rem;
-  switch (s.tmw) {
-    case 1: return launch_cfg<2, 4, 1, A_KM, B_RM>(a, s.panels, batch, st);
-    case 2: return launch_cfg<2, 4, 2, A_KM, B_RM>(a, s.panels, batch, st);
-    case 3: return launch_cfg<2, 4, 3, A_KM, B_RM>(a, s.panels, batch, st);
-    case 4: return launch_cfg<2, 4, 4, A_KM, B_RM>(a, s.panels, batch, st);
-    default: return launch_cfg<2, 4, 5, A_KM, B_RM>(a, s.panels, batch, st);
+  if (nc == 128) {                                  // 2 x 4 waves: panel = 32 * (units per wave) rows
+    static const int caps_rm[] = {4, 6, 8, 10, 12};
+    static const int caps_km[] = {4, 8, 12};
+    const Sizing s = A_KM ? size_panels(a.M, caps_km, 3, chunks, batch) : size_panels(a.M, caps_rm, 5, chunks, batch);
+    if (s.cap == 0) return RELGNN_EUNSUPPORTED;
+    a.units_base = s.base; a.units_rem = s.rem;
+    const int panels = s.panels;
+    switch (s.cap) {
+      RELGNN_PANEL_CASE(4, 2, 4, 1, 0); RELGNN_PANEL_CASE(8, 2, 4, 2, 0); RELGNN_PANEL_CASE(12, 2, 4, 3, 0);
+      default: break;
+    }
+    if constexpr (!A_KM) {
+      switch (s.cap) {
+        RELGNN_PANEL_CASE(6, 2, 4, 1, 1); RELGNN_PANEL_CASE(10, 2, 4, 2, 1);
+        default: break;
+      }
+    }
+    return RELGNN_EUNSUPPORTED;
   }
+  {                                                 // 4 x 2 waves: 64 columns
+    static const int caps[] = {8, 16};
+    const Sizing s = size_panels(a.M, caps, 2, chunks, batch);
+    if (s.cap == 0) return RELGNN_EUNSUPPORTED;
+    a.units_base = s.base; a.units_rem = s.rem;
+    const int panels = s.panels;
+    switch (s.cap) {
+      RELGNN_PANEL_CASE(8, 4, 2, 1, 0); RELGNN_PANEL_CASE(16, 4, 2, 2, 0);
+      default: break;
+    }
+    return RELGNN_EUNSUPPORTED;
+  }
+#undef RELGNN_PANEL_CASE
 }
 
 }  // namespace
@@ -399,9 +503,12 @@ int relgnn_panel_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t l
   if (split_k_rows > 0 && (bias || act != RELGNN_ACT_LINEAR || split_k_rows % BK != 0)) return RELGNN_EINVAL;
   if (a_rows && layout == RELGNN_GEMM_TN && (split_k_rows > 0 ? split_k_rows : K) > KIDX_MAX) return RELGNN_EUNSUPPORTED;
   if (b_select && (rows_per_select <= 0 || rows_per_select % 128 != 0)) return RELGNN_EINVAL;
+  if (N % 64 != 0) return RELGNN_EUNSUPPORTED;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || !aligned16(zeros) || (bias && !aligned16(bias)) || lda % 4 || ldb % 4 ||
-      ldc % 4 || K % 4 || ldc < N)
+      ldc % 4 || ldc < N)
     return RELGNN_EUNSUPPORTED;
+  // k-contiguous operands are staged 4 k at a time; k-major ones (both operands of TN) one whole k row at a time
+  if (layout != RELGNN_GEMM_TN && K % 4 != 0) return RELGNN_EUNSUPPORTED;
   if (layout == RELGNN_GEMM_TN && M % 4 != 0) return RELGNN_EUNSUPPORTED;
   if (a_batch_stride % 4 || b_batch_stride % 4 || c_batch_stride % 4 || b_select_stride % 4) return RELGNN_EUNSUPPORTED;
   PanelArgs a{};

@@ -149,8 +149,8 @@ def _zeros(device):
 
 
 def panel_gemm_supported(layout: int, a: torch.Tensor, b: torch.Tensor, n_out: int = None) -> bool:
-    """Shapes relgnn_panel_gemm_f32 takes: fp32 device operands with 16-byte aligned dense rows, N % 128 == 0, K % 4 == 0
-    (TN: M % 4 == 0)."""
+    """Shapes relgnn_panel_gemm_f32 takes: fp32 device operands with 16-byte aligned dense rows, N % 64 == 0, K % 4 == 0
+    (TN: M % 4 == 0 instead)."""
     if not (_rows_ok(a) and _rows_ok(b)):
         return False
     if layout == GEMM_NN:
@@ -163,7 +163,7 @@ def panel_gemm_supported(layout: int, a: torch.Tensor, b: torch.Tensor, n_out: i
             return False
     if n_out is not None:
         N = n_out
-    return N % 128 == 0 and K % 4 == 0 and K > 0
+    return N % 64 == 0 and (K % 4 == 0 or layout == GEMM_TN) and K > 0
 
 
 def panel_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0, *,

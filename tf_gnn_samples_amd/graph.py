@@ -587,6 +587,15 @@ class SidePairs:
                                                   torch.tensor(chunks, device=dev, dtype=torch.int64))
         del self._by_type, self._ids
 
+    def panel_indices(self):
+        """(row -> node as int32 with -1 for padding rows, tile -> edge type as int32): the index operands of
+        relgnn_panel_gemm_f32 (gathered rows, per-tile kernel)."""
+        cached = getattr(self, "_panel_idx", None)
+        if cached is None:
+            node32 = torch.where(self.node == self.V, torch.full_like(self.node, -1), self.node).to(torch.int32).contiguous()
+            cached = self._panel_idx = (node32, self.chunk_type.to(torch.int32).contiguous())
+        return cached
+
     def weight_grad_plan(self, num_sub_rows: int):
         """CSR that sums per-tile partial weight gradients [num_tiles * K, 1024] (K = num_sub_rows 1024-float slices
         of one [Din, Dout] partial) into [L * K, 1024]: out row (l, j) <- rows (tile * K + j) for the tiles of type l."""

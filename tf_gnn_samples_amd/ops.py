@@ -485,10 +485,64 @@ def blocked_linear(X, offsets, weights):
     return _BlockedLinear.apply(X, [int(o) for o in offsets], *weights)
 
 
+class _TypedLinearPanel(torch.autograd.Function):
+    """_TypedLinear on the row-panel MFMA kernel (csrc/panel_gemm.hip): the gather H[node[r]] and the per-tile kernel
+    selection happen in the kernel's load addresses.  Nothing [P, Din] (the gathered rows) and nothing [tiles, Din, Dout] (a
+    per-tile copy of the kernels) is materialised, forward or backward:
+      forward   Y  = gather(H) @ W_type            one launch (NN, gathered rows, per-tile B)
+      backward  dX = dY @ W_type^T                 one launch (NT with the kernels as stored), summed into nodes over the
+                                                   node -> rows CSR by the gather-reduce kernel (ascending type order)
+                dW = per-tile gather(H)^T @ dY     one launch (TN, gathered reduction rows, one product per tile), the per-tile
+                                                   partials summed per type by the gather-reduce kernel (tile order)"""
+
+    @staticmethod
+    def forward(ctx, H, side, W):
+        from .dense import GEMM_NN, panel_gemm
+        L, Din, Dout = W.shape
+        node32, tile_type = side.panel_indices()
+        Y = panel_gemm(GEMM_NN, H, W, a_rows=node32, num_rows=side.P, b_select=tile_type, rows_per_select=side.chunk)
+        ctx.side, ctx.shape = side, (L, Din, Dout)
+        ctx.save_for_backward(H, W)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        from .dense import GEMM_NT, GEMM_TN, panel_gemm
+        H, W = ctx.saved_tensors
+        side = ctx.side
+        L, Din, Dout = ctx.shape
+        gY = gY.contiguous()
+        node32, tile_type = side.panel_indices()
+        gH = gW = None
+        if ctx.needs_input_grad[0]:
+            gX = panel_gemm(GEMM_NT, gY, W, b_select=tile_type, rows_per_select=side.chunk, dims=(side.P, Din, Dout))
+            gH = _seg_reduce_raw(_lib.AGG_SUM, gX, side.node_rowptr, 1, side.node_col, None, H.shape[0])
+        if ctx.needs_input_grad[2]:
+            tiles = side.P // side.chunk
+            part = panel_gemm(GEMM_TN, H, gY, a_rows=node32, batch=tiles, strides=(0, side.chunk * Dout, Din * Dout),
+                              dims=(Din, Dout, side.chunk))                          # [tiles, Din, Dout]
+            n = Din * Dout
+            sub = 1024 if n % 1024 == 0 else n
+            K = n // sub
+            rowptr, col = side.weight_grad_plan(K)
+            gW = _seg_reduce_raw(_lib.AGG_SUM, part.view(-1, sub), rowptr, 1, col, None, L * K).view(L, Din, Dout)
+        return gH, None, gW
+
+
+def _typed_panel_ok(H, side, weights) -> bool:
+    Din, Dout = weights[0].shape
+    # (forward: N = Dout; input gradient: N = Din; both must be panel widths)
+    return (os.environ.get("RELGNN_TYPED", "panel") == "panel" and H.is_cuda and side.chunk == 512 and Din % 64 == 0
+            and Dout % 64 == 0 and side.P > 0 and H.data_ptr() % 16 == 0)
+
+
 def typed_linear(H, side, weights):
     """[P, Dout] table over the non-empty (node,type) buckets of `side` (graph.SidePairs); weights: L x [Din, Dout]."""
     _check_f32(H, "H")
-    return _TypedLinear.apply(H.contiguous(), side, *weights)
+    H = H.contiguous()
+    if _typed_panel_ok(H, side, weights):
+        return _TypedLinearPanel.apply(H, side, torch.stack(list(weights)))
+    return _TypedLinear.apply(H, side, *weights)
 
 
 def pair_messages_reduce_fused(P, Q, graph, w, aggregation: str, activation: Optional[str]):
