@@ -43,7 +43,6 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-GRAPHS_PER_RANK = 64          # one rank's data fold: 4 batches of ~16 graphs per epoch
 GRAPHS_PER_BATCH = 16         # BASELINE.json configs[1]: ~2 M edges per batch
 
 
@@ -56,6 +55,10 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true", help="skip the kernel roofline section (rank 0, N=1 only)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (same-batch step, forward only, H2D)")
+    ap.add_argument("--config", default="C2", choices=["C2", "C5"],
+                    help="C2 (default): BASELINE configs[1], RGCN on PPI-shaped batches — the headline metric.  C5: BASELINE "
+                         "configs[4], GNN-FiLM on VarMisuse-shaped batches (23 edge types, h=128, 10 layers), ~1.2 M edges per rank "
+                         "and step, sharded by graph with ONE all-reduce of the ~46 MB FiLM gradient per step")
     ap.add_argument("--cpu-sample-graphs", type=int, default=4)
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
@@ -90,19 +93,45 @@ def spawn_ranks(args) -> int:
 # ------------------------------------------------------------------------------------------------------------------
 # data
 # ------------------------------------------------------------------------------------------------------------------
-def build_local_fold(rank, world):
-    """GRAPHS_PER_RANK * world PPI-shaped graphs (seed 0), sharded over ranks by edge count (LPT); this rank's shard."""
+CONFIGS = {
+    # graphs per rank and epoch, graphs per batch (sizes the node budget of a batch)
+    "C2": {"graphs_per_rank": 64, "graphs_per_batch": 16},
+    "C5": {"graphs_per_rank": 200, "graphs_per_batch": 50},
+}
+
+
+def build_local_fold(rank, world, config="C2"):
+    """This rank's shard of the fold: graphs_per_rank * world synthetic graphs, graph i drawn from its own generator stream
+    default_rng([seed, i]) (tasks/synthetic.py), sharded over ranks by edge count (LPT).  The sizes of ALL graphs cost one
+    draw each (the node count is the stream's first draw), so a rank builds only the graphs it owns — at 8 ranks that is 1/8 of
+    the host work and memory of generating the whole fold everywhere."""
     from tf_gnn_samples_amd.parallel import shard_graphs_by_edges
     from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
-    from tf_gnn_samples_amd.tasks.synthetic import ppi_shaped_generator_params
-    gen = ppi_shaped_generator_params(num_graphs=GRAPHS_PER_RANK * world, seed=0)
-    task = PPI_Task(PPI_Task.default_params())
-    task.load_synthetic(gen["num_graphs"], 1, seed=gen["seed"])
-    graphs = task._loaded_data[DataFold.TRAIN]
-    edge_counts = [sum(len(a) for a in g.adjacency_lists) for g in graphs]
+    from tf_gnn_samples_amd.tasks import synthetic as S
+    n_graphs = CONFIGS[config]["graphs_per_rank"] * world
+    seed = 0
+    if config == "C2":
+        gen = S.ppi_shaped_generator_params(num_graphs=n_graphs, seed=seed)
+        size_of, make = S.ppi_shaped_graph_size, S.make_ppi_shaped_graph
+        kw = {k: gen[k] for k in ("mean_nodes", "std_nodes", "min_nodes", "max_nodes", "fwd_edges_per_node")}
+        make_kw = dict(kw, feature_size=gen["feature_size"], num_labels=gen["num_labels"],
+                       target_lognormal_sigma=gen["target_lognormal_sigma"])
+    else:
+        gen = {"num_graphs": n_graphs, "seed": seed, "shape": "VarMisuse-like program graphs: 23 edge types (11 base types x "
+               "fwd/bkwd + self loops, tasks/varmisuse_task.py:22-28,244-247), ~2500 nodes, 4.7 forward edges per node, two "
+               "chain-like types carry 60 % of the edges", "feature_size": 128}
+        size_of, make, kw, make_kw = S.varmisuse_shaped_graph_size, S.make_varmisuse_shaped_graph, {}, {}
+    gen["per_graph_streams"] = "numpy default_rng([seed, graph_index])"
+    edge_counts = [size_of(seed, i, **kw)[1] for i in range(n_graphs)]
     shard = shard_graphs_by_edges(edge_counts, world)[rank]
-    local = [graphs[i] for i in shard]
-    task._loaded_data[DataFold.TRAIN] = local      # the other ranks' graphs (1.3 GB of host memory at 8 ranks) die here
+    local = [make(seed, i, **make_kw) for i in shard]
+    task = PPI_Task(PPI_Task.default_params())
+    g0 = local[0]
+    # (the PPI head — per-node sigmoid cross-entropy — also stands in for the VarMisuse task's candidate head, which with its
+    # data pipeline is outside the path, SURVEY.md 2a)
+    task.restore_from_metadata({'num_edge_types': len(g0.adjacency_lists), 'initial_node_feature_size': g0.node_features.shape[1],
+                                'num_labels': g0.node_labels.shape[1]})
+    task._loaded_data[DataFold.TRAIN] = local
     return task, local, gen
 
 
@@ -122,10 +151,10 @@ def build_local_batch(rank, world, device):
     return task, mb, DeviceBatch(mb, device), gen, local
 
 
-def c2_batch(task, graphs, device):
-    """The first GRAPHS_PER_BATCH graphs of the fold as ONE resident batch (secondary same-batch figures, CPU baseline)."""
+def c2_batch(task, graphs, device, n=GRAPHS_PER_BATCH):
+    """The first n graphs of the fold as ONE resident batch (secondary same-batch figures, CPU baseline)."""
     from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch
-    mb = next(task.make_minibatch_iterator(list(graphs[:GRAPHS_PER_BATCH]), DataFold.VALIDATION, 10 ** 9))
+    mb = next(task.make_minibatch_iterator(list(graphs[:n]), DataFold.VALIDATION, 10 ** 9))
     return mb, DeviceBatch(mb, device)
 
 
@@ -264,6 +293,27 @@ def roofline_section(device, iters, with_pmc):
     return roof
 
 
+def other_configs_section(timeout_s=240):
+    """BASELINE.json configs[2..4] (C3 GGNN/QM9 mean + max, C4 RGAT, C5 GNN-FiLM rank share) on this GPU through bench_other.py
+    (a child process, like the roofline: its own allocator state, bounded by a timeout): step time, edges/s and the
+    algorithmic-bytes rate of each config's gather kernel from HIP events."""
+    env = dict(os.environ)
+    env.setdefault("LOCAL_RANK", "0")
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "bench_other.py")], cwd=str(ROOT), env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+    except subprocess.TimeoutExpired:
+        return {"error": "bench_other.py timed out after %d s" % timeout_s}
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    if r.returncode != 0 and not rows:
+        return {"error": "bench_other.py failed (rc %d): %s" % (r.returncode, r.stderr[-300:])}
+    return {"what": "the other BASELINE.json configs on one MI355X: training step on a fixed resident batch (bucketing rebuilt per "
+                    "step, fwd + bwd + clip + Adam), forward-only pass, and the config's gather kernel timed with HIP events",
+            "configs": rows}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # secondary host/transfer figures
 # ------------------------------------------------------------------------------------------------------------------
@@ -352,41 +402,32 @@ def cpu_baseline(sample_graphs, params):
         with torch.no_grad():
             forward()
 
-    # torch-CPU with every available thread can be slower than with fewer (OpenMP barriers on the many small ops):
-    # probe a truncated problem at a few thread counts and keep the fastest.
-    state["adj"] = [a[:20000] for a in full_adj]
-    best = None
-    for threads in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
-        torch.set_num_threads(threads)
-        train_step()
-        t0 = time.time()
-        train_step()
-        dt_probe = time.time() - t0
-        if best is None or dt_probe < best[1]:
-            best = (threads, dt_probe)
-    cores = best[0]
-    torch.set_num_threads(cores)
-    state["adj"] = full_adj
-
-    def timed(fn, budget_s, max_n):
-        fn()  # warm-up
-        t0 = time.time()
-        n = 0
-        while True:
+    # SURVEY.md 8d / BASELINE.md 3 protocol: fixed thread count = the CPU quota of this process, 2 warm-ups, median of 5,
+    # a forward-only leg (the reference's validation pass) and a training leg; bounded to ~60 s of host time in total.
+    def timed(fn, warmups, reps, budget_s):
+        t_begin = time.time()
+        for _ in range(warmups):
             fn()
-            n += 1
-            if time.time() - t0 > budget_s or n >= max_n:
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+            if time.time() - t_begin > budget_s and len(ts) >= 3:
                 break
-        return (time.time() - t0) / n, n
+        return float(np.median(ts)), len(ts)
 
-    dt_fwd, n_fwd = timed(fwd_step, 5.0, 3)
-    dt, n = timed(train_step, 10.0, 3)
+    dt_fwd, n_fwd = timed(fwd_step, 2, 5, 20.0)
+    dt, n = timed(train_step, 2, 5, 40.0)
     torch.set_num_threads(max(1, effective_cpu_count() // 2))
     return {"value": mb.num_edges / dt, "unit": "edges/sec", "cores": cores, "kind": "port",
             "host": "%d hardware threads visible, cgroup CPU quota %d" % (os.cpu_count() or 1, effective_cpu_count()),
-            "sample": "full train step (fwd+bwd) on the first %d of the bench batch's %d graphs (%d edges, %d nodes), %d timed "
-                      "steps after 1 warm-up, torch-CPU fp32 restatement of gnns/rgcn.py op order incl. the per-edge matmul; "
-                      "forward-only leg: %d timed passes" % (len(sample_graphs), GRAPHS_PER_BATCH, mb.num_edges, mb.num_nodes, n, n_fwd),
+            "sample": "the first %d of the bench batch's %d graphs (%d edges, %d nodes; the whole batch would take ~4x as long per "
+                      "step — the default bench run has to stay within minutes — and nothing is scaled: value = the sample's edges / "
+                      "the sample's median step time); torch-CPU fp32 restatement of gnns/rgcn.py op order incl. the per-edge "
+                      "matmul, %d threads (= the CPU quota); training leg: full step fwd+bwd, median of %d after 2 warm-ups; "
+                      "forward-only leg: median of %d after 2 warm-ups"
+                      % (len(sample_graphs), GRAPHS_PER_BATCH, mb.num_edges, mb.num_nodes, cores, n, n_fwd),
             "ms_per_step": dt * 1e3,
             "forward_only_value": mb.num_edges / dt_fwd, "forward_only_ms": dt_fwd * 1e3}
 
@@ -421,17 +462,27 @@ def main():
     sys.stdout = sys.stderr if rank == 0 else open(os.devnull, "w")
 
     from tf_gnn_samples_amd.graph import check_pending_graph_errors, clear_graph_cache
-    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.models import RGCN_Model, name_to_model_class
     from tf_gnn_samples_amd.models.sparse_graph_model import MetricsReadback
     from tf_gnn_samples_amd.tasks import DataFold
-    task, fold, gen_params = build_local_fold(rank, world)
-    params = RGCN_Model.default_params()
-    params.update(hidden_size=256, graph_num_layers=3, graph_num_timesteps_per_layer=1,
-                  message_aggregation_function="sum", graph_activation_function="ReLU",
-                  graph_layer_input_dropout_keep_prob=1.0)   # README.md:32 of the reference
+    cfg = CONFIGS[args.config]
+    task, fold, gen_params = build_local_fold(rank, world, args.config)
+    if args.config == "C2":
+        model_cls = RGCN_Model
+        params = model_cls.default_params()
+        params.update(hidden_size=256, graph_num_layers=3, graph_num_timesteps_per_layer=1,
+                      message_aggregation_function="sum", graph_activation_function="ReLU",
+                      graph_layer_input_dropout_keep_prob=1.0)   # README.md:32 of the reference
+    else:
+        model_cls, extra = name_to_model_class("GNN-FiLM")
+        params = model_cls.default_params()
+        params.update(extra)
+        params.update(hidden_size=128, graph_num_layers=10, graph_dense_between_every_num_gnn_layers=1,
+                      graph_residual_connection_every_num_layers=2,          # tasks/default_hypers/VarMisuse_GNN-FiLM.json
+                      graph_layer_input_dropout_keep_prob=1.0)
     nodes = sorted(len(g.node_features) for g in fold)
-    params['max_nodes_in_batch'] = int(sum(nodes) / max(1, len(fold) // GRAPHS_PER_BATCH)) + nodes[-1]
-    model = RGCN_Model(params, task, device=str(device))
+    params['max_nodes_in_batch'] = int(sum(nodes) / max(1, len(fold) // cfg["graphs_per_batch"])) + nodes[-1]
+    model = model_cls(params, task, device=str(device))
     reducer = GradientAllReducer(model.optimizer.params) if world > 1 else None
 
     def batch_stream():
@@ -453,11 +504,26 @@ def main():
         m['f1_score']
         state["fetched"] += 1
 
+    cur_stream = torch.cuda.current_stream(device)
+    marks = {"step_end": [], "reduce": [], "step_edges": []}     # HIP events on the launch stream (GPU-side durations)
+
+    def reduce_hook(batch):
+        def hook(_params):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur_stream)
+            reducer(float(batch.num_nodes))
+            e1.record(cur_stream)
+            marks["reduce"].append((e0, e1))
+        return hook
+
     def one_step():
         batch = state["upcoming"]
-        hook = (lambda ps: reducer(float(batch.num_nodes))) if reducer is not None else None
-        m = model.train_step(batch, grad_hook=hook)
+        m = model.train_step(batch, grad_hook=reduce_hook(batch) if reducer is not None else None)
         readback = MetricsReadback(m)             # async D2H of this step's metrics into pinned memory
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(cur_stream)
+        marks["step_end"].append(end)
+        marks["step_edges"].append(batch.num_edges)
         state["upcoming"] = next(stream)          # assembly + bucketing of the next batch, enqueued behind this step
         if state["pending"] is not None:
             fetch(state["pending"])
@@ -473,6 +539,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     state.update(edges=0, nodes=0, graphs=0, host_wait=0.0)
+    for k in marks:
+        marks[k].clear()
+    start_mark = torch.cuda.Event(enable_timing=True)
+    start_mark.record(cur_stream)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -483,22 +553,38 @@ def main():
     elapsed = time.perf_counter() - t0
     fetch(state["pending"])
     check_pending_graph_errors()   # deferred device-side index validation of every step's bucketing
-    local_counts = [float(state["edges"]), float(state["nodes"]), float(state["graphs"])]
+    # per-step GPU-side durations of THIS rank (end-of-step event to end-of-step event), its all-reduce time, host wait
+    ends = [start_mark] + marks["step_end"]
+    step_ms = np.array([ends[i].elapsed_time(ends[i + 1]) for i in range(len(ends) - 1)]) if len(ends) > 1 else np.zeros(1)
+    reduce_ms = np.array([a.elapsed_time(b) for a, b in marks["reduce"]]) if marks["reduce"] else np.zeros(1)
+    local_counts = [float(state["edges"]), float(state["nodes"]), float(state["graphs"]), float(step_ms.min()),
+                    float(np.median(step_ms)), float(step_ms.max()), float(reduce_ms.mean()),
+                    state["host_wait"] / max(1, args.steps) * 1e3, elapsed * 1e3 / max(1, args.steps)]
+    step_edges = np.array(marks["step_edges"], dtype=np.float64)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        per_rank = torch.zeros((world, 3), dtype=torch.float64, device=device)
+        per_rank = torch.zeros((world, len(local_counts)), dtype=torch.float64, device=device)
         per_rank[rank] = torch.tensor(local_counts, dtype=torch.float64, device=device)
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        edges_rs = torch.zeros((world, len(step_edges)), dtype=torch.float64, device=device)
+        edges_rs[rank] = torch.as_tensor(step_edges, device=device)
+        dist.all_reduce(edges_rs, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         per_rank = per_rank.cpu().numpy()
+        edges_rs = edges_rs.cpu().numpy()
     else:
         per_rank = np.array([local_counts])
-    total_edges, total_nodes, total_graphs = (float(x) for x in per_rank.sum(0))
+        edges_rs = step_edges[None, :]
+    total_edges, total_nodes, total_graphs = (float(x) for x in per_rank[:, :3].sum(0))
+    # the ranks meet once per step (the all-reduce): a step lasts as long as its largest shard
+    imbalance = edges_rs.max(0) / np.maximum(edges_rs.mean(0), 1.0) if edges_rs.size else np.ones(1)
     pipeline = type(next(iter(model._native_batchers.values()))[1]).__name__ if model._native_batchers else "numpy iterator"
 
     result = {
-        "metric": "edges/sec (whole node), RGCN PPI h=256 training, distinct batches (the reference's epoch-loop definition)",
+        "metric": ("edges/sec (whole node), RGCN PPI h=256 training, distinct batches (the reference's epoch-loop definition)"
+                   if args.config == "C2" else
+                   "edges/sec (whole node), GNN-FiLM VarMisuse-shaped h=128 training (BASELINE configs[4]), distinct batches"),
         "value": total_edges / elapsed,
         "unit": "edges/sec",
         "n_gpus": world,
@@ -511,11 +597,15 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "C2: RGCN on synthetic PPI-shaped batches (~%d graphs, ~%.2f M edges, ~%d k nodes each), 3 edge types "
-                        "[fwd,self,bkwd], h=256, 3 layers, sum aggregation, 1/in-degree normalisation, F=50 -> 121 labels; "
-                        "step = next distinct batch of a shuffled epoch assembled from the HBM-resident fold + bucketing + fwd + "
-                        "bwd + clip + Adam + metrics fetch (one step late)"
-                        % (GRAPHS_PER_BATCH, total_edges / world / args.steps / 1e6, total_nodes / world / args.steps / 1e3),
+            "workload": ("C2: RGCN on synthetic PPI-shaped batches (~%d graphs, ~%.2f M edges, ~%d k nodes each), 3 edge types "
+                         "[fwd,self,bkwd], h=256, 3 layers, sum aggregation, 1/in-degree normalisation, F=50 -> 121 labels; "
+                         if args.config == "C2" else
+                         "C5: GNN-FiLM on synthetic VarMisuse-shaped batches (~%d graphs, ~%.2f M edges, ~%d k nodes per rank and "
+                         "step), 23 edge types, h=128, 10 layers, residual every 2, Dense between all layers, sum aggregation, "
+                         "per-node sigmoid head (stand-in for the task head); ")
+                        % (cfg["graphs_per_batch"], total_edges / world / args.steps / 1e6, total_nodes / world / args.steps / 1e3)
+                        + "step = next distinct batch of a shuffled epoch assembled from the HBM-resident fold + bucketing + fwd + "
+                          "bwd + (N > 1: one all-reduce of the flat gradient) + clip + Adam + metrics fetch (one step late)",
             "graphs_per_rank": len(fold), "max_nodes_in_batch": params['max_nodes_in_batch'],
             "input_pipeline": pipeline, "generator": gen_params, "parallelism": "dp%d-by-graph" % world,
             "edges_all_ranks_timed_region": int(total_edges), "nodes_all_ranks_timed_region": int(total_nodes),
@@ -523,6 +613,19 @@ def main():
         "world_size": world,
         "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none (1 rank)",
         "per_rank_edges": [int(x) for x in per_rank[:, 0]],
+        # what a bad scaling curve would have to be explained with: GPU-side step durations per rank (HIP events at the end of
+        # every step on the launch stream), the all-reduce (pack + scale + collective + unscale, GPU-side), each rank's host wait
+        # for its one-step-late metrics copy (~0: that rank's host is its bottleneck), and the per-step edge imbalance between
+        # ranks (a step lasts as long as its largest shard)
+        "per_rank": {
+            "gpu_step_ms_min": [round(float(x), 4) for x in per_rank[:, 3]],
+            "gpu_step_ms_median": [round(float(x), 4) for x in per_rank[:, 4]],
+            "gpu_step_ms_max": [round(float(x), 4) for x in per_rank[:, 5]],
+            "allreduce_ms_mean": [round(float(x), 4) for x in per_rank[:, 6]],
+            "host_blocked_on_gpu_ms_per_step": [round(float(x), 4) for x in per_rank[:, 7]],
+            "wall_ms_per_step": [round(float(x), 4) for x in per_rank[:, 8]],
+        },
+        "step_edge_imbalance_max_over_mean": {"mean": float(imbalance.mean()), "max": float(imbalance.max())},
         "gradient_allreduce_bytes": reducer.nbytes if reducer is not None else 0,
         "gemm_autotuned": False,
         "final_loss": state["loss"],
@@ -534,7 +637,7 @@ def main():
     }
 
     # ---- secondary figures (rank 0, single GPU): same-batch step, forward only, transfers ---------------------------
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "C2":
         try:
             mb, batch = c2_batch(task, fold, device)
             from tf_gnn_samples_amd.graph import RelGraph
@@ -586,7 +689,9 @@ def main():
             result["roofline"] = roofline_section(device, args.kernel_iters, not args.no_pmc)
         except Exception as e:
             result["roofline"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["other_configs"] = other_configs_section()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C2":
         try:
             result["cpu_baseline"] = cpu_baseline(fold[:args.cpu_sample_graphs], params)
         except Exception as e:  # the baseline is reporting only; never lose the GPU number over it

@@ -99,3 +99,29 @@ def test_two_rank_gloo_gradient_equals_union_batch():
     for _, _, grads in results:
         for a, b in zip(grads, full):
             assert np.abs(a - b).max() < 1e-5 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("config", ["C2", "C5"])
+def test_bench_ranks_build_only_their_own_graphs(config, monkeypatch):
+    """bench.py's fold: graph i comes from its own generator stream, so the by-edge sharding is planned from one draw per graph and
+    every rank builds only its shard.  The shards of all ranks partition the fold, a rank's graphs equal the ones a single-rank
+    run of the same total size would build for those indices, and the planned sizes equal the built sizes."""
+    import bench
+    from tf_gnn_samples_amd.tasks import synthetic as S
+    monkeypatch.setitem(bench.CONFIGS, config, {"graphs_per_rank": 3, "graphs_per_batch": 2})
+    world = 4
+    size_of = S.ppi_shaped_graph_size if config == "C2" else S.varmisuse_shaped_graph_size
+    make = S.make_ppi_shaped_graph if config == "C2" else S.make_varmisuse_shaped_graph
+    planned = [size_of(0, i) for i in range(3 * world)]
+    seen_edges = []
+    for rank in range(world):
+        task, local, gen = bench.build_local_fold(rank, world, config)
+        assert len(local) >= 1 and task.num_edge_types == (3 if config == "C2" else 23)
+        for g in local:
+            n, e = len(g.node_features), sum(len(a) for a in g.adjacency_lists)
+            assert (n, e) in planned
+            seen_edges.append(e)
+    assert sorted(seen_edges) == sorted(e for _, e in planned)               # a partition of the fold
+    g_again = make(0, 5)
+    g_first = make(0, 5)
+    assert all(np.array_equal(a, b) for a, b in zip(g_again.adjacency_lists, g_first.adjacency_lists))

@@ -138,17 +138,26 @@ def test_c2_full_batch_model_gradients(gpu_device, c2):
     loss.backward()
     assert abs(float(metrics['loss']) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
 
-    worst_rel = 0.0
+    # Criterion: 1e-5 ABSOLUTE on every entry of every gradient (north star), max-abs and max-rel recorded; plus, on all
+    # but a handful of entries, agreement to 1e-5 of the gradient's largest entry.  The handful: a ReLU unit whose float32
+    # pre-activation lies within the forward error (~3e-6) of zero takes the other branch than in float64 — about one unit
+    # in a million of the 25 M here — and its whole gradient path (~1e-6 absolute) appears in one run and not in the other.
+    def check(got, ref, what):
+        assert_parity(got, ref, strict_abs=True, what=what)
+        err = np.abs(got.detach().cpu().numpy().astype(np.float64) - ref).ravel()
+        scale = float(np.abs(ref).max())
+        bulk = float(np.quantile(err, 0.999)) / scale
+        assert bulk <= 2e-5, (what, bulk)
+        return bulk
+
+    bulk = {}
     for n in names:
         ref = (W[n[len("graph_model/"):]] if n.startswith("graph_model/") else head[n]).grad.numpy()
         got = model.variables[n].grad
         assert got is not None, n
-        a, r = assert_parity(got, ref, strict_abs=True, what="C2 full batch d loss / d %s" % n)
-        worst_rel = max(worst_rel, r)
-    a, r = assert_parity(x_hip.grad, x.grad.numpy(), strict_abs=True, what="C2 full batch d loss / d initial_node_features")
-    worst_rel = max(worst_rel, r)
-    # fp32 reductions over 32 k nodes / 1.85 M messages against float64: relative to the largest entry of each gradient
-    assert worst_rel < 2e-4, worst_rel
+        bulk[n] = check(got, ref, "C2 full batch d loss / d %s" % n)
+    bulk["initial_node_features"] = check(x_hip.grad, x.grad.numpy(), "C2 full batch d loss / d initial_node_features")
+    print("99.9th percentile of |err| / max|grad|:", {k: "%.1e" % v for k, v in bulk.items()})
 
 
 def test_c4_rgat_on_the_c2_batch(gpu_device, c2):

@@ -2,8 +2,8 @@
 where a re-associated sum breaks first.
 
 Three ways the HIP path can evaluate gnns/rgcn.py:84-114 (all the same function up to float32 rounding):
-  aggregate_first_f64   default: bucket sums A_l[v] = sum 1/(c+1e-7) h_u in float64 accumulators, then ONE GEMM [V, L*D] @ [L*D, D]
-  aggregate_first_f32   RELGNN_AGG_ACC=f32: the same with sequential float32 bucket sums (round 2's default)
+  aggregate_first_f32   default: bucket sums A_l[v] = sum 1/(c+1e-7) h_u (sequential float32), then ONE GEMM [V, L*D] @ [L*D, D]
+  aggregate_first_f64   RELGNN_AGG_ACC=f64: the same with float64 bucket accumulators, rounded once (isolates the GEMM's share)
   transform_first       RELGNN_RGCN_ORDER=transform_first: T = H [W_0|..|W_L-1], then the sequential float32 fold of scaled rows
                         of T in the reference's message order (round 1's order; differs from the reference only by the order
                         inside each K = D dot product)
@@ -31,7 +31,7 @@ VARIANTS = {
     "aggregate_first_f32": {"RELGNN_RGCN_ORDER": "aggregate_first", "RELGNN_AGG_ACC": "f32"},
     "transform_first": {"RELGNN_RGCN_ORDER": "transform_first", "RELGNN_AGG_ACC": "f32"},
 }
-DEFAULT = "aggregate_first_f64"
+DEFAULT = "aggregate_first_f32"
 
 
 def _dev(x, dev):

@@ -89,6 +89,32 @@ __device__ __forceinline__ GroupGeom geom(int64_t n_rows, int64_t n_logical_bloc
   return r;
 }
 
+// The L + 1 bucket boundaries of a node (and, with compact tables, the rows of its buckets) are fetched by the group's lanes
+// with ONE coalesced load each and handed around with shuffles; the walk then visits the NON-EMPTY types only (a bit mask
+// from the boundaries).  Walking all L types with a dependent rowptr load (and a brow load) per type made every node a chain
+// of ~L + 2 x (non-empty types) serial L2 round trips — on VarMisuse-shaped graphs (23 types, ~7 non-empty per node) the
+// kernels were latency-bound at 45 % of the HBM rate.  Needs L < G (else the per-type loads of the plain walk).
+template <int G>
+struct NodeBuckets {
+  int rp;            // lane gl holds rowptr[v*L + gl] (gl <= L)
+  int br;            // lane gl holds the row of bucket (v, gl) (gl < L)
+  uint32_t mask;     // bit l set: bucket (v, l) is non-empty
+  __device__ __forceinline__ int begin(int l) const { return __shfl(rp, l, G); }
+  __device__ __forceinline__ int end(int l) const { return __shfl(rp, l + 1, G); }
+  __device__ __forceinline__ int row(int l) const { return __shfl(br, l, G); }
+};
+template <int G>
+__device__ __forceinline__ NodeBuckets<G> load_buckets(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ brow,
+                                                       int64_t v, int L, int gl, int g) {
+  NodeBuckets<G> nb;
+  nb.rp = gl <= L ? rowptr[v * L + gl] : 0;
+  nb.br = gl < L ? (brow ? brow[v * L + gl] : (int)(v * L + gl)) : -1;
+  const int nxt = __shfl_down(nb.rp, 1, G);
+  const uint64_t ball = __ballot(gl < L && nxt > nb.rp);
+  nb.mask = (uint32_t)((ball >> (g * G)) & ((G >= 32) ? 0xffffffffull : ((1ull << G) - 1)));
+  return nb;
+}
+
 // -----------------------------------------------------------------------------------------
 // forward:  out[v] = finalize( AGG_l AGG_{p in (v,l)} act(pre_act(w[p], T[col[p]], rows(v,l))) )
 // -----------------------------------------------------------------------------------------
@@ -110,47 +136,60 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(
     cc[c] = min(gg.gl + G * c, D4 - 1);
     acc[c] = f4(IS_MAX ? -FLT_MAX : 0.f);
   }
-  const int seg_b = rowptr[v * L], seg_e = rowptr[(v + 1) * L];
-  int b = seg_b;
-  for (int l = 0; l < L; ++l) {
-    const int e = rowptr[v * L + l + 1];
-    if (b < e) {
-      float4 ra[NCH], rb[NCH];
-      const float4* arow = A + (brow ? (int64_t)brow[v * L + l] : v * L + l) * lda4;
+  int seg_b, seg_e;
+  auto bucket = [&](int b, int e, int64_t arow_id) {
+    float4 ra[NCH], rb[NCH];
+    const float4* arow = A + arow_id * lda4;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        ra[c] = arow[cc[c]];
-        rb[c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+    for (int c = 0; c < NCH; ++c) {
+      ra[c] = arow[cc[c]];
+      rb[c] = (KIND == KIND_FILM) ? arow[D4 + cc[c]] : f4(0.f);
+    }
+    for (int p = b; p < e; p += PU) {
+      int r[PU];
+      float ww[PU];
+      float4 t[PU][NCH];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int idx = min(p + u, e - 1);
+        r[u] = col[idx];
+        ww[u] = w ? w[idx] : 1.f;
       }
-      for (int p = b; p < e; p += PU) {
-        int r[PU];
-        float ww[PU];
-        float4 t[PU][NCH];
 #pragma unroll
-        for (int u = 0; u < PU; ++u) {
-          const int idx = min(p + u, e - 1);
-          r[u] = col[idx];
-          ww[u] = w ? w[idx] : 1.f;
-        }
+      for (int u = 0; u < PU; ++u)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) t[u][c] = T[(int64_t)r[u] * ldt4 + cc[c]];
+      with_act(act, [&](auto a_tag) {
+        constexpr int ACT = decltype(a_tag)::value;
 #pragma unroll
         for (int u = 0; u < PU; ++u)
+          if (p + u < e) {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) t[u][c] = T[(int64_t)r[u] * ldt4 + cc[c]];
-        with_act(act, [&](auto a_tag) {
-          constexpr int ACT = decltype(a_tag)::value;
-#pragma unroll
-          for (int u = 0; u < PU; ++u)
-            if (p + u < e) {
-#pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                const float4 m = act4_t<ACT>(pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
-                acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
-              }
+            for (int c = 0; c < NCH; ++c) {
+              const float4 m = act4_t<ACT>(pre_act<KIND>(ww[u], t[u][c], ra[c], rb[c]));
+              acc[c] = IS_MAX ? max4(acc[c], m) : acc[c] + m;
             }
-        });
-      }
+          }
+      });
     }
-    b = e;
+  };
+  if (G < 64 && L < G) {
+    const NodeBuckets<G> nb = load_buckets<G>(rowptr, brow, v, L, gg.gl, gg.g);
+    seg_b = nb.begin(0);
+    seg_e = nb.end(L - 1);
+    for (uint32_t m = nb.mask; m; m &= m - 1) {          // ascending type order = the reference's message order
+      const int l = __builtin_ctz(m);
+      bucket(nb.begin(l), nb.end(l), nb.row(l));
+    }
+  } else {
+    seg_b = rowptr[v * L];
+    seg_e = rowptr[(v + 1) * L];
+    int b = seg_b;
+    for (int l = 0; l < L; ++l) {
+      const int e = rowptr[v * L + l + 1];
+      if (b < e) bucket(b, e, brow ? (int64_t)brow[v * L + l] : v * L + l);
+      b = e;
+    }
   }
   const float n = (float)max(seg_e - seg_b, 1);
 #pragma unroll
@@ -188,15 +227,14 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
     cc[c] = min(gg.gl + G * c, D4 - 1);
     g[c] = gagg[v * ldg4 + cc[c]];
   }
-  int b = rowptr[v * L];
-  for (int l = 0; l < L; ++l) {
-    const int e = rowptr[v * L + l + 1];
+  // one bucket (v, l) = messages [b, e): its gradient row goes to `orow` (-1: an empty bucket of a compact table owns no row)
+  auto bucket = [&](int b, int e, int64_t arow_id, int64_t orow) {
     float4 s1[NCH], s2[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) s1[c] = s2[c] = f4(0.f);
     if (b < e) {
       float4 ra[NCH], rb[NCH];
-      const float4* arow = A + (brow ? (int64_t)brow[v * L + l] : v * L + l) * lda4;
+      const float4* arow = A + arow_id * lda4;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         ra[c] = arow[cc[c]];
@@ -235,8 +273,6 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
           }
       }
     }
-    // compact row tables (brow): only non-empty buckets own a row
-    const int64_t orow = brow ? (b < e ? (int64_t)brow[v * L + l] : -1) : v * L + l;
     if (orow >= 0) {
       float4* grow = gA + orow * ldga4;
 #pragma unroll
@@ -246,7 +282,27 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_kernel(
           if constexpr (KIND == KIND_FILM) grow[D4 + gg.gl + G * c] = s2[c];
         }
     }
-    b = e;
+  };
+  if (G < 64 && L < G) {
+    const NodeBuckets<G> nb = load_buckets<G>(rowptr, brow, v, L, gg.gl, gg.g);
+    if (brow) {                                            // compact tables: only non-empty buckets own a row
+      for (uint32_t m = nb.mask; m; m &= m - 1) {
+        const int l = __builtin_ctz(m);
+        const int row = nb.row(l);
+        bucket(nb.begin(l), nb.end(l), row, row);
+      }
+    } else {                                               // dense tables: every (v, l) row is written (zeros when empty)
+      for (int l = 0; l < L; ++l) bucket(nb.begin(l), nb.end(l), v * L + l, v * L + l);
+    }
+  } else {
+    int b = rowptr[v * L];
+    for (int l = 0; l < L; ++l) {
+      const int e = rowptr[v * L + l + 1];
+      // compact row tables (brow): only non-empty buckets own a row
+      const int64_t row = brow ? (b < e ? (int64_t)brow[v * L + l] : -1) : v * L + l;
+      bucket(b, e, row, row);
+      b = e;
+    }
   }
 }
 

@@ -96,7 +96,12 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   constexpr int A_FLOATS = PR * BK, B_FLOATS = NC * BK;
   constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
   constexpr int PA = A_FLOATS / 256, PB = B_FLOATS / 256, P = PA + PB;     // 1 KiB DMA pieces per stage
-  constexpr int G = (P + 7) / 8;                    // pieces per wave and k-tile (the last ones may be duplicates)
+  // Only waves 0-3 (one per SIMD) issue the DMA; their partners 4-7 go from the barrier straight into their MFMAs.  With
+  // all eight waves issuing, both waves of a SIMD spend the first few hundred cycles after every barrier on address
+  // arithmetic and DMA issue while the matrix pipe idles (measured: 8 % of the k-loop); with one loader per SIMD the partner
+  // keeps the pipe busy meanwhile and the loader catches up when the partner has run out of MFMAs.
+  constexpr int LOADERS = 4;
+  constexpr int G = (P + LOADERS - 1) / LOADERS;    // pieces per loader wave and k-tile (the last ones may be duplicates)
   constexpr int WPIECES = 2 * T32 + T16;            // A pieces (16-row blocks) per wave-row group
   static_assert(!A_KM || T16 == 0, "k-major A: 32-row tiles only (the column swizzle needs 32-column multiples)");
   static_assert(WM * WN == 8, "8 waves");
@@ -142,16 +147,17 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   // k-contiguous A image: 16-row pieces in panel-row order; rows [32 t, 32 t + 32) of a wave form one 32-row block
   // (slot(i, kq) = 4 i + (kq ^ ((i >> 3) & 3)), i = row inside the block), the 16-row strip one 16-row block
   // (slot(i, kq) = 4 i + (kq ^ 2 (i >> 3))): both conflict-free for ds_read_b128 (16-lane groups of gfx950).
+  const bool loader = wave < LOADERS;
   const float* src[G];
-  int64_t step[G];
+  int step[G];                                       // elements per k-tile (fits: 16 * ld)
   int kk[G];                                         // k (inside the tile) of this lane's 16 bytes: for the K tail
   int piece[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const int c = min(wave + 8 * g, P - 1);          // wave-uniform; past the end: a duplicate of the last piece
+    const int c = min((wave & (LOADERS - 1)) + LOADERS * g, P - 1);   // wave-uniform; past the end: a duplicate of the last piece
     piece[g] = c;
     const float* s;
-    int64_t st;
+    int st;
     int k_in;
     if (c < PA) {
       if constexpr (A_KM) {
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
         const bool ok = m < rows_here;
         // (gathered k rows: `s` is the column part only, the row is looked up per tile in issue())
         s = ok ? Ab + (gather_k ? 0 : (int64_t)(kbeg + k) * a.lda) + m0 + m : a.zeros + 4 * lane;
-        st = ok ? (gather_k ? 1 : (int64_t)BK * a.lda) : 0;
+        st = ok ? (gather_k ? 1 : BK * (int)a.lda) : 0;
         k_in = k;
       } else {
         const int cw = c % WPIECES;                  // piece inside the wave-row group
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
         const int k = f / NC, np = f % NC;
         const int n = np ^ (16 * ((k >> 2) & 1));
         s = Bb + (int64_t)(kbeg + k) * a.ldb + n0 + n;
-        st = (int64_t)BK * a.ldb;
+        st = BK * (int)a.ldb;
         k_in = k;
       }
     }
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   const float* zsrc = a.zeros + 4 * lane;
 
   auto issue = [&](int t, int stage) {
+    if (!loader) return;
     float* dst = lds + stage * STAGE_FLOATS;
     const int krem = kend - (kbeg + t * BK);         // >= 1; < 16 only for the K tail
     const bool tail = krem < BK;                     // uniform: only the last tile of a K range that is not a multiple of 16
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   Frags f0, f1;
   if (ntiles > 0) {
     issue(0, 0);
-    if (ntiles > 1) { issue(1, 1); wait_vm<G>(); } else { wait_vm<0>(); }
+    if (ntiles > 1) { issue(1, 1); if (loader) wait_vm<G>(); } else { wait_vm<0>(); }
     __builtin_amdgcn_s_barrier();
     if (ntiles > 2) issue(2, 2);
     read_frags(f0, 0);
@@ -322,11 +329,16 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   // iteration t: fragments of tile t are in registers (or on their way: the compiler waits at first use);
   // DMA in flight: tiles t+1, t+2.
   auto iteration = [&](int t, Frags& cur, Frags& nxt) {       // t + 1 < ntiles
-    if (t + 2 < ntiles) wait_vm<G>(); else wait_vm<0>();       // my pieces of tile t+1 have landed
+    if (loader) {                                              // my pieces of tile t+1 have landed
+      if (t + 2 < ntiles) wait_vm<G>(); else wait_vm<0>();
+    }
     wait_lgkm0();                                              // my reads of tile t's stage are done
     __builtin_amdgcn_s_barrier();                              // -> tile t+1 complete for everybody, stage of tile t free
     if (t + 3 < ntiles) issue(t + 3, t % STAGES);
     read_frags(nxt, (t + 1) % STAGES);
+    // the LDS reads go out BEFORE the MFMA block (left alone, hipcc sinks them behind it: their latency then lands in front of
+    // the next barrier instead of under ~2000 cycles of matrix work)
+    __builtin_amdgcn_sched_barrier(0);
     mfmas(cur);
   };
   int t = 0;
@@ -407,7 +419,8 @@ Sizing size_panels(int M, const int* caps, int n_caps, int column_chunks, int ba
     const int base = units / panels, rem = units % panels;
     if (base + (rem ? 1 : 0) > cap) continue;
     // cost ~ rounds x (units the kernel is compiled for): padded MFMA work per workgroup slot
-    const double cost = (double)((panels + want - 1) / want) * cap;
+    // (ties go to the larger panel: fewer workgroups re-stream the right operand)
+    const double cost = (double)((panels + want - 1) / want) * cap + 1e-6 * panels;
     if (cost < best_cost) { best_cost = cost; best = Sizing{cap, panels, base, rem}; }
   }
   return best;
@@ -415,8 +428,14 @@ Sizing size_panels(int M, const int* caps, int n_caps, int column_chunks, int ba
 
 template <bool A_KM, bool B_RM>
 int dispatch(PanelArgs a, int batch, int force_rows_per_panel, hipStream_t st) {
-  // column geometry: 256-wide panels (8 waves across) when N allows, else 128, else 64
-  const int nc = a.N % 256 == 0 ? 256 : (a.N % 128 == 0 ? 128 : (a.N % 64 == 0 ? 64 : 0));
+  // column geometry: 256-wide panels (8 waves across) when N allows, else 128, else 64.  Short reductions (K <= 256: 16 k-tiles
+  // or fewer per panel) take the 128-wide geometry even when 256 divides N: its panels need half the registers, two workgroups
+  // share a CU and one's prologue / epilogue runs under the other's k-loop.  RELGNN_PANEL_NC=64|128|256 overrides (experiments).
+  static const int forced_nc = [] { const char* e = getenv("RELGNN_PANEL_NC"); return e ? atoi(e) : 0; }();
+  int nc = a.N % 256 == 0 ? 256 : (a.N % 128 == 0 ? 128 : (a.N % 64 == 0 ? 64 : 0));
+  const int k_len = a.split_k ? a.k_chunk : a.K;
+  if (nc == 256 && k_len <= 256) nc = 128;
+  if (forced_nc && a.N % forced_nc == 0 && (forced_nc == 64 || forced_nc == 128 || forced_nc == 256)) nc = forced_nc;
   if (nc == 0) return RELGNN_EUNSUPPORTED;
   const int chunks = a.N / nc;
 #define RELGNN_PANEL_CASE(CAP, WM_, WN_, T32_, T16_) \
@@ -511,6 +530,7 @@ int relgnn_panel_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t l
   if (layout != RELGNN_GEMM_TN && K % 4 != 0) return RELGNN_EUNSUPPORTED;
   if (layout == RELGNN_GEMM_TN && M % 4 != 0) return RELGNN_EUNSUPPORTED;
   if (a_batch_stride % 4 || b_batch_stride % 4 || c_batch_stride % 4 || b_select_stride % 4) return RELGNN_EUNSUPPORTED;
+  if (lda > (1 << 26) || ldb > (1 << 26)) return RELGNN_EUNSUPPORTED;       // per-tile address steps are kept in 32 bits
   PanelArgs a{};
   a.A = A; a.lda = lda; a.a_rows = a_rows; a.B = B; a.ldb = ldb; a.b_select = b_select; a.rows_per_select = rows_per_select;
   a.b_select_stride = b_select_stride; a.bias = bias; a.zeros = zeros; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;

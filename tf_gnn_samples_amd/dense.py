@@ -21,6 +21,9 @@ _OWN_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "mfma"
 # node count not seen before, i.e. for every batch of a shuffled epoch).  Default "lib": the same library through
 # relgnn_blaslt_gemm_f32 (csrc/blaslt_gemm.hip), which caches the solution per (layout, N, K, V / 4096).
 _CACHED_LIB_GEMM = os.environ.get("RELGNN_GEMM", "lib") != "torch"
+# RELGNN_GEMM=panel: forward / input-gradient products through the row-panel MFMA kernel (csrc/panel_gemm.hip) wherever its
+# shape constraints hold (N % 64 == 0, K % 4 == 0); the weight gradients keep their routes.
+_PANEL_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "panel"
 _STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 _WORKSPACE = {}
@@ -49,6 +52,10 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
              accumulate: bool = False, relu: bool = False) -> torch.Tensor:
     """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
     Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU)."""
+    if (_PANEL_GEMM and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
+            and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
+        from . import _lib
+        return panel_gemm(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
     if not (_CACHED_LIB_GEMM and _lib_rows_ok(a) and _lib_rows_ok(b) and (bias is None or (bias.is_cuda and bias.is_contiguous()
                                                                                           and bias.dtype == torch.float32))):
         if layout == GEMM_NN:
