@@ -275,33 +275,6 @@ int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* ro
 int relgnn_act_bwd_from_output(int32_t act, const float* y, const float* gout, int64_t n,
                                float* gin, void* stream);
 
-/*
- * Fused aggregate -> transform on the matrix cores (csrc/agg_transform.hip) for the dense-weight layers:
- *   out[s,:] = act( f_mode( sum_l ( sum_{p in (s,l)} w[p] * X[col[p],:] ) @ W_l ) ),  mode in {SUM, MEAN, SQRT_N}
- * = gnns/rgcn.py:84-114 / ggnn.py:76-89 with the per-edge-type Dense applied AFTER the (linear) aggregation as an
- * exact-f32 MFMA GEMM (v_mfma_f32_32x32x2_f32) that runs UNDER the gather (wave-specialised producers / consumers);
- * the [V, L*D] table of transformed states never reaches memory.  The input gradient
- *   dX[u,:] = sum_l ( sum_{p in (source u, l)} w_p dOut[tgt_p,:] ) @ W_l^T
- * is the same call on the by-source buckets with the transposed weights packed (row_stride 1, col_stride ld).
- *   X       : [num_rows_x, ldx] gathered table (first Din columns);  col: [M] row of X per bucket position
- *   rowptr  : [num_out * L + 1] bucket (s, l) = positions rowptr[s*L + l] .. rowptr[s*L + l + 1]
- *   packed_weights : relgnn_agg_transform_pack_weights() of the L matrices; element (k, n) of matrix l is read at
- *                    W + l*type_stride + k*row_stride + n*col_stride
- *   agg_out : optional [num_out, ld_agg >= L*Din]: the aggregated rows A[s, l*Din:(l+1)*Din] = sum_p w_p X[col_p]
- *             (operand of the weight gradient dW_l = A_l^T @ dOut), or NULL
- *   err_flag: device int32 (zeroed by the caller); bit 0 is set if an in-kernel producer/consumer hand-off timed out
- *             (results are then undefined; the Python wrapper raises) — every in-kernel wait is bounded.
- * relgnn_agg_transform_supported(Din, Dout) != 0 for the widths the kernel is instantiated for (128 / 256 each);
- * RELGNN_EUNSUPPORTED otherwise and for MAX (it does not commute with the transform).
- */
-int relgnn_agg_transform_supported(int32_t Din, int32_t Dout);
-int relgnn_agg_transform_pack_weights(const float* W, int32_t num_edge_types, int32_t Din, int32_t Dout, int64_t type_stride,
-                                      int64_t row_stride, int64_t col_stride, float* packed, void* stream);
-int relgnn_agg_transform_fwd(int32_t mode, int32_t act, const float* X, int64_t num_rows_x, int64_t ldx, int32_t Din,
-                             const int32_t* rowptr, int64_t num_out, int32_t num_edge_types, const int32_t* col, const float* w,
-                             const float* packed_weights, int32_t Dout, float* out, int64_t ldo, float* agg_out, int64_t ld_agg,
-                             int32_t* err_flag, void* stream);
-
 /* ========================================================================== *
  * 3. GNN-FiLM fused message kernels  (gnns/gnn_film.py:86-116)
  * ========================================================================== */
@@ -674,20 +647,15 @@ int relgnn_plan_assemble(const int64_t* ids, int32_t num_batch_graphs, int32_t n
  * Replaces the MatMul of every bias-free / biased Keras Dense on the path when it is evaluated node-side: the
  * per-edge-type transforms (gnns/rgcn.py:70-74,98; ggnn.py:63-67,80-81; rgat.py:95-96; gnn_film.py:92-94,102),
  * the inter-layer Dense (models/sparse_graph_model.py:194-200) and the MatMul gradients TF derives for them.
- * v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulation (bitwise an fmaf chain in k order), no reduced precision.
+ * The products below are exact fp32 (v_mfma_f32_32x32x2_f32 in relgnn_panel_gemm_f32 / relgnn_gemm_tn_stream_f32, fp32
+ * solutions of the library in relgnn_blaslt_gemm_f32): f32 operands, f32 accumulation, no reduced precision.  Layouts:
  *   RELGNN_GEMM_NN  C[M,N] = act(A[M,K] @ B[K,N] + bias)      A, B row-major
  *   RELGNN_GEMM_NT  C[M,N] = A[M,K] @ Bt[N,K]^T               Bt row-major (dX = G @ W^T with Bt = W)
  *   RELGNN_GEMM_TN  C[M,N] = At[K,M]^T @ B[K,N]               At row-major (dW = X^T @ G, K = node dimension)
- * k_splits > 1 (no bias / activation): the K range is cut into k_splits chunks, chunk z writes its partial product to
- * C + z*M*ldc; the caller sums the k_splits slabs (fixed order: deterministic).
- * Requirements (RELGNN_EUNSUPPORTED otherwise): 16-byte aligned rows, N % 4 == 0, K % 4 == 0 (NN, NT) / M % 4 == 0 (TN).
  */
 #define RELGNN_GEMM_NN 0
 #define RELGNN_GEMM_NT 1
 #define RELGNN_GEMM_TN 2
-int relgnn_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
-                    float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t k_splits, void* stream);
-
 /*
  * The same three products as PLAIN LIBRARY GEMMs (hipBLASLt), for the layers that are not fused: what torch.mm runs, minus
  * the per-call solution lookup.  Every batch of a shuffled epoch has its own node count, so every call is a shape the

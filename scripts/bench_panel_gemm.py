@@ -1,6 +1,5 @@
 #!/usr/bin/env python
-"""relgnn_panel_gemm_f32 against the library GEMMs (hipBLASLt through relgnn_blaslt_gemm_f32 / torch.bmm) and the round-2
-hand-written kernel on the shapes of the path, interleaved rounds in one process, random operands:
+"""relgnn_panel_gemm_f32 against the library GEMMs (hipBLASLt through relgnn_blaslt_gemm_f32 / torch.bmm) on the shapes of the path, interleaved rounds in one process, random operands:
   dense   the C2 step's node-side products (aggregate-first order): [V, 768] @ [768, 256] forward and input gradient, the
           inter-layer Dense, the transform-first shapes, the [768, 256] weight gradient as K-split slabs
   typed   the C5 (GNN-FiLM, VarMisuse-shaped) per-(node, type) transforms: gathered rows x per-tile kernels, K = 128
@@ -60,9 +59,6 @@ def dense_shapes():
             a = rnd(V, K)
             b = rnd(K, N) * 0.1 if layout == NN else rnd(N, K) * 0.1
             v = {"panel": lambda: DN.panel_gemm(layout, a, b), "lib": lambda: DN.lib_gemm(layout, a, b)}
-            if os.environ.get("WITH_OLD"):
-                os.environ["RELGNN_GEMM"] = "mfma"
-                v["old_own"] = lambda: DN.own_gemm(layout, a, b)
             res = time_variants(v)
             ref = (a.double() @ b.double()) if layout == NN else (a.double() @ b.double().t())
             err = float((DN.panel_gemm(layout, a, b).double() - ref).abs().max())
@@ -111,8 +107,20 @@ def typed_shapes():
             report("typed dW partials %d x [%d,512]x[512,%d]" % (tiles, Din, Dout), 2.0 * P * Din * Dout, res)
 
 
+def pmc_target():
+    """A few launches of the panel kernel and of the library GEMM on the C2 layer shape (run under rocprofv3 --pmc)."""
+    V, K, N = 36096, 768, 256
+    a, b = rnd(V, K), rnd(K, N) * 0.1
+    for _ in range(6):
+        DN.panel_gemm(NN, a, b)
+        DN.lib_gemm(NN, a, b)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dense", "typed"]
+    if "pmc" in which:
+        pmc_target()
     if "dense" in which:
         dense_shapes()
     if "typed" in which:

@@ -1,5 +1,5 @@
 """Host-side cost of a library GEMM call when the node dimension changes from call to call (every batch of a shuffled
-epoch has its own V) vs when it repeats; and of relgnn_gemm_f32 (no solution lookup)."""
+epoch has its own V) vs when it repeats."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,7 +19,6 @@ for _ in range(3): xs[0] @ w
 print("library, NEW shape each call      median %.0f us  max %.0f us" % host_us(lambda a: a @ w, xs[1:]))
 print("library, same shapes again         median %.0f us  max %.0f us" % host_us(lambda a: a @ w, xs[1:]))
 print("library, ONE shape repeated        median %.0f us  max %.0f us" % host_us(lambda a: a @ w, [xs[0]] * 50))
-print("relgnn_gemm_f32, new shapes        median %.0f us  max %.0f us" % host_us(lambda a: D.own_gemm(D.GEMM_NN, a, w), [torch.rand(31000 + 41 * i, 768, device=dev) for i in range(50)]))
 print("relgnn_blaslt_gemm_f32, new shapes median %.0f us  max %.0f us" % host_us(lambda a: D.lib_gemm(D.GEMM_NN, a, w), [torch.rand(32000 + 43 * i, 768, device=dev) for i in range(50)]))
 g = torch.rand(30000, 256, device=dev)
 print("relu_ (elementwise)                median %.0f us  max %.0f us" % host_us(lambda a: a.relu_(), [g] * 50))

@@ -1,5 +1,5 @@
 """Weight-gradient GEMM dW = X^T @ G at the shapes of a C2 step: streaming kernel (csrc/gemm_tn_stream.hip) vs the library
-split-K path vs relgnn_gemm_f32 TN; checks the result against float64."""
+split-K path; checks the result against float64."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,8 +27,6 @@ for V in (36411, 30011, 1000003, 777):
         tl = t(lambda: D.matmul_tn_splitk(a, b))
         own = ""
         D._OWN_GEMM = True
-        if D.own_gemm_supported(D.GEMM_TN, a, b):
-            own = "| own LDS kernel %7.1f us" % t(lambda: D.own_gemm(D.GEMM_TN, a, b))
         D._OWN_GEMM = False
         fl = 2.0 * V * M * N
         print("  [V,%3d]^T@[V,%3d]  stream %7.1f us %6.1f TF (rel err %.1e) | library split-K %7.1f us %6.1f TF %s"

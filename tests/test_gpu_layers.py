@@ -338,42 +338,6 @@ def test_every_model_trains_a_step(gpu_device, model_name):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-def test_fused_mfma_kernel_reports_unsupported_widths(gpu_device):
-    from tf_gnn_samples_amd import _lib, ops
-    assert ops.fused_transform_supported(256, 256, _lib.AGG_SUM) and ops.fused_transform_supported(128, 256, _lib.AGG_MEAN)
-    assert not ops.fused_transform_supported(320, 320, _lib.AGG_SUM)      # widths the kernel is not instantiated for
-    assert not ops.fused_transform_supported(256, 256, _lib.AGG_MAX)      # max does not commute with the transform
-
-
-@pytest.mark.parametrize("Din,Dout", [(256, 256), (128, 128), (256, 128), (128, 256)])
-@pytest.mark.parametrize("agg,norm", [("sum", True), ("mean", False), ("sqrt_n", False)])
-def test_fused_mfma_aggregate_transform(gpu_device, Din, Dout, agg, norm):
-    """csrc/agg_transform.hip (f32 MFMA, aggregate-then-transform) == the oracle's transform-then-aggregate RGCN."""
-    from tf_gnn_samples_amd import ops
-    from tf_gnn_samples_amd.graph import RelGraph
-    rng, adj, deg = _graph(21)
-    V, L = 150, 3
-    w = rgcn_weights(rng, L, Din, Dout)
-    h = np.tanh(rng.standard_normal((V, Din))).astype(np.float32)
-    ref = G.sparse_rgcn_layer(h, adj, deg, Dout, 1, "tanh", agg, norm, weights=w)
-    g = RelGraph(_dev(adj, gpu_device), V)
-    wt = g.degree_scale(_dev(deg, gpu_device)) if norm else None
-    W = torch.stack([torch.as_tensor(w["Edge_%i_Weight/kernel" % l], device=gpu_device) for l in range(L)]).requires_grad_(True)
-    hd = torch.as_tensor(h, device=gpu_device).requires_grad_(True)
-    out = ops.fused_aggregate_transform(hd, W, g, wt, agg, "tanh")
-    assert _close(out, ref)
-    gout = np.random.default_rng(0).standard_normal(out.shape).astype(np.float32)
-    out.backward(torch.as_tensor(gout, device=gpu_device))
-    hr = torch.as_tensor(h, dtype=torch.float64).requires_grad_(True)
-    wr = {k: torch.as_tensor(v, dtype=torch.float64).requires_grad_(True) for k, v in w.items()}
-    R.sparse_rgcn_layer(hr, [torch.as_tensor(a) for a in adj], torch.as_tensor(deg), Dout, 1, "tanh", agg, norm,
-                        weights=wr).backward(torch.as_tensor(gout, dtype=torch.float64))
-    assert float((hd.grad.cpu().double() - hr.grad).abs().max()) < 4e-5 * max(1.0, float(hr.grad.abs().max()))
-    for l in range(L):
-        gr = wr["Edge_%i_Weight/kernel" % l].grad
-        assert float((W.grad[l].cpu().double() - gr).abs().max()) < 4e-5 * max(1.0, float(gr.abs().max()))
-
-
 @pytest.mark.parametrize("full_state,tie", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("agg,norm", [("sum", True), ("mean", False)])
 def test_rgdcn_layer(gpu_device, full_state, tie, agg, norm):

@@ -47,10 +47,6 @@ _SIGNATURES = {
     "relgnn_seg_max_count": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_seg_max_bwd": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "relgnn_act_bwd_from_output": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _ptr, _ptr]),
-    "relgnn_agg_transform_supported": (ctypes.c_int, [_c_i32, _c_i32]),
-    "relgnn_agg_transform_pack_weights": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _c_i64, _ptr, _ptr]),
-    "relgnn_agg_transform_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr,
-                                                _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_film_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_film_bwd_film": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_film_bwd_msg_masked": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
@@ -85,7 +81,6 @@ _SIGNATURES = {
     "relgnn_layer_norm_groups": (_c_i64, [_c_i64, _c_i32]),
     "relgnn_layer_norm_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _c_f32, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_layer_norm_bwd": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _ptr]),
-    "relgnn_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_panel_gemm_zeros_floats": (ctypes.c_int, []),
     "relgnn_panel_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr, _c_i32, _c_i64, _ptr, _ptr, _ptr,
                                              _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _c_i64, _c_i32, _ptr]),

@@ -330,6 +330,97 @@ __global__ __launch_bounds__(256) void seg_max_bwd_kernel(
   }
 }
 
+// ---- the same two passes with float4 lanes (rows of D % 4 == 0 floats, 16-byte aligned) ---------------------------------
+// G lanes per output row (G = 8 / 16 / 32 for D <= 32 / 64 / 128, else 64 with a chunk loop), 64 / G rows per wave, four
+// entries' indices and rows in flight per lane group before the first compare: the structure of seg_reduce_group_kernel.
+// Same arithmetic as the scalar kernels above (the product w * x is compared with the stored maximum bit for bit).
+__device__ __forceinline__ float4 eq4(float4 a, float4 b) {
+  return make_float4(a.x == b.x ? 1.f : 0.f, a.y == b.y ? 1.f : 0.f, a.z == b.z ? 1.f : 0.f, a.w == b.w ? 1.f : 0.f);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void seg_max_count_vec_kernel(
+    const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr, int64_t num_segments,
+    int32_t stride, const int32_t* __restrict__ col, const float* __restrict__ w, const float4* __restrict__ out,
+    const float4* __restrict__ gout, int64_t ldo4, float4* __restrict__ gsel, int64_t nlb) {
+  constexpr int U = 4;
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63, g = lane / G, gl = lane % G;
+  const int64_t s = (lb * 4 + (threadIdx.x >> 6)) * (64 / G) + g;
+  if (s >= num_segments) return;
+  const int beg = rowptr[s * stride], end = rowptr[(s + 1) * stride];
+  for (int c = gl; c < D4; c += G) {
+    const float4 o = out[s * ldo4 + c];
+    float4 cnt = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg; p < end; p += U) {
+      int r[U];
+      float ww[U];
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = min(p + u, end - 1);
+        r[u] = col[idx];
+        ww[u] = w ? w[idx] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = X[(int64_t)r[u] * ldx4 + c];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + u < end) {
+          const float4 e = eq4(make_float4(ww[u] * v[u].x, ww[u] * v[u].y, ww[u] * v[u].z, ww[u] * v[u].w), o);
+          cnt.x += e.x; cnt.y += e.y; cnt.z += e.z; cnt.w += e.w;
+        }
+    }
+    const float4 gg = gout[s * ldo4 + c];
+    gsel[s * ldo4 + c] = make_float4(cnt.x > 0.f ? gg.x / cnt.x : 0.f, cnt.y > 0.f ? gg.y / cnt.y : 0.f,
+                                     cnt.z > 0.f ? gg.z / cnt.z : 0.f, cnt.w > 0.f ? gg.w / cnt.w : 0.f);
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void seg_max_bwd_vec_kernel(
+    const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr_b, int64_t num_rows,
+    int32_t stride_b, const int32_t* __restrict__ seg_b, const float* __restrict__ w_b, const float4* __restrict__ out,
+    const float4* __restrict__ gsel, int64_t ldo4, float4* __restrict__ gX, int64_t ldgx4, int64_t nlb) {
+  constexpr int U = 4;
+  const int64_t lb = xcd_logical_block(nlb);
+  if (lb < 0) return;
+  const int lane = threadIdx.x & 63, g = lane / G, gl = lane % G;
+  const int64_t r = (lb * 4 + (threadIdx.x >> 6)) * (64 / G) + g;
+  if (r >= num_rows) return;
+  const int beg = rowptr_b[r * stride_b], end = rowptr_b[(r + 1) * stride_b];
+  for (int c = gl; c < D4; c += G) {
+    const float4 x = X[r * ldx4 + c];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = beg; q < end; q += U) {
+      int sg[U];
+      float wq[U];
+      float4 o[U], gs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = min(q + u, end - 1);
+        sg[u] = seg_b[idx];
+        wq[u] = w_b ? w_b[idx] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        o[u] = out[(int64_t)sg[u] * ldo4 + c];
+        gs[u] = gsel[(int64_t)sg[u] * ldo4 + c];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (q + u < end) {
+          const float4 e = eq4(make_float4(wq[u] * x.x, wq[u] * x.y, wq[u] * x.z, wq[u] * x.w), o[u]);
+          // (select, not multiply: 0 * inf from an overflowed gradient must not turn the other entries into NaN)
+          acc.x += e.x != 0.f ? wq[u] * gs[u].x : 0.f; acc.y += e.y != 0.f ? wq[u] * gs[u].y : 0.f;
+          acc.z += e.z != 0.f ? wq[u] * gs[u].z : 0.f; acc.w += e.w != 0.f ? wq[u] * gs[u].w : 0.f;
+        }
+    }
+    gX[r * ldgx4 + c] = acc;
+  }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(256) void act_bwd_from_output_kernel(const float* __restrict__ y,
                                                                   const float* __restrict__ gout,
@@ -584,6 +675,20 @@ int relgnn_seg_max_count(const float* X, int64_t ldx, int32_t D, const int32_t* 
   if (D < 0 || num_segments < 0 || seg_stride <= 0) return RELGNN_EINVAL;
   if (num_segments == 0 || D == 0) return RELGNN_OK;
   if (!rowptr || !out || !gout || !gsel) return RELGNN_EINVAL;
+  if (D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && aligned16(X) && aligned16(out) && aligned16(gout) && aligned16(gsel)) {
+    const int D4 = D / 4;
+    hipStream_t st = as_stream(stream);
+#define RELGNN_MAXCNT(GG)                                                                                              \
+  {                                                                                                                    \
+    const int64_t nlb = (num_segments + 4 * (64 / GG) - 1) / (4 * (64 / GG));                                          \
+    seg_max_count_vec_kernel<GG><<<(unsigned)(((nlb + 7) / 8) * 8), 256, 0, st>>>(                                      \
+        (const float4*)X, ldx / 4, D4, rowptr, num_segments, seg_stride, col, w, (const float4*)out, (const float4*)gout, \
+        ldo / 4, (float4*)gsel, nlb);                                                                                  \
+  }
+    if (D4 <= 8) RELGNN_MAXCNT(8) else if (D4 <= 16) RELGNN_MAXCNT(16) else if (D4 <= 32) RELGNN_MAXCNT(32) else RELGNN_MAXCNT(64)
+#undef RELGNN_MAXCNT
+    return launch_status();
+  }
   seg_max_count_kernel<<<(unsigned)((num_segments + 3) / 4), 256, 0, as_stream(stream)>>>(
       X, ldx, D, rowptr, num_segments, seg_stride, col, w, out, gout, ldo, gsel);
   return launch_status();
@@ -596,6 +701,21 @@ int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* ro
   if (D < 0 || num_rows_x < 0 || seg_stride_b <= 0) return RELGNN_EINVAL;
   if (num_rows_x == 0 || D == 0) return RELGNN_OK;
   if (!X || !rowptr_b || !gX) return RELGNN_EINVAL;
+  if (D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldgx % 4 == 0 && aligned16(X) && aligned16(out) && aligned16(gsel) &&
+      aligned16(gX)) {
+    const int D4 = D / 4;
+    hipStream_t st = as_stream(stream);
+#define RELGNN_MAXBWD(GG)                                                                                              \
+  {                                                                                                                    \
+    const int64_t nlb = (num_rows_x + 4 * (64 / GG) - 1) / (4 * (64 / GG));                                            \
+    seg_max_bwd_vec_kernel<GG><<<(unsigned)(((nlb + 7) / 8) * 8), 256, 0, st>>>(                                        \
+        (const float4*)X, ldx / 4, D4, rowptr_b, num_rows_x, seg_stride_b, seg_b, w_b, (const float4*)out,              \
+        (const float4*)gsel, ldo / 4, (float4*)gX, ldgx / 4, nlb);                                                     \
+  }
+    if (D4 <= 8) RELGNN_MAXBWD(8) else if (D4 <= 16) RELGNN_MAXBWD(16) else if (D4 <= 32) RELGNN_MAXBWD(32) else RELGNN_MAXBWD(64)
+#undef RELGNN_MAXBWD
+    return launch_status();
+  }
   seg_max_bwd_kernel<<<(unsigned)((num_rows_x + 3) / 4), 256, 0, as_stream(stream)>>>(
       X, ldx, D, rowptr_b, num_rows_x, seg_stride_b, seg_b, w_b, out, gsel, ldo, gX, ldgx);
   return launch_status();

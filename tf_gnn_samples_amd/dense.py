@@ -13,10 +13,6 @@ import os
 
 import torch
 
-# RELGNN_GEMM=mfma routes the node-side GEMMs through the hand-written exact-fp32 MFMA kernel (csrc/gemm_f32.hip) for
-# every shape it supports.  Default: the library (hipBLASLt, cached solutions) — measured on MI355X at the C2 shapes
-# (scripts/bench_gemm.py, K = 256): library default solutions 100-119 TFLOP/s, own kernel 77-92 TFLOP/s.
-_OWN_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "mfma"
 # RELGNN_GEMM=torch: library GEMMs through torch.mm (a hipBLASLt solution lookup per call: ~70 us of host time for every
 # node count not seen before, i.e. for every batch of a shuffled epoch).  Default "lib": the same library through
 # relgnn_blaslt_gemm_f32 (csrc/blaslt_gemm.hip), which caches the solution per (layout, N, K, V / 4096).
@@ -107,40 +103,6 @@ def _rows_ok(t: torch.Tensor) -> bool:
     return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0
             and (t.stride(0) >= t.shape[1] or t.shape[0] == 1)
             and t.data_ptr() % 16 == 0 and t.shape[0] < 2 ** 31 and t.shape[1] < 2 ** 31)
-
-
-def own_gemm_supported(layout: int, a: torch.Tensor, b: torch.Tensor) -> bool:
-    """Shapes relgnn_gemm_f32 takes: 16-byte aligned rows, N % 4 == 0 and K % 4 == 0 (NN / NT) or M % 4 == 0 (TN)."""
-    if not (_OWN_GEMM and _rows_ok(a) and _rows_ok(b)):
-        return False
-    if layout == GEMM_NN:        # a [M, K], b [K, N]
-        return a.shape[1] == b.shape[0] and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0 and a.shape[1] > 0
-    if layout == GEMM_NT:        # a [M, K], b [N, K]
-        return a.shape[1] == b.shape[1] and a.shape[1] % 4 == 0 and b.shape[0] % 4 == 0 and a.shape[1] > 0
-    return a.shape[0] == b.shape[0] and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0 and a.shape[0] > 0   # a [K, M], b [K, N]
-
-
-def own_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0) -> torch.Tensor:
-    """relgnn_gemm_f32: NN a @ b (+ bias, activation) | NT a @ b^T | TN a^T @ b (reduction over the rows, split into
-    chunks whose partial products are summed in a fixed order)."""
-    from . import _lib
-    lib = _lib.load_library()
-    st = _lib.current_stream()
-    if layout == GEMM_NN:
-        M, K, N = a.shape[0], a.shape[1], b.shape[1]
-    elif layout == GEMM_NT:
-        M, K, N = a.shape[0], a.shape[1], b.shape[0]
-    else:
-        K, M, N = a.shape[0], a.shape[1], b.shape[1]
-    splits = 1
-    if layout == GEMM_TN:
-        big = N % 128 == 0 and M >= 128
-        tiles = ((M + 127) // 128) * ((N + 127) // 128) if big else ((M + 63) // 64) * ((N + 63) // 64)
-        splits = int(max(1, min((512 if big else 768) // max(tiles, 1), K // 256)))
-    out = torch.empty((splits, M, N) if splits > 1 else (M, N), dtype=torch.float32, device=a.device)
-    _lib.check(lib.relgnn_gemm_f32(layout, act, _lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
-                                   b.stride(0), _lib.ptr(bias), _lib.ptr(out), N, M, N, K, splits, st), "relgnn_gemm_f32")
-    return out.sum(0) if splits > 1 else out
 
 
 _ZEROS = {}
@@ -259,8 +221,6 @@ def tn_stream_gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor = None) -
 
 def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T @ b for a [V, M], b [V, N] (both row-major), reduction over V split into S chunks."""
-    if own_gemm_supported(GEMM_TN, a, b):
-        return own_gemm(GEMM_TN, a, b)
     V, M = a.shape
     N = b.shape[1]
     # small outputs (every Dense of the path except the stacked per-type transforms): the streaming kernel — measured at
@@ -322,8 +282,6 @@ class _DenseFn(torch.autograd.Function):
     def forward(ctx, x, kernel, bias):
         ctx.save_for_backward(x, kernel)
         ctx.has_bias = bias is not None
-        if own_gemm_supported(GEMM_NN, x, kernel) and (bias is None or bias.is_contiguous()):
-            return own_gemm(GEMM_NN, x, kernel, bias)
         return lib_gemm(GEMM_NN, x, kernel, bias)
 
     @staticmethod
@@ -334,7 +292,7 @@ class _DenseFn(torch.autograd.Function):
         gx = None                          # read in place: every consumer below takes a leading dimension; an expanded one,
                                            # strides (0, 1), is materialised)
         if ctx.needs_input_grad[0]:
-            gx = own_gemm(GEMM_NT, g, kernel) if own_gemm_supported(GEMM_NT, g, kernel) else lib_gemm(GEMM_NT, g, kernel)
+            gx = lib_gemm(GEMM_NT, g, kernel)
         gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), g) \
             if ctx.needs_input_grad[1] else None
         gb = None

@@ -24,15 +24,6 @@ from ._common import concat_edge_kernels, reduce_and_activate, require_weights
 from .pair import pair_messages_reduce
 
 
-def fused_mfma_enabled() -> bool:
-    """RELGNN_FUSED_MFMA=1 selects the fused aggregate -> exact-f32 MFMA transform kernel (csrc/agg_transform.hip) for
-    forward and input gradient.  Parity-green, but measured on MI355X at C2 (scripts/exp_agg_first.py): 270 us per layer
-    forward vs 194 us for the two-kernel aggregate-then-transform order below (its 8 gather waves per workgroup keep
-    half as many row loads in flight as the stand-alone gather kernel: gather phase alone 186 us vs 87 us; MFMA phase
-    alone 109 us) -> not the default."""
-    return os.environ.get("RELGNN_FUSED_MFMA", "0") == "1"
-
-
 def aggregate_first_enabled() -> bool:
     """Default order for sum / mean / sqrt_n: gather + reduce the raw states into the (target, type) buckets, then ONE
     GEMM with the stacked kernels (ops.aggregate_then_transform).  RELGNN_RGCN_ORDER=transform_first restores
@@ -72,14 +63,6 @@ def sparse_rgcn_layer(node_embeddings: torch.Tensor,
 
     cur_node_states = node_embeddings
     mode, act = ops.aggregation_mode_id(message_aggregation_function), ops.activation_id(activation_function)
-    if (not use_both_source_and_target and fused_mfma_enabled() and act in ops._FUSABLE_ACTS
-            and ops.fused_transform_supported(in_dim, state_dim, mode) and (num_timesteps == 1 or in_dim == state_dim)):
-        # aggregate-then-transform on the matrix cores: one kernel per timestep (csrc/agg_transform.hip)
-        w_stack = torch.stack([weights["Edge_%i_Weight/kernel" % l] for l in range(L)], dim=0)   # [L, D, state_dim]
-        for _ in range(num_timesteps):
-            cur_node_states = ops.fused_aggregate_transform(cur_node_states, w_stack, graph, w,
-                                                            message_aggregation_function, activation_function)
-        return cur_node_states
     if not use_both_source_and_target and graph.wants_pair_tables():
         # many edge types, most (node,type) buckets empty: transform the non-empty ones only (graph.PairTables)
         pairs = graph.pair_tables()

@@ -594,8 +594,6 @@ class Sparse_Graph_Model(ABC):
             m, mb = pending
             m = m.get()
             check_pending_graph_errors()
-            from .. import ops
-            ops.check_agg_transform_errors()      # no-op unless the fused kernel ran (RELGNN_FUSED_MFMA=1)
             state["graphs"] += mb.num_graphs
             state["nodes"] += mb.num_nodes
             state["edges"] += mb.num_edges

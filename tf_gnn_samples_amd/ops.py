@@ -737,108 +737,6 @@ def rgat_attention(T, s_src, s_tgt, graph, num_heads: int, slope: float = 0.2):
     return _RgatAttention.apply(T, s_src, s_tgt, graph, int(num_heads), float(slope))
 
 
-# ---- fused aggregate -> MFMA transform (csrc/agg_transform.hip) -------------------------------------
-def fused_transform_supported(d_in: int, d_out: int, mode: int) -> bool:
-    return (mode in (_lib.AGG_SUM, _lib.AGG_MEAN, _lib.AGG_SQRT_N)
-            and bool(_lib.load_library().relgnn_agg_transform_supported(int(d_in), int(d_out))))
-
-
-def _agg_transform(X, rowptr, num_out, L, col, w, packed, d_in, d_out, mode, act, want_agg):
-    lib = _lib.load_library()
-    out = torch.empty((num_out, d_out), dtype=torch.float32, device=X.device)
-    agg = torch.empty((num_out, L * d_in), dtype=torch.float32, device=X.device) if want_agg else None
-    _lib.check(lib.relgnn_agg_transform_fwd(mode, act, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), d_in,
-                                            _lib.ptr(rowptr), num_out, L, _lib.ptr(col), _lib.ptr(w), _lib.ptr(packed), d_out,
-                                            _lib.ptr(out), d_out, _lib.ptr(agg), L * d_in, _lib.ptr(_agg_error_flag(X.device)),
-                                            _lib.current_stream()), "relgnn_agg_transform_fwd")
-    return out, agg
-
-
-_AGG_ERR = {}
-
-
-def _agg_error_flag(device):
-    """One device int32 per GPU that the fused kernel ORs a bit into if an in-kernel hand-off timed out; read back by
-    check_agg_transform_errors() at the next natural sync point (never silently ignored)."""
-    key = (device.type, device.index)
-    if key not in _AGG_ERR:
-        _AGG_ERR[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _AGG_ERR[key]
-
-
-def check_agg_transform_errors():
-    for flag in _AGG_ERR.values():
-        if int(flag.item()) != 0:
-            flag.zero_()
-            raise _lib.RelGnnLibraryError("fused aggregate->transform kernel: producer/consumer hand-off timed out")
-
-
-def _pack_agg_weights(W, transposed: bool):
-    """W [L, Din, Dout] -> MFMA operand order of W_l (or of W_l^T for the input gradient)."""
-    lib = _lib.load_library()
-    L, d_in, d_out = W.shape
-    packed = torch.empty(L * d_in * d_out, dtype=torch.float32, device=W.device)
-    if transposed:      # matrix l = W_l^T [Dout, Din]: element (k, n) = W_l[n, k]
-        args = (d_out, d_in, d_in * d_out, 1, d_out)
-    else:
-        args = (d_in, d_out, d_in * d_out, d_out, 1)
-    _lib.check(lib.relgnn_agg_transform_pack_weights(_lib.ptr(W), L, *args, _lib.ptr(packed), _lib.current_stream()),
-               "relgnn_agg_transform_pack_weights")
-    return packed
-
-
-class _FusedAggregateTransform(torch.autograd.Function):
-    """out = act(f_mode(sum_l (sum_{p in (v,l)} w_p H[src_p]) @ W_l)); W: [L, Din, Dout].
-    Forward: ONE kernel (wave-specialised: gather into LDS tiles under exact-f32 MFMAs); it also emits the aggregated
-    rows A [V, L*Din] when a gradient is needed.  Backward: dH = the SAME kernel on the by-source buckets with W_l^T
-    (the [V, L*Dout] per-type gradient table of the unfused path never exists either); dW_l = A_l^T @ dOut, one
-    split-K GEMM over the node dimension."""
-
-    @staticmethod
-    def forward(ctx, H, W, graph, w, mode: int, act: int):
-        H, W = H.contiguous(), W.contiguous()
-        L, d_in, d_out = W.shape
-        V = graph.V
-        need_grad = H.requires_grad or W.requires_grad
-        out, agg = _agg_transform(H, graph.rowptr_t, V, L, graph.src_t, w, _pack_agg_weights(W, False), d_in, d_out,
-                                  mode, act, need_grad and W.requires_grad)
-        ctx.graph, ctx.w, ctx.mode, ctx.act = graph, w, mode, act
-        ctx.save_for_backward(W, agg, out if act != _lib.ACT_LINEAR else None)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        from .dense import GEMM_NN, lib_gemm, matmul_tn_splitk
-        lib = _lib.load_library()
-        graph, w, mode, act = ctx.graph, ctx.w, ctx.mode, ctx.act
-        W, agg, out = ctx.saved_tensors
-        L, d_in, d_out = W.shape
-        V = graph.V
-        gout = gout.contiguous()
-        if act != _lib.ACT_LINEAR:
-            g = torch.empty_like(gout)
-            _lib.check(lib.relgnn_act_bwd_from_output(act, _lib.ptr(out), _lib.ptr(gout), gout.numel(), _lib.ptr(g),
-                                                      _lib.current_stream()), "relgnn_act_bwd_from_output")
-            gout = g
-        gH = gW = None
-        if ctx.needs_input_grad[0]:
-            plan = graph.plan_transformed(w)            # by-source buckets + weights (mean / sqrt_n factor folded in)
-            gH, _ = _agg_transform(gout, graph.rowptr_s, V, L, graph.tgt_s, plan.w_bwd(mode), _pack_agg_weights(W, True),
-                                   d_out, d_in, _lib.AGG_SUM, _lib.ACT_LINEAR, False)
-        if ctx.needs_input_grad[1]:
-            f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
-            gsc = gout if f is None else gout * f.unsqueeze(1)
-            gW = matmul_tn_splitk(agg, gsc).view(L, d_in, d_out)
-        return gH, gW, None, None, None, None
-
-
-def fused_aggregate_transform(H, W, graph, w, aggregation: str, activation: Optional[str]):
-    mode, act = aggregation_mode_id(aggregation), activation_id(activation)
-    if act not in _FUSABLE_ACTS:
-        raise ValueError("activation %r cannot be fused" % activation)
-    return _FusedAggregateTransform.apply(H, W, graph, w, mode, act)
-
-
 # ---- aggregate, then transform (two kernels, no fusion): gather from the SMALL table -------------------------------------
 def aggregate_acc64() -> bool:
     """RELGNN_AGG_ACC=f32|f64: accumulator width of the bucket sums that feed the K = L*D GEMM of the aggregate-first order.
