@@ -88,7 +88,7 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F
 // any multiple of 16 rows and the panels of a call can be equal to within one 16-row unit.
 // A_KM: A is given k-major (A[m][k] at A + k*lda + m: the X^T of a weight gradient); B_RM: B is given as [N, K] row-major
 // (k contiguous: the W of an input gradient).
-template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM>
+template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM, int SCHED = 1>
 __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   constexpr int RW = 32 * T32 + 16 * T16;           // rows per wave
   constexpr int PR = RW * WM;                       // panel rows
@@ -335,11 +335,20 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
     wait_lgkm0();                                              // my reads of tile t's stage are done
     __builtin_amdgcn_s_barrier();                              // -> tile t+1 complete for everybody, stage of tile t free
     if (t + 3 < ntiles) issue(t + 3, t % STAGES);
-    read_frags(nxt, (t + 1) % STAGES);
-    // the LDS reads go out BEFORE the MFMA block (left alone, hipcc sinks them behind it: their latency then lands in front of
-    // the next barrier instead of under ~2000 cycles of matrix work)
     __builtin_amdgcn_sched_barrier(0);
+    read_frags(nxt, (t + 1) % STAGES);
     mfmas(cur);
+    // Issue order inside the tile: the matrix pipe starts at once (tile t's fragments are in registers) and the LDS reads of
+    // tile t+1 go out one at a time BETWEEN MFMAs, in the issue slots the pipe leaves free.  Left alone hipcc sinks the reads
+    // behind the MFMA block (their latency then lands in front of the next barrier); all reads first, the earlier form of this
+    // loop, idles the pipe for the ~300 cycles it takes two waves per SIMD to issue them.  RELGNN_PANEL_SCHED picks the form.
+    if constexpr (SCHED == 1) {
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+      }
+    }
   };
   int t = 0;
   for (; t + 2 < ntiles; t += 2) {
