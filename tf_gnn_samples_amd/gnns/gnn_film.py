@@ -51,7 +51,10 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
     ops.activation_id(activation_function)
     w = graph.degree_scale(type_to_num_incoming_edges) if normalize_by_num_incoming else None
     # many-type graphs leave most (node,type) buckets empty: transform only the non-empty ones (graph.PairTables)
-    pairs = graph.pair_tables() if (mode != _lib.AGG_MAX and graph.wants_pair_tables()) else None
+    # max aggregation and graphs with hub buckets (RelGraph.has_long_buckets) take the materialised route below: its reduction is
+    # the gather-reduce kernel, which splits long buckets into chunked virtual rows (the fused kernel gives one lane group to a node)
+    unfused = mode == _lib.AGG_MAX or graph.has_long_buckets
+    pairs = graph.pair_tables() if (not unfused and graph.wants_pair_tables()) else None
     if pairs is None:
         w_msg = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")               # [D, L*state_dim]
         w_film = concat_edge_kernels(weights, L, "Edge_%i_FiLM_Computations/kernel")   # [D, L*2*state_dim]
@@ -68,8 +71,8 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
             continue
         transformed = dense(cur_node_states, w_msg).view(num_nodes * L, state_dim)      # row v*L+l = h_v W_l
         film = dense(cur_node_states, w_film).view(num_nodes * L, 2 * state_dim)        # row v*L+l = [gamma | beta]
-        if mode == _lib.AGG_MAX:
-            # max backward needs the materialised messages (tie handling); not a shipped configuration
+        if unfused:
+            # (max backward needs the materialised messages for its tie handling; not a shipped configuration)
             msgs = transformed.index_select(0, graph.key_by_source.long())
             if w is not None:
                 msgs = graph.w_original_order(w).unsqueeze(1) * msgs

@@ -18,8 +18,12 @@ from ..utils import apply_activation, get_activation
 def pair_messages_reduce(p: torch.Tensor, q: torch.Tensor, graph, w: Optional[torch.Tensor],
                          aggregation: str, message_activation: Optional[str],
                          output_activation: Optional[str]) -> torch.Tensor:
-    """out[v] = act_out( AGG_p act_msg( w[p] * (P[col[p]] + Q[v*L + l(p)]) ) )"""
-    if ops.aggregation_mode_id(aggregation) == _lib.AGG_MAX:
+    """out[v] = act_out( AGG_p act_msg( w[p] * (P[col[p]] + Q[v*L + l(p)]) ) )
+
+    The fused kernel gives ONE lane group to a target node; a graph that is known to hold hub buckets (RelGraph.has_long_buckets:
+    more than ops.LONG_SEGMENT messages in one bucket) takes the materialised route instead, whose reduction is the gather-reduce
+    kernel with chunked virtual rows (ops.SplitPlan) — slower per message, but no wave walks 1e4+ messages alone."""
+    if ops.aggregation_mode_id(aggregation) == _lib.AGG_MAX or graph.has_long_buckets:
         msgs = ops.pair_materialize(p, q, graph, None)                 # [M, D] type-major order
         if w is not None:
             msgs = graph.w_original_order(w).unsqueeze(1) * msgs

@@ -30,6 +30,24 @@ def rgat_layer_variables(num_edge_types: int, in_dim: int, state_dim: int):
     return specs
 
 
+def _attention_from_segment_ops(T, s_src, s_tgt, graph, num_heads: int, slope: float):
+    """rgat.py:98-136 op for op on materialised per-message tensors (reference message order): logits, segmented
+    log-softmax over ALL incoming messages of a target per head (dpu_utils unsorted_segment_log_softmax), exp, weighted sum."""
+    plan = graph.plan_messages()
+    tgt = plan.col_b.long()                                                   # target node of every message
+    src_rows, tgt_rows = graph.key_by_source.long(), graph.key_by_target.long()
+    logits = torch.nn.functional.leaky_relu(s_src.index_select(0, src_rows) + s_tgt.index_select(0, tgt_rows), slope)   # [M, K]
+    seg_max = ops.seg_gather_reduce(logits.detach(), plan, "max", None)                                                  # [V, K]
+    shifted = logits - seg_max.index_select(0, tgt)
+    e = torch.exp(shifted)
+    log_den = torch.log(ops.seg_gather_reduce(e, plan, "sum", None).clamp_min(1e-37))   # (targets without messages: never gathered)
+    alpha = torch.exp(shifted - log_den.index_select(0, tgt))                                                            # [M, K]
+    M, K = alpha.shape
+    D = T.shape[1]
+    msgs = (alpha.unsqueeze(2) * T.index_select(0, src_rows).view(M, K, D // K)).reshape(M, D)
+    return ops.seg_gather_reduce(msgs, plan, "sum", None)
+
+
 def sparse_rgat_layer(node_embeddings: torch.Tensor,
                       adjacency_lists: List[torch.Tensor],
                       state_dim: Optional[int],
@@ -73,7 +91,14 @@ def sparse_rgat_layer(node_embeddings: torch.Tensor,
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
         transformed = dense(cur_node_states, w_cat)                                               # [V, L*width]
-        if fused_scores:   # score tables, softmax and weighted sum as one autograd node (csrc/rgat_scores.hip)
+        if graph.has_long_buckets:
+            # hub targets: the attention kernels give one wave to a target; compose rgat.py:98-136 from the segment ops instead,
+            # whose gather-reduce kernel splits long buckets into chunked virtual rows (ops.SplitPlan)
+            t4 = transformed.view(num_nodes, L, num_heads, dh)
+            s_src = (t4 * att_src.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)
+            s_tgt = (t4 * att_tgt.unsqueeze(0)).sum(-1).reshape(num_nodes * L, num_heads)
+            aggregated = _attention_from_segment_ops(transformed.view(num_nodes * L, width), s_src, s_tgt, graph, num_heads, 0.2)
+        elif fused_scores:   # score tables, softmax and weighted sum as one autograd node (csrc/rgat_scores.hip)
             aggregated = ops.rgat_layer_attention(transformed.view(num_nodes * L, width), att_flat, graph, num_heads, 0.2)
         else:
             t4 = transformed.view(num_nodes, L, num_heads, dh)

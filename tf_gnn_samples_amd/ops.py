@@ -907,9 +907,10 @@ class _MessageActReduce(torch.autograd.Function):
 
 
 def message_act_reduce(msgs, graph, w, aggregation: str, activation: Optional[str]):
-    """Sum-like aggregations only (max: apply the activation, then seg_gather_reduce over plan_messages())."""
+    """Sum-like aggregations only (max: apply the activation, then seg_gather_reduce over plan_messages()); graphs with hub
+    buckets take that route too (its gather-reduce splits long buckets into chunked virtual rows)."""
     mode = aggregation_mode_id(aggregation)
-    if mode == _lib.AGG_MAX or msgs.shape[1] % 4 != 0:
+    if mode == _lib.AGG_MAX or msgs.shape[1] % 4 != 0 or graph.has_long_buckets:
         from .utils import apply_activation, get_activation
         if w is not None:
             msgs = graph.w_original_order(w).unsqueeze(1) * msgs
