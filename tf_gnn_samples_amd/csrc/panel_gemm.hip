@@ -41,7 +41,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
-constexpr int STAGES = 3;
 constexpr int KIDX_MAX = 1024;          // k-major A with gathered k rows: the row ids of the K range live in LDS
 
 struct PanelArgs {
@@ -88,7 +87,10 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F
 // any multiple of 16 rows and the panels of a call can be equal to within one 16-row unit.
 // A_KM: A is given k-major (A[m][k] at A + k*lda + m: the X^T of a weight gradient); B_RM: B is given as [N, K] row-major
 // (k contiguous: the W of an input gradient).
-template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM, int SCHED = 1>
+// STAGES: depth of the LDS ring = k-tiles of DMA in flight + 1 (3 or 4).  Measured on the typed C5 shapes (128-row panels, gathered
+// rows, ~1 us of matrix work per k-tile): 4 stages = 3 stages within noise (292 / 274 / 236 us vs 286 / 259 / 231 us for forward /
+// input gradient / weight-gradient partials) — the prefetch distance is not what those shapes wait for; 3 everywhere.
+template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM, int SCHED = 1, int STAGES = 3>
 __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   constexpr int RW = 32 * T32 + 16 * T16;           // rows per wave
   constexpr int PR = RW * WM;                       // panel rows
@@ -318,23 +320,29 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   };
 
   // ---- pipeline --------------------------------------------------------------------------------------------------
+  // (my own DMA: leave `tiles` k-tiles in flight, wait for everything older)
+  auto wait_dma = [&](int tiles) {
+    if (!loader) return;
+    if constexpr (STAGES == 4) { if (tiles >= 2) { wait_vm<2 * G>(); return; } }
+    if (tiles >= 1) wait_vm<G>(); else wait_vm<0>();
+  };
   Frags f0, f1;
   if (ntiles > 0) {
-    issue(0, 0);
-    if (ntiles > 1) { issue(1, 1); if (loader) wait_vm<G>(); } else { wait_vm<0>(); }
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i)
+      if (i < ntiles) issue(i, i);
+    wait_dma(min(STAGES - 2, ntiles - 1));           // tile 0 has landed
     __builtin_amdgcn_s_barrier();
-    if (ntiles > 2) issue(2, 2);
+    if (STAGES - 1 < ntiles) issue(STAGES - 1, STAGES - 1);
     read_frags(f0, 0);
   }
   // iteration t: fragments of tile t are in registers (or on their way: the compiler waits at first use);
-  // DMA in flight: tiles t+1, t+2.
+  // DMA in flight: tiles t+1 .. t+STAGES-1.
   auto iteration = [&](int t, Frags& cur, Frags& nxt) {       // t + 1 < ntiles
-    if (loader) {                                              // my pieces of tile t+1 have landed
-      if (t + 2 < ntiles) wait_vm<G>(); else wait_vm<0>();
-    }
+    wait_dma(min(STAGES - 2, ntiles - 2 - t));                 // my pieces of tile t+1 have landed
     wait_lgkm0();                                              // my reads of tile t's stage are done
     __builtin_amdgcn_s_barrier();                              // -> tile t+1 complete for everybody, stage of tile t free
-    if (t + 3 < ntiles) issue(t + 3, t % STAGES);
+    if (t + STAGES < ntiles) issue(t + STAGES, t % STAGES);
     __builtin_amdgcn_sched_barrier(0);
     read_frags(nxt, (t + 1) % STAGES);
     mfmas(cur);
