@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int q = blockIdx.x, z = blockIdx.z;
+
   const int u0 = q * a.units_base + min(q, a.units_rem);
   const int nu = a.units_base + (q < a.units_rem ? 1 : 0);
   const int m0 = u0 * 16;
