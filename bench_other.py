@@ -147,8 +147,10 @@ def c5_task_and_graphs(num_graphs, seed=0, first_index=0):
     from tf_gnn_samples_amd.tasks import PPI_Task
     from tf_gnn_samples_amd.tasks.synthetic import make_varmisuse_shaped_graph
     task = PPI_Task(PPI_Task.default_params())
-    task._PPI_Task__num_edge_types = 23; task._PPI_Task__initial_node_feature_size = 128; task._PPI_Task__num_labels = 1
     graphs = [make_varmisuse_shaped_graph(seed, first_index + i) for i in range(num_graphs)]
+    g0 = graphs[0]
+    task.restore_from_metadata({'num_edge_types': len(g0.adjacency_lists), 'initial_node_feature_size': g0.node_features.shape[1],
+                                'num_labels': g0.node_labels.shape[1]})
     return task, graphs
 
 

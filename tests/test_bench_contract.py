@@ -39,8 +39,25 @@ def _check_line(d, full):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_c_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_a_bench.json")))
     _check_line(d, full=True)
+    r = d["roofline"]
+    # the line is quoted on the workload no cache can help; the upper bound on Infinity-Cache hits rides along
+    assert "giant_uniform" in r["workload"] and 0.0 < r["frac_hbm_proper_lower_bound"] <= r["frac"]
+    assert r["frac_of_measured_copy_ceiling"] <= 1.0
+    lo, hi = r["skewed_giant"]["frac_range"]
+    assert 0.0 < lo < hi <= 1.0
+    # every BASELINE config is in the driver-visible record, each with its gather kernel's rate
+    cfgs = d["other_configs"]["configs"]
+    assert {c["config"][:2] for c in cfgs} == {"C3", "C4", "C5"} and len(cfgs) == 4
+    for c in cfgs:
+        assert c["train_ms"] > 0 and c["fwd_ms"] > 0 and c["dominant_gather_kernel"]["algorithmic_GBps"] > 0
+    # per-rank statistics (one entry per rank)
+    for k in ("gpu_step_ms_min", "gpu_step_ms_median", "gpu_step_ms_max", "allreduce_ms_mean", "host_blocked_on_gpu_ms_per_step"):
+        assert len(d["per_rank"][k]) == d["world_size"]
+    assert d["step_edge_imbalance_max_over_mean"]["max"] >= 1.0 - 1e-9
+    c = d["cpu_baseline"]
+    assert "median of 5" in c["sample"] and "2 warm-ups" in c["sample"] and c["forward_only_value"] > c["value"]
 
 
 def test_bench_refuses_to_run_without_a_gpu_or_with_too_few():

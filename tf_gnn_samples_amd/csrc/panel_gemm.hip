@@ -41,6 +41,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
+#ifndef RELGNN_PANEL_STAGES
+#define RELGNN_PANEL_STAGES 4
+#endif
 constexpr int KIDX_MAX = 1024;          // k-major A with gathered k rows: the row ids of the K range live in LDS
 
 struct PanelArgs {
@@ -87,10 +90,10 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F
 // any multiple of 16 rows and the panels of a call can be equal to within one 16-row unit.
 // A_KM: A is given k-major (A[m][k] at A + k*lda + m: the X^T of a weight gradient); B_RM: B is given as [N, K] row-major
 // (k contiguous: the W of an input gradient).
-// STAGES: depth of the LDS ring = k-tiles of DMA in flight + 1 (3 or 4).  Measured on the typed C5 shapes (128-row panels, gathered
-// rows, ~1 us of matrix work per k-tile): 4 stages = 3 stages within noise (292 / 274 / 236 us vs 286 / 259 / 231 us for forward /
-// input gradient / weight-gradient partials) — the prefetch distance is not what those shapes wait for; 3 everywhere.
-template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM, int SCHED = 1, int STAGES = 3>
+// STAGES: depth of the LDS ring = k-tiles of DMA in flight + 1 (3 or 4; -DRELGNN_PANEL_STAGES).  4: the C2 step with the dense
+// GEMMs on this kernel 2.316 ms against 2.361 ms with 3 (library: 2.222); no difference on the typed C5 shapes (128-row panels,
+// gathered rows: 292 / 274 / 236 us vs 286 / 259 / 231 us for forward / input gradient / weight-gradient partials).
+template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM, int SCHED = 1, int STAGES = RELGNN_PANEL_STAGES>
 __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   constexpr int RW = 32 * T32 + 16 * T16;           // rows per wave
   constexpr int PR = RW * WM;                       // panel rows
