@@ -721,6 +721,40 @@ int relgnn_panel_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t l
                           int32_t batch, int64_t a_batch_stride, int64_t b_batch_stride, int64_t c_batch_stride,
                           int32_t split_k_rows, void* stream);
 
+/*
+ * relgnn_limb_gemm_f32 / relgnn_limb_split_f32 — the same Dense products (tf.layers.dense / tf.matmul of gnns/rgcn.py:96-98 and
+ * their input gradient) at fp32 accuracy on the bf16 matrix pipe: every fp32 operand is carried as THREE bf16 limbs
+ * (x = hi + mid + lo exactly: 3 x 8 significant bits) and a product keeps the six limb products of weight >= 2^-16, each
+ * exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the dropped ones are < 2^-23 of |x w| (csrc/limb_gemm.hip).
+ * gfx950 has no xf32 / TF32 form; its fp32-input MFMA runs at 1/16 of the bf16 rate.
+ *   limb format   "limb tiles": an [R, C] matrix (C % 16 == 0) as ceil(R / 32) x C / 16 tiles of 32 rows x 16 columns in
+ *                 row-major tile order; a tile = three 1 KiB blocks (hi, mid, lo); a block holds element (i, k) at bf16 index
+ *                 (k / 8) * 256 + i * 8 + k % 8 (the LDS image and MFMA operand layout: one DMA instruction per block); rows
+ *                 past R are zeros.  relgnn_limb_elements(R, C) = bf16 elements of the whole thing
+ *   split         X fp32 [rows, cols] (ldx) -> limb tiles of X (transpose == 0) or of X^T (transpose != 0)
+ *   gemm          C[m][n] = act(bias[n] + sum_k A[m][k] * B[n][k]): A = limb tiles of an [M, K] matrix, B = limb tiles of an
+ *                 [N, K] matrix, C fp32 [M, N] (ldc); bias nullable; zeros = 1 KiB of zero bytes in device memory
+ *                 (relgnn_panel_gemm_zeros_floats floats)
+ *   gemm_xf32     the same product with the LEFT operand given as plain fp32 [M, K] (lda) and split inside the kernel on its way
+ *                 into LDS — the form the path uses: activations / gradients stay fp32 in HBM (what their producers write and
+ *                 what the weight-gradient product reads), only the weights (a few hundred KB, split once per step) exist as limbs
+ * Requirements (RELGNN_EUNSUPPORTED otherwise): K % 16 == 0, N % 256 == 0, 16-byte aligned bases.
+ */
+int64_t relgnn_limb_elements(int64_t rows, int64_t cols);
+/* measurement switch, process-wide (0 = the shipped configuration; the bits select variants under test, see csrc/limb_gemm.hip) */
+void relgnn_limb_gemm_tuning(int32_t flags);
+int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, int32_t transpose, uint16_t* out, void* stream);
+int relgnn_limb_gemm_f32(int32_t act, const uint16_t* A, const uint16_t* B, const float* bias, const void* zeros, float* C,
+                         int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,
+                          float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* The Dense product as the path calls it, fp32 in / fp32 out: splits the weights B (RELGNN_GEMM_NN: [K, N] as tf.layers.dense
+ * stores its kernel; RELGNN_GEMM_NT: [N, K]) into limb_ws (>= relgnn_limb_elements(N, K) bf16 elements of device scratch, reusable
+ * by the next call on the same stream), then runs relgnn_limb_gemm_xf32: C = act(bias + A @ B) resp. A @ B^T. */
+int relgnn_limb_dense_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                          const void* zeros, uint16_t* limb_ws, int64_t limb_ws_elements, float* C, int64_t ldc, int32_t M,
+                          int32_t N, int32_t K, void* stream);
+
 /* ========================================================================== *
  * 11. Dynamic per-target convolution kernels  (gnns/rgdcn.py:126-160)
  * ========================================================================== */

@@ -84,6 +84,13 @@ _SIGNATURES = {
     "relgnn_panel_gemm_zeros_floats": (ctypes.c_int, []),
     "relgnn_panel_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr, _c_i32, _c_i64, _ptr, _ptr, _ptr,
                                              _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _c_i64, _c_i32, _ptr]),
+    "relgnn_limb_elements": (_c_i64, [_c_i64, _c_i64]),
+    "relgnn_limb_gemm_tuning": (None, [_c_i32]),
+    "relgnn_limb_split_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr, _ptr]),
+    "relgnn_limb_gemm_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
+    "relgnn_limb_gemm_xf32": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
+    "relgnn_limb_dense_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _c_i32,
+                                             _c_i32, _c_i32, _ptr]),
     "relgnn_blaslt_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32,
                                               _c_i64, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_gemm_tn_stream_workspace_bytes": (_c_i64, [_c_i32, _c_i32, _c_i64]),

@@ -1,0 +1,506 @@
+// fp32 products on the bf16 matrix pipe: every fp32 operand is carried as THREE bf16 limbs, x = x_hi + x_mid + x_lo EXACTLY
+// (3 x 8 significant bits = the 24 of an fp32 value; bf16 has fp32's exponent range), and a product is the six limb products
+// whose weight is >= 2^-16 of the leading one, each exact in fp32 (8 x 8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
+//
+//     x * w  ~=  x_hi w_hi + (x_hi w_mid + x_mid w_hi) + (x_hi w_lo + x_mid w_mid + x_lo w_hi)
+//
+// The three dropped products (mid*lo, lo*mid, lo*lo) are below 2^-23 of |x w| — less than the rounding of ONE fp32 accumulation
+// step — so the result is in the same error class as the exact-fp32 pipe (v_mfma_f32_32x32x2_f32): measured against float64 on
+// the C2 layer shapes in tests/test_gpu_limb_gemm.py and, end to end, in tests/test_gpu_parity_margin.py.  Why bother: gfx950
+// has no xf32 / TF32 form and its fp32-input MFMA runs at the vector rate, 1/16 of the bf16 rate (MI355X_MICROARCH.md); six
+// bf16 products per fp32 product leave a factor 16 / 6 = 2.7 on the matrix pipe.
+//
+// What it replaces: the node-side Dense products of gnns/rgcn.py:96-98 in the aggregate-first order, out = A [V, L*D] @ W, and
+// their input gradient dA = dOut @ W^T — C[m][n] = act(bias[n] + sum_k A[m][k] * B[n][k]), both operands k-contiguous.
+//
+// Limb format ("limb tiles"): an [R, C] matrix (C % 16 == 0) is stored as ceil(R / 32) x C / 16 tiles of 32 rows x 16 columns;
+// a tile is three 1 KiB blocks (hi, mid, lo), a block holds element (i, k) at bf16 index (k / 8) * 256 + i * 8 + k % 8 — which is
+// the LDS image AND the MFMA operand layout, so one DMA instruction moves one block as 1 KiB of consecutive bytes (eight full
+// cache lines; with plain row-major planes a block is 32 row segments of 32 bytes, every cache line is fetched into L1 four times
+// and the kernel runs at the vector-memory rate: 113 us instead of 60 for [36 k, 768] x [768, 256], profiles/r03_limb_gemm.jsonl).
+// Rows past R in the last tile row are zeros.  relgnn_limb_split_f32 writes the format from an fp32 matrix (optionally
+// transposed: the forward product wants W^T); producers that hold the values in registers can write it directly.
+//
+// Geometry and staging follow panel_gemm.hip: a workgroup (8 waves = 1 x 8) owns a panel of 32*T32 <= 160 rows x 256 columns
+// x full K; k-tile = 16; operands go global -> LDS by global_load_lds_dwordx4 into a 4-stage ring (counted vmcnt, raw s_barrier),
+// one loader wave per SIMD.  An LDS block is one limb block = one DMA instruction = one ds_read_b128 per lane: lane
+// (i = lane & 31, h = lane >> 5) owns row i, k = 8 h .. 8 h + 7, stored at 16 B * lane — conflict-free for the 16-lane groups of gfx950's ds_read_b128 (rows 0-3, 12-15, 20-27 of one k half hit 16
+// different bank quads).  The W limbs are the MFMA's A operand and the X limbs its B operand, so a lane ends up with four
+// consecutive output columns of one output row (one 16-byte store), as in panel_gemm.hip.
+#include "common.h"
+#include "lds_dma.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+using namespace relgnn;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BK = 16;
+constexpr int STAGES = 4;
+int g_limb_flags = 0;                  // relgnn_limb_gemm_tuning
+
+struct LimbArgs {
+  const uint16_t* A;                   // limb tiles of the [M, K] left operand (XF32: unused)
+  const float* Ax; int64_t lda;        // XF32: the left operand as fp32 [M, K], row-major
+  const uint16_t* B;                   // limb tiles of the [N, K] right operand
+  const float* bias; const uint16_t* zeros;
+  float* C; int64_t ldc;
+  int32_t M, N, K, act;
+  int32_t units_base, units_rem;       // panel q covers 32-row units [q*base + min(q, rem), +base + (q < rem))
+  int32_t panels, chunks;              // row panels x 256-column chunks = logical workgroups
+  int32_t flags;                       // tuning switches (relgnn_limb_gemm_tuning)
+};
+
+// ---- fp32 -> three bf16 limbs ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // two fp32 -> two bf16 (round to nearest even), packed
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// (x0, x1) -> the packed limbs; each subtraction is exact, so hi + mid + lo == x bit for bit
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m, uint4& l) {
+  split_pair(v[0], v[1], h.x, m.x, l.x);
+  split_pair(v[2], v[3], h.y, m.y, l.y);
+  split_pair(v[4], v[5], h.z, m.z, l.z);
+  split_pair(v[6], v[7], h.w, m.w, l.w);
+}
+
+// XF32 = false: both operands arrive as limb tiles (DMA for everything).
+// XF32 = true : the LEFT operand is plain fp32 [M, K] — what the producers of the path write (seg_reduce buckets, gradients) and
+//               what the weight-gradient product reads — and is split on its way into LDS: waves 0 .. T32-1 load it (thread = one
+//               row x 16 k = 64 B, two neighbouring threads one 128-byte line of a 32-k super-tile), split it in registers
+//               (v_cvt_pk_bf16_f32 + exact subtractions, ~6 VALU per element, every element once per workgroup) and write the
+//               limb blocks with ds_write_b128; the other waves issue the DMA of the W limb tiles.  No limb copy of the left
+//               operand ever exists in HBM (it would be 6 B per element written and read again; the split pass alone costs
+//               48 us for [36 k, 768], profiles/r03_limb_gemm.jsonl).
+// ABL (experiments only, results wrong when != 0): bit 0 no DMA after the prologue, bit 1 no fragment reads in the loop,
+// bit 2 no waits / barrier in the loop.
+template <int T32, bool XF32, int ABL = 0>
+__global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
+  constexpr int NC = 256;
+  constexpr int PA = 3 * T32, PB = 3 * (NC / 32), P = PA + PB;     // 1 KiB blocks per k-tile
+  constexpr int STAGE_BYTES = P * 1024;
+  // DMA: XF32: the W blocks only, by the last 4 (T32 <= 4) or 3 waves; else everything, by waves 0-3 (one per SIMD)
+  constexpr int LOADERS = XF32 ? (T32 <= 4 ? 4 : 3) : 4;
+  constexpr int FIRST_LOADER = XF32 ? 8 - LOADERS : 0;
+  constexpr int PD = XF32 ? PB : P;                                // blocks that arrive by DMA
+  constexpr int G = (PD + LOADERS - 1) / LOADERS;
+  static_assert(STAGES * STAGE_BYTES <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // chunk index fastest and one contiguous range of logical workgroups per XCD: the column chunks of a row panel (dA: three)
+  // run next to each other under one L2 and fetch the panel's left operand from HBM once
+  const int64_t lb = xcd_logical_block((int64_t)a.panels * a.chunks);
+  if (lb < 0) return;
+  const int q = (int)(lb / a.chunks), chunk = (int)(lb % a.chunks);
+  const int u0 = q * a.units_base + min(q, a.units_rem);
+  const int nu = a.units_base + (q < a.units_rem ? 1 : 0);
+  const int m0 = u0 * 32;
+  const int rows_here = min(nu * 32, a.M - m0);
+  const int n0 = chunk * NC;
+  const int ntiles = a.K / BK;
+
+  // ---- DMA sources ---------------------------------------------------------------------------------------------------
+  const bool loader = wave >= FIRST_LOADER && wave < FIRST_LOADER + LOADERS;
+  const uint16_t* src[G];
+  int step[G];
+  int piece[G];
+  constexpr int TILE = 3 * 512;                       // bf16 elements of one limb tile
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    // wave-uniform; past the end: a duplicate of the last block
+    const int lw = max(wave - FIRST_LOADER, 0);
+    const int c = (XF32 ? PA : 0) + min(lw + LOADERS * g, PD - 1);
+    piece[g] = c;
+    if (c < PA) {
+      const int tm = c / 3, pl = c % 3;
+      const bool ok = tm < nu;                        // a tile row of this panel (rows past M inside it are stored zeros)
+      src[g] = ok ? a.A + ((int64_t)(u0 + tm) * ntiles) * TILE + pl * 512 + 8 * lane : a.zeros + 8 * lane;
+      step[g] = ok ? TILE : 0;
+    } else {
+      const int cb = c - PA;
+      const int wn_ = cb / 3, pl = cb % 3;
+      src[g] = a.B + ((int64_t)(n0 / 32 + wn_) * ntiles) * TILE + pl * 512 + 8 * lane;
+      step[g] = TILE;
+    }
+  }
+  // (the next k-tile of my blocks [G0, G1): a k-tile's DMA may be issued in parts, in block order)
+  auto issue_part = [&](int stage, auto g0_c, auto g1_c) {
+    constexpr int G0 = decltype(g0_c)::value, G1 = decltype(g1_c)::value;
+    if (!loader) return;
+    unsigned char* dst = lds + stage * STAGE_BYTES;
+#pragma unroll
+    for (int g = G0; g < G1; ++g) {
+      dma16(src[g], dst + piece[g] * 1024);
+      src[g] += step[g];
+    }
+  };
+  auto issue = [&](int stage) { issue_part(stage, std::integral_constant<int, 0>{}, std::integral_constant<int, G>{}); };
+  auto wait_dma = [&](int tiles) {                   // leave `tiles` k-tiles of my own DMA in flight
+    if (!loader) return;
+    if (tiles >= 3) wait_vm<3 * G>();
+    else if (tiles == 2) wait_vm<2 * G>();
+    else if (tiles == 1) wait_vm<G>();
+    else wait_vm<0>();
+  };
+
+  // ---- XF32: the left operand's way into LDS -------------------------------------------------------------------------
+  // Thread (r = tid >> 1, hf = tid & 1) of waves 0 .. T32-1 owns row r of the panel, k-tile 2 S + hf of every 32-k super-tile S:
+  // 16 fp32 = 64 B per super-tile (4 x dwordx4), two limb chunks (k 0-7, k 8-15) per plane.  Super-tile S is loaded during
+  // k-tile 2S-4, its first chunks are split and stored at the top of k-tile 2S-2, the second ones at the top of k-tile 2S-1:
+  // after the barrier inside k-tile 2S-3 released the two stages, before the barrier inside k-tile 2S-1 publishes k-tile 2S.
+  const bool xwave = XF32 && wave < T32;
+  const int xr = tid >> 1, xhf = tid & 1;
+  const bool xrow_ok = xwave && xr < rows_here;
+  const float* xsrc = XF32 ? a.Ax + (int64_t)(m0 + (xrow_ok ? xr : 0)) * a.lda + 16 * xhf : nullptr;
+  const int xblock = (3 * (xr >> 5)) * 1024 + (xr & 31) * 16;      // byte offset of (tile row, row) inside a stage, chunk 0, plane hi
+  f32x4 xv[4];                                                     // the super-tile in flight
+  float xh[8];                                                     // second chunk of the super-tile being stored
+  auto x_load = [&](int S) {
+    const bool ok = xrow_ok && 2 * S + xhf < ntiles;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xv[j] = ok ? *reinterpret_cast<const f32x4*>(xsrc + 32 * S + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto x_store = [&](int S, int half, const float* v) {            // 8 values -> chunk `half` of k-tile 2 S + xhf
+    if (2 * S + xhf >= ntiles || xr >= 32 * nu) return;           // (a tile row the panel does not have is never multiplied)
+    uint4 h, m, l;
+    split8(v, h, m, l);
+    unsigned char* p = lds + ((2 * S + xhf) % STAGES) * STAGE_BYTES + xblock + half * 512;
+    *reinterpret_cast<uint4*>(p) = h;
+    *reinterpret_cast<uint4*>(p + 1024) = m;
+    *reinterpret_cast<uint4*>(p + 2048) = l;
+  };
+  auto x_first = [&](int S) {                                      // chunk 0 now, chunk 1 kept for the next k-tile
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = xv[0][j]; v[4 + j] = xv[1][j]; xh[j] = xv[2][j]; xh[4 + j] = xv[3][j]; }
+    x_store(S, 0, v);
+  };
+
+  // ---- fragments -----------------------------------------------------------------------------------------------------
+  struct Limbs { bf16x8 hi, mid, lo; };
+  auto read_x = [&](int stage, int tm) {
+    const unsigned char* p = lds + stage * STAGE_BYTES + (3 * tm) * 1024 + 16 * lane;
+    Limbs f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p);
+    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    return f;
+  };
+  auto read_w = [&](int stage) {
+    const unsigned char* p = lds + stage * STAGE_BYTES + (PA + 3 * wave) * 1024 + 16 * lane;
+    Limbs f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p);
+    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    return f;
+  };
+  f32x16 acc[T32];
+#pragma unroll
+  for (int tm = 0; tm < T32; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+  // small terms first: the three 2^-16 products, then the two 2^-8 ones, then the leading one
+  auto products = [&](f32x16 c, const Limbs& w, const Limbs& x) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, c, 0, 0, 0);
+    return c;
+  };
+
+  // ---- pipeline ------------------------------------------------------------------------------------------------------
+  // The W limbs of a k-tile stay in registers for the whole tile; the X limbs rotate through two register sets, row tile
+  // tm+1 read while tile tm is in the matrix pipe.  The synchronisation point sits in front of the LAST row tile of k-tile t:
+  // by then every read of stage t % 4 has been issued, so the barrier releases that stage, and the reads of k-tile t+1 (its W
+  // limbs, its first X tile) go out under the last row tile's six MFMAs.  The DMA of k-tile t+3 is issued during k-tile t, a few
+  // instructions in front of every row tile but the last (its stage, (t-1) % 4, was released inside k-tile t-1).
+  Limbs w_cur, w_nxt, xs[2];
+  constexpr int SLOTS = T32 > 1 ? T32 - 1 : 1;
+  constexpr int PER = (G + SLOTS - 1) / SLOTS;
+  constexpr int C1 = PER < G ? PER : G, C2 = 2 * PER < G ? 2 * PER : G, C3 = 3 * PER < G ? 3 * PER : G;
+  if (ntiles > 0) {
+#pragma unroll
+    for (int i = 0; i < STAGES; ++i)
+      if (i < ntiles) issue(i);
+    if constexpr (XF32) {
+      if (xwave) {
+        x_load(0);
+        x_first(0);
+        x_store(0, 1, xh);
+        x_load(1);
+      }
+    }
+    wait_dma(min(STAGES - 1, ntiles - 1));
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    w_cur = read_w(0);
+    xs[0] = read_x(0, 0);
+  }
+  // k-tile t; row tile tm lives in register set (tm + PAR) & 1 (PAR alternates from k-tile to k-tile when T32 is odd)
+  auto ktile = [&](int t, auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    const int stage = t % STAGES;
+    const bool more = t + 1 < ntiles;
+    const bool feed = !(ABL & 1) && t >= 1 && t + STAGES - 1 < ntiles;
+    const int fstage = (t + STAGES - 1) % STAGES;
+    // XF32: this k-tile's share of the split, at the top of the k-tile (the SIMD partner feeds the matrix pipe meanwhile; moving
+    // wave 4's share — it shares SIMD 0 with wave 0 — two row tiles down was measured: 83.3 vs 81.3 us, no gain).
+    auto x_work = [&]() {
+      const int S = (t >> 1) + 1;
+      if (2 * S < ntiles) {
+        if ((t & 1) == 0) {
+          x_first(S);
+          x_load(S + 1);
+        } else {
+          x_store(S, 1, xh);
+        }
+      }
+    };
+    if constexpr (XF32) {
+      if (xwave) x_work();
+    }
+#pragma unroll
+    for (int tm = 0; tm < T32; ++tm) {
+      Limbs& xc = xs[(tm + PAR) & 1];
+      Limbs& xn = xs[(tm + PAR + 1) & 1];
+      if (feed) {                                              // blocks [tm * PER, (tm + 1) * PER) of k-tile t + 3
+        if (tm == 0) issue_part(fstage, std::integral_constant<int, 0>{}, std::integral_constant<int, C1>{});
+        if (tm == 1 && SLOTS > 1) issue_part(fstage, std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{});
+        if (tm == 2 && SLOTS > 2) issue_part(fstage, std::integral_constant<int, C2>{}, std::integral_constant<int, C3>{});
+        if (tm == 3 && SLOTS > 3) issue_part(fstage, std::integral_constant<int, C3>{}, std::integral_constant<int, G>{});
+      }
+      if (tm == T32 - 1) {
+        if (more) {
+          if constexpr (!(ABL & 4)) {
+            // my blocks of k-tile t+1 have landed (issued so far: up to k-tile t+3)
+            if constexpr (!(ABL & 1)) wait_dma(min(STAGES - 2, ntiles - 2 - t));
+            wait_lgkm0();                                      // my reads of stage t % 4 and my limb stores are done
+            __builtin_amdgcn_s_barrier();                      // -> k-tile t+1 complete for everybody, stage t % 4 free
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!(ABL & 2)) {
+            w_nxt = read_w((t + 1) % STAGES);
+            xn = read_x((t + 1) % STAGES, 0);
+          } else { w_nxt = w_cur; xn = xc; }
+        }
+        acc[tm] = products(acc[tm], w_cur, xc);
+      } else {
+        if constexpr (!(ABL & 2)) xn = read_x(stage, tm + 1); else xn = xc;
+        acc[tm] = products(acc[tm], w_cur, xc);
+      }
+    }
+    w_cur = w_nxt;
+  };
+  if constexpr (T32 & 1) {
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+      ktile(t, std::integral_constant<int, 0>{});
+      ktile(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < ntiles) ktile(t, std::integral_constant<int, 0>{});
+  } else {
+    for (int t = 0; t < ntiles; ++t) ktile(t, std::integral_constant<int, 0>{});
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  // 32x32 tile: lane holds output row (lane & 31) x columns 8 c + 4 h + {0..3}, c = 0..3 (register r = 4 c + {0..3})
+  const int i32 = lane & 31, h32 = lane >> 5;
+  const int colw = n0 + wave * 32;
+  auto finish = [&](f32x4 v, int col) {
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+    if (a.act != RELGNN_ACT_LINEAR) {
+      v[0] = act_rt(a.act, v[0]); v[1] = act_rt(a.act, v[1]); v[2] = act_rt(a.act, v[2]); v[3] = act_rt(a.act, v[3]);
+    }
+    return v;
+  };
+#pragma unroll
+  for (int tm = 0; tm < T32; ++tm) {
+    const int r = tm * 32 + i32;
+    if (r < rows_here) {
+      float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = colw + 8 * c + 4 * h32;
+        const f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+        *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
+      }
+    }
+  }
+}
+
+// One workgroup = 32 rows x 64 columns of the OUTPUT matrix (4 waves; a wave: 8 rows x 8 groups of 8 k): every wave writes whole
+// 128-byte lines of the limb blocks (8 consecutive rows x 16 bytes) and, untransposed, reads 256 consecutive bytes per row.
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void limb_split_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols,
+                                                         uint16_t* __restrict__ out) {
+  // output matrix: [R, C] = X (or X^T)
+  const int R = TRANSPOSE ? cols : rows, C = TRANSPOSE ? rows : cols;
+  const int KT = C / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rb = blockIdx.y;
+  const int i = 8 * wave + (lane & 7);                // row inside the 32-row tile
+  const int g8 = blockIdx.x * 8 + (lane >> 3);        // group of 8 k
+  if (g8 * 8 >= C) return;
+  const int r = rb * 32 + i;
+  float v[8];
+  if (r < R) {
+    if constexpr (TRANSPOSE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = X[(int64_t)(8 * g8 + j) * ldx + r];
+    } else {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + 8 * g8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + 8 * g8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  uint4 h, m, l;
+  split8(v, h, m, l);
+  const int kt = g8 >> 1, hh = g8 & 1;
+  uint16_t* o = out + ((int64_t)rb * KT + kt) * 1536 + hh * 256 + i * 8;
+  *reinterpret_cast<uint4*>(o) = h;
+  *reinterpret_cast<uint4*>(o + 512) = m;
+  *reinterpret_cast<uint4*>(o + 1024) = l;
+}
+
+template <int T32, bool XF32, int ABL = 0>
+int launch_limb(const LimbArgs& a, hipStream_t st) {
+  const int64_t logical = (int64_t)a.panels * a.chunks;
+  limb_gemm_kernel<T32, XF32, ABL><<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, st>>>(a);
+  return launch_status();
+}
+
+template <bool XF32>
+int dispatch_limb(LimbArgs a, hipStream_t st) {
+  a.chunks = a.N / 256;
+  a.flags = g_limb_flags;
+  // panels: the fewest 32-row units per panel such that panels x chunks fills a whole number of rounds of the 256 CUs
+  const int units = (a.M + 31) / 32;
+  int want = 256 / a.chunks;
+  if (want < 1) want = 1;
+  int best_cap = 0, best_panels = 0;
+  double best_cost = 1e30;
+  for (int cap = 1; cap <= 5; ++cap) {
+    int rounds = (units + want * cap - 1) / (want * cap);
+    if (rounds < 1) rounds = 1;
+    int panels = rounds * want;
+    if (panels > units) panels = units;
+    if ((units + panels - 1) / panels > cap) continue;
+    const double cost = (double)((panels + want - 1) / want) * (cap + 0.35) + 1e-6 * panels;    // 0.35: prologue + epilogue
+    if (cost < best_cost) { best_cost = cost; best_cap = cap; best_panels = panels; }
+  }
+  if (!best_cap) return RELGNN_EUNSUPPORTED;
+  a.panels = best_panels; a.units_base = units / best_panels; a.units_rem = units % best_panels;
+#ifdef RELGNN_LIMB_ABLATE
+  if (best_cap == 5) {
+    const char* e = getenv("RELGNN_LIMB_ABLATE");
+    switch (e ? atoi(e) : 0) {
+      case 1: return launch_limb<5, XF32, 1>(a, st);
+      case 2: return launch_limb<5, XF32, 2>(a, st);
+      case 3: return launch_limb<5, XF32, 3>(a, st);
+      case 7: return launch_limb<5, XF32, 7>(a, st);
+      default: break;
+    }
+  }
+#endif
+  switch (best_cap) {
+    case 1: return launch_limb<1, XF32>(a, st);
+    case 2: return launch_limb<2, XF32>(a, st);
+    case 3: return launch_limb<3, XF32>(a, st);
+    case 4: return launch_limb<4, XF32>(a, st);
+    default: return launch_limb<5, XF32>(a, st);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void relgnn_limb_gemm_tuning(int32_t flags) { g_limb_flags = flags; }
+
+int64_t relgnn_limb_elements(int64_t rows, int64_t cols) { return ((rows + 31) / 32) * (cols / 16) * 1536; }
+
+int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, int32_t transpose, uint16_t* out, void* stream) {
+  if (rows < 0 || cols < 0 || ldx < cols) return RELGNN_EINVAL;
+  if (rows == 0 || cols == 0) return RELGNN_OK;
+  if (!X || !out) return RELGNN_EINVAL;
+  const int R = transpose ? cols : rows, C = transpose ? rows : cols;
+  if (C % 16 != 0 || !aligned16(out) || (!transpose && (!aligned16(X) || ldx % 4))) return RELGNN_EUNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 31) / 32));
+  if (transpose) limb_split_kernel<true><<<grid, 256, 0, st>>>(X, ldx, rows, cols, out);
+  else limb_split_kernel<false><<<grid, 256, 0, st>>>(X, ldx, rows, cols, out);
+  return launch_status();
+}
+
+static int limb_common_checks(int32_t act, const void* A, const void* B, const float* bias, const void* zeros, float* C,
+                              int64_t ldc, int32_t M, int32_t N, int32_t K) {
+  if (M < 0 || N < 0 || K < 0 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!A || !B || !C || !zeros) return RELGNN_EINVAL;
+  if (K == 0 || K % BK != 0 || N % 256 != 0) return RELGNN_EUNSUPPORTED;
+  if (!aligned16(A) || !aligned16(B) || !aligned16(C) || !aligned16(zeros) || (bias && !aligned16(bias)) || ldc % 4 || ldc < N)
+    return RELGNN_EUNSUPPORTED;
+  return -1;      // go on
+}
+
+int relgnn_limb_gemm_f32(int32_t act, const uint16_t* A, const uint16_t* B, const float* bias, const void* zeros, float* C,
+                         int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  const int rc = limb_common_checks(act, A, B, bias, zeros, C, ldc, M, N, K);
+  if (rc >= 0) return rc;
+  LimbArgs a{};
+  a.A = A; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.act = act;
+  return dispatch_limb<false>(a, as_stream(stream));
+}
+
+int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,
+                          float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  const int rc = limb_common_checks(act, A, B, bias, zeros, C, ldc, M, N, K);
+  if (rc >= 0) return rc;
+  if (lda % 4 || lda < K) return RELGNN_EUNSUPPORTED;
+  LimbArgs a{};
+  a.Ax = A; a.lda = lda; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M;
+  a.N = N; a.K = K; a.act = act;
+  return dispatch_limb<true>(a, as_stream(stream));
+}
+
+// The Dense product as the path calls it: fp32 activations x fp32 weights.  The weights (N x K elements, a few hundred KB) are
+// split into limb_ws first — one more ~3 us kernel on the same stream, no host round trip — then the product runs with the left
+// operand split in flight.  layout NN: B is [K, N] (tf.layers.dense kernels as stored); NT: B is [N, K] (the same kernel for the
+// input gradient).
+int relgnn_limb_dense_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                          const void* zeros, uint16_t* limb_ws, int64_t limb_ws_elements, float* C, int64_t ldc, int32_t M,
+                          int32_t N, int32_t K, void* stream) {
+  if (layout != RELGNN_GEMM_NN && layout != RELGNN_GEMM_NT) return RELGNN_EINVAL;
+  const int rc = limb_common_checks(act, A, B, bias, zeros, C, ldc, M, N, K);
+  if (rc >= 0) return rc;
+  if (!limb_ws || limb_ws_elements < relgnn_limb_elements(N, K)) return RELGNN_EINVAL;
+  if (lda % 4 || lda < K) return RELGNN_EUNSUPPORTED;
+  const int s = layout == RELGNN_GEMM_NN ? relgnn_limb_split_f32(B, ldb, K, N, 1, limb_ws, stream)
+                                         : relgnn_limb_split_f32(B, ldb, N, K, 0, limb_ws, stream);
+  if (s != RELGNN_OK) return s;
+  return relgnn_limb_gemm_xf32(act, A, lda, limb_ws, bias, zeros, C, ldc, M, N, K, stream);
+}
+
+}  // extern "C"

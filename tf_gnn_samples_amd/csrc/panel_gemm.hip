@@ -31,6 +31,7 @@
 // fragment reads one tile ahead of the matrix pipe; the waits are counted by hand (raw s_barrier: __syncthreads() would drain
 // the DMA queue).
 #include "common.h"
+#include "lds_dma.h"
 
 #include <stdlib.h>
 
@@ -41,9 +42,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
-#ifndef RELGNN_PANEL_STAGES
-#define RELGNN_PANEL_STAGES 4
-#endif
 constexpr int KIDX_MAX = 1024;          // k-major A with gathered k rows: the row ids of the K range live in LDS
 
 struct PanelArgs {
@@ -59,41 +57,19 @@ struct PanelArgs {
   int32_t units_base, units_rem;       // panel q covers 16-row units [q*base + min(q, rem), +base + (q < rem))
 };
 
-__device__ __forceinline__ float act_rt(int act, float x) {
-  switch (act) {
-    case RELGNN_ACT_TANH: return act_fwd<RELGNN_ACT_TANH>(x);
-    case RELGNN_ACT_RELU: return act_fwd<RELGNN_ACT_RELU>(x);
-    case RELGNN_ACT_LEAKY_RELU: return act_fwd<RELGNN_ACT_LEAKY_RELU>(x);
-    case RELGNN_ACT_ELU: return act_fwd<RELGNN_ACT_ELU>(x);
-    case RELGNN_ACT_SELU: return act_fwd<RELGNN_ACT_SELU>(x);
-    case RELGNN_ACT_GELU: return act_fwd<RELGNN_ACT_GELU>(x);
-    default: return x;
-  }
-}
-
-__device__ __forceinline__ void dma16(const float* src, float* lds_dst) {
-  __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
-                                       reinterpret_cast<uintptr_t>(src)),
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// lgkmcnt(0) through the builtin (gfx9 encoding: vmcnt 63 = bits [15:14|3:0], expcnt 7 = bits [6:4], lgkmcnt = bits [11:8]):
-// hipcc's own wait insertion does not see an inline-asm wait and would add a conservative lgkmcnt(0) in front of the MFMA
-// block — after the NEXT tile's fragment reads have been issued, which is exactly the overlap this loop exists for.
-__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
-
 // WM x WN waves.  Every wave owns RW = 32*T32 + 16*T16 output rows x 32 columns: T32 tiles of v_mfma_f32_32x32x2_f32 (the
 // shape that sustains ~137 TFLOP/s on this chip; 16x16x4 sustains 113: profiles/r02_c_mfma_rate.txt, r03 ablation) and, for
 // row counts that are an odd multiple of 16, one 16-row strip as two v_mfma_f32_16x16x4_f32 tiles — so that a panel can be
 // any multiple of 16 rows and the panels of a call can be equal to within one 16-row unit.
 // A_KM: A is given k-major (A[m][k] at A + k*lda + m: the X^T of a weight gradient); B_RM: B is given as [N, K] row-major
 // (k contiguous: the W of an input gradient).
-// STAGES: depth of the LDS ring = k-tiles of DMA in flight + 1 (3 or 4; -DRELGNN_PANEL_STAGES).  4: the C2 step with the dense
-// GEMMs on this kernel 2.316 ms against 2.361 ms with 3 (library: 2.222); no difference on the typed C5 shapes (128-row panels,
-// gathered rows: 292 / 274 / 236 us vs 286 / 259 / 231 us for forward / input gradient / weight-gradient partials).
-template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM, int SCHED = 1, int STAGES = RELGNN_PANEL_STAGES>
+// The LDS ring holds STAGES super-tiles of SUB k-tiles each; the workgroup synchronises (counted DMA wait, barrier, next DMA
+// batch) once per super-tile.  Measured (scripts/bench_panel_units.py, K = 768, every CU one panel of u 16-row units): the kernel
+// takes (0.41 us + 0.23 us x u) per k-tile, and that does NOT move with the ring: 4 x 1 = 3 x 2 (half the barriers) = 3 x 1 to
+// within 1 % at every u (u = 9: 117.2 / 117.9 / 119.0 us; library 108.6).  The matrix pipe alone, at the clock this chip holds
+// under fp32 MFMA load (136 TFLOP/s for 32x32x2, 113 for 16x16x4 in a register-only loop), needs 109 us for that shape.
+// Default: 4 x 1.
+template <int WM, int WN, int T32, int T16, bool A_KM, bool B_RM, int SCHED = 1, int SUB = 1, int STAGES = 4>
 __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   constexpr int RW = 32 * T32 + 16 * T16;           // rows per wave
   constexpr int PR = RW * WM;                       // panel rows
@@ -111,7 +87,8 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   static_assert(!A_KM || T16 == 0, "k-major A: 32-row tiles only (the column swizzle needs 32-column multiples)");
   static_assert(WM * WN == 8, "8 waves");
   // ONE shared object (a second one makes hipcc wait vmcnt(0) before every fragment read of a DMA pipeline)
-  __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE_FLOATS + (A_KM ? KIDX_MAX : 0)];
+  constexpr int NSLOT = STAGES * SUB;               // k-tile slots of the ring
+  __shared__ __attribute__((aligned(16))) float lds[NSLOT * STAGE_FLOATS + (A_KM ? KIDX_MAX : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,7 +116,7 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   const int ntiles = (kend - kbeg + BK - 1) / BK;
   // k-major A whose k rows are gathered (dW of a typed transform: A[m][k] = H[a_rows[k]][m]): the row ids of this K range
   const bool gather_k = A_KM && a.a_rows != nullptr;
-  int* kidx = reinterpret_cast<int*>(lds + STAGES * STAGE_FLOATS);
+  int* kidx = reinterpret_cast<int*>(lds + NSLOT * STAGE_FLOATS);
   if constexpr (A_KM) {
     if (gather_k) {
       // (independent batches: product z reduces over rows a_rows[z*K .. z*K + K); a K split: over a_rows[kbeg .. kend))
@@ -213,15 +190,15 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   auto issue = [&](int t, int stage) {
     if (!loader) return;
     float* dst = lds + stage * STAGE_FLOATS;
-    const int krem = kend - (kbeg + t * BK);         // >= 1; < 16 only for the K tail
-    const bool tail = krem < BK;                     // uniform: only the last tile of a K range that is not a multiple of 16
+    const int krem = kend - (kbeg + t * BK);         // < 16 only for the K tail; <= 0 for the tiles that pad the last super-tile
+    const bool tail = krem < BK;                     // uniform
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const float* s = src[g];
       if (tail && kk[g] >= krem) s = zsrc;
       if constexpr (A_KM) {
         if (gather_k && piece[g] < PA && step[g] != 0) {       // step 0 marks a lane that reads zeros throughout
-          const int row = kidx[t * BK + kk[g]];
+          const int row = kk[g] < krem ? kidx[t * BK + kk[g]] : -1;
           s = row >= 0 ? src[g] + (int64_t)row * a.lda : zsrc;
         } else {
           src[g] += step[g];
@@ -324,31 +301,40 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const PanelArgs a) {
   };
 
   // ---- pipeline --------------------------------------------------------------------------------------------------
-  // (my own DMA: leave `tiles` k-tiles in flight, wait for everything older)
-  auto wait_dma = [&](int tiles) {
+  // (my own DMA: leave `supers` super-tiles in flight, wait for everything older; every super-tile is SUB * G instructions —
+  //  the tiles that pad the last one read zeros)
+  auto wait_dma = [&](int supers) {
     if (!loader) return;
-    if constexpr (STAGES == 4) { if (tiles >= 2) { wait_vm<2 * G>(); return; } }
-    if (tiles >= 1) wait_vm<G>(); else wait_vm<0>();
+    if constexpr (STAGES == 4) { if (supers >= 2) { wait_vm<2 * SUB * G>(); return; } }
+    if (supers >= 1) wait_vm<SUB * G>(); else wait_vm<0>();
+  };
+  const int nsuper = (ntiles + SUB - 1) / SUB;
+  auto issue_super = [&](int S) {                    // super-tile S -> slots (S % STAGES) * SUB ..
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) issue(S * SUB + j, (S % STAGES) * SUB + j);
   };
   Frags f0, f1;
   if (ntiles > 0) {
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
-      if (i < ntiles) issue(i, i);
-    wait_dma(min(STAGES - 2, ntiles - 1));           // tile 0 has landed
+      if (i < nsuper) issue_super(i);
+    wait_dma(min(STAGES - 2, nsuper - 1));           // super-tile 0 has landed
     __builtin_amdgcn_s_barrier();
-    if (STAGES - 1 < ntiles) issue(STAGES - 1, STAGES - 1);
+    if (STAGES - 1 < nsuper) issue_super(STAGES - 1);
     read_frags(f0, 0);
   }
-  // iteration t: fragments of tile t are in registers (or on their way: the compiler waits at first use);
-  // DMA in flight: tiles t+1 .. t+STAGES-1.
+  // iteration t: fragments of tile t are in registers (or on their way: the compiler waits at first use).  Tile t+1 is in the
+  // same super-tile (already landed, no synchronisation) or the first of the next one (wait, barrier, issue the one after the ring).
   auto iteration = [&](int t, Frags& cur, Frags& nxt) {       // t + 1 < ntiles
-    wait_dma(min(STAGES - 2, ntiles - 2 - t));                 // my pieces of tile t+1 have landed
-    wait_lgkm0();                                              // my reads of tile t's stage are done
-    __builtin_amdgcn_s_barrier();                              // -> tile t+1 complete for everybody, stage of tile t free
-    if (t + STAGES < ntiles) issue(t + STAGES, t % STAGES);
+    if ((t + 1) % SUB == 0) {
+      const int S = (t + 1) / SUB;                             // the super-tile whose first tile is read below
+      wait_dma(min(STAGES - 2, nsuper - 1 - S));               // my pieces of super-tile S have landed
+      wait_lgkm0();                                            // my reads of super-tile S-1 are done
+      __builtin_amdgcn_s_barrier();                            // -> S complete for everybody, the slots of S-1 free
+      if (S - 1 + STAGES < nsuper) issue_super(S - 1 + STAGES);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(nxt, (t + 1) % STAGES);
+    read_frags(nxt, (t + 1) % NSLOT);
     mfmas(cur);
     // Issue order inside the tile: the matrix pipe starts at once (tile t's fragments are in registers) and the LDS reads of
     // tile t+1 go out one at a time BETWEEN MFMAs, in the issue slots the pipe leaves free.  Left alone hipcc sinks the reads

@@ -20,6 +20,14 @@ _CACHED_LIB_GEMM = os.environ.get("RELGNN_GEMM", "lib") != "torch"
 # RELGNN_GEMM=panel: forward / input-gradient products through the row-panel MFMA kernel (csrc/panel_gemm.hip) wherever its
 # shape constraints hold (N % 64 == 0, K % 4 == 0); the weight gradients keep their routes.
 _PANEL_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "panel"
+# RELGNN_GEMM=limb: forward / input-gradient products of tall operands (>= _LIMB_MIN_ROWS rows, N % 256 == 0, K % 16 == 0,
+# K <= _LIMB_MAX_K) through relgnn_limb_dense_f32 (csrc/limb_gemm.hip): every fp32 value as three bf16 limbs, six bf16 MFMA
+# products per fp32 product, fp32 accumulation.  Same error class as the exact-fp32 pipe for the reduction lengths of the path
+# (K <= 768: 4.0e-6 vs 5.3e-6 against float64 at [36 k, 768] x [768, 256]); the error grows faster with K than an fmaf chain's
+# (2.2x the fp32 product's at K = 1040 .. 4096), hence the K limit.
+_LIMB_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "limb"
+_LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
+_LIMB_WS = {}
 _STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 _WORKSPACE = {}
@@ -48,6 +56,9 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
              accumulate: bool = False, relu: bool = False) -> torch.Tensor:
     """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
     Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU)."""
+    if _LIMB_GEMM and layout != GEMM_TN and out is None and not accumulate and _limb_route_ok(layout, a, b, bias):
+        from . import _lib
+        return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
     if (_PANEL_GEMM and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
         from . import _lib
@@ -165,6 +176,102 @@ def panel_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
         sel_stride, _lib.ptr(bias), _lib.ptr(_zeros(a.device)), out.data_ptr(), ldc, M, N, K, batch, strides[0], strides[1],
         strides[2] if batch > 1 and strides[2] else (M * ldc if batch > 1 else 0), int(split_k_rows), _lib.current_stream()),
         "relgnn_panel_gemm_f32")
+    return out
+
+
+class Limbs:
+    """An fp32 [rows, cols] matrix as three bf16 limbs per element in the tiled layout of csrc/limb_gemm.hip (include/relgnn.h:
+    "limb tiles").  `data` is the flat bf16 buffer."""
+    __slots__ = ("data", "rows", "cols")
+
+    def __init__(self, data: torch.Tensor, rows: int, cols: int):
+        self.data, self.rows, self.cols = data, int(rows), int(cols)
+
+    def to_float64(self) -> torch.Tensor:
+        """hi + mid + lo as float64 [rows, cols] (tests)."""
+        RB, KT = (self.rows + 31) // 32, self.cols // 16
+        t = self.data.view(RB, KT, 3, 2, 32, 8).double().sum(2)              # [RB, KT, h, i, 8]
+        return t.permute(0, 3, 1, 2, 4).reshape(RB * 32, self.cols)[:self.rows]
+
+
+def limb_split(x: torch.Tensor, transpose: bool = False, out: "Limbs" = None) -> "Limbs":
+    """fp32 [R, C] -> the three bf16 limbs of x (or of x^T), x = hi + mid + lo exactly (relgnn_limb_split_f32)."""
+    from . import _lib
+    lib = _lib.load_library()
+    if not _rows_ok(x):
+        x = x.contiguous()
+    R, C = x.shape
+    rows, cols = (C, R) if transpose else (R, C)
+    if out is None:
+        out = Limbs(torch.empty(int(lib.relgnn_limb_elements(rows, cols)), dtype=torch.bfloat16, device=x.device), rows, cols)
+    elif (out.rows, out.cols) != (rows, cols):
+        raise ValueError("limb_split: out holds a [%d, %d] matrix, not [%d, %d]" % (out.rows, out.cols, rows, cols))
+    _lib.check(lib.relgnn_limb_split_f32(x.data_ptr(), x.stride(0), R, C, 1 if transpose else 0, out.data.data_ptr(),
+                                         _lib.current_stream()), "relgnn_limb_split_f32")
+    return out
+
+
+def limb_gemm_supported(M: int, N: int, K: int) -> bool:
+    return N % 256 == 0 and K % 16 == 0 and K > 0
+
+
+def limb_gemm(a: "Limbs", b: "Limbs", bias: torch.Tensor = None, act: int = 0, out: torch.Tensor = None) -> torch.Tensor:
+    """act(bias + A @ B^T) in fp32 from the limbs of A [M, K] and B [N, K] (relgnn_limb_gemm_f32): six bf16 MFMA products per
+    fp32 product, fp32 accumulation — fp32-class accuracy at up to 2.7x the fp32-input MFMA rate."""
+    from . import _lib
+    lib = _lib.load_library()
+    if a.cols != b.cols:
+        raise ValueError("limb_gemm: reduction lengths differ (%d, %d)" % (a.cols, b.cols))
+    M, N, K = a.rows, b.rows, a.cols
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.data.device)
+    _lib.check(lib.relgnn_limb_gemm_f32(act, a.data.data_ptr(), b.data.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.data.device)),
+                                        out.data_ptr(), out.stride(0), M, N, K, _lib.current_stream()), "relgnn_limb_gemm_f32")
+    return out
+
+
+def limb_gemm_xf32(a: torch.Tensor, b: "Limbs", bias: torch.Tensor = None, act: int = 0, out: torch.Tensor = None) -> torch.Tensor:
+    """act(bias + a @ B^T) with a fp32 [M, K] (dense rows) split inside the kernel and B [N, K] as limbs (relgnn_limb_gemm_xf32)."""
+    from . import _lib
+    lib = _lib.load_library()
+    if not _rows_ok(a):
+        a = a.contiguous()
+    M, K = a.shape
+    if K != b.cols:
+        raise ValueError("limb_gemm_xf32: reduction lengths differ (%d, %d)" % (K, b.cols))
+    if out is None:
+        out = torch.empty((M, b.rows), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_limb_gemm_xf32(act, a.data_ptr(), a.stride(0), b.data.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
+                                         out.data_ptr(), out.stride(0), M, b.rows, K, _lib.current_stream()), "relgnn_limb_gemm_xf32")
+    return out
+
+
+def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias) -> bool:
+    if not (_rows_ok(a) and _rows_ok(b)) or a.shape[0] < _LIMB_MIN_ROWS:
+        return False
+    K, N = (a.shape[1], b.shape[1]) if layout == GEMM_NN else (a.shape[1], b.shape[0])
+    if (b.shape[0] if layout == GEMM_NN else b.shape[1]) != K:
+        return False
+    return (N % 256 == 0 and K % 16 == 0 and 16 <= K <= _LIMB_MAX_K
+            and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0)))
+
+
+def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0) -> torch.Tensor:
+    """NN act(bias + a @ b) | NT a @ b^T through relgnn_limb_dense_f32: b (the weights) split into limbs in a per-(device, stream)
+    scratch buffer, a split inside the product kernel."""
+    from . import _lib
+    lib = _lib.load_library()
+    M, K = a.shape
+    N = b.shape[1] if layout == GEMM_NN else b.shape[0]
+    need = int(lib.relgnn_limb_elements(N, K))
+    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
+    ws = _LIMB_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _LIMB_WS[key] = torch.empty(max(need, 1 << 20), dtype=torch.bfloat16, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_limb_dense_f32(layout, act, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _lib.ptr(bias),
+                                         _lib.ptr(_zeros(a.device)), ws.data_ptr(), ws.numel(), out.data_ptr(), out.stride(0), M, N, K,
+                                         _lib.current_stream()), "relgnn_limb_dense_f32")
     return out
 
 
