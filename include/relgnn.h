@@ -748,6 +748,15 @@ int relgnn_limb_gemm_f32(int32_t act, const uint16_t* A, const uint16_t* B, cons
                          int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,
                           float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* Weight gradients dW = A^T @ G (A [V, J] = the saved layer input, G [V, C] = the output gradient; tf.gradients of the Dense
+ * products above) on the same limb arithmetic: both operands fp32 row-major, split AND transposed in flight (the reduction index is
+ * the row of both).  The kernel takes the first V - V % 32 rows, cut into relgnn_limb_gemm_tn_chunks(V, J, C) chunks; chunk z writes
+ * its partial product to P + z*J*C; the caller sums the slabs in chunk order and adds the product of the last V % 32 rows
+ * (relgnn_sum_slabs_tail_f32 does both in one pass: deterministic).
+ * Requirements (RELGNN_EUNSUPPORTED otherwise): V >= 32, J % 32 == 0, C % 256 == 0, 16-byte aligned rows. */
+int64_t relgnn_limb_gemm_tn_chunks(int32_t V, int32_t J, int32_t C);
+int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* P, int32_t V, int32_t J, int32_t C,
+                            void* stream);
 /* The Dense product as the path calls it, fp32 in / fp32 out: splits the weights B (RELGNN_GEMM_NN: [K, N] as tf.layers.dense
  * stores its kernel; RELGNN_GEMM_NT: [N, K]) into limb_ws (>= relgnn_limb_elements(N, K) bf16 elements of device scratch, reusable
  * by the next call on the same stream), then runs relgnn_limb_gemm_xf32: C = act(bias + A @ B) resp. A @ B^T. */

@@ -54,3 +54,15 @@ for name, M, N, K in shapes:
                       "lib_TFLOPs": round(fl / t_lib / 1e6, 1), "max_abs_out": round(float(truth.abs().max()), 3),
                       "err_limb_vs_f64": e_limb, "err_f32_vs_f64": e_f32,
                       "max_abs_limb_minus_f32": float((out - ref32).abs().max())}), flush=True)
+
+for name, V, J, C in [("dW   A[V,768]^T @ G[V,256]", 36096, 768, 256), ("dW   V=40111", 40111, 768, 256), ("dW   [V,256]^T @ [V,256]", 36096, 256, 256)]:
+    a = torch.rand((V, J), device=dev, generator=gen) * 2 - 1
+    g = (torch.rand((V, C), device=dev, generator=gen) * 2 - 1) * 0.05
+    out = DN.limb_gemm_tn(a, g)
+    ref = DN.matmul_tn_splitk(a, g)
+    truth = a.double().t() @ g.double()
+    t_limb = timed(lambda: DN.limb_gemm_tn(a, g))
+    t_lib = timed(lambda: DN.matmul_tn_splitk(a, g))
+    print(json.dumps({"shape": name, "V": V, "J": J, "C": C, "limb_tn_us": round(t_limb, 1), "f32_route_us": round(t_lib, 1),
+                      "max_abs_out": round(float(truth.abs().max()), 3), "err_limb_vs_f64": float((out.double() - truth).abs().max()),
+                      "err_f32_vs_f64": float((ref.double() - truth).abs().max())}), flush=True)

@@ -126,3 +126,22 @@ def test_limb_dense_is_the_product_of_the_path(gpu_device, layout):
         truth = a.double() @ W.double().t()
     assert torch.equal(out, want)
     assert float((out.double() - truth).abs().max()) <= 6e-6
+
+
+@pytest.mark.parametrize("V", [32, 33, 95, 257, 4099, 36096])
+@pytest.mark.parametrize("J,C", [(768, 256), (256, 256), (32, 256), (64, 512), (96, 256)])
+def test_limb_gemm_tn_matches_float64(gpu_device, V, J, C):
+    """dW = A^T @ G with both operands split and transposed in flight; every panel geometry (T32 = 4, 2, 1), ragged chunks."""
+    from tf_gnn_samples_amd import dense as DN
+    if V > 5000 and (J, C) not in ((768, 256), (256, 256)):
+        pytest.skip("two large shapes are enough")
+    big = torch.full((V, J + 8), float("nan"), device=gpu_device)
+    a = big[:, 4:4 + J]
+    a.copy_(_rand((V, J), gpu_device, V + J))
+    g = _rand((V, C), gpu_device, V + C + 5, 0.05)
+    out = DN.limb_gemm_tn(a, g)
+    truth = a.double().t() @ g.double()
+    f32 = a.contiguous().t() @ g
+    e_limb = float((out.double() - truth).abs().max())
+    e_f32 = float((f32.double() - truth).abs().max())
+    assert e_limb <= max(3.0 * e_f32, 8e-7 * max(1.0, float(truth.abs().max()))), (e_limb, e_f32)

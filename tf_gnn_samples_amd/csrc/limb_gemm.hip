@@ -57,10 +57,10 @@ struct LimbArgs {
 };
 
 // ---- fp32 -> three bf16 limbs ----------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // two fp32 -> two bf16 (round to nearest even), packed
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));      // v_cvt_pk_bf16_f32
 }
 // (x0, x1) -> the packed limbs; each subtraction is exact, so hi + mid + lo == x bit for bit
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
@@ -345,6 +345,210 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
   }
 }
 
+// ---- weight gradients: P[z] = A[rows of chunk z]^T @ G[rows of chunk z] ------------------------------------------------------
+// dW = A^T G for A [V, J], G [V, 256 c] (both fp32 row-major: the reduction index is the ROW of both).  Same matrix-pipe core,
+// same LDS blocks, but both operands are split in flight and TRANSPOSED on the way: a thread loads a 4-column x 8-row patch
+// (8 x dwordx4, a wave covers whole 1 KiB rows of G / 512-byte row pieces of A), and the 8 values of one column — 8 consecutive
+// reduction indices — are exactly one 16-byte limb chunk.  No DMA, no limb copy of anything in HBM.  A workgroup owns 32*T32
+// output rows (j) x 256 columns (c) x one chunk of the reduction; the chunks' partial products are summed afterwards in chunk
+// order (relgnn_sum_slabs_tail_f32: deterministic, like the fp32 split-K route it replaces).
+struct LimbTnArgs {
+  const float* A; int64_t lda;         // [V, J]
+  const float* G; int64_t ldg;         // [V, C]
+  float* P;                            // [Z][J][C] partial products
+  int32_t V, J, C;
+  int32_t rows_per_chunk;              // % 32 == 0
+  int32_t panels, chunks, Z;
+};
+
+template <int T32>
+__global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
+  constexpr int NC = 256, PR = 32 * T32;
+  constexpr int PA = 3 * T32, PB = 3 * (NC / 32), P = PA + PB;
+  constexpr int STAGE_BYTES = P * 1024;
+  constexpr int XG = PR / 4;                          // 4-column groups of the panel's rows
+  constexpr int ITEMS = 256 + 4 * XG;                 // per 32-row super-tile: G: 64 groups x 4 row octets, A: XG x 4
+  static_assert(ITEMS <= 512 && STAGES * STAGE_BYTES <= 160 * 1024, "geometry");
+  // (+ 3 KiB that nobody reads: where the limb stores of idle threads and of k-tiles past the end go — the split code has no
+  //  branches, so that it sits in one basic block with the MFMAs of its k-tile and the scheduler can interleave the two)
+  constexpr int DUMP = STAGES * STAGE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE_BYTES + 3072];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per_z = a.panels * a.chunks;
+  const int64_t lb = xcd_logical_block((int64_t)per_z * a.Z);
+  if (lb < 0) return;
+  const int z = (int)(lb / per_z), pc = (int)(lb % per_z);
+  const int q = pc / a.chunks, chunk = pc % a.chunks;
+  const int j0 = q * PR, n0 = chunk * NC;
+  const int r_beg = z * a.rows_per_chunk;
+  const int r_end = min(a.V, r_beg + a.rows_per_chunk);
+  const int ntiles = (r_end - r_beg) / BK;                         // even and > 0: whole 32-row super-tiles only
+
+  // ---- my patch: 4 columns x 8 reduction rows of every super-tile ---------------------------------------------------
+  const bool is_g = tid < 256;
+  const bool active = tid < ITEMS;
+  const int idx = is_g ? tid : (active ? tid - 256 : 0);           // (idle threads shadow item 0 of A: loads in bounds, stores dumped)
+  const int grp = is_g ? (idx & 63) : (idx % XG);                  // column group
+  const int oct = is_g ? (idx >> 6) : (idx / XG);                  // row octet inside the super-tile: k-tile oct / 2, chunk oct % 2
+  const int col = 4 * grp;                                         // first of my 4 columns inside the tile rows of the operand
+  const float* base = is_g ? a.G + n0 + col : a.A + j0 + col;
+  const int64_t ld = is_g ? a.ldg : a.lda;
+  // LDS blocks of THIS kernel keep row i of a tile at slot i ^ ((i >> 3) & 3) (16 B each): the fragment reads stay conflict-free
+  // (the XOR permutes inside aligned groups of four slots) and the limb stores — 8 lanes = 8 column groups = rows 4 a + c — hit
+  // 8 different bank quads instead of two (4-way conflicts: 114 -> 9x us at [36 k, 768]^T x [36 k, 256])
+  const int blk = ((is_g ? PA : 0) + 3 * (col >> 5)) * 1024 + (oct & 1) * 512 + (col & 31) * 16;
+  const int cswz = ((col & 31) >> 3) & 3;                          // column c of my patch goes to slot (col & 31) + (c ^ cswz)
+  const int dump = DUMP + lane * 16;
+  f32x4 pv[8];                                                      // the patch in flight: pv[m][c]
+  float ph[16];                                                     // columns 2, 3 of the patch being stored
+  const int nsuper = ntiles / 2;                                    // whole super-tiles only (the host hands over V - V % 32 rows)
+  auto p_load = [&](int S) {                                        // (past the end: some valid row; such a patch is never stored)
+    const int r0 = r_beg + 32 * S + 8 * oct;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) pv[m] = *reinterpret_cast<const f32x4*>(base + (int64_t)min(r0 + m, a.V - 1) * ld);
+  };
+  auto p_store = [&](int S, int c, const float* v) {                // 8 reduction values of column c -> one chunk per plane
+    uint4 h, m, l;
+    split8(v, h, m, l);
+    const int off = (active && S < nsuper) ? ((2 * S + (oct >> 1)) % STAGES) * STAGE_BYTES + blk + (c ^ cswz) * 16 : dump;
+    *reinterpret_cast<uint4*>(lds + off) = h;
+    *reinterpret_cast<uint4*>(lds + off + 1024) = m;
+    *reinterpret_cast<uint4*>(lds + off + 2048) = l;
+  };
+  // step 0 .. 3 of a super-tile's split: columns 0 (+ keep columns 2, 3 aside: the next load reuses pv), 1 | 2, 3
+  auto p_step = [&](int S, auto step_c) {
+    constexpr int STEP = decltype(step_c)::value;
+    float v[8];
+    if constexpr (STEP == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { v[m] = pv[m][0]; ph[m] = pv[m][2]; ph[8 + m] = pv[m][3]; }
+      p_store(S, 0, v);
+    } else if constexpr (STEP == 1) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = pv[m][1];
+      p_store(S, 1, v);
+    } else if constexpr (STEP == 2) {
+      p_store(S, 2, ph);
+    } else {
+      p_store(S, 3, ph + 8);
+    }
+  };
+
+  // ---- fragments / products (as in limb_gemm_kernel) ------------------------------------------------------------------
+  struct Limbs { bf16x8 hi, mid, lo; };
+  auto read_x = [&](int stage, int tm) {
+    const unsigned char* p = lds + stage * STAGE_BYTES + (3 * tm) * 1024 + 16 * (lane ^ ((lane >> 3) & 3));
+    Limbs f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p);
+    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    return f;
+  };
+  auto read_w = [&](int stage) {
+    const unsigned char* p = lds + stage * STAGE_BYTES + (PA + 3 * wave) * 1024 + 16 * (lane ^ ((lane >> 3) & 3));
+    Limbs f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p);
+    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    return f;
+  };
+  f32x16 acc[T32];
+#pragma unroll
+  for (int tm = 0; tm < T32; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+  auto products = [&](f32x16 c, const Limbs& w, const Limbs& x) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, c, 0, 0, 0);
+    return c;
+  };
+
+  // ---- pipeline: super-tile S is loaded during k-tile 2S-4, split and stored during k-tiles 2S-2 (columns 0, 1) and 2S-1
+  // (columns 2, 3) — after the barrier inside k-tile 2S-3 released its two stages, before the barrier inside k-tile 2S-1
+  // publishes k-tile 2S ---------------------------------------------------------------------------------------------------
+  // Super-tile S is loaded during k-tile 2S-4, split and stored during k-tiles 2S-2 (columns 0, 1) and 2S-1 (columns 2, 3): after
+  // the barrier inside k-tile 2S-3 released its two stages, before the barrier inside k-tile 2S-1 publishes k-tile 2S.
+  // Program order inside a k-tile: [reads of the next row tile, six MFMAs, one step of the split] per row tile in front of the
+  // barrier, with a scheduling fence behind each — the MFMAs go out first and the ~55 VALU instructions of the step run while
+  // they occupy the pipe.  (Split first, MFMAs after — what hipcc makes of it when left alone — puts both waves of a SIMD in
+  // their VALU phase at the same time, the barrier keeps them in step, and the pipe idles: 124 us instead of 100 at
+  // [36 k, 768]^T x [36 k, 256].)
+  Limbs w_cur, w_nxt, xs[2];
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  p_load(0);
+  p_step(0, I0{}); p_step(0, I1{}); p_step(0, I2{}); p_step(0, I3{});
+  p_load(1);
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+  w_cur = read_w(0);
+  xs[0] = read_x(0, 0);
+  auto ktile = [&](int t, auto odd_c) {
+    constexpr int ODD = decltype(odd_c)::value;
+    constexpr int PAR = (T32 & 1) ? ODD : 0;                   // row tile tm lives in register set (tm + PAR) & 1
+    constexpr int PRE = T32 - 1;                               // row tiles in front of the barrier
+    const int stage = t % STAGES;
+    const bool more = t + 1 < ntiles;
+    const int S = (t >> 1) + 1;
+    if constexpr (PRE == 0) {                                  // one row tile: nothing to hide the split under
+      if constexpr (ODD == 0) { p_step(S, I0{}); p_step(S, I1{}); p_load(S + 1); } else { p_step(S, I2{}); p_step(S, I3{}); }
+    }
+#pragma unroll
+    for (int tm = 0; tm < T32; ++tm) {
+      Limbs& xc = xs[(tm + PAR) & 1];
+      Limbs& xn = xs[(tm + PAR + 1) & 1];
+      if (tm == T32 - 1) {
+        if (more) {
+          wait_lgkm0();                                        // my reads of stage t % 4 and my limb stores are done
+          __builtin_amdgcn_s_barrier();                        // -> k-tile t+1 complete for everybody, stage t % 4 free
+          __builtin_amdgcn_sched_barrier(0);
+          w_nxt = read_w((t + 1) % STAGES);
+          xn = read_x((t + 1) % STAGES, 0);
+        }
+      } else {
+        xn = read_x(stage, tm + 1);
+      }
+      acc[tm] = products(acc[tm], w_cur, xc);
+      if constexpr (PRE >= 1) {
+        if (tm < PRE) {
+          constexpr int A_AT = 0, B_AT = PRE >= 2 ? 1 : 0, L_AT = PRE >= 3 ? 2 : PRE - 1;
+          if (tm == A_AT) { if constexpr (ODD == 0) p_step(S, I0{}); else p_step(S, I2{}); }
+          if (tm == B_AT) { if constexpr (ODD == 0) p_step(S, I1{}); else p_step(S, I3{}); }
+          if (tm == L_AT) { if constexpr (ODD == 0) p_load(S + 1); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    w_cur = w_nxt;
+  };
+  {
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+      ktile(t, I0{});
+      ktile(t + 1, I1{});
+    }
+  }
+
+  // ---- partial product of this chunk ------------------------------------------------------------------------------------
+  const int i32 = lane & 31, h32 = lane >> 5;
+  const int colw = n0 + wave * 32;
+  float* slab = a.P + (int64_t)z * a.J * a.C;
+#pragma unroll
+  for (int tm = 0; tm < T32; ++tm) {
+    float* crow = slab + (int64_t)(j0 + tm * 32 + i32) * a.C;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<f32x4*>(crow + colw + 8 * c + 4 * h32) =
+          f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+  }
+}
+
 // One workgroup = 32 rows x 64 columns of the OUTPUT matrix (4 waves; a wave: 8 rows x 8 groups of 8 k): every wave writes whole
 // 128-byte lines of the limb blocks (8 consecutive rows x 16 bytes) and, untransposed, reads 256 consecutive bytes per row.
 template <bool TRANSPOSE>
@@ -483,6 +687,55 @@ int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16
   a.Ax = A; a.lda = lda; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M;
   a.N = N; a.K = K; a.act = act;
   return dispatch_limb<true>(a, as_stream(stream));
+}
+
+// rows per chunk (% 32 == 0) and number of chunks for the V - V % 32 rows the kernel takes
+static void limb_tn_geometry(int32_t V, int32_t J, int32_t C, int* t32, int* rows, int* Z) {
+  const int units = J / 32;
+  *t32 = units % 4 == 0 ? 4 : (units % 2 == 0 ? 2 : 1);
+  const int per_z = (units / *t32) * (C / 256);
+  const int vmain = V - V % 32;
+  int z0 = 256 / per_z;
+  if (z0 < 1) z0 = 1;
+  const int max_z = (vmain + 255) / 256;               // a chunk is at least 256 rows
+  if (z0 > max_z) z0 = max_z;
+  if (z0 < 1) z0 = 1;
+  *rows = ((vmain + z0 - 1) / z0 + 31) / 32 * 32;
+  *Z = *rows > 0 ? (vmain + *rows - 1) / *rows : 0;
+}
+
+int64_t relgnn_limb_gemm_tn_chunks(int32_t V, int32_t J, int32_t C) {
+  if (V < 32 || J <= 0 || C <= 0 || J % 32 != 0 || C % 256 != 0) return 0;
+  int t32, rows, Z;
+  limb_tn_geometry(V, J, C, &t32, &rows, &Z);
+  return Z;
+}
+
+// P [chunks][J][C] = per-chunk partial products of A^T G over the first V - V % 32 rows (A [V, J], G [V, C], fp32 row-major;
+// J % 32 == 0, C % 256 == 0, V >= 32); chunks = relgnn_limb_gemm_tn_chunks(V, J, C).  The caller sums the slabs in order and adds
+// the last V % 32 rows' product: relgnn_sum_slabs_tail_f32 does both in one pass.
+int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* P, int32_t V, int32_t J, int32_t C,
+                            void* stream) {
+  if (V < 0 || J < 0 || C < 0) return RELGNN_EINVAL;
+  if (J == 0 || C == 0) return RELGNN_OK;
+  if (V < 32) return RELGNN_EUNSUPPORTED;
+  if (!A || !G || !P) return RELGNN_EINVAL;
+  if (J % 32 != 0 || C % 256 != 0 || lda % 4 || ldg % 4 || lda < J || ldg < C || !aligned16(A) || !aligned16(G) || !aligned16(P))
+    return RELGNN_EUNSUPPORTED;
+  LimbTnArgs a{};
+  a.A = A; a.lda = lda; a.G = G; a.ldg = ldg; a.P = P; a.V = V - V % 32; a.J = J; a.C = C;
+  int t32, rows, Z;
+  limb_tn_geometry(V, J, C, &t32, &rows, &Z);
+  a.panels = (J / 32) / t32; a.chunks = C / 256; a.rows_per_chunk = rows; a.Z = Z;
+  const int64_t logical = (int64_t)a.panels * a.chunks * a.Z;
+  const unsigned grid = (unsigned)(8 * ((logical + 7) / 8));
+  hipStream_t st = as_stream(stream);
+  switch (t32) {
+    case 4: limb_gemm_tn_kernel<4><<<grid, 512, 0, st>>>(a); break;
+    case 2: limb_gemm_tn_kernel<2><<<grid, 512, 0, st>>>(a); break;
+    default: limb_gemm_tn_kernel<1><<<grid, 512, 0, st>>>(a); break;
+  }
+  return launch_status();
 }
 
 // The Dense product as the path calls it: fp32 activations x fp32 weights.  The weights (N x K elements, a few hundred KB) are

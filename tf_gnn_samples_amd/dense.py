@@ -13,19 +13,25 @@ import os
 
 import torch
 
-# RELGNN_GEMM=torch: library GEMMs through torch.mm (a hipBLASLt solution lookup per call: ~70 us of host time for every
-# node count not seen before, i.e. for every batch of a shuffled epoch).  Default "lib": the same library through
-# relgnn_blaslt_gemm_f32 (csrc/blaslt_gemm.hip), which caches the solution per (layout, N, K, V / 4096).
-_CACHED_LIB_GEMM = os.environ.get("RELGNN_GEMM", "lib") != "torch"
-# RELGNN_GEMM=panel: forward / input-gradient products through the row-panel MFMA kernel (csrc/panel_gemm.hip) wherever its
-# shape constraints hold (N % 64 == 0, K % 4 == 0); the weight gradients keep their routes.
-_PANEL_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "panel"
-# RELGNN_GEMM=limb: forward / input-gradient products of tall operands (>= _LIMB_MIN_ROWS rows, N % 256 == 0, K % 16 == 0,
-# K <= _LIMB_MAX_K) through relgnn_limb_dense_f32 (csrc/limb_gemm.hip): every fp32 value as three bf16 limbs, six bf16 MFMA
-# products per fp32 product, fp32 accumulation.  Same error class as the exact-fp32 pipe for the reduction lengths of the path
-# (K <= 768: 4.0e-6 vs 5.3e-6 against float64 at [36 k, 768] x [768, 256]); the error grows faster with K than an fmaf chain's
-# (2.2x the fp32 product's at K = 1040 .. 4096), hence the K limit.
-_LIMB_GEMM = os.environ.get("RELGNN_GEMM", "lib") == "limb"
+# RELGNN_GEMM selects the route of the node-side Dense products (forward / input gradient / weight gradient):
+#   limb  (default) tall operands (>= _LIMB_MIN_ROWS rows; N % 256 == 0, K % 16 == 0, K <= _LIMB_MAX_K; weight gradients with
+#         J % 32 == 0, C % 256 == 0 and more than 256 x 256 outputs) through csrc/limb_gemm.hip: every fp32 value as three bf16
+#         limbs (exact), six bf16 MFMA products per fp32 product, fp32 accumulation.  Against float64 at [36 k, 768] x [768, 256]:
+#         4.0e-6 (exact-fp32 library GEMM: 5.3e-6); the C2 layer against the oracle: 3.8e-6 abs (library: 6.2e-6,
+#         profiles/r03_parity_margin*.json).  The error grows faster with K than an fmaf chain's (2.2x the fp32 product's at
+#         K = 1040 .. 4096), hence the K limit.  Everything else falls through to `lib`.
+#   lib   exact fp32 through relgnn_blaslt_gemm_f32 (hipBLASLt, solution cached per (layout, N, K, V / 4096)), small weight
+#         gradients through relgnn_gemm_tn_stream_f32
+#   panel forward / input-gradient products through the exact-fp32 row-panel MFMA kernel (csrc/panel_gemm.hip) wherever its shape
+#         constraints hold (N % 64 == 0, K % 4 == 0); the weight gradients keep their `lib` routes
+#   torch library GEMMs through torch.mm (a hipBLASLt solution lookup per call: ~70 us of host time for every node count not
+#         seen before, i.e. for every batch of a shuffled epoch)
+_GEMM_MODE = os.environ.get("RELGNN_GEMM", "limb")
+if _GEMM_MODE not in ("limb", "lib", "panel", "torch"):
+    raise ValueError("RELGNN_GEMM must be one of limb, lib, panel, torch (got %r)" % _GEMM_MODE)
+_CACHED_LIB_GEMM = _GEMM_MODE != "torch"
+_PANEL_GEMM = _GEMM_MODE == "panel"
+_LIMB_GEMM = _GEMM_MODE == "limb"
 _LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
 _LIMB_WS = {}
 _STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
@@ -275,6 +281,32 @@ def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
     return out
 
 
+def limb_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return (_rows_ok(a) and _rows_ok(b) and a.shape[0] == b.shape[0] and a.shape[0] >= _LIMB_MIN_ROWS and a.shape[1] % 32 == 0
+            and b.shape[1] % 256 == 0)
+
+
+def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T @ b for a [V, J], b [V, C] (weight gradient) through relgnn_limb_gemm_tn_f32 + the in-order slab sum."""
+    from . import _lib
+    lib = _lib.load_library()
+    V, J = a.shape
+    C = b.shape[1]
+    Z = int(lib.relgnn_limb_gemm_tn_chunks(V, J, C))
+    if Z <= 0:
+        raise ValueError("limb_gemm_tn: unsupported shape [%d, %d]^T @ [%d, %d]" % (V, J, V, C))
+    parts = torch.empty((Z, J, C), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_limb_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), parts.data_ptr(), V, J, C,
+                                           _lib.current_stream()), "relgnn_limb_gemm_tn_f32")
+    # the slabs in chunk order + the last V % 32 rows (exact fp32), one pass
+    R = V % 32
+    out = torch.empty((J, C), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_sum_slabs_tail_f32(_lib.ptr(parts), Z, J, C, a[V - R:].data_ptr() if R else None, a.stride(0),
+                                             b[V - R:].data_ptr() if R else None, b.stride(0), R, _lib.ptr(out),
+                                             _lib.current_stream()), "relgnn_sum_slabs_tail_f32")
+    return out
+
+
 def enable_gemm_autotuning(max_tuning_ms_per_solution: int = 30, tune: bool = True) -> bool:
     """PyTorch TunableOp: for every GEMM shape the step uses, time the candidate rocBLAS / hipBLASLt solutions once
     (at first use) and keep the fastest.  Measured on MI355X, config C2: 2.72 -> 2.39 ms per training step (the fp32
@@ -335,6 +367,8 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     # 33 vs 57, [128 x 128] 30 vs 56; the library wins for [768 x 256] (131 vs 223) and for V ~ 1e6 (scripts/exp_tn_stream.py)
     if _STREAM_TN and M * N <= 256 * 256 and 0 < V <= (1 << 18) and _lib_rows_ok(a) and _lib_rows_ok(b):
         return tn_stream_gemm(a, b)
+    if _LIMB_GEMM and limb_tn_supported(a, b):
+        return limb_gemm_tn(a, b)
     S = _split_count(V, M, N)
     if S <= 1:
         return lib_gemm(GEMM_TN, a, b)
