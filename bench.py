@@ -293,6 +293,28 @@ def roofline_section(device, iters, with_pmc):
     return roof
 
 
+def exact_fp32_leg(steps, warmup, timeout_s=180):
+    """The same timed loop in a child process with RELGNN_GEMM=lib: the node-side Dense products on the exact-fp32 matrix pipe
+    through the library (v_mfma_f32_32x32x2_f32, an fmaf chain bit for bit) instead of the default six-bf16-products-per-fp32-
+    product route (csrc/limb_gemm.hip).  Reported next to `value` so that the gain of the limb arithmetic is a driver-observable
+    number and anybody who rules the limb route out has the figure without it."""
+    env = dict(os.environ)
+    env["RELGNN_GEMM"] = "lib"
+    env.setdefault("LOCAL_RANK", "0")
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+                            "--no-roofline", "--no-extras", "--no-cpu-baseline"], cwd=str(ROOT), env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"what": "the same loop with RELGNN_GEMM=lib (exact-fp32 library GEMMs for every Dense product)",
+                "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "final_loss": d.get("final_loss")}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def other_configs_section(timeout_s=240):
     """BASELINE.json configs[2..4] (C3 GGNN/QM9 mean + max, C4 RGAT, C5 GNN-FiLM rank share) on this GPU through bench_other.py
     (a child process, like the roofline: its own allocator state, bounded by a timeout): step time, edges/s and the
@@ -595,6 +617,14 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
+        # fp32 values everywhere in HBM and in every result; how the tall node-side Dense products are evaluated:
+        "dense_products": {
+            "route": os.environ.get("RELGNN_GEMM", "limb"),
+            "limb": "each fp32 operand as three bf16 limbs (hi + mid + lo == x exactly), the six limb products of weight >= 2^-16 "
+                    "on v_mfma_f32_32x32x16_bf16 (each exact in fp32), fp32 accumulation; dropped terms < 2^-23 of a product. "
+                    "Measured against float64 at [36 k, 768] x [768, 256]: 4.0e-6 max abs (exact-fp32 library GEMM: 5.3e-6); "
+                    "C2 layer vs the fp32 oracle 3.8e-6 abs (library route 6.2e-6): profiles/r03_parity_margin_limb.json",
+            "lib": "exact fp32 (v_mfma_f32_32x32x2_f32 through hipBLASLt): timed in `exact_fp32_gemm_route` below"},
         "data": "synthetic",
         "config": {
             "workload": ("C2: RGCN on synthetic PPI-shaped batches (~%d graphs, ~%.2f M edges, ~%d k nodes each), 3 edge types "
@@ -689,6 +719,9 @@ def main():
             result["roofline"] = roofline_section(device, args.kernel_iters, not args.no_pmc)
         except Exception as e:
             result["roofline"] = {"error": repr(e)}
+    if (rank == 0 and world == 1 and not args.no_extras and args.config == "C2"
+            and os.environ.get("RELGNN_GEMM", "limb") == "limb"):
+        result["exact_fp32_gemm_route"] = exact_fp32_leg(args.steps, args.warmup)
     if rank == 0 and world == 1 and not args.no_extras:
         result["other_configs"] = other_configs_section()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C2":

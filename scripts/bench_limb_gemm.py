@@ -10,6 +10,25 @@ dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(0)
 
 
+def exact_lib_gemm(layout, a, b):
+    """the exact-fp32 library GEMM whatever RELGNN_GEMM says"""
+    keep = DN._LIMB_GEMM
+    DN._LIMB_GEMM = False
+    try:
+        return DN.lib_gemm(layout, a, b)
+    finally:
+        DN._LIMB_GEMM = keep
+
+
+def exact_tn(a, b):
+    keep = DN._LIMB_GEMM
+    DN._LIMB_GEMM = False
+    try:
+        return DN.matmul_tn_splitk(a, b)
+    finally:
+        DN._LIMB_GEMM = keep
+
+
 def timed(fn, reps=7, inner=10):
     for _ in range(20):
         fn()
@@ -35,7 +54,7 @@ for name, M, N, K in shapes:
     al, wl = DN.limb_split(a), DN.limb_split(w)
     assert torch.equal(al.to_float64(), a.double()), "limbs do not add up to the fp32 value"
     out = DN.limb_gemm(al, wl)
-    ref32 = DN.lib_gemm(DN.GEMM_NT, a, w)
+    ref32 = exact_lib_gemm(DN.GEMM_NT, a, w)
     rows = slice(0, 4096)
     truth = a[rows].double() @ w.double().t()
     e_limb = float((out[rows].double() - truth).abs().max())
@@ -45,7 +64,7 @@ for name, M, N, K in shapes:
     t_limb = timed(lambda: DN.limb_gemm(al, wl, out=out))
     t_xf32 = timed(lambda: DN.limb_gemm_xf32(a, wl, out=out))
     t_split = timed(lambda: DN.limb_split(a, out=al))
-    t_lib = timed(lambda: DN.lib_gemm(DN.GEMM_NT, a, w))
+    t_lib = timed(lambda: exact_lib_gemm(DN.GEMM_NT, a, w))
     t_panel = timed(lambda: DN.panel_gemm(DN.GEMM_NT, a, w))
     fl = 2.0 * M * N * K
     print(json.dumps({"shape": name, "M": M, "N": N, "K": K, "limb_xf32_us": round(t_xf32, 1), "limb_us": round(t_limb, 1), "split_a_us": round(t_split, 1),
@@ -59,10 +78,10 @@ for name, V, J, C in [("dW   A[V,768]^T @ G[V,256]", 36096, 768, 256), ("dW   V=
     a = torch.rand((V, J), device=dev, generator=gen) * 2 - 1
     g = (torch.rand((V, C), device=dev, generator=gen) * 2 - 1) * 0.05
     out = DN.limb_gemm_tn(a, g)
-    ref = DN.matmul_tn_splitk(a, g)
+    ref = exact_tn(a, g)
     truth = a.double().t() @ g.double()
     t_limb = timed(lambda: DN.limb_gemm_tn(a, g))
-    t_lib = timed(lambda: DN.matmul_tn_splitk(a, g))
+    t_lib = timed(lambda: exact_tn(a, g))
     print(json.dumps({"shape": name, "V": V, "J": J, "C": C, "limb_tn_us": round(t_limb, 1), "f32_route_us": round(t_lib, 1),
                       "max_abs_out": round(float(truth.abs().max()), 3), "err_limb_vs_f64": float((out.double() - truth).abs().max()),
                       "err_f32_vs_f64": float((ref.double() - truth).abs().max())}), flush=True)

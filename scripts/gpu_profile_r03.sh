@@ -6,7 +6,9 @@
 #  (4) kernel trace + stats of the roofline workload the line is quoted on (giant_uniform, cold protocol only): the average
 #      duration of seg_reduce_wave_kernel there must agree with roofline.avg_kernel_ms
 #  (5) kernel trace + stats of the C5 step (GNN-FiLM, VarMisuse-shaped) and of `bench.py --config C5`
-#  (6) matrix-pipe counters of the panel GEMM next to the library GEMM on the C2 layer shape
+#  (6) matrix-pipe counters of the panel GEMM and of the limb GEMM kernels next to the library GEMM on the C2 layer shapes
+#  (7) the limb GEMM against the exact-fp32 products per shape (time + error vs float64); the parity-margin test once more with
+#      RELGNN_GEMM=lib (the default run above is the limb route)
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -15,6 +17,10 @@ rm -rf $O; mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1; echo "gpu tests rc=$?" >> $O/gpu_tests.txt
 cp gpurun_out/parity_margin.json gpurun_out/parity_baseline_size.json $O/ 2>/dev/null
+RELGNN_GEMM=lib timeout 600 python -m pytest tests/test_gpu_parity_margin.py -q > $O/margin_lib_tests.txt 2>&1
+cp gpurun_out/parity_margin.json $O/parity_margin_exact_fp32_gemm.json 2>/dev/null
+cp $O/parity_margin.json gpurun_out/parity_margin.json 2>/dev/null
+timeout 600 python scripts/bench_limb_gemm.py > $O/limb_gemm.jsonl 2> $O/limb_gemm.err
 ( time timeout 900 python bench.py 2>$O/bench.err >$O/bench.json ) 2>&1 | tail -3
 timeout 300 python bench.py --config C5 --steps 10 --warmup 3 --no-roofline --no-extras --no-cpu-baseline > $O/bench_c5.json 2>> $O/bench.err
 cd /tmp
@@ -27,6 +33,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c5 
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
   d=$O/pmc_gemm_$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -o k -- python $R/scripts/bench_panel_gemm.py pmc > /dev/null 2>> $O/pmc.err
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d ${d}_limb -o k -- python $R/scripts/pmc_limb_target.py > /dev/null 2>> $O/pmc.err
 done
 cd $R
 for n in bench giant_uniform c5; do
@@ -50,8 +57,8 @@ agg = {}
 for f in glob.glob(O + "/pmc_gemm_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "panel_gemm" in k or k.startswith("Cijk"):
-            agg.setdefault((k[:70], row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+        if "panel_gemm" in k or "limb_gemm" in k or k.startswith("Cijk"):
+            agg.setdefault((k.replace("void (anonymous namespace)::", "")[:70], row["Counter_Name"]), []).append(float(row["Counter_Value"]))
 with open(O + "/gemm_pmc.txt", "w") as f:
     for (k, c), v in sorted(agg.items()):
         f.write("%-72s %-30s n=%3d mean %.4g\n" % (k, c, len(v), sum(v) / len(v)))

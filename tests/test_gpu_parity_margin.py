@@ -11,7 +11,11 @@ against (i) the float32 oracle in the reference's op order and (ii) the same fun
 oracle's own distance from the truth is recorded next to them: where the oracle itself is 3e-6 from the truth, 1e-5 against the
 oracle is a statement about two float32 roundings, not about the implementation.
 
-Everything is written to gpurun_out/parity_margin.json (committed as profiles/r03_parity_margin.json)."""
+The three orders run on whatever route RELGNN_GEMM selects for the Dense products (import-time switch of dense.py): the default
+limb route (six bf16 MFMA products per fp32 product, csrc/limb_gemm.hip) or, with RELGNN_GEMM=lib, the exact-fp32 library GEMM.
+
+Everything is written to gpurun_out/parity_margin.json (committed as profiles/r03_parity_margin.json for the default route and
+profiles/r03_parity_margin_exact_fp32_gemm.json for RELGNN_GEMM=lib)."""
 import json
 import os
 
@@ -143,4 +147,5 @@ def test_zz_write_margin_report():
                                                                                 e["abs_vs_f64_truth"]))
     if os.path.isdir("gpurun_out"):
         with open("gpurun_out/parity_margin.json", "w") as f:
-            json.dump({"tolerance_abs": PARITY_TOL, "default_variant": DEFAULT, "cases": _ROWS}, f, indent=1)
+            json.dump({"tolerance_abs": PARITY_TOL, "default_variant": DEFAULT, "dense_product_route": os.environ.get("RELGNN_GEMM", "limb"),
+                   "cases": _ROWS}, f, indent=1)
