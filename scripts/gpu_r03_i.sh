@@ -3,7 +3,7 @@
 # before that the tests and the per-shape benchmark of the shipped build
 mkdir -p gpurun_out/r03i
 timeout 600 python -m pytest tests/test_gpu_limb_gemm.py -x -q 2>&1 | tail -3
-timeout 600 python scripts/bench_limb_gemm.py 2>/dev/null | python -c "
+timeout 600 python scripts/bench_limb_gemm.py 2>/dev/null | tee gpurun_out/r03i/limb_gemm.jsonl | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
