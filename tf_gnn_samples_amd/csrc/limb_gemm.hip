@@ -229,7 +229,10 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
   // The W limbs of a k-tile stay in registers for the whole tile; the X limbs rotate through two register sets, row tile
   // tm+1 read while tile tm is in the matrix pipe.  (The six MFMAs of a row tile form a dependent chain on one accumulator;
   // taking the row tiles in pairs with the 2 x 6 MFMAs alternating between two accumulators was measured: no change, 75.3 us and
-  // 59.5 us for the MFMA-only loop either way — the chain is not what keeps the bf16 pipe at ~60 % busy.)  The synchronisation point sits in front of the LAST row tile of k-tile t:
+  // 59.5 us for the MFMA-only loop either way — the chain is not what keeps the bf16 pipe at ~60 % busy.  A copy of the loop per
+  // wave role with a straight-line steady-state form — no role tests, constant wait counts, W register sets alternating by the
+  // parity of t — was measured too: -12 % / -2 % / -1 % at 64 / 96 / 128-row panels, but 256 VGPRs and spills at 160 rows, the
+  // panel height of the C2 batches: +5 %.  Not kept.)  The synchronisation point sits in front of the LAST row tile of k-tile t:
   // by then every read of stage t % 4 has been issued, so the barrier releases that stage, and the reads of k-tile t+1 (its W
   // limbs, its first X tile) go out under the last row tile's six MFMAs.  The DMA of k-tile t+3 is issued during k-tile t, a few
   // instructions in front of every row tile but the last (its stage, (t-1) % 4, was released inside k-tile t-1).
