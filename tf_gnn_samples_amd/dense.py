@@ -262,7 +262,8 @@ def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias) -> bool:
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0)))
 
 
-def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0) -> torch.Tensor:
+def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0,
+               out: torch.Tensor = None) -> torch.Tensor:
     """NN act(bias + a @ b) | NT a @ b^T through relgnn_limb_dense_f32: b (the weights) split into limbs in a per-(device, stream)
     scratch buffer, a split inside the product kernel."""
     from . import _lib
@@ -274,11 +275,20 @@ def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
     ws = _LIMB_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = _LIMB_WS[key] = torch.empty(max(need, 1 << 20), dtype=torch.bfloat16, device=a.device)
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _lib.check(lib.relgnn_limb_dense_f32(layout, act, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _lib.ptr(bias),
                                          _lib.ptr(_zeros(a.device)), ws.data_ptr(), ws.numel(), out.data_ptr(), out.stride(0), M, N, K,
                                          _lib.current_stream()), "relgnn_limb_dense_f32")
     return out
+
+
+def mm_into(layout: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[:] = a @ b (GEMM_NN) | a @ b^T (GEMM_NT) into a preallocated row block: the limb route when the shapes allow
+    (RELGNN_GEMM=limb), else the library through torch.mm.  For the per-edge-type row blocks of an edge MLP (ops._BlockedLinear)."""
+    if _LIMB_GEMM and _limb_route_ok(layout, a, b, None) and _rows_ok(out):
+        return limb_dense(layout, a, b, out=out)
+    return torch.mm(a, b if layout == GEMM_NN else b.t(), out=out)
 
 
 def limb_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:

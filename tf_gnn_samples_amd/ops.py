@@ -450,19 +450,20 @@ class _BlockedLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, offsets, *weights):
+        from .dense import GEMM_NN, mm_into
         X = X.contiguous()
         Y = torch.empty((X.shape[0], weights[0].shape[1]), dtype=X.dtype, device=X.device)
         for l, W in enumerate(weights):
             a, b = offsets[l], offsets[l + 1]
             if b > a:
-                torch.mm(X[a:b], W, out=Y[a:b])
+                mm_into(GEMM_NN, X[a:b], W, Y[a:b])
         ctx.offsets = offsets
         ctx.save_for_backward(X, *weights)
         return Y
 
     @staticmethod
     def backward(ctx, gY):
-        from .dense import matmul_tn_splitk
+        from .dense import GEMM_NT, matmul_tn_splitk, mm_into
         X, *weights = ctx.saved_tensors
         offsets = ctx.offsets
         gY = gY.contiguous()
@@ -472,7 +473,7 @@ class _BlockedLinear(torch.autograd.Function):
             a, b = offsets[l], offsets[l + 1]
             if b > a:
                 if gX is not None:
-                    torch.mm(gY[a:b], W.t(), out=gX[a:b])
+                    mm_into(GEMM_NT, gY[a:b], W, gX[a:b])
                 gW.append(matmul_tn_splitk(X[a:b], gY[a:b]) if ctx.needs_input_grad[2 + l] else None)
             else:
                 gW.append(torch.zeros_like(W) if ctx.needs_input_grad[2 + l] else None)
