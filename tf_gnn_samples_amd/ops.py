@@ -747,6 +747,21 @@ def aggregate_acc64() -> bool:
     return os.environ.get("RELGNN_AGG_ACC", "f32") == "f64"
 
 
+# RELGNN_BWD_OVERLAP=1 (default): the weight gradient of the aggregate-first RGCN layer on a side stream next to the input gradient's
+# gather.  Measured on the C2 step, alternated twice in one process group: 2.006 / 2.014 ms without, 1.955 / 1.955 ms with (round 2
+# measured the opposite, 3.08 vs 2.94 ms, with the library's split-K GEMM in that place: it wanted the same CUs and the same L2 as the
+# gather; the limb kernel is one 147 KB-LDS workgroup per CU that leaves registers and the L2 path to the gather's waves).
+_BWD_OVERLAP = os.environ.get("RELGNN_BWD_OVERLAP", "1") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _AggregateThenTransform(torch.autograd.Function):
     """out = act(f_mode(sum_l A_l @ W_l)),  A_l[v] = sum_{p in (v,l)} w_p H[src_p]   (W: [L, Din, Dout]).
 
@@ -797,15 +812,30 @@ class _AggregateThenTransform(torch.autograd.Function):
                                                       _lib.current_stream()), "relgnn_act_bwd_from_output")
             gout = g
         gH = gW = None
+        # The weight gradient (matrix-pipe bound, one workgroup per CU, 147 KB of LDS, no L2 pressure) does not depend on the input
+        # gradient's gather (L2-latency bound, no LDS, few registers): it runs on a side stream next to it (fork / join by events,
+        # capturable in a hipGraph; the result is the same bits, the kernels are the same).
+        side = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[0] and _BWD_OVERLAP and gout.is_cuda:
+            side = _side_stream(gout.device)
+            cur = torch.cuda.current_stream(gout.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                f = _mode_factor(graph, mode)
+                gsc = gout if f is None else gout * f.unsqueeze(1)
+                gW = matmul_tn_splitk(agg, gsc).view(L, d_in, d_out)
+            for t in (agg, gout, gsc):
+                t.record_stream(side)
         if ctx.needs_input_grad[0]:
             plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
             gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
                                  plan.num_rows_x, acc64=aggregate_acc64()).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
             # (dH = sum_l dT_l @ W_l^T: the stacked [L*Dout, Din] right operand is W_l^T row blocks, 0.8 MB re-laid per step)
             gH = lib_gemm(GEMM_NN, gT, W.permute(0, 2, 1).reshape(L * d_out, d_in))
-        if ctx.needs_input_grad[1]:
-            # (running this GEMM on a second stream next to the L2-bound gather above was measured: 3.08 vs 2.94 ms per
-            # step — the two kernels contend for the same CUs instead of overlapping)
+        if side is not None:
+            torch.cuda.current_stream(gout.device).wait_stream(side)
+            gW.record_stream(torch.cuda.current_stream(gout.device))
+        elif ctx.needs_input_grad[1]:
             f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
             gsc = gout if f is None else gout * f.unsqueeze(1)
             gW = matmul_tn_splitk(agg, gsc).view(L, d_in, d_out)
