@@ -741,8 +741,6 @@ int relgnn_panel_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t l
  * Requirements (RELGNN_EUNSUPPORTED otherwise): K % 16 == 0, N % 256 == 0, 16-byte aligned bases.
  */
 int64_t relgnn_limb_elements(int64_t rows, int64_t cols);
-/* measurement switch, process-wide (0 = the shipped configuration; the bits select variants under test, see csrc/limb_gemm.hip) */
-void relgnn_limb_gemm_tuning(int32_t flags);
 int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, int32_t transpose, uint16_t* out, void* stream);
 int relgnn_limb_gemm_f32(int32_t act, const uint16_t* A, const uint16_t* B, const float* bias, const void* zeros, float* C,
                          int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);

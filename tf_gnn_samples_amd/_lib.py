@@ -85,7 +85,6 @@ _SIGNATURES = {
     "relgnn_panel_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr, _c_i32, _c_i64, _ptr, _ptr, _ptr,
                                              _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _c_i64, _c_i64, _c_i64, _c_i32, _ptr]),
     "relgnn_limb_elements": (_c_i64, [_c_i64, _c_i64]),
-    "relgnn_limb_gemm_tuning": (None, [_c_i32]),
     "relgnn_limb_split_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr, _ptr]),
     "relgnn_limb_gemm_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_limb_gemm_xf32": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),

@@ -42,7 +42,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BK = 16;
 constexpr int STAGES = 4;
-int g_limb_flags = 0;                  // relgnn_limb_gemm_tuning
 
 struct LimbArgs {
   const uint16_t* A;                   // limb tiles of the [M, K] left operand (XF32: unused)
@@ -53,7 +52,6 @@ struct LimbArgs {
   int32_t M, N, K, act;
   int32_t units_base, units_rem;       // panel q covers 32-row units [q*base + min(q, rem), +base + (q < rem))
   int32_t panels, chunks;              // row panels x 256-column chunks = logical workgroups
-  int32_t flags;                       // tuning switches (relgnn_limb_gemm_tuning)
 };
 
 // ---- fp32 -> three bf16 limbs ----------------------------------------------------------------------------------------
@@ -602,7 +600,6 @@ int launch_limb(const LimbArgs& a, hipStream_t st) {
 template <bool XF32>
 int dispatch_limb(LimbArgs a, hipStream_t st) {
   a.chunks = a.N / 256;
-  a.flags = g_limb_flags;
   // panels: the fewest 32-row units per panel such that panels x chunks fills a whole number of rounds of the 256 CUs
   const int units = (a.M + 31) / 32;
   int want = 256 / a.chunks;
@@ -644,8 +641,6 @@ int dispatch_limb(LimbArgs a, hipStream_t st) {
 }  // namespace
 
 extern "C" {
-
-void relgnn_limb_gemm_tuning(int32_t flags) { g_limb_flags = flags; }
 
 int64_t relgnn_limb_elements(int64_t rows, int64_t cols) { return ((rows + 31) / 32) * (cols / 16) * 1536; }
 

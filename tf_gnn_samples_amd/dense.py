@@ -217,10 +217,6 @@ def limb_split(x: torch.Tensor, transpose: bool = False, out: "Limbs" = None) ->
     return out
 
 
-def limb_gemm_supported(M: int, N: int, K: int) -> bool:
-    return N % 256 == 0 and K % 16 == 0 and K > 0
-
-
 def limb_gemm(a: "Limbs", b: "Limbs", bias: torch.Tensor = None, act: int = 0, out: torch.Tensor = None) -> torch.Tensor:
     """act(bias + A @ B^T) in fp32 from the limbs of A [M, K] and B [N, K] (relgnn_limb_gemm_f32): six bf16 MFMA products per
     fp32 product, fp32 accumulation — fp32-class accuracy at up to 2.7x the fp32-input MFMA rate."""
