@@ -747,11 +747,16 @@ def aggregate_acc64() -> bool:
     return os.environ.get("RELGNN_AGG_ACC", "f32") == "f64"
 
 
-# RELGNN_BWD_OVERLAP=1 (default): the weight gradient of the aggregate-first RGCN layer on a side stream next to the input gradient's
+# RELGNN_BWD_OVERLAP=1 (default on the limb route): the weight gradient of the aggregate-first RGCN layer on a side stream next to the input gradient's
 # gather.  Measured on the C2 step, alternated twice in one process group: 2.006 / 2.014 ms without, 1.955 / 1.955 ms with (round 2
 # measured the opposite, 3.08 vs 2.94 ms, with the library's split-K GEMM in that place: it wanted the same CUs and the same L2 as the
 # gather; the limb kernel is one 147 KB-LDS workgroup per CU that leaves registers and the L2 path to the gather's waves).
-_BWD_OVERLAP = os.environ.get("RELGNN_BWD_OVERLAP", "1") == "1"
+# With the exact-fp32 routes (RELGNN_GEMM=lib / panel) the default is off: 2.45 vs 2.22 ms.
+def _bwd_overlap_default() -> str:
+    return "1" if os.environ.get("RELGNN_GEMM", "limb") == "limb" else "0"
+
+
+_BWD_OVERLAP = os.environ.get("RELGNN_BWD_OVERLAP", _bwd_overlap_default()) == "1"
 _SIDE_STREAMS = {}
 
 
