@@ -42,6 +42,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BK = 16;
 constexpr int STAGES = 4;
+#ifdef RELGNN_LIMB_TIMING
+unsigned long long* g_limb_timing = nullptr;   // diagnostic build: per-wave cycle totals of the k-loop's segments
+#define TSTAMP(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define TSTAMP(v)
+#endif
 
 struct LimbArgs {
   const uint16_t* A;                   // limb tiles of the [M, K] left operand (XF32: unused)
@@ -52,6 +58,9 @@ struct LimbArgs {
   int32_t M, N, K, act;
   int32_t units_base, units_rem;       // panel q covers 32-row units [q*base + min(q, rem), +base + (q < rem))
   int32_t panels, chunks;              // row panels x 256-column chunks = logical workgroups
+#ifdef RELGNN_LIMB_TIMING
+  unsigned long long* timing;          // [workgroup][wave][8] cycle totals per loop segment (diagnostic build only)
+#endif
 };
 
 // ---- fp32 -> three bf16 limbs ----------------------------------------------------------------------------------------
@@ -168,15 +177,25 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
   const int xblock = (3 * (xr >> 5)) * 1024 + (xr & 31) * 16;      // byte offset of (tile row, row) inside a stage, chunk 0, plane hi
   f32x4 xv[4];                                                     // the super-tile in flight
   float xh[8];                                                     // second chunk of the super-tile being stored
+  // The loads are issued by EVERY wave, outside any branch, from an address that is always valid (a wave or row that has nothing to
+  // split reads the zero block, a super-tile past the end re-reads the last one; what must not count is zeroed in x_store).  Inside
+  // the `if (xwave)` region hipcc loaded into temporaries and copied them into the loop-carried registers at the region's end,
+  // behind an s_waitcnt vmcnt(0): every load was synchronous — the even k-tiles' split step took 1550-1750 ticks against 335 without
+  // its loads (s_memtime stamps, scripts/bench_limb_timing.py), and all eight waves waited for it at the barrier.
+  const float* xbase = xrow_ok ? xsrc : reinterpret_cast<const float*>(a.zeros);
+  const int xkmax = xrow_ok ? a.K - 16 - 16 * xhf : 0;
   auto x_load = [&](int S) {
-    const bool ok = xrow_ok && 2 * S + xhf < ntiles;
+    const float* p = xbase + min(32 * S, xkmax);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xv[j] = ok ? *reinterpret_cast<const f32x4*>(xsrc + 32 * S + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(p + 4 * j);
   };
   auto x_store = [&](int S, int half, const float* v) {            // 8 values -> chunk `half` of k-tile 2 S + xhf
     if (2 * S + xhf >= ntiles || xr >= 32 * nu) return;           // (a tile row the panel does not have is never multiplied)
+    float z[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = xrow_ok ? v[i] : 0.f;      // rows past M inside the panel
     uint4 h, m, l;
-    split8(v, h, m, l);
+    split8(z, h, m, l);
     unsigned char* p = lds + ((2 * S + xhf) % STAGES) * STAGE_BYTES + xblock + half * 512;
     *reinterpret_cast<uint4*>(p) = h;
     *reinterpret_cast<uint4*>(p + 1024) = m;
@@ -243,12 +262,12 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     for (int i = 0; i < STAGES; ++i)
       if (i < ntiles) issue(i);
     if constexpr (XF32) {
+      x_load(0);
       if (xwave) {
-        x_load(0);
         x_first(0);
         x_store(0, 1, xh);
-        x_load(1);
       }
+      x_load(1);
     }
     wait_dma(min(STAGES - 1, ntiles - 1));
     wait_lgkm0();
@@ -257,28 +276,35 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     xs[0] = read_x(0, 0);
   }
   // k-tile t; row tile tm lives in register set (tm + PAR) & 1 (PAR alternates from k-tile to k-tile when T32 is odd)
+#ifdef RELGNN_LIMB_TIMING
+  unsigned long long seg[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
   auto ktile = [&](int t, auto par_c) {
     constexpr int PAR = decltype(par_c)::value;
     const int stage = t % STAGES;
     const bool more = t + 1 < ntiles;
     const bool feed = !(ABL & 1) && t >= 1 && t + STAGES - 1 < ntiles;
+    TSTAMP(ts0);
     const int fstage = (t + STAGES - 1) % STAGES;
     // XF32: this k-tile's share of the split, at the top of the k-tile (the SIMD partner feeds the matrix pipe meanwhile; moving
     // wave 4's share — it shares SIMD 0 with wave 0 — two row tiles down was measured: 83.3 vs 81.3 us, no gain).
-    auto x_work = [&]() {
-      const int S = (t >> 1) + 1;
-      if (2 * S < ntiles) {
-        if ((t & 1) == 0) {
-          x_first(S);
-          x_load(S + 1);
-        } else {
-          x_store(S, 1, xh);
-        }
-      }
-    };
+    // XF32: this k-tile's step of the split, at the top of the k-tile (the SIMD partner feeds the matrix pipe meanwhile; wave 4
+    // shares SIMD 0 with wave 0 — moving its step two row tiles down only moves the imbalance: 83.0 / 75.1 us against 81.4 / 68.1 at
+    // 160 / 128-row panels).  The loads of the next super-tile follow for ALL waves, outside any branch.
     if constexpr (XF32) {
-      if (xwave) x_work();
+      const int S = (t >> 1) + 1;
+      if ((t & 1) == 0) {
+        if (xwave && 2 * S < ntiles) x_first(S);
+        x_load(S + 1);
+      } else {
+        if (xwave && 2 * S < ntiles) x_store(S, 1, xh);
+      }
     }
+#ifdef RELGNN_LIMB_TIMING
+    TSTAMP(ts1);
+    if (t & 1) seg[6] += ts1 - ts0; else seg[0] += ts1 - ts0;
+    unsigned long long tsb = ts1;
+#endif
 #pragma unroll
     for (int tm = 0; tm < T32; ++tm) {
       Limbs& xc = xs[(tm + PAR) & 1];
@@ -291,11 +317,18 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
       }
       if (tm == T32 - 1) {
         if (more) {
+          TSTAMP(ts2);
           if constexpr (!(ABL & 4)) {
             // my blocks of k-tile t+1 have landed (issued so far: up to k-tile t+3)
             if constexpr (!(ABL & 1)) wait_dma(min(STAGES - 2, ntiles - 2 - t));
+            TSTAMP(ts3);
             wait_lgkm0();                                      // my reads of stage t % 4 and my limb stores are done
+            TSTAMP(ts4);
             __builtin_amdgcn_s_barrier();                      // -> k-tile t+1 complete for everybody, stage t % 4 free
+            TSTAMP(ts5);
+#ifdef RELGNN_LIMB_TIMING
+            seg[1] += ts2 - tsb; seg[2] += ts3 - ts2; seg[3] += ts4 - ts3; seg[4] += ts5 - ts4; tsb = ts5;
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (!(ABL & 2)) {
@@ -304,6 +337,9 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
           } else { w_nxt = w_cur; xn = xc; }
         }
         acc[tm] = products(acc[tm], w_cur, xc);
+#ifdef RELGNN_LIMB_TIMING
+        { TSTAMP(ts6); seg[5] += ts6 - tsb; }
+#endif
       } else {
         if constexpr (!(ABL & 2)) xn = read_x(stage, tm + 1); else xn = xc;
         acc[tm] = products(acc[tm], w_cur, xc);
@@ -322,6 +358,13 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     for (int t = 0; t < ntiles; ++t) ktile(t, std::integral_constant<int, 0>{});
   }
 
+#ifdef RELGNN_LIMB_TIMING
+  if (a.timing && lane == 0 && lb < 64) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a.timing[(lb * 8 + wave) * 8 + i] = seg[i];
+    a.timing[(lb * 8 + wave) * 8 + 7] = ntiles;
+  }
+#endif
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // 32x32 tile: lane holds output row (lane & 31) x columns 8 c + 4 h + {0..3}, c = 0..3 (register r = 4 c + {0..3})
   const int i32 = lane & 31, h32 = lane >> 5;
@@ -600,6 +643,9 @@ int launch_limb(const LimbArgs& a, hipStream_t st) {
 template <bool XF32>
 int dispatch_limb(LimbArgs a, hipStream_t st) {
   a.chunks = a.N / 256;
+#ifdef RELGNN_LIMB_TIMING
+  a.timing = g_limb_timing;
+#endif
   // panels: the fewest 32-row units per panel such that panels x chunks fills a whole number of rounds of the 256 CUs
   const int units = (a.M + 31) / 32;
   int want = 256 / a.chunks;
@@ -641,6 +687,10 @@ int dispatch_limb(LimbArgs a, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+#ifdef RELGNN_LIMB_TIMING
+void relgnn_limb_timing_buffer(unsigned long long* p) { g_limb_timing = p; }
+#endif
 
 int64_t relgnn_limb_elements(int64_t rows, int64_t cols) { return ((rows + 31) / 32) * (cols / 16) * 1536; }
 
