@@ -141,3 +141,33 @@ def test_captured_train_step_matches_eager_steps(gpu_device, which):
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=5e-5, err_msg=n)
         assert float(np.mean(np.abs(b - a) > 1e-6)) < 0.01, n
     assert losses_e[-1] < losses_e[0]
+
+
+def test_backward_overlap_on_a_side_stream_gives_the_same_bits(gpu_device, monkeypatch):
+    """RELGNN_BWD_OVERLAP: the aggregate-first layer's weight gradient on a side stream next to the input gradient's gather is the
+    same kernels on the same operands — gradients must be bit-identical to the single-stream order, run after run, and the caching
+    allocator must not hand the side stream's buffers out early (many iterations, fresh tensors every time)."""
+    from tf_gnn_samples_amd import ops
+    from tf_gnn_samples_amd.graph import RelGraph
+    rng = np.random.default_rng(5)
+    V, L, D = 6000, 3, 256
+    adj = random_relational_graph(rng, V, L, [60000, 6000, 60000])
+    g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)
+    w = None                                   # unweighted sums (the normalisation weights only change the gather's operand)
+    H0 = torch.as_tensor(rng.standard_normal((V, D)).astype(np.float32), device=gpu_device)
+    W0 = torch.as_tensor((rng.standard_normal((L, D, D)) * 0.05).astype(np.float32), device=gpu_device)
+    gout = torch.as_tensor(rng.standard_normal((V, D)).astype(np.float32), device=gpu_device)
+
+    def grads(overlap):
+        monkeypatch.setattr(ops, "_BWD_OVERLAP", overlap)
+        H, W = H0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+        out = ops.aggregate_then_transform(H, W, g, w, "sum", "relu")
+        out.backward(gout)
+        return H.grad.clone(), W.grad.clone()
+
+    base = grads(False)
+    for _ in range(20):
+        got = grads(True)
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
+        junk = [torch.empty((V, D), device=gpu_device).normal_() for _ in range(3)]      # churn the allocator between iterations
+        del junk
