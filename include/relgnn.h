@@ -742,10 +742,27 @@ int relgnn_panel_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t l
  */
 int64_t relgnn_limb_elements(int64_t rows, int64_t cols);
 int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, int32_t transpose, uint16_t* out, void* stream);
+/* `batch` matrices at X + i * x_batch_stride -> limb tiles at out + i * relgnn_limb_elements(R, C) (one launch) */
+int relgnn_limb_split_batch_f32(const float* X, int64_t ldx, int64_t x_batch_stride, int32_t rows, int32_t cols, int32_t transpose,
+                                int32_t batch, uint16_t* out, void* stream);
 int relgnn_limb_gemm_f32(int32_t act, const uint16_t* A, const uint16_t* B, const float* bias, const void* zeros, float* C,
                          int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,
                           float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need
+ * (gnns/gnn_film.py:92-106; the limb counterpart of relgnn_panel_gemm_f32's a_rows / b_select for the forward product and the input
+ * gradient; K = 128 there):
+ *   a_rows (nullable)   output row r reads A[a_rows[r], :] (a_rows[r] < 0: a row of zeros)
+ *   B, num_b, b_batch_stride, b_select (nullable), rows_per_select
+ *                       num_b weight matrices at B + i * b_batch_stride floats (RELGNN_GEMM_NN: [K, N] each, RELGNN_GEMM_NT: [N, K]
+ *                       each); rows [p * rows_per_select, (p+1) * rows_per_select) of the output use matrix b_select[p]
+ *                       (rows_per_select % 128 == 0); without b_select num_b must be 1
+ *   limb_ws             >= num_b * relgnn_limb_elements(N, K) bf16 elements of device scratch (all matrices are split first)
+ * Requirements (RELGNN_EUNSUPPORTED otherwise): N % 128 == 0, K % 16 == 0, 16-byte aligned rows. */
+int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const float* B,
+                              int64_t ldb, int32_t num_b, int64_t b_batch_stride, const int32_t* b_select, int32_t rows_per_select,
+                              const float* bias, const void* zeros, uint16_t* limb_ws, int64_t limb_ws_elements, float* C,
+                              int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 /* Weight gradients dW = A^T @ G (A [V, J] = the saved layer input, G [V, C] = the output gradient; tf.gradients of the Dense
  * products above) on the same limb arithmetic: both operands fp32 row-major, split AND transposed in flight (the reduction index is
  * the row of both).  The kernel takes the first V - V % 32 rows, cut into relgnn_limb_gemm_tn_chunks(V, J, C) chunks; chunk z writes

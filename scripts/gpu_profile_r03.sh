@@ -21,6 +21,7 @@ RELGNN_GEMM=lib timeout 600 python -m pytest tests/test_gpu_parity_margin.py -q 
 cp gpurun_out/parity_margin.json $O/parity_margin_exact_fp32_gemm.json 2>/dev/null
 cp $O/parity_margin.json gpurun_out/parity_margin.json 2>/dev/null
 timeout 600 python scripts/bench_limb_gemm.py > $O/limb_gemm.jsonl 2> $O/limb_gemm.err
+timeout 600 python scripts/bench_limb_typed.py > $O/limb_typed.jsonl 2>> $O/limb_gemm.err
 ( time timeout 900 python bench.py 2>$O/bench.err >$O/bench.json ) 2>&1 | tail -3
 timeout 300 python bench.py --config C5 --steps 10 --warmup 3 --no-roofline --no-extras --no-cpu-baseline > $O/bench_c5.json 2>> $O/bench.err
 cd /tmp

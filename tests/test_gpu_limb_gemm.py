@@ -145,3 +145,55 @@ def test_limb_gemm_tn_matches_float64(gpu_device, V, J, C):
     e_limb = float((out.double() - truth).abs().max())
     e_f32 = float((f32.double() - truth).abs().max())
     assert e_limb <= max(3.0 * e_f32, 8e-7 * max(1.0, float(truth.abs().max()))), (e_limb, e_f32)
+
+
+@pytest.mark.parametrize("M", [1, 127, 128, 129, 300, 5000, 70000])
+@pytest.mark.parametrize("layout,N,K", [("NN", 128, 128), ("NT", 128, 128), ("NN", 640, 128), ("NN", 384, 16), ("NN", 128, 32),
+                                        ("NT", 128, 272), ("NN", 256, 48)])
+def test_limb_dense_sel_plain(gpu_device, M, layout, N, K):
+    """relgnn_limb_dense_sel_f32 without gather / selection: 128 x 128 panels, every k-tile count parity, bias + activation."""
+    from tf_gnn_samples_amd import _lib, dense as DN
+    if M > 5000 and (N, K) != (128, 128):
+        pytest.skip("one large case per layout")
+    a = _rand((M, K), gpu_device, M + K)
+    if layout == "NN":
+        W = _rand((K, N), gpu_device, N + 1, 0.1)
+        b = _rand((N,), gpu_device, 3)
+        out = DN.limb_dense_sel(DN.GEMM_NN, a, W, b, _lib.ACT_TANH)
+        truth = torch.tanh(a.double() @ W.double() + b.double())
+        f32 = torch.tanh(a @ W + b)
+    else:
+        W = _rand((N, K), gpu_device, N + 2, 0.1)
+        out = DN.limb_dense_sel(DN.GEMM_NT, a, W)
+        truth = a.double() @ W.double().t()
+        f32 = a @ W.t()
+    e, e32 = float((out.double() - truth).abs().max()), float((f32.double() - truth).abs().max())
+    assert e <= max(3.0 * e32, 8e-7 * max(1.0, float(truth.abs().max()))), (e, e32)
+
+
+@pytest.mark.parametrize("layout,Din,Dout", [("NN", 128, 128), ("NN", 128, 256), ("NT", 128, 128), ("NT", 256, 128)])
+def test_limb_dense_sel_gathered_rows_and_per_tile_weights(gpu_device, layout, Din, Dout):
+    """The typed transform Y[r] = H[node[r]] @ W_type(tile(r)) and its input gradient dX[r] = dY[r] @ W_type^T: 512-row tiles, 23
+    kernels, padding rows (-1), against float64 and against relgnn_panel_gemm_f32 (exact fp32) on the same operands."""
+    from tf_gnn_samples_amd import dense as DN
+    L, tiles, V = 23, 37, 5000
+    g = torch.Generator(device="cpu").manual_seed(Din + Dout)
+    tile_type = torch.sort(torch.randint(0, L, (tiles,), generator=g)).values.to(torch.int32).to(gpu_device)
+    P = tiles * 512
+    W = _rand((L, Din, Dout), gpu_device, 5, 0.1)
+    if layout == "NN":
+        H = _rand((V, Din), gpu_device, 6)
+        node = torch.randint(0, V, (P,), generator=g).to(torch.int32)
+        node[torch.rand(P, generator=g) < 0.1] = -1
+        node = node.to(gpu_device)
+        out = DN.limb_dense_sel(DN.GEMM_NN, H, W, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512)
+        ref = DN.panel_gemm(DN.GEMM_NN, H, W, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512)
+        Hg = torch.where((node >= 0).unsqueeze(1), H[node.clamp(min=0).long()], torch.zeros((), device=gpu_device)).double()
+        truth = torch.bmm(Hg.view(tiles, 512, Din), W.double()[tile_type.long()]).view(P, Dout)
+    else:
+        gY = _rand((P, Dout), gpu_device, 7)
+        out = DN.limb_dense_sel(DN.GEMM_NT, gY, W, b_select=tile_type, rows_per_select=512)
+        ref = DN.panel_gemm(DN.GEMM_NT, gY, W, b_select=tile_type, rows_per_select=512, dims=(P, Din, Dout))
+        truth = torch.bmm(gY.double().view(tiles, 512, Dout), W.double()[tile_type.long()].transpose(1, 2)).view(P, Din)
+    e, e32 = float((out.double() - truth).abs().max()), float((ref.double() - truth).abs().max())
+    assert e <= max(3.0 * e32, 8e-7 * max(1.0, float(truth.abs().max()))), (e, e32)

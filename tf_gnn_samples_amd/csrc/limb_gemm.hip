@@ -391,6 +391,204 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
   }
 }
 
+// ---- 128 x 128 panels, gathered rows, per-panel weights: the per-(node, type) transforms of many-type graphs --------------------------
+//     C[r][n] = act(bias[n] + sum_k A[rows[r]][k] * B_sel(r)[n][k]),   n in a 128-column chunk     (gnns/gnn_film.py:92-106; rgcn.py,
+//     ggnn.py on VarMisuse-shaped batches; K = 128 there: eight k-tiles per panel)
+// With so short a reduction a panel is mostly latency (gather the rows, split, 8 k-tiles, 64 KB of stores), so the geometry is chosen
+// for TWO workgroups per CU: 128 rows x 128 columns, 8 waves = 2 row groups x 4 column tiles (a wave: 2 row tiles x 32 columns),
+// 3 stages of 24 KiB, <= 128 VGPRs.  Waves 0-3 issue the DMA of the W limb blocks (3 per k-tile each); waves 4-7 split the fp32 rows,
+// waves 4-5 the even k-tiles and waves 6-7 the odd ones: a thread owns one row x one whole k-tile (64 B) every second k-tile, loaded
+// four k-tiles before it is split (by every wave, outside any branch: see limb_gemm_kernel) into the stage the barrier of the
+// previous k-tile released.  rows (nullable): output row r reads A[rows[r]] (< 0: zeros) — the tf.nn.embedding_lookup of the
+// (node, type) tables in the load addresses; b_select (nullable): rows [p * rows_per_select, ..) use the limb tiles at
+// B + b_select[p] * b_stride (one Edge_%i kernel per 512-row tile; rows_per_select % 128 == 0).
+constexpr int SEL_STAGES = 3;
+
+struct LimbSelArgs {
+  const float* Ax; int64_t lda; const int32_t* rows;
+  const uint16_t* B; const int32_t* b_select; int32_t rows_per_select; int64_t b_stride;
+  const float* bias; const uint16_t* zeros; float* C; int64_t ldc;
+  int32_t M, N, K, act;
+  int32_t panels, chunks;
+};
+
+__global__ __launch_bounds__(512, 2) void limb_gemm_sel_kernel(const LimbSelArgs a) {
+  constexpr int TW = 2, T32 = 4, PR = 128, NC = 128;
+  constexpr int PA = 3 * T32, PB = 3 * (NC / 32), P = PA + PB;     // 12 + 12 blocks
+  constexpr int STAGE_BYTES = P * 1024;
+  constexpr int G = PB / 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SEL_STAGES * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int64_t lb = xcd_logical_block((int64_t)a.panels * a.chunks);
+  if (lb < 0) return;
+  const int q = (int)(lb / a.chunks), chunk = (int)(lb % a.chunks);
+  const int m0 = q * PR;
+  const int rows_here = min(PR, a.M - m0);
+  const int n0 = chunk * NC;
+  const int ntiles = a.K / BK;
+  const uint16_t* Bp = a.B + (a.b_select ? (int64_t)a.b_select[m0 / a.rows_per_select] * a.b_stride : 0);
+
+  // ---- W by DMA (waves 0-3) -------------------------------------------------------------------------------------------------
+  const bool loader = wave < 4;
+  constexpr int TILE = 3 * 512;
+  const uint16_t* src[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int cb = (wave & 3) + 4 * g;
+    src[g] = Bp + ((int64_t)(n0 / 32 + cb / 3) * ntiles) * TILE + (cb % 3) * 512 + 8 * lane;
+  }
+  auto issue_w = [&](int stage) {
+    if (!loader) return;
+    unsigned char* dst = lds + stage * STAGE_BYTES + PA * 1024;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      dma16(src[g], dst + ((wave & 3) + 4 * g) * 1024);
+      src[g] += TILE;
+    }
+  };
+  // (the loads of the split below are issued by the loader waves too, from the zero block: a count that leaves them out waits for
+  //  MORE of the older DMA instructions than necessary, never for fewer)
+  auto wait_w = [&](int tiles) {
+    if (!loader) return;
+    if (tiles >= 1) wait_vm<G>(); else wait_vm<0>();
+  };
+
+  // ---- the split (waves 4-7): thread x = tid & 255 owns row x & 127, chunk x >> 7 (k 8h .. 8h+7) of EVERY k-tile: 32 B per k-tile,
+  // two register sets (even / odd k-tiles), each loaded two k-tiles before it is split ------------------------------------------
+  const bool xwave = wave >= 4;
+  const int x = tid & 255;
+  const int xr = x & 127, xh_ = x >> 7;
+  int64_t row = -1;
+  if (xwave && xr < rows_here) row = a.rows ? (int64_t)a.rows[m0 + xr] : (int64_t)(m0 + xr);
+  const bool xok = row >= 0;
+  const float* xbase = xok ? a.Ax + row * a.lda + 8 * xh_ : reinterpret_cast<const float*>(a.zeros);
+  const int xkmax = xok ? a.K - 16 : 0;
+  const int xblock = (3 * (xr >> 5)) * 1024 + xh_ * 512 + (xr & 31) * 16;
+  f32x4 xva[2], xvb[2];                               // my chunk of an even / an odd k-tile in flight
+  auto x_load = [&](f32x4 (&v)[2], int kt) {          // (every wave, no branch; past the end: the last k-tile again)
+    const float* p = xbase + min(16 * kt, xkmax);
+    v[0] = *reinterpret_cast<const f32x4*>(p);
+    v[1] = *reinterpret_cast<const f32x4*>(p + 4);
+  };
+  auto x_split = [&](const f32x4 (&v)[2], int kt) {   // my chunk of k-tile kt -> stage kt % 3
+    float z[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { z[i] = xok ? v[0][i] : 0.f; z[4 + i] = xok ? v[1][i] : 0.f; }
+    uint4 h, m, l;
+    split8(z, h, m, l);
+    unsigned char* p = lds + (kt % SEL_STAGES) * STAGE_BYTES + xblock;
+    *reinterpret_cast<uint4*>(p) = h;
+    *reinterpret_cast<uint4*>(p + 1024) = m;
+    *reinterpret_cast<uint4*>(p + 2048) = l;
+  };
+
+  // ---- fragments / products -----------------------------------------------------------------------------------------------
+  struct Limbs { bf16x8 hi, mid, lo; };
+  auto read_blk = [&](int stage, int blk) {
+    const unsigned char* p = lds + stage * STAGE_BYTES + blk * 1024 + 16 * lane;
+    Limbs f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p);
+    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    return f;
+  };
+  f32x16 acc[TW];
+#pragma unroll
+  for (int tm = 0; tm < TW; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+  auto products = [&](f32x16 c, const Limbs& w, const Limbs& xx) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xx.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, xx.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, xx.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xx.mid, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, xx.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xx.hi, c, 0, 0, 0);
+    return c;
+  };
+
+  // ---- pipeline: k-tile t is multiplied while k-tile t+1 is complete in LDS and k-tile t+2 arrives (W by DMA, X split from the
+  // register set of its parity, whose next load — k-tile t+4 — follows) ----------------------------------------------------------
+  if (ntiles > 0) {
+    issue_w(0);
+    if (1 < ntiles) issue_w(1);
+    x_load(xva, 0);
+    x_load(xvb, 1);
+    if (xwave) {
+      x_split(xva, 0);
+      if (1 < ntiles) x_split(xvb, 1);
+    }
+    x_load(xva, 2);
+    x_load(xvb, 3);
+    wait_w(min(1, ntiles - 1));
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+  }
+  Limbs w_cur, w_nxt, x0, x1;
+  if (ntiles > 0) {
+    w_cur = read_blk(0, PA + 3 * wn);
+    x0 = read_blk(0, 3 * (wm * TW));
+  }
+  // (four register sets — a lead of four k-tiles instead of two — need 138 VGPRs: one workgroup per CU, 278 instead of 247 us)
+  auto ktile = [&](int t, auto odd_c) {
+    constexpr int ODD = decltype(odd_c)::value;
+    f32x4 (&xv)[2] = ODD ? xvb : xva;
+    const int stage = t % SEL_STAGES;
+    const bool more = t + 1 < ntiles;
+    if (t + 2 < ntiles) issue_w((t + 2) % SEL_STAGES);
+    if (xwave && t + 2 < ntiles) x_split(xv, t + 2);
+    x_load(xv, t + 4);
+    x1 = read_blk(stage, 3 * (wm * TW + 1));
+    acc[0] = products(acc[0], w_cur, x0);
+    if (more) {
+      // W tile t+1 was issued at k-tile t-1 (or in the prologue); after it: W tile t+2 (this k-tile) and loads of the split
+      wait_w(t + 2 < ntiles ? 1 : 0);
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      w_nxt = read_blk((t + 1) % SEL_STAGES, PA + 3 * wn);
+      x0 = read_blk((t + 1) % SEL_STAGES, 3 * (wm * TW));
+    }
+    acc[1] = products(acc[1], w_cur, x1);
+    w_cur = w_nxt;
+  };
+  {
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+      ktile(t, std::integral_constant<int, 0>{});
+      ktile(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < ntiles) ktile(t, std::integral_constant<int, 0>{});
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  const int i32 = lane & 31, h32 = lane >> 5;
+  const int colw = n0 + wn * 32;
+  auto finish = [&](f32x4 v, int col) {
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+    if (a.act != RELGNN_ACT_LINEAR) {
+      v[0] = act_rt(a.act, v[0]); v[1] = act_rt(a.act, v[1]); v[2] = act_rt(a.act, v[2]); v[3] = act_rt(a.act, v[3]);
+    }
+    return v;
+  };
+#pragma unroll
+  for (int tm = 0; tm < TW; ++tm) {
+    const int r = (wm * TW + tm) * 32 + i32;
+    if (r < rows_here) {
+      float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = colw + 8 * c + 4 * h32;
+        const f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+        *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
+      }
+    }
+  }
+}
+
 // ---- weight gradients: P[z] = A[rows of chunk z]^T @ G[rows of chunk z] ------------------------------------------------------
 // dW = A^T G for A [V, J], G [V, 256 c] (both fp32 row-major: the reduction index is the ROW of both).  Same matrix-pipe core,
 // same LDS blocks, but both operands are split in flight and TRANSPOSED on the way: a thread loads a 4-column x 8-row patch
@@ -599,7 +797,9 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
 // 128-byte lines of the limb blocks (8 consecutive rows x 16 bytes) and, untransposed, reads 256 consecutive bytes per row.
 template <bool TRANSPOSE>
 __global__ __launch_bounds__(256) void limb_split_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols,
-                                                         uint16_t* __restrict__ out) {
+                                                         uint16_t* __restrict__ out, int64_t x_stride, int64_t out_stride) {
+  X += (int64_t)blockIdx.z * x_stride;                // batch: one matrix per blockIdx.z
+  out += (int64_t)blockIdx.z * out_stride;
   // output matrix: [R, C] = X (or X^T)
   const int R = TRANSPOSE ? cols : rows, C = TRANSPOSE ? rows : cols;
   const int KT = C / 16;
@@ -694,17 +894,24 @@ void relgnn_limb_timing_buffer(unsigned long long* p) { g_limb_timing = p; }
 
 int64_t relgnn_limb_elements(int64_t rows, int64_t cols) { return ((rows + 31) / 32) * (cols / 16) * 1536; }
 
-int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, int32_t transpose, uint16_t* out, void* stream) {
-  if (rows < 0 || cols < 0 || ldx < cols) return RELGNN_EINVAL;
-  if (rows == 0 || cols == 0) return RELGNN_OK;
+int relgnn_limb_split_batch_f32(const float* X, int64_t ldx, int64_t x_batch_stride, int32_t rows, int32_t cols, int32_t transpose,
+                                int32_t batch, uint16_t* out, void* stream) {
+  if (rows < 0 || cols < 0 || ldx < cols || batch < 0) return RELGNN_EINVAL;
+  if (rows == 0 || cols == 0 || batch == 0) return RELGNN_OK;
   if (!X || !out) return RELGNN_EINVAL;
   const int R = transpose ? cols : rows, C = transpose ? rows : cols;
-  if (C % 16 != 0 || !aligned16(out) || (!transpose && (!aligned16(X) || ldx % 4))) return RELGNN_EUNSUPPORTED;
+  if (C % 16 != 0 || !aligned16(out) || (!transpose && (!aligned16(X) || ldx % 4 || x_batch_stride % 4)) || batch > 65535)
+    return RELGNN_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 31) / 32));
-  if (transpose) limb_split_kernel<true><<<grid, 256, 0, st>>>(X, ldx, rows, cols, out);
-  else limb_split_kernel<false><<<grid, 256, 0, st>>>(X, ldx, rows, cols, out);
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 31) / 32), (unsigned)batch);
+  const int64_t os = relgnn_limb_elements(R, C);
+  if (transpose) limb_split_kernel<true><<<grid, 256, 0, st>>>(X, ldx, rows, cols, out, x_batch_stride, os);
+  else limb_split_kernel<false><<<grid, 256, 0, st>>>(X, ldx, rows, cols, out, x_batch_stride, os);
   return launch_status();
+}
+
+int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, int32_t transpose, uint16_t* out, void* stream) {
+  return relgnn_limb_split_batch_f32(X, ldx, 0, rows, cols, transpose, 1, out, stream);
 }
 
 static int limb_common_checks(int32_t act, const void* A, const void* B, const float* bias, const void* zeros, float* C,
@@ -785,6 +992,37 @@ int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t
     case 2: limb_gemm_tn_kernel<2><<<grid, 512, 0, st>>>(a); break;
     default: limb_gemm_tn_kernel<1><<<grid, 512, 0, st>>>(a); break;
   }
+  return launch_status();
+}
+
+// 128 x 128 panels with gathered rows and per-panel weights (limb_gemm_sel_kernel): the weights are `num_b` fp32 matrices at
+// B + i * b_batch_stride (RELGNN_GEMM_NN: [K, N] each; RELGNN_GEMM_NT: [N, K] each), all split into limb_ws first (one launch).
+int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const float* B,
+                              int64_t ldb, int32_t num_b, int64_t b_batch_stride, const int32_t* b_select, int32_t rows_per_select,
+                              const float* bias, const void* zeros, uint16_t* limb_ws, int64_t limb_ws_elements, float* C,
+                              int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  if (layout != RELGNN_GEMM_NN && layout != RELGNN_GEMM_NT) return RELGNN_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || num_b < 1 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!A || !B || !C || !limb_ws || !zeros) return RELGNN_EINVAL;
+  if (K == 0 || K % BK != 0 || N % 128 != 0) return RELGNN_EUNSUPPORTED;
+  if (!aligned16(A) || !aligned16(B) || !aligned16(C) || !aligned16(zeros) || (bias && !aligned16(bias)) || ldc % 4 || ldc < N ||
+      lda % 4 || lda < K)
+    return RELGNN_EUNSUPPORTED;
+  if (b_select && (rows_per_select <= 0 || rows_per_select % 128 != 0)) return RELGNN_EINVAL;
+  if (!b_select && num_b != 1) return RELGNN_EINVAL;
+  const int64_t per = relgnn_limb_elements(N, K);
+  if (limb_ws_elements < per * num_b) return RELGNN_EINVAL;
+  const int sp = layout == RELGNN_GEMM_NN ? relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, K, N, 1, num_b, limb_ws, stream)
+                                          : relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, N, K, 0, num_b, limb_ws, stream);
+  if (sp != RELGNN_OK) return sp;
+  LimbSelArgs a{};
+  a.Ax = A; a.lda = lda; a.rows = a_rows; a.B = limb_ws; a.b_select = b_select; a.rows_per_select = rows_per_select; a.b_stride = per;
+  a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
+  a.chunks = N / 128;
+  a.panels = (M + 127) / 128;
+  const int64_t logical = (int64_t)a.panels * a.chunks;
+  limb_gemm_sel_kernel<<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, as_stream(stream)>>>(a);
   return launch_status();
 }
 

@@ -62,9 +62,12 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
              accumulate: bool = False, relu: bool = False) -> torch.Tensor:
     """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
     Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU)."""
-    if _LIMB_GEMM and layout != GEMM_TN and out is None and not accumulate and _limb_route_ok(layout, a, b, bias):
+    if _LIMB_GEMM and layout != GEMM_TN and out is None and not accumulate:
         from . import _lib
-        return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
+        if _limb_route_ok(layout, a, b, bias):
+            return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
+        if _limb_route_ok(layout, a, b, bias, columns=128):        # the D = 128 models: 128 x 128 panels, two workgroups per CU
+            return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
     if (_PANEL_GEMM and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
         from . import _lib
@@ -248,13 +251,13 @@ def limb_gemm_xf32(a: torch.Tensor, b: "Limbs", bias: torch.Tensor = None, act: 
     return out
 
 
-def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias) -> bool:
+def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias, columns: int = 256) -> bool:
     if not (_rows_ok(a) and _rows_ok(b)) or a.shape[0] < _LIMB_MIN_ROWS:
         return False
     K, N = (a.shape[1], b.shape[1]) if layout == GEMM_NN else (a.shape[1], b.shape[0])
     if (b.shape[0] if layout == GEMM_NN else b.shape[1]) != K:
         return False
-    return (N % 256 == 0 and K % 16 == 0 and 16 <= K <= _LIMB_MAX_K
+    return (N % columns == 0 and K % 16 == 0 and 16 <= K <= _LIMB_MAX_K
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0)))
 
 
@@ -285,6 +288,35 @@ def mm_into(layout: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) ->
     if _LIMB_GEMM and _limb_route_ok(layout, a, b, None) and _rows_ok(out):
         return limb_dense(layout, a, b, out=out)
     return torch.mm(a, b if layout == GEMM_NN else b.t(), out=out)
+
+
+def _limb_ws(device, need: int) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _LIMB_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _LIMB_WS[key] = torch.empty(max(need, 1 << 20), dtype=torch.bfloat16, device=device)
+    return ws
+
+
+def limb_dense_sel(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0, *,
+                   a_rows: torch.Tensor = None, num_rows: int = None, b_select: torch.Tensor = None, rows_per_select: int = 0
+                   ) -> torch.Tensor:
+    """relgnn_limb_dense_sel_f32: the limb product in 128 x 128 panels.  b: [K, N] / [N, K] (NN / NT) or, with b_select,
+    [num_b, K, N] / [num_b, N, K]; a_rows: int32 row ids of `a` per output row (< 0: zeros), num_rows output rows."""
+    from . import _lib
+    lib = _lib.load_library()
+    K = a.shape[1]
+    num_b = b.shape[0] if b.dim() == 3 else 1
+    N = b.shape[-1] if layout == GEMM_NN else b.shape[-2]
+    M = int(num_rows) if a_rows is not None else a.shape[0]
+    need = int(lib.relgnn_limb_elements(N, K)) * num_b
+    ws = _limb_ws(a.device, need)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_limb_dense_sel_f32(layout, act, a.data_ptr(), a.stride(0), _lib.ptr(a_rows), b.data_ptr(), b.stride(-2),
+                                             num_b, b.stride(0) if b.dim() == 3 else 0, _lib.ptr(b_select), int(rows_per_select),
+                                             _lib.ptr(bias), _lib.ptr(_zeros(a.device)), ws.data_ptr(), ws.numel(), out.data_ptr(),
+                                             out.stride(0), M, N, K, _lib.current_stream()), "relgnn_limb_dense_sel_f32")
+    return out
 
 
 def limb_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:

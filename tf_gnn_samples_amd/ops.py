@@ -498,17 +498,20 @@ class _TypedLinearPanel(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, H, side, W):
-        from .dense import GEMM_NN, panel_gemm
+        from .dense import GEMM_NN, limb_dense_sel, panel_gemm
         L, Din, Dout = W.shape
         node32, tile_type = side.panel_indices()
-        Y = panel_gemm(GEMM_NN, H, W, a_rows=node32, num_rows=side.P, b_select=tile_type, rows_per_select=side.chunk)
+        if _typed_limb_ok(Din, Dout):
+            Y = limb_dense_sel(GEMM_NN, H, W, a_rows=node32, num_rows=side.P, b_select=tile_type, rows_per_select=side.chunk)
+        else:
+            Y = panel_gemm(GEMM_NN, H, W, a_rows=node32, num_rows=side.P, b_select=tile_type, rows_per_select=side.chunk)
         ctx.side, ctx.shape = side, (L, Din, Dout)
         ctx.save_for_backward(H, W)
         return Y
 
     @staticmethod
     def backward(ctx, gY):
-        from .dense import GEMM_NT, GEMM_TN, panel_gemm
+        from .dense import GEMM_NT, GEMM_TN, limb_dense_sel, panel_gemm
         H, W = ctx.saved_tensors
         side = ctx.side
         L, Din, Dout = ctx.shape
@@ -516,7 +519,10 @@ class _TypedLinearPanel(torch.autograd.Function):
         node32, tile_type = side.panel_indices()
         gH = gW = None
         if ctx.needs_input_grad[0]:
-            gX = panel_gemm(GEMM_NT, gY, W, b_select=tile_type, rows_per_select=side.chunk, dims=(side.P, Din, Dout))
+            if _typed_limb_ok(Dout, Din):
+                gX = limb_dense_sel(GEMM_NT, gY, W, b_select=tile_type, rows_per_select=side.chunk)
+            else:
+                gX = panel_gemm(GEMM_NT, gY, W, b_select=tile_type, rows_per_select=side.chunk, dims=(side.P, Din, Dout))
             gH = _seg_reduce_raw(_lib.AGG_SUM, gX, side.node_rowptr, 1, side.node_col, None, H.shape[0])
         if ctx.needs_input_grad[2]:
             tiles = side.P // side.chunk
@@ -528,6 +534,12 @@ class _TypedLinearPanel(torch.autograd.Function):
             rowptr, col = side.weight_grad_plan(K)
             gW = _seg_reduce_raw(_lib.AGG_SUM, part.view(-1, sub), rowptr, 1, col, None, L * K).view(L, Din, Dout)
         return gH, None, gW
+
+
+def _typed_limb_ok(k: int, n: int) -> bool:
+    """The limb route (relgnn_limb_dense_sel_f32) for a typed product with reduction length k and n output columns."""
+    from . import dense
+    return dense._LIMB_GEMM and n % 128 == 0 and k % 16 == 0 and 16 <= k <= dense._LIMB_MAX_K
 
 
 def _typed_panel_ok(H, side, weights) -> bool:
