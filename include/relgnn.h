@@ -745,6 +745,14 @@ int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t col
 /* `batch` matrices at X + i * x_batch_stride -> limb tiles at out + i * relgnn_limb_elements(R, C) (one launch) */
 int relgnn_limb_split_batch_f32(const float* X, int64_t ldx, int64_t x_batch_stride, int32_t rows, int32_t cols, int32_t transpose,
                                 int32_t batch, uint16_t* out, void* stream);
+/* n matrices of different shapes in ONE launch (host arrays of n entries each): item d writes X[d] (or its transpose) as k-tiles
+ * kt_offset[d] .. kt_offset[d] + C/16 - 1 of a limb matrix with kt_total[d] k-tiles per 32-row block at out[d] (kt_offset 0 and
+ * kt_total = C/16: a whole matrix, as relgnn_limb_split_f32; several items with one `out` lay matrices side by side along k, e.g. the
+ * stacked right operand [W_0 | W_1 | ..] of the input gradient of gnns/rgcn.py:96-98 without forming it in fp32).  The weight operands
+ * of a training step change once per step (the optimizer's update): the host side splits them all behind it with this entry. */
+int relgnn_limb_split_multi_f32(int32_t n, const float* const* X, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
+                                const int32_t* transpose, uint16_t* const* out, const int32_t* kt_offset, const int32_t* kt_total,
+                                void* stream);
 int relgnn_limb_gemm_f32(int32_t act, const uint16_t* A, const uint16_t* B, const float* bias, const void* zeros, float* C,
                          int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,

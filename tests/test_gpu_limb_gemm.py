@@ -197,3 +197,112 @@ def test_limb_dense_sel_gathered_rows_and_per_tile_weights(gpu_device, layout, D
         truth = torch.bmm(gY.double().view(tiles, 512, Dout), W.double()[tile_type.long()].transpose(1, 2)).view(P, Din)
     e, e32 = float((out.double() - truth).abs().max()), float((ref.double() - truth).abs().max())
     assert e <= max(3.0 * e32, 8e-7 * max(1.0, float(truth.abs().max()))), (e, e32)
+
+
+def test_weight_limb_images_equal_single_splits(gpu_device):
+    """relgnn_limb_split_multi_f32 (one launch for the weights of a step) writes the images relgnn_limb_split_f32 writes, for the
+    three operand kinds, incl. the stacked [W_0 | W_1 | ..] operand that is never formed in fp32, and for more matrices than one
+    launch takes."""
+    from tf_gnn_samples_amd import dense as DN
+    DN._WEIGHT_LIMBS.clear()
+    W = _rand((3, 256, 256), gpu_device, 1, 0.1)
+    Wd = _rand((256, 512), gpu_device, 2, 0.1)
+    a = DN.weight_limbs(W.view(768, 256), DN.WEIGHT_NN)
+    assert torch.equal(a, DN.limb_split(W.view(768, 256), transpose=True).data)
+    b = DN.weight_limbs(Wd, DN.WEIGHT_NT)
+    assert torch.equal(b, DN.limb_split(Wd).data)
+    c = DN.weight_limbs(W, DN.WEIGHT_NT)                               # [W_0 | W_1 | W_2]: B [Din, L*Dout]
+    stacked = W.permute(0, 2, 1).reshape(768, 256)                    # B^T = [K = L*Dout, N = Din]
+    assert torch.equal(c, DN.limb_split(stacked, transpose=True).data)
+    separate = [_rand((256, 256), gpu_device, 40 + l, 0.1) for l in range(3)]      # three variables, not one stack
+    d = DN.weight_limbs(separate, DN.WEIGHT_NN)
+    assert torch.equal(d, DN.limb_split(torch.cat(separate, 0), transpose=True).data)
+    e = DN.weight_limbs(separate, DN.WEIGHT_NT)
+    assert torch.equal(e, DN.limb_split(torch.cat(separate, 1)).data)
+    many = [_rand((48, 32), gpu_device, 10 + i) for i in range(30)]    # 30 items: two launches
+    DN.weights_changed()
+    for m in many:
+        DN.weight_limbs(m, DN.WEIGHT_NT)
+    DN.weights_changed()
+    got = [DN.weight_limbs(m, DN.WEIGHT_NT) for m in many]            # the first request re-splits all 30 + the 3 above
+    for m, g in zip(many, got):
+        assert torch.equal(g, DN.limb_split(m).data)
+    DN._WEIGHT_LIMBS.clear()
+
+
+def test_weight_limb_cache_follows_the_weights(gpu_device):
+    """A cached image is replaced after an in-place write (version counter), after weights_changed() (writes through raw
+    pointers, as the fused optimizer launch does), and when another tensor takes the address."""
+    from tf_gnn_samples_amd import dense as DN
+    DN._WEIGHT_LIMBS.clear()
+    x = _rand((4608, 256), gpu_device, 3)
+    w = _rand((256, 256), gpu_device, 4, 0.1)
+    y0 = DN.lib_gemm(DN.GEMM_NN, x, w, weight=True)
+    assert torch.equal(y0, DN.lib_gemm(DN.GEMM_NN, x, w))
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert torch.equal(DN.lib_gemm(DN.GEMM_NN, x, w, weight=True), DN.lib_gemm(DN.GEMM_NN, x, w))
+    w.data.mul_(0.5)                                                  # (a write the version counter of w does not see)
+    stale = DN.lib_gemm(DN.GEMM_NN, x, w, weight=True)
+    DN.weights_changed()
+    fresh = DN.lib_gemm(DN.GEMM_NN, x, w, weight=True)
+    assert torch.equal(fresh, y0) and torch.equal(fresh, DN.lib_gemm(DN.GEMM_NN, x, w))
+    assert not torch.equal(stale, fresh)                              # documents why weights_changed() exists
+    ptr = w.data_ptr()
+    del w
+    w2 = _rand((256, 256), gpu_device, 5, 0.1)
+    if w2.data_ptr() == ptr:
+        assert torch.equal(DN.lib_gemm(DN.GEMM_NN, x, w2, weight=True), DN.lib_gemm(DN.GEMM_NN, x, w2))
+    DN._WEIGHT_LIMBS.clear()
+
+
+def test_grouped_gemms_equal_the_stacked_products(gpu_device):
+    """The aggregate-first layer's two products over the per-edge-type kernels as they are (no stacked operand in fp32): same bits
+    as the products with the stacked operands."""
+    from tf_gnn_samples_amd import dense as DN
+    Ws = [_rand((256, 256), gpu_device, 6 + l, 0.1) for l in range(3)]
+    x = _rand((9000, 768), gpu_device, 7)
+    for relu in (False, True):
+        assert torch.equal(DN.grouped_nn_gemm(x, Ws, relu=relu), DN.lib_gemm(DN.GEMM_NN, x, torch.cat(Ws, 0), relu=relu))
+    stackedT = torch.cat([w.t() for w in Ws], 0)
+    ref = DN.lib_gemm(DN.GEMM_NN, x, stackedT)
+    assert torch.equal(DN.grouped_nt_gemm(x, Ws), ref)
+    truth = x.double() @ stackedT.double()
+    assert float((ref.double() - truth).abs().max()) < 4e-6 * max(1.0, float(truth.abs().max()))
+    W5 = [_rand((128, 64), gpu_device, 20 + l, 0.1) for l in range(5)]           # not a limb shape: the library route
+    g5 = _rand((5000, 320), gpu_device, 9)
+    t5 = g5.double() @ torch.cat([w.t() for w in W5], 0).double()
+    assert float((DN.grouped_nt_gemm(g5, W5).double() - t5).abs().max()) < 1e-5
+    x5 = _rand((5000, 640), gpu_device, 10)
+    assert float((DN.grouped_nn_gemm(x5, W5).double() - x5.double() @ torch.cat(W5, 0).double()).abs().max()) < 1e-5
+
+
+def test_training_steps_with_and_without_the_weight_limb_cache(gpu_device):
+    """Three fused clip + Adam steps of the C2-shaped model: the parameters are the same bits whether the weights' limbs are
+    split per product or once per step."""
+    from tf_gnn_samples_amd import dense as DN
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    task = PPI_Task(PPI_Task.default_params()); task.load_synthetic(3, 1, seed=3)
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
+    results = []
+    for cached in (True, False):
+        DN._WEIGHT_LIMBS.clear()
+        DN._WEIGHT_LIMB_CACHE = cached
+        try:
+            torch.manual_seed(0)
+            p = RGCN_Model.default_params()
+            p.update(hidden_size=256, graph_num_layers=3, graph_layer_input_dropout_keep_prob=1.0, random_seed=0)
+            model = RGCN_Model(p, task, device=str(gpu_device))
+            batch = DeviceBatch(mb, gpu_device)
+            for _ in range(3):
+                model.train_step(batch)
+            with torch.no_grad():
+                model.forward_batch(batch, training=False)            # (an evaluation pass right behind an update)
+            results.append([q.detach().clone() for q in model.optimizer.params])
+        finally:
+            DN._WEIGHT_LIMB_CACHE = True
+    assert mb.num_nodes >= 4096                                       # (the limb route is what ran)
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    DN._WEIGHT_LIMBS.clear()

@@ -171,3 +171,4 @@ def test_backward_overlap_on_a_side_stream_gives_the_same_bits(gpu_device, monke
         assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
         junk = [torch.empty((V, D), device=gpu_device).normal_() for _ in range(3)]      # churn the allocator between iterations
         del junk
+

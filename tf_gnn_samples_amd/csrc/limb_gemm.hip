@@ -796,17 +796,13 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
 // One workgroup = 32 rows x 64 columns of the OUTPUT matrix (4 waves; a wave: 8 rows x 8 groups of 8 k): every wave writes whole
 // 128-byte lines of the limb blocks (8 consecutive rows x 16 bytes) and, untransposed, reads 256 consecutive bytes per row.
 template <bool TRANSPOSE>
-__global__ __launch_bounds__(256) void limb_split_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols,
-                                                         uint16_t* __restrict__ out, int64_t x_stride, int64_t out_stride) {
-  X += (int64_t)blockIdx.z * x_stride;                // batch: one matrix per blockIdx.z
-  out += (int64_t)blockIdx.z * out_stride;
-  // output matrix: [R, C] = X (or X^T)
+__device__ __forceinline__ void limb_split_tile(const float* __restrict__ X, int64_t ldx, int rows, int cols,
+                                                uint16_t* __restrict__ out, int KT, int kt_off, int bx, int rb) {
+  // output matrix: [R, C] = X (or X^T), written as k-tiles kt_off .. kt_off + C / 16 - 1 of a limb matrix with KT k-tiles per row block
   const int R = TRANSPOSE ? cols : rows, C = TRANSPOSE ? rows : cols;
-  const int KT = C / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rb = blockIdx.y;
   const int i = 8 * wave + (lane & 7);                // row inside the 32-row tile
-  const int g8 = blockIdx.x * 8 + (lane >> 3);        // group of 8 k
+  const int g8 = bx * 8 + (lane >> 3);                // group of 8 k
   if (g8 * 8 >= C) return;
   const int r = rb * 32 + i;
   float v[8];
@@ -826,11 +822,38 @@ __global__ __launch_bounds__(256) void limb_split_kernel(const float* __restrict
   }
   uint4 h, m, l;
   split8(v, h, m, l);
-  const int kt = g8 >> 1, hh = g8 & 1;
+  const int kt = kt_off + (g8 >> 1), hh = g8 & 1;
   uint16_t* o = out + ((int64_t)rb * KT + kt) * 1536 + hh * 256 + i * 8;
   *reinterpret_cast<uint4*>(o) = h;
   *reinterpret_cast<uint4*>(o + 512) = m;
   *reinterpret_cast<uint4*>(o + 1024) = l;
+}
+
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void limb_split_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols,
+                                                         uint16_t* __restrict__ out, int64_t x_stride, int64_t out_stride) {
+  X += (int64_t)blockIdx.z * x_stride;                // batch: one matrix per blockIdx.z
+  out += (int64_t)blockIdx.z * out_stride;
+  limb_split_tile<TRANSPOSE>(X, ldx, rows, cols, out, (TRANSPOSE ? rows : cols) / 16, 0, blockIdx.x, blockIdx.y);
+}
+
+// Several matrices in one launch (the weight operands of a training step, split once after the optimizer's update): item d owns
+// the blocks [block_end[d-1], block_end[d]); an item may be a column range (k-tiles kt_off ..) of a wider limb matrix.
+constexpr int SPLIT_MULTI_MAX = 24;
+struct SplitItem {
+  const float* X; int64_t ldx; uint16_t* out;
+  int32_t rows, cols, transpose, kt_off, kt_total, gx, block_end;
+};
+struct SplitMultiArgs { SplitItem it[SPLIT_MULTI_MAX]; int32_t n; };
+
+__global__ __launch_bounds__(256) void limb_split_multi_kernel(const SplitMultiArgs a) {
+  int d = 0;
+  while (d + 1 < a.n && (int)blockIdx.x >= a.it[d].block_end) ++d;
+  const SplitItem& it = a.it[d];
+  const int local = (int)blockIdx.x - (d ? a.it[d - 1].block_end : 0);
+  const int bx = local % it.gx, rb = local / it.gx;
+  if (it.transpose) limb_split_tile<true>(it.X, it.ldx, it.rows, it.cols, it.out, it.kt_total, it.kt_off, bx, rb);
+  else limb_split_tile<false>(it.X, it.ldx, it.rows, it.cols, it.out, it.kt_total, it.kt_off, bx, rb);
 }
 
 template <int T32, bool XF32, int ABL = 0>
@@ -912,6 +935,35 @@ int relgnn_limb_split_batch_f32(const float* X, int64_t ldx, int64_t x_batch_str
 
 int relgnn_limb_split_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, int32_t transpose, uint16_t* out, void* stream) {
   return relgnn_limb_split_batch_f32(X, ldx, 0, rows, cols, transpose, 1, out, stream);
+}
+
+int relgnn_limb_split_multi_f32(int32_t n, const float* const* X, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
+                                const int32_t* transpose, uint16_t* const* out, const int32_t* kt_offset, const int32_t* kt_total,
+                                void* stream) {
+  if (n < 0 || (n > 0 && (!X || !ldx || !rows || !cols || !transpose || !out || !kt_offset || !kt_total))) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  for (int32_t first = 0; first < n; first += SPLIT_MULTI_MAX) {
+    SplitMultiArgs a{};
+    int blocks = 0;
+    a.n = 0;
+    for (int32_t d = first; d < n && a.n < SPLIT_MULTI_MAX; ++d) {
+      const int R = transpose[d] ? cols[d] : rows[d], C = transpose[d] ? rows[d] : cols[d];
+      if (rows[d] < 0 || cols[d] < 0 || C % 16 != 0 || kt_offset[d] < 0 || kt_offset[d] + C / 16 > kt_total[d]) return RELGNN_EINVAL;
+      if (R == 0 || C == 0) continue;
+      if (!X[d] || !out[d]) return RELGNN_EINVAL;
+      if (!aligned16(X[d]) || !aligned16(out[d]) || ldx[d] % 4 || ldx[d] < cols[d]) return RELGNN_EUNSUPPORTED;
+      SplitItem& it = a.it[a.n++];
+      it.X = X[d]; it.ldx = ldx[d]; it.out = out[d]; it.rows = rows[d]; it.cols = cols[d]; it.transpose = transpose[d];
+      it.kt_off = kt_offset[d]; it.kt_total = kt_total[d]; it.gx = (C + 63) / 64;
+      blocks += it.gx * ((R + 31) / 32);
+      it.block_end = blocks;
+    }
+    if (!a.n) continue;
+    limb_split_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(a);
+    const int rc = launch_status();
+    if (rc != RELGNN_OK) return rc;
+  }
+  return RELGNN_OK;
 }
 
 static int limb_common_checks(int32_t act, const void* A, const void* B, const float* bias, const void* zeros, float* C,

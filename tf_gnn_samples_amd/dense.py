@@ -59,13 +59,14 @@ def _workspace(device):
 
 
 def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, out: torch.Tensor = None,
-             accumulate: bool = False, relu: bool = False) -> torch.Tensor:
+             accumulate: bool = False, relu: bool = False, weight: bool = False) -> torch.Tensor:
     """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
-    Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU)."""
+    Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU).
+    weight=True: b is a parameter (or a view of one) — the limb route keeps its limb image across the step (weight_limbs)."""
     if _LIMB_GEMM and layout != GEMM_TN and out is None and not accumulate:
         from . import _lib
         if _limb_route_ok(layout, a, b, bias):
-            return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
+            return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR, weight=weight)
         if _limb_route_ok(layout, a, b, bias, columns=128):        # the D = 128 models: 128 x 128 panels, two workgroups per CU
             return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
     if (_PANEL_GEMM and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
@@ -261,11 +262,180 @@ def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias, columns:
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0)))
 
 
+# ---- the limbs of the step's WEIGHT operands: split once per optimizer step, all of them in one launch ----------------------------
+# A weight is the right operand of two or three products per step (forward, input gradient) and changes once per step.  Its limb
+# image is kept per (device, stream) until the weights change: the optimizer's fused update writes through raw pointers (tensor
+# versions do not move) and says so through weights_changed(); every other in-place write moves the tensor's version, which is
+# compared too.  The first request after a change re-splits every image that the previous step used (relgnn_limb_split_multi_f32);
+# an image may be several matrices side by side along k (the per-edge-type kernels of a layer), so neither the stacked
+# [L*Din, Dout] operand of the forward product nor the stacked W^T of the input gradient is ever formed in fp32.
+# C2: 8 split launches + 3 stacks + 3 re-layouts per step -> 1 launch.  Under stream capture nothing is cached (a replay re-runs
+# kernels, not this code): the image is split on every request.
+_WEIGHT_LIMB_CACHE = os.environ.get("RELGNN_WEIGHT_LIMB_CACHE", "1") == "1"
+_WEIGHT_LIMBS = {}
+_WEIGHT_GEN = [0]
+WEIGHT_NN, WEIGHT_NT = "nn", "nt"
+
+
+def weights_changed() -> None:
+    """Parameters were rewritten in place through raw pointers (models/sparse_graph_model.py: the fused clip + Adam launch)."""
+    _WEIGHT_GEN[0] += 1
+
+
+class _WeightImage:
+    __slots__ = ("refs", "items", "versions", "gen", "used_gen", "buf")     # (no strong reference to the weights)
+
+
+def _weight_matrices(w):
+    """A weight operand as a list of 2-D matrices laid side by side along k: a matrix, a [L, ., .] stack or a sequence."""
+    if torch.is_tensor(w):
+        return [w] if w.dim() == 2 else list(w.unbind(0))
+    return list(w)
+
+
+def _weight_image_shape(ws, kind: str):
+    """(N, K) of B [N, K] = [w_0^T | w_1^T | ..] (WEIGHT_NN: w_l [K_l, N]) or [w_0 | w_1 | ..] (WEIGHT_NT: w_l [N, K_l])."""
+    if kind == WEIGHT_NN:
+        return ws[0].shape[1], sum(m.shape[0] for m in ws)
+    return ws[0].shape[0], sum(m.shape[1] for m in ws)
+
+
+def weight_image_ok(ws, kind: str) -> bool:
+    ws = _weight_matrices(ws)
+    n = ws[0].shape[1] if kind == WEIGHT_NN else ws[0].shape[0]
+    for m in ws:
+        if not (m.is_cuda and m.dtype == torch.float32 and m.dim() == 2 and m.stride(1) == 1 and m.stride(0) % 4 == 0
+                and m.stride(0) >= m.shape[1] and m.data_ptr() % 16 == 0):
+            return False
+        if (m.shape[1] if kind == WEIGHT_NN else m.shape[0]) != n or (m.shape[0] if kind == WEIGHT_NN else m.shape[1]) % 16 != 0:
+            return False
+    return True
+
+
+def _weight_image_items(ws, kind: str, buf: torch.Tensor):
+    """(X, ldx, rows, cols, transpose, out, kt_offset, kt_total) per matrix of the image."""
+    total = _weight_image_shape(ws, kind)[1] // 16
+    items, kt = [], 0
+    for m in ws:
+        items.append((m.data_ptr(), m.stride(0), m.shape[0], m.shape[1], 1 if kind == WEIGHT_NN else 0, buf.data_ptr(), kt, total))
+        kt += (m.shape[0] if kind == WEIGHT_NN else m.shape[1]) // 16
+    return items
+
+
+def _split_weight_images(images) -> None:
+    import ctypes
+    from . import _lib
+    lib = _lib.load_library()
+    items = [it for im in images for it in im.items]
+    n = len(items)
+    cols = list(zip(*items))
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+    _lib.check(lib.relgnn_limb_split_multi_f32(n, vp(*cols[0]), i64(*cols[1]), i32(*cols[2]), i32(*cols[3]), i32(*cols[4]),
+                                               vp(*cols[5]), i32(*cols[6]), i32(*cols[7]), _lib.current_stream()),
+               "relgnn_limb_split_multi_f32")
+
+
+def weight_limbs(w, kind: str) -> torch.Tensor:
+    """The limb image (flat bf16 buffer) of a weight operand as the right operand B [N, K] of relgnn_limb_gemm_xf32; w: a matrix, a
+    [L, ., .] stack or a sequence of matrices (laid side by side along k):
+      WEIGHT_NN  w_l [K_l, N]:  [x_0 | x_1 | ..] @ [w_0; w_1; ..] = sum_l x_l @ w_l     (Dense forward; gnns/rgcn.py:96-98 summed over
+                                                                                          the edge types in one product)
+      WEIGHT_NT  w_l [N, K_l]:  [g_0 | g_1 | ..] @ [w_0 | w_1 | ..]^T = sum_l g_l @ w_l^T   (the input gradients of the same)
+    Valid until the next weights_changed() / in-place write to a matrix; on the current stream."""
+    from . import _lib
+    lib = _lib.load_library()
+    ws = _weight_matrices(w)
+    rows, cols = _weight_image_shape(ws, kind)
+    dev = ws[0].device
+    if torch.cuda.is_current_stream_capturing() or not _WEIGHT_LIMB_CACHE:
+        im = _WeightImage()
+        im.buf = torch.empty(int(lib.relgnn_limb_elements(rows, cols)), dtype=torch.bfloat16, device=dev)
+        im.items = _weight_image_items(ws, kind, im.buf)
+        _split_weight_images([im])
+        return im.buf
+    import weakref
+    table = _WEIGHT_LIMBS.setdefault((dev, torch.cuda.current_stream(dev).cuda_stream), {})
+    key = (kind,) + tuple((m.data_ptr(), m.shape[0], m.shape[1], m.stride(0)) for m in ws)
+    gen = _WEIGHT_GEN[0]
+    im = table.get(key)
+    bases = [m._base if m._base is not None else m for m in ws]
+    if im is not None and any(r() is not b for r, b in zip(im.refs, bases)):
+        im = None                                        # another tensor lives at that address now
+    if im is not None and im.gen == gen and im.versions == [m._version for m in ws]:
+        im.used_gen = gen
+        return im.buf
+    if im is None:
+        im = table[key] = _WeightImage()
+        im.refs, im.gen, im.versions, im.used_gen = [weakref.ref(b) for b in bases], -1, None, gen
+        im.buf = torch.empty(int(lib.relgnn_limb_elements(rows, cols)), dtype=torch.bfloat16, device=dev)
+        im.items = _weight_image_items(ws, kind, im.buf)
+    todo = [im]
+    for k, other in list(table.items()):
+        if other is im:
+            continue
+        alive = [r() for r in other.refs]
+        if any(b is None for b in alive) or other.used_gen < gen - 1:       # gone, or not part of the last step: forget it
+            del table[k]
+        elif other.gen != gen or other.versions != [b._version for b in alive]:
+            todo.append(other)
+    _split_weight_images(todo)
+    for t in todo:
+        t.gen, t.versions = gen, [r()._version for r in t.refs]
+    im.used_gen = gen
+    return im.buf
+
+
+def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, act: int = 0,
+                     out: torch.Tensor = None) -> torch.Tensor:
+    """act(bias + a @ B^T) with B = weight_limbs(w, kind), a fp32 [M, K] split inside the kernel (relgnn_limb_gemm_xf32)."""
+    from . import _lib
+    lib = _lib.load_library()
+    n, k = _weight_image_shape(_weight_matrices(w), kind)
+    if a.shape[1] != k:
+        raise ValueError("limb_gemm_weight: a is [%d, %d], the weight operand has K = %d" % (a.shape[0], a.shape[1], k))
+    buf = weight_limbs(w, kind)
+    if out is None:
+        out = torch.empty((a.shape[0], n), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_limb_gemm_xf32(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
+                                         out.data_ptr(), out.stride(0), a.shape[0], n, k, _lib.current_stream()),
+               "relgnn_limb_gemm_xf32")
+    return out
+
+
+def _limb_group_ok(a: torch.Tensor, ws, kind: str) -> bool:
+    if not (_LIMB_GEMM and _rows_ok(a) and a.shape[0] >= _LIMB_MIN_ROWS and weight_image_ok(ws, kind)):
+        return False
+    n, k = _weight_image_shape(ws, kind)
+    return a.shape[1] == k and n % 256 == 0 and 16 <= k <= _LIMB_MAX_K
+
+
+def grouped_nn_gemm(a: torch.Tensor, kernels, relu: bool = False) -> torch.Tensor:
+    """(relu of) sum_l a[:, block l] @ kernels[l] for a [V, sum_l K_l], kernels[l] [K_l, N]: gnns/rgcn.py:96-98 summed over the
+    edge types in one product (the aggregate-first layer's forward)."""
+    from . import _lib
+    kernels = list(kernels)
+    if _limb_group_ok(a, kernels, WEIGHT_NN):
+        return limb_gemm_weight(a, kernels, WEIGHT_NN, None, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
+    return lib_gemm(GEMM_NN, a, torch.cat(kernels, dim=0) if len(kernels) > 1 else kernels[0], relu=relu)
+
+
+def grouped_nt_gemm(g: torch.Tensor, kernels) -> torch.Tensor:
+    """sum_l g[:, block l] @ kernels[l]^T for g [V, sum_l K_l], kernels[l] [N, K_l]: the input gradient of grouped_nn_gemm's layer
+    (dH = sum_l dT_l @ W_l^T)."""
+    kernels = list(kernels)
+    if _limb_group_ok(g, kernels, WEIGHT_NT):
+        return limb_gemm_weight(g, kernels, WEIGHT_NT)
+    # (the stacked [sum K_l, N] right operand is W_l^T row blocks, 0.8 MB re-laid per call at C2)
+    return lib_gemm(GEMM_NN, g, torch.cat([k.t() for k in kernels], dim=0))
+
+
 def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0,
-               out: torch.Tensor = None) -> torch.Tensor:
+               out: torch.Tensor = None, weight: bool = False) -> torch.Tensor:
     """NN act(bias + a @ b) | NT a @ b^T through relgnn_limb_dense_f32: b (the weights) split into limbs in a per-(device, stream)
     scratch buffer, a split inside the product kernel."""
     from . import _lib
+    if weight:           # b is a parameter (or a view of one): its limbs are kept across the products of a step
+        return limb_gemm_weight(a, b, WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT, bias, act, out)
     lib = _lib.load_library()
     M, K = a.shape
     N = b.shape[1] if layout == GEMM_NN else b.shape[0]
@@ -461,7 +631,7 @@ class _DenseFn(torch.autograd.Function):
     def forward(ctx, x, kernel, bias):
         ctx.save_for_backward(x, kernel)
         ctx.has_bias = bias is not None
-        return lib_gemm(GEMM_NN, x, kernel, bias)
+        return lib_gemm(GEMM_NN, x, kernel, bias, weight=True)
 
     @staticmethod
     def backward(ctx, g):
@@ -471,7 +641,9 @@ class _DenseFn(torch.autograd.Function):
         gx = None                          # read in place: every consumer below takes a leading dimension; an expanded one,
                                            # strides (0, 1), is materialised)
         if ctx.needs_input_grad[0]:
-            gx = lib_gemm(GEMM_NT, g, kernel)
+            gx = lib_gemm(GEMM_NT, g, kernel, weight=True)
+        # (the weight gradient on a side stream next to the input gradient, as ops._AggregateThenTransform does with its gather, was
+        # measured and lost: both are matrix-pipe kernels, 2.02 vs 1.94 ms per C2 step)
         gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), g) \
             if ctx.needs_input_grad[1] else None
         gb = None
@@ -491,7 +663,7 @@ class _DenseReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kernel, bias):
-        y = lib_gemm(GEMM_NN, x, kernel, bias, relu=True)
+        y = lib_gemm(GEMM_NN, x, kernel, bias, relu=True, weight=True)
         ctx.save_for_backward(x, kernel, y)
         ctx.has_bias = bias is not None
         return y
@@ -505,7 +677,7 @@ class _DenseReluFn(torch.autograd.Function):
         _lib.check(_lib.load_library().relgnn_act_bwd_from_output(_lib.ACT_RELU, _lib.ptr(y), _lib.ptr(g), g.numel(),
                                                                   _lib.ptr(gm), _lib.current_stream()),
                    "relgnn_act_bwd_from_output")
-        gx = lib_gemm(GEMM_NT, gm, kernel) if ctx.needs_input_grad[0] else None
+        gx = lib_gemm(GEMM_NT, gm, kernel, weight=True) if ctx.needs_input_grad[0] else None
         gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), gm) \
             if ctx.needs_input_grad[1] else None
         gb = column_sum(gm) if ctx.has_bias and ctx.needs_input_grad[2] else None

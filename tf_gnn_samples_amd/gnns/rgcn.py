@@ -75,9 +75,9 @@ def sparse_rgcn_layer(node_embeddings: torch.Tensor,
         return cur_node_states
     if (not use_both_source_and_target and aggregate_first_enabled() and mode != _lib.AGG_MAX and act in ops._FUSABLE_ACTS
             and in_dim % 4 == 0 and state_dim % 4 == 0):
-        w_stack = torch.stack([weights["Edge_%i_Weight/kernel" % l] for l in range(L)], dim=0)   # [L, D, state_dim]
+        kernels = [weights["Edge_%i_Weight/kernel" % l] for l in range(L)]                       # L x [D, state_dim]
         for _ in range(num_timesteps):
-            cur_node_states = ops.aggregate_then_transform(cur_node_states, w_stack, graph, w,
+            cur_node_states = ops.aggregate_then_transform(cur_node_states, kernels, graph, w,
                                                            message_aggregation_function, activation_function)
         return cur_node_states
     if not use_both_source_and_target:

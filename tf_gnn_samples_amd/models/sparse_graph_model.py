@@ -100,6 +100,8 @@ class TFStyleOptimizer:
             else:
                 _lib.check(lib.relgnn_mt_adam_clip(h_p, h_g, h_m, h_v, h_n, n, _lib.ptr(norms), float(self.clip), lr_t,
                                                    b1, b2, eps, st), "relgnn_mt_adam_clip")
+        from ..dense import weights_changed
+        weights_changed()                  # (written through raw pointers: the tensors' version counters did not move)
 
     def _device_state(self):
         """[steps taken, lr_t] in device memory, seeded from the host step count."""
@@ -289,6 +291,8 @@ class CapturedTrainStep:
         if opt.t != self._expected_t:
             opt.sync_device_step_count()
         self.graph.replay()
+        from ..dense import weights_changed
+        weights_changed()                  # the replayed update rewrote the parameters: limb images kept by eager code are stale
         opt.t += 1
         self._expected_t = opt.t
         return self.metrics

@@ -790,16 +790,17 @@ class _AggregateThenTransform(torch.autograd.Function):
     dW_l = A_l^T @ dOut from the saved aggregated rows."""
 
     @staticmethod
-    def forward(ctx, H, W, graph, w, mode: int, act: int, act_name):
-        from .dense import GEMM_NN, lib_gemm
-        H, W = H.contiguous(), W.contiguous()
-        L, d_in, d_out = W.shape
+    def forward(ctx, H, graph, w, mode: int, act: int, act_name, *kernels):
+        from .dense import grouped_nn_gemm
+        H = H.contiguous()
+        L = len(kernels)                                # kernels[l]: [Din, Dout], the per-edge-type variables themselves
+        d_in, d_out = kernels[0].shape
         V = graph.V
         agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
                               acc64=aggregate_acc64()).view(V, L * d_in)
         f = _mode_factor(graph, mode)
-        fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the library GEMM's epilogue
-        out = lib_gemm(GEMM_NN, agg, W.view(L * d_in, d_out), relu=fused_relu)
+        fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the product's epilogue
+        out = grouped_nn_gemm(agg, kernels, relu=fused_relu)
         if f is not None:
             out.mul_(f.unsqueeze(1))
         if act == _lib.ACT_RELU:
@@ -810,17 +811,18 @@ class _AggregateThenTransform(torch.autograd.Function):
         elif act != _lib.ACT_LINEAR:
             from .utils import apply_activation, get_activation
             out = apply_activation(get_activation(act_name), out)
-        ctx.graph, ctx.w, ctx.mode, ctx.act = graph, w, mode, act
-        ctx.save_for_backward(W, agg if W.requires_grad else None, out if act != _lib.ACT_LINEAR else None)
+        ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L = graph, w, mode, act, L
+        want_w = any(k.requires_grad for k in kernels)
+        ctx.save_for_backward(agg if want_w else None, out if act != _lib.ACT_LINEAR else None, *kernels)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        from .dense import GEMM_NN, lib_gemm, matmul_tn_splitk
+        from .dense import grouped_nt_gemm, matmul_tn_splitk
         lib = _lib.load_library()
-        graph, w, mode, act = ctx.graph, ctx.w, ctx.mode, ctx.act
-        W, agg, out = ctx.saved_tensors
-        L, d_in, d_out = W.shape
+        graph, w, mode, act, L = ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L
+        agg, out, *kernels = ctx.saved_tensors
+        d_in, d_out = kernels[0].shape
         V = graph.V
         gout = gout.contiguous()
         if act != _lib.ACT_LINEAR:
@@ -829,41 +831,45 @@ class _AggregateThenTransform(torch.autograd.Function):
                                                       _lib.current_stream()), "relgnn_act_bwd_from_output")
             gout = g
         gH = gW = None
+        want_w = any(ctx.needs_input_grad[6:])
         # The weight gradient (matrix-pipe bound, one workgroup per CU, 147 KB of LDS, no L2 pressure) does not depend on the input
         # gradient's gather (L2-latency bound, no LDS, few registers): it runs on a side stream next to it (fork / join by events,
         # capturable in a hipGraph; the result is the same bits, the kernels are the same).
         side = None
-        if ctx.needs_input_grad[1] and ctx.needs_input_grad[0] and _BWD_OVERLAP and gout.is_cuda:
+        if want_w and ctx.needs_input_grad[0] and _BWD_OVERLAP and gout.is_cuda:
             side = _side_stream(gout.device)
             cur = torch.cuda.current_stream(gout.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 f = _mode_factor(graph, mode)
                 gsc = gout if f is None else gout * f.unsqueeze(1)
-                gW = matmul_tn_splitk(agg, gsc).view(L, d_in, d_out)
+                gW = matmul_tn_splitk(agg, gsc)
             for t in (agg, gout, gsc):
                 t.record_stream(side)
         if ctx.needs_input_grad[0]:
             plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
             gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
                                  plan.num_rows_x, acc64=aggregate_acc64()).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
-            # (dH = sum_l dT_l @ W_l^T: the stacked [L*Dout, Din] right operand is W_l^T row blocks, 0.8 MB re-laid per step)
-            gH = lib_gemm(GEMM_NN, gT, W.permute(0, 2, 1).reshape(L * d_out, d_in))
+            gH = grouped_nt_gemm(gT, kernels)           # dH = sum_l dT_l @ W_l^T
         if side is not None:
             torch.cuda.current_stream(gout.device).wait_stream(side)
             gW.record_stream(torch.cuda.current_stream(gout.device))
-        elif ctx.needs_input_grad[1]:
+        elif want_w:
             f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
             gsc = gout if f is None else gout * f.unsqueeze(1)
-            gW = matmul_tn_splitk(agg, gsc).view(L, d_in, d_out)
-        return gH, gW, None, None, None, None, None
+            gW = matmul_tn_splitk(agg, gsc)
+        gWs = tuple(gW[l * d_in:(l + 1) * d_in] if ctx.needs_input_grad[6 + l] else None for l in range(L)) \
+            if gW is not None else (None,) * L           # dW_l = A_l^T @ dOut: row block l of [L*Din, Dout]
+        return (gH, None, None, None, None, None) + gWs
 
 
 def aggregate_then_transform(H, W, graph, w, aggregation: str, activation: Optional[str]):
     mode, act = aggregation_mode_id(aggregation), activation_id(activation)
     if mode == _lib.AGG_MAX or act not in _FUSABLE_ACTS:
         raise ValueError("aggregate_then_transform: max aggregation / %r do not apply" % activation)
-    return _AggregateThenTransform.apply(H, W, graph, w, mode, act, activation)
+    # W: the per-edge-type kernels [Din, Dout] (a sequence: the variables themselves — nothing is stacked) or one [L, Din, Dout] tensor
+    kernels = W.unbind(0) if torch.is_tensor(W) else tuple(W)
+    return _AggregateThenTransform.apply(H, graph, w, mode, act, activation, *kernels)
 
 
 # ---- RGDCN dynamic kernels applied node-side (csrc/rgdcn.hip) --------------------------------------------------------
