@@ -88,15 +88,18 @@ def test_hub_speedup(gpu_device):
 
     def t(g):
         plan = g.plan_untransformed(None)
-        for _ in range(2):
+        for _ in range(3):
             ops.seg_gather_reduce(X, plan, "sum", None)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(5):
-            out = ops.seg_gather_reduce(X, plan, "sum", None)
-        b.record(); torch.cuda.synchronize()
-        return a.elapsed_time(b) / 5, out
+        best = float("inf")
+        for _ in range(4):                      # best of four rounds: one allocator / clock hiccup must not decide a test
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                out = ops.seg_gather_reduce(X, plan, "sum", None)
+            b.record(); torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) / 5)
+        return best, out
     ts, a = t(split)
     tp, b = t(plain)
     assert torch.allclose(a, b, rtol=1e-4, atol=0.5)
