@@ -176,7 +176,7 @@ def test_limb_dense_sel_gathered_rows_and_per_tile_weights(gpu_device, layout, D
     """The typed transform Y[r] = H[node[r]] @ W_type(tile(r)) and its input gradient dX[r] = dY[r] @ W_type^T: 512-row tiles, 23
     kernels, padding rows (-1), against float64 and against relgnn_panel_gemm_f32 (exact fp32) on the same operands."""
     from tf_gnn_samples_amd import dense as DN
-    L, tiles, V = 23, 37, 5000
+    L, tiles, V = 23, 71, 5000
     g = torch.Generator(device="cpu").manual_seed(Din + Dout)
     tile_type = torch.sort(torch.randint(0, L, (tiles,), generator=g)).values.to(torch.int32).to(gpu_device)
     P = tiles * 512
@@ -306,3 +306,28 @@ def test_training_steps_with_and_without_the_weight_limb_cache(gpu_device):
     for a, b in zip(*results):
         assert torch.equal(a, b)
     DN._WEIGHT_LIMBS.clear()
+
+
+@pytest.mark.parametrize("rps,tiles,last", [(128, 300, 128), (256, 140, 200), (384, 90, 1), (512, 70, 300), (512, 65, 512)])
+def test_limb_dense_sel_tile_sizes_and_ragged_last_tile(gpu_device, rps, tiles, last):
+    """K = 128 and >= 32 k rows take the persistent weights-resident form (runs of 128-row panels per workgroup, the weights
+    replaced where the select tile's type changes): every tile height, unsorted types, a last tile that is cut short, rows of
+    zeros; against float64 and against relgnn_panel_gemm_f32 (exact fp32) where that kernel takes the tile height."""
+    from tf_gnn_samples_amd import dense as DN
+    L, V = 7, 3000
+    g = torch.Generator(device="cpu").manual_seed(rps)
+    M = (tiles - 1) * rps + last
+    tile_type = torch.randint(0, L, (tiles,), generator=g).to(torch.int32).to(gpu_device)
+    W = _rand((L, 128, 256), gpu_device, 5, 0.1)
+    H = _rand((V, 128), gpu_device, 6)
+    node = torch.randint(0, V, (M,), generator=g).to(torch.int32)
+    node[torch.rand(M, generator=g) < 0.1] = -1
+    node = node.to(gpu_device)
+    out = DN.limb_dense_sel(DN.GEMM_NN, H, W, a_rows=node, num_rows=M, b_select=tile_type, rows_per_select=rps)
+    Hg = torch.where((node >= 0).unsqueeze(1), H[node.clamp(min=0).long()], torch.zeros((), device=gpu_device)).double()
+    sel = tile_type.long().repeat_interleave(rps)[:M]
+    truth = torch.einsum("rk,rkn->rn", Hg, W.double()[sel])
+    assert float((out.double() - truth).abs().max()) <= 2e-6 * max(1.0, float(truth.abs().max()))
+    if rps == 512 and last == 512:
+        ref = DN.panel_gemm(DN.GEMM_NN, H, W, a_rows=node, num_rows=M, b_select=tile_type, rows_per_select=rps)
+        assert float((out - ref).abs().max()) <= 4e-6 * max(1.0, float(truth.abs().max()))

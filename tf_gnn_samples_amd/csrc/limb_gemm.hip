@@ -43,6 +43,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BK = 16;
 constexpr int STAGES = 4;
 #ifdef RELGNN_LIMB_TIMING
+__device__ unsigned long long* g_limb_timing_dev = nullptr;
 unsigned long long* g_limb_timing = nullptr;   // diagnostic build: per-wave cycle totals of the k-loop's segments
 #define TSTAMP(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
 #else
@@ -589,6 +590,233 @@ __global__ __launch_bounds__(512, 2) void limb_gemm_sel_kernel(const LimbSelArgs
   }
 }
 
+// ---- K = 128 with the weights RESIDENT in LDS: persistent workgroups over runs of 128-row panels --------------------------------
+// The per-(node, type) transforms of the many-type models (gnns/gnn_film.py:92-106) are K = 128 products over ~1e6 gathered rows: in
+// limb_gemm_sel_kernel every 128-row panel fetched its 96 KB of weight limbs again (more than its 64 KB of rows or its 64 KB of
+// results) behind a cold pipeline of 8 k-tiles.  Here one workgroup per CU owns a contiguous run of panels of one 128-column chunk:
+// the 8 x 12 KB of weight limbs stay in LDS until the edge type of the select tile changes (the tiles are sorted by type); the rows
+// stream through a 4-stage ring that never drains — all 512 threads gather (one 32-byte chunk per 32 k, a panel ahead, in four
+// register sets; the row ids two panels ahead) and split; the stores of panel p leave while panel p+1 is multiplied.
+// 160 KB of LDS, one workgroup per CU.
+constexpr int TILE_RING = 4;
+
+__global__ __launch_bounds__(512) void limb_gemm_tile_kernel(const LimbSelArgs a) {
+  constexpr int TW = 2, PR = 128, NC = 128, KT = 8;
+  constexpr int PA = 12, WB = 12;                      // 1 KiB blocks per k-tile: rows 4 x 3 limbs, weights 4 x 3 limbs
+  constexpr int W_BYTES = KT * WB * 1024, STAGE_BYTES = PA * 1024;
+  constexpr int OUT_BYTES = 8 * 2048;                  // per wave: 16 result rows x 128 B on their way out
+  __shared__ __attribute__((aligned(16))) unsigned char lds[W_BYTES + TILE_RING * STAGE_BYTES + OUT_BYTES];
+  unsigned char* const ring = lds + W_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  TSTAMP(t_begin);
+  const int64_t lb = xcd_logical_block((int64_t)a.panels * a.chunks);      // panels: workgroups per column chunk here
+  if (lb < 0) return;
+  const int g = (int)(lb / a.chunks), chunk = (int)(lb % a.chunks);
+  const int all = (a.M + PR - 1) / PR;                // 128-row panels of the product
+  const int base = all / a.panels, rem = all % a.panels;
+  const int p0 = g * base + min(g, rem), np = base + (g < rem ? 1 : 0);     // my run of panels
+  if (np == 0) return;
+  const int n0 = chunk * NC;
+  auto type_of = [&](int p) { return a.b_select ? a.b_select[((p0 + p) * PR) / a.rows_per_select] : 0; };
+
+  // ---- the weights: 96 blocks, 12 per wave --------------------------------------------------------------------------------
+  constexpr int TILE = 3 * 512;
+  auto load_w = [&](int type) {
+    const uint16_t* Bp = a.B + (int64_t)type * a.b_stride;
+#pragma unroll
+    for (int gq = 0; gq < KT * WB / 8; ++gq) {
+      const int i = wave + 8 * gq, kt = i / WB, cb = i % WB;
+      dma16(Bp + ((int64_t)(n0 / 32 + cb / 3) * KT + kt) * TILE + (cb % 3) * 512 + 8 * lane, lds + i * 1024);
+    }
+  };
+  int type_cur = type_of(0);
+  load_w(type_cur);
+
+  // ---- the rows: thread = (row xr of the panel, chunk c4 of a 32-k super-tile) ------------------------------------------------
+  // (consecutive lanes = consecutive rows: the limb stores of 8 lanes are 128 contiguous bytes, conflict-free; four lanes per row —
+  //  one 128-byte line per quad — loaded no faster and cost 4-way conflicts on those stores)
+  const int xr = tid & 127, c4 = tid >> 7;
+  auto row_id = [&](int p) -> int64_t {               // the table row behind my row of panel p; < 0: a row of zeros
+    const int r = (p0 + min(p, np - 1)) * PR + xr;
+    int64_t row = a.rows ? (int64_t)a.rows[min(r, a.M - 1)] : (int64_t)r;
+    return (p < np && r < a.M) ? row : -1;
+  };
+  auto row_ptr = [&](int64_t id) -> const float* { return id >= 0 ? a.Ax + id * a.lda + 8 * c4 : nullptr; };
+  // k-tile 2j + (c4 >> 1) of a panel lives in ring stage (2j + (c4 >> 1)) % 4 (8 k-tiles per panel: the same stage in every panel)
+  const int xblock = (3 * (xr >> 5)) * 1024 + (c4 & 1) * 512 + (xr & 31) * 16;
+  f32x4 xv[4][2];                                     // super-tile j of a panel in flight
+  auto x_load = [&](f32x4 (&v)[2], const float* rp, int j) {      // (every thread, no branch)
+    const float* p = rp ? rp + 32 * j : reinterpret_cast<const float*>(a.zeros);
+    v[0] = *reinterpret_cast<const f32x4*>(p);
+    v[1] = *reinterpret_cast<const f32x4*>(p + 4);
+  };
+  auto x_split = [&](const f32x4 (&v)[2], bool ok, int j) {
+    float z[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { z[i] = ok ? v[0][i] : 0.f; z[4 + i] = ok ? v[1][i] : 0.f; }
+    uint4 h, m, l;
+    split8(z, h, m, l);
+    unsigned char* p = ring + ((2 * j + (c4 >> 1)) % TILE_RING) * STAGE_BYTES + xblock;
+    *reinterpret_cast<uint4*>(p) = h;
+    *reinterpret_cast<uint4*>(p + 1024) = m;
+    *reinterpret_cast<uint4*>(p + 2048) = l;
+  };
+
+  struct Limbs { bf16x8 hi, mid, lo; };
+  auto read3 = [&](const unsigned char* p) {
+    Limbs f;
+    f.hi = *reinterpret_cast<const bf16x8*>(p);
+    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    return f;
+  };
+  auto read_w = [&](int kt) { return read3(lds + (kt * WB + 3 * wn) * 1024 + 16 * lane); };
+  auto read_x = [&](int kt, int tm) { return read3(ring + (kt % TILE_RING) * STAGE_BYTES + (3 * (wm * TW + tm)) * 1024 + 16 * lane); };
+  f32x16 acc[TW];
+#pragma unroll
+  for (int tm = 0; tm < TW; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+  const int i32 = lane & 31, h32 = lane >> 5;
+  const int colw = n0 + wn * 32;
+  const bool plain_out = !a.bias && a.act == RELGNN_ACT_LINEAR;
+  auto finish = [&](f32x4 v, int col) {
+    if (plain_out) return v;
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+    if (a.act != RELGNN_ACT_LINEAR) {
+      v[0] = act_rt(a.act, v[0]); v[1] = act_rt(a.act, v[1]); v[2] = act_rt(a.act, v[2]); v[3] = act_rt(a.act, v[3]);
+    }
+    return v;
+  };
+  // A lane of the 32 x 32 result holds 4 x 16 bytes of ONE row (columns 8c + 4h ..): stored directly, every 128-byte line of C is
+  // written as four 32-byte pieces by four instructions.  Each wave turns its tile through 2 KB of LDS (16 rows at a time, 16-byte
+  // slots XOR-swizzled by the row) so that 8 consecutive lanes write one whole line.
+  unsigned char* const obuf = lds + W_BYTES + TILE_RING * STAGE_BYTES + wave * 2048;
+  auto store_panel = [&](int p) __attribute__((always_inline)) {
+    const int m0 = (p0 + p) * PR;
+#pragma unroll
+    for (int tm = 0; tm < TW; ++tm) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if ((i32 >> 4) == half) {
+          const int rr = i32 & 15;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int col = colw + 8 * c + 4 * h32;
+            const f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+            *reinterpret_cast<f32x4*>(obuf + rr * 128 + (((2 * c + h32) ^ (rr & 7)) << 4)) = finish(v, col);
+          }
+        }
+        wait_lgkm0();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int rr = (lane >> 3) + 8 * k, p8 = lane & 7;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(obuf + rr * 128 + ((p8 ^ (rr & 7)) << 4));
+          const int r = m0 + (wm * TW + tm) * 32 + 16 * half + rr;
+          if (r < a.M) *reinterpret_cast<f32x4*>(a.C + (int64_t)r * a.ldc + colw + 4 * p8) = v;
+        }
+        wait_lgkm0();                                  // (the reads are done before the next half overwrites the slots)
+      }
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) acc[tm][r16] = 0.f;
+    }
+  };
+
+  // ---- prologue: panel 0's four super-tiles in flight, super-tile 0 split; row pointers one panel, row ids two panels ahead ------
+  const int64_t id0 = row_id(0);
+  int64_t id_nxt = row_id(1), id_nn = row_id(2);
+  const float* const ptr0 = row_ptr(id0);
+  bool ok_cur = id0 >= 0;
+  x_load(xv[0], ptr0, 0);
+  x_load(xv[1], ptr0, 1);
+  x_load(xv[2], ptr0, 2);
+  x_load(xv[3], ptr0, 3);
+  x_split(xv[0], ok_cur, 0);
+  wait_vm<0>();                                       // the weights have landed (and the rest of panel 0, needed next anyway)
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+#ifdef RELGNN_LIMB_TIMING
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  TSTAMP(t_pro);
+  seg[0] = t_pro - t_begin;
+#endif
+
+  // Super-tile j of panel p (k-tiles 2j, 2j+1 in ring stages 2j % 4, (2j+1) % 4): ONE barrier per 32 k.  While its 24 products run
+  // (the two row tiles alternate, so that no MFMA waits for the one before it), super-tile j+1 (of the next panel when j = 3) is
+  // split from its register set into the other two stages — they were read one super-tile ago, before the last barrier — and
+  // set j, split one super-tile ago, is reloaded for the next panel (three super-tiles, 48 KB per CU, ahead of its split; a lead of
+  // seven super-tiles in eight register sets only lengthened the queues in front of the stores: 259 vs 227 us).
+  auto two = [&](const Limbs& w, const Limbs& xa, const Limbs& xb) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xa.lo, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xb.lo, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, xa.hi, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, xb.hi, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, xa.mid, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, xb.mid, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xa.mid, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xb.mid, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, xa.hi, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, xb.hi, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xa.hi, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xb.hi, acc[1], 0, 0, 0);
+  };
+  for (int p = 0; p < np; ++p) {
+    const float* const ptr_nxt = row_ptr(id_nxt);
+    const bool ok_nxt = id_nxt >= 0;
+    const int64_t id_n3 = row_id(p + 3);              // (needed two panels from now)
+    auto supertile = [&](auto j_c) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_c)::value;
+      constexpr int jn = (j + 1) % 4;
+      TSTAMP(q0);
+      const Limbs wa = read_w(2 * j), xa0 = read_x(2 * j, 0), xa1 = read_x(2 * j, 1);
+      x_split(xv[jn], j == 3 ? ok_nxt : ok_cur, jn);  // (past the last panel: zeros that nobody reads)
+      TSTAMP(q1);
+      x_load(xv[j], ptr_nxt, j);
+      const Limbs wb = read_w(2 * j + 1), xb0 = read_x(2 * j + 1, 0), xb1 = read_x(2 * j + 1, 1);
+      two(wa, xa0, xa1);
+      two(wb, xb0, xb1);
+      TSTAMP(q2);
+      if constexpr (j == 3) store_panel(p);
+      TSTAMP(q3);
+      wait_lgkm0();
+      TSTAMP(q4);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef RELGNN_LIMB_TIMING
+      { TSTAMP(q5); seg[1] += q1 - q0; seg[2] += q2 - q1; seg[3] += q3 - q2; seg[4] += q4 - q3; seg[5] += q5 - q4; }
+#endif
+    };
+    supertile(std::integral_constant<int, 0>{});
+    supertile(std::integral_constant<int, 1>{});
+    supertile(std::integral_constant<int, 2>{});
+    supertile(std::integral_constant<int, 3>{});
+    ok_cur = ok_nxt;
+    id_nxt = id_nn;
+    id_nn = id_n3;
+    if (p + 1 < np) {                                  // the next panel belongs to another edge type: its weights replace these
+      const int t = type_of(p + 1);
+      if (t != type_cur) {                             // (every wave is past the barrier behind the last product of panel p)
+        type_cur = t;
+        load_w(t);
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#ifdef RELGNN_LIMB_TIMING
+  if (g_limb_timing_dev && lane == 0 && lb < 64) {
+    TSTAMP(t_end);
+    seg[6] = t_end - t_begin; seg[7] = np;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_limb_timing_dev[(lb * 8 + wave) * 8 + i] = seg[i];
+  }
+#endif
+}
+
 // ---- weight gradients: P[z] = A[rows of chunk z]^T @ G[rows of chunk z] ------------------------------------------------------
 // dW = A^T G for A [V, J], G [V, 256 c] (both fp32 row-major: the reduction index is the ROW of both).  Same matrix-pipe core,
 // same LDS blocks, but both operands are split in flight and TRANSPOSED on the way: a thread loads a 4-column x 8-row patch
@@ -912,7 +1140,10 @@ int dispatch_limb(LimbArgs a, hipStream_t st) {
 extern "C" {
 
 #ifdef RELGNN_LIMB_TIMING
-void relgnn_limb_timing_buffer(unsigned long long* p) { g_limb_timing = p; }
+void relgnn_limb_timing_buffer(unsigned long long* p) {
+  g_limb_timing = p;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_limb_timing_dev), &p, sizeof(p));
+}
 #endif
 
 int64_t relgnn_limb_elements(int64_t rows, int64_t cols) { return ((rows + 31) / 32) * (cols / 16) * 1536; }
@@ -1072,6 +1303,16 @@ int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64
   a.Ax = A; a.lda = lda; a.rows = a_rows; a.B = limb_ws; a.b_select = b_select; a.rows_per_select = rows_per_select; a.b_stride = per;
   a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
   a.chunks = N / 128;
+  // K = 128, tall: persistent workgroups with the weights resident in LDS (limb_gemm_tile_kernel), one per CU
+  static const bool tile_form = []() { const char* e = getenv("RELGNN_LIMB_TILE"); return !(e && e[0] == '0'); }();
+  // (typed products — large by construction; a plain product needs ~4 panels per workgroup before this form pays: measured)
+  if (tile_form && K == 128 && M >= 128 * 256 && (b_select || (int64_t)M * a.chunks >= (int64_t)128 * 256 * 4)) {
+    if (!b_select) a.rows_per_select = 128;
+    a.panels = 256 / a.chunks > 0 ? 256 / a.chunks : 1;          // workgroups per column chunk
+    const int64_t logical = (int64_t)a.panels * a.chunks;
+    limb_gemm_tile_kernel<<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, as_stream(stream)>>>(a);
+    return launch_status();
+  }
   a.panels = (M + 127) / 128;
   const int64_t logical = (int64_t)a.panels * a.chunks;
   limb_gemm_sel_kernel<<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, as_stream(stream)>>>(a);
