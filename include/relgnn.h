@@ -766,7 +766,10 @@ int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16
  *                       each); rows [p * rows_per_select, (p+1) * rows_per_select) of the output use matrix b_select[p]
  *                       (rows_per_select % 128 == 0); without b_select num_b must be 1
  *   limb_ws             >= num_b * relgnn_limb_elements(N, K) bf16 elements of device scratch (all matrices are split first)
- * Requirements (RELGNN_EUNSUPPORTED otherwise): N % 128 == 0, K % 16 == 0, 16-byte aligned rows. */
+ * Requirements (RELGNN_EUNSUPPORTED otherwise): K % 16 == 0, 16-byte aligned rows of A; N % 128 == 0 and 16-byte aligned rows of C,
+ * or (num_b == 1, no b_select) any N and ldc >= N: the last 128-column chunk is cut at N when it is stored (the [V, 121] logits of the
+ * PPI head, tasks/ppi_task.py:165-178); limb_ws then holds relgnn_limb_elements(N rounded up to 128, K) elements.
+ * K = 128 and >= 32 k rows: persistent workgroups with the weights resident in LDS (see csrc/limb_gemm.hip). */
 int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const float* B,
                               int64_t ldb, int32_t num_b, int64_t b_batch_stride, const int32_t* b_select, int32_t rows_per_select,
                               const float* bias, const void* zeros, uint16_t* limb_ws, int64_t limb_ws_elements, float* C,

@@ -331,3 +331,32 @@ def test_limb_dense_sel_tile_sizes_and_ragged_last_tile(gpu_device, rps, tiles, 
     if rps == 512 and last == 512:
         ref = DN.panel_gemm(DN.GEMM_NN, H, W, a_rows=node, num_rows=M, b_select=tile_type, rows_per_select=rps)
         assert float((out - ref).abs().max()) <= 4e-6 * max(1.0, float(truth.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K,bias,act", [(9000, 121, 256, True, "linear"), (5000, 250, 64, False, "tanh"), (4100, 97, 128, True, "relu"),
+                                            (40000, 121, 128, True, "linear")])
+def test_limb_dense_sel_cut_last_chunk(gpu_device, M, N, K, bias, act):
+    """N that is not a multiple of 128 (the 121 labels of the PPI head): the last chunk is cut at N, rows of C are not 16-byte
+    aligned; nothing is written past a row's N columns."""
+    from tf_gnn_samples_amd import _lib, dense as DN
+    a = _rand((M, K), gpu_device, M + N)
+    W = _rand((K, N), gpu_device, N + 1, 0.1)
+    b = _rand((N,), gpu_device, 3) if bias else None
+    code = {"linear": _lib.ACT_LINEAR, "tanh": _lib.ACT_TANH, "relu": _lib.ACT_RELU}[act]
+    out = DN.limb_dense_sel(DN.GEMM_NN, a, W, b, code)
+    assert out.shape == (M, N) and out.is_contiguous()
+    z = a.double() @ W.double() + (b.double() if bias else 0.0)
+    truth = {"linear": z, "tanh": torch.tanh(z), "relu": torch.relu(z)}[act]
+    z32 = a @ W + (b if bias else 0.0)
+    f32 = {"linear": z32, "tanh": torch.tanh(z32), "relu": torch.relu(z32)}[act]
+    e, e32 = float((out.double() - truth).abs().max()), float((f32.double() - truth).abs().max())
+    assert e <= max(3.0 * e32, 8e-7 * max(1.0, float(truth.abs().max()))), (e, e32)
+    # the route the Dense layers take, and its gradients through the library routes
+    if act == "linear" and N == 121:
+        x = a.clone().requires_grad_(True)
+        k = W.clone().requires_grad_(True)
+        bb = b.clone().requires_grad_(True)
+        y = DN.dense(x, k, bb)
+        assert torch.equal(y, out)
+        y.backward(torch.ones_like(y))
+        assert float((x.grad.double() - W.double().sum(1)).abs().max()) < 1e-4

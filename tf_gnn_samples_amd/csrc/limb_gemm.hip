@@ -411,6 +411,7 @@ struct LimbSelArgs {
   const float* bias; const uint16_t* zeros; float* C; int64_t ldc;
   int32_t M, N, K, act;
   int32_t panels, chunks;
+  int32_t n_valid;                     // columns that exist in C (<= N = chunks * 128: the last chunk may be cut, e.g. 121 labels)
 };
 
 __global__ __launch_bounds__(512, 2) void limb_gemm_sel_kernel(const LimbSelArgs a) {
@@ -575,16 +576,46 @@ __global__ __launch_bounds__(512, 2) void limb_gemm_sel_kernel(const LimbSelArgs
     }
     return v;
   };
+  if (a.n_valid == a.N && a.ldc % 4 == 0) {
 #pragma unroll
-  for (int tm = 0; tm < TW; ++tm) {
-    const int r = (wm * TW + tm) * 32 + i32;
-    if (r < rows_here) {
-      float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
+    for (int tm = 0; tm < TW; ++tm) {
+      const int r = (wm * TW + tm) * 32 + i32;
+      if (r < rows_here) {
+        float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int col = colw + 8 * c + 4 * h32;
-        const f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
-        *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
+        for (int c = 0; c < 4; ++c) {
+          const int col = colw + 8 * c + 4 * h32;
+          const f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+          *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
+        }
+      }
+    }
+  } else {
+    // a cut last chunk and / or rows that are not 16-byte aligned (the [V, 121] logits of the PPI head): element by element
+#pragma unroll
+    for (int tm = 0; tm < TW; ++tm) {
+      const int r = (wm * TW + tm) * 32 + i32;
+      if (r < rows_here) {
+        float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int col0 = colw + 8 * c + 4 * h32;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[tm][4 * c + e];
+            if (a.bias && col0 + e < a.n_valid) v[e] += a.bias[col0 + e];
+            if (a.act != RELGNN_ACT_LINEAR) v[e] = act_rt(a.act, v[e]);
+          }
+          if (col0 + 3 < a.n_valid) {                 // (4-byte aligned 16-byte store: global memory takes it)
+            typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+            *reinterpret_cast<f32x4_u*>(crow + col0) = f32x4_u{v[0], v[1], v[2], v[3]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col0 + e < a.n_valid) crow[col0 + e] = v[e];
+          }
+        }
       }
     }
   }
@@ -1288,25 +1319,30 @@ int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64
   if (M < 0 || N < 0 || K < 0 || num_b < 1 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
   if (M == 0 || N == 0) return RELGNN_OK;
   if (!A || !B || !C || !limb_ws || !zeros) return RELGNN_EINVAL;
-  if (K == 0 || K % BK != 0 || N % 128 != 0) return RELGNN_EUNSUPPORTED;
-  if (!aligned16(A) || !aligned16(B) || !aligned16(C) || !aligned16(zeros) || (bias && !aligned16(bias)) || ldc % 4 || ldc < N ||
-      lda % 4 || lda < K)
-    return RELGNN_EUNSUPPORTED;
+  if (K == 0 || K % BK != 0) return RELGNN_EUNSUPPORTED;
+  // N % 128 != 0 (one weight matrix only): the last 128-column chunk is cut at N when it is stored; C rows need no alignment then
+  const bool cut = N % 128 != 0 || ldc % 4 != 0;
+  const int32_t n_valid = N;
+  N = (N + 127) / 128 * 128;
+  if (cut && (b_select || num_b != 1)) return RELGNN_EUNSUPPORTED;
+  if (!aligned16(A) || !aligned16(B) || !aligned16(zeros) || ldc < n_valid || lda % 4 || lda < K) return RELGNN_EUNSUPPORTED;
+  if (!cut && (!aligned16(C) || (bias && !aligned16(bias)))) return RELGNN_EUNSUPPORTED;
   if (b_select && (rows_per_select <= 0 || rows_per_select % 128 != 0)) return RELGNN_EINVAL;
   if (!b_select && num_b != 1) return RELGNN_EINVAL;
-  const int64_t per = relgnn_limb_elements(N, K);
+  const int64_t per = relgnn_limb_elements(N, K);      // (row blocks past ceil(n_valid / 32) are never written: they only feed columns that are not stored)
   if (limb_ws_elements < per * num_b) return RELGNN_EINVAL;
-  const int sp = layout == RELGNN_GEMM_NN ? relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, K, N, 1, num_b, limb_ws, stream)
-                                          : relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, N, K, 0, num_b, limb_ws, stream);
+  const int sp = layout == RELGNN_GEMM_NN ? relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, K, n_valid, 1, num_b, limb_ws, stream)
+                                          : relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, n_valid, K, 0, num_b, limb_ws, stream);
   if (sp != RELGNN_OK) return sp;
   LimbSelArgs a{};
+  a.n_valid = n_valid;
   a.Ax = A; a.lda = lda; a.rows = a_rows; a.B = limb_ws; a.b_select = b_select; a.rows_per_select = rows_per_select; a.b_stride = per;
   a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
   a.chunks = N / 128;
   // K = 128, tall: persistent workgroups with the weights resident in LDS (limb_gemm_tile_kernel), one per CU
   static const bool tile_form = []() { const char* e = getenv("RELGNN_LIMB_TILE"); return !(e && e[0] == '0'); }();
   // (typed products — large by construction; a plain product needs ~4 panels per workgroup before this form pays: measured)
-  if (tile_form && K == 128 && M >= 128 * 256 && (b_select || (int64_t)M * a.chunks >= (int64_t)128 * 256 * 4)) {
+  if (tile_form && !cut && K == 128 && M >= 128 * 256 && (b_select || (int64_t)M * a.chunks >= (int64_t)128 * 256 * 4)) {
     if (!b_select) a.rows_per_select = 128;
     a.panels = 256 / a.chunks > 0 ? 256 / a.chunks : 1;          // workgroups per column chunk
     const int64_t logical = (int64_t)a.panels * a.chunks;

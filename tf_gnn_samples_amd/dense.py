@@ -33,6 +33,7 @@ _CACHED_LIB_GEMM = _GEMM_MODE != "torch"
 _PANEL_GEMM = _GEMM_MODE == "panel"
 _LIMB_GEMM = _GEMM_MODE == "limb"
 _LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
+_LIMB_CUT = os.environ.get("RELGNN_LIMB_CUT", "1") == "1"       # N % 128 >= 96 on the 128-column panels (last chunk cut at N)
 _LIMB_WS = {}
 _STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
@@ -68,6 +69,8 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
         if _limb_route_ok(layout, a, b, bias):
             return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR, weight=weight)
         if _limb_route_ok(layout, a, b, bias, columns=128):        # the D = 128 models: 128 x 128 panels, two workgroups per CU
+            return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
+        if layout == GEMM_NN and _limb_cut_route_ok(a, b, bias):   # N just short of a multiple of 128 (the 121 labels of the PPI head)
             return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
     if (_PANEL_GEMM and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
@@ -429,6 +432,17 @@ def grouped_nt_gemm(g: torch.Tensor, kernels) -> torch.Tensor:
     return lib_gemm(GEMM_NN, g, torch.cat([k.t() for k in kernels], dim=0))
 
 
+def _limb_cut_route_ok(a: torch.Tensor, b: torch.Tensor, bias) -> bool:
+    """a @ b (+ bias) with b [K, N], N % 128 >= 96: the 128-column panels with the last one cut at N (library pick for
+    [36 k, 256] @ [256, 121]: 59-65 us; this route: measured in profiles/)."""
+    if not _LIMB_CUT or not _rows_ok(a) or a.shape[0] < _LIMB_MIN_ROWS:
+        return False
+    K, N = a.shape[1], b.shape[1]
+    return (b.is_cuda and b.dtype == torch.float32 and b.dim() == 2 and b.is_contiguous() and b.shape[0] == K and b.data_ptr() % 16 == 0
+            and N % 128 >= 96 and K % 16 == 0 and 16 <= K <= _LIMB_MAX_K
+            and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32)))
+
+
 def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0,
                out: torch.Tensor = None, weight: bool = False) -> torch.Tensor:
     """NN act(bias + a @ b) | NT a @ b^T through relgnn_limb_dense_f32: b (the weights) split into limbs in a per-(device, stream)
@@ -479,7 +493,7 @@ def limb_dense_sel(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Te
     num_b = b.shape[0] if b.dim() == 3 else 1
     N = b.shape[-1] if layout == GEMM_NN else b.shape[-2]
     M = int(num_rows) if a_rows is not None else a.shape[0]
-    need = int(lib.relgnn_limb_elements(N, K)) * num_b
+    need = int(lib.relgnn_limb_elements((N + 127) // 128 * 128, K)) * num_b
     ws = _limb_ws(a.device, need)
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _lib.check(lib.relgnn_limb_dense_sel_f32(layout, act, a.data_ptr(), a.stride(0), _lib.ptr(a_rows), b.data_ptr(), b.stride(-2),
