@@ -623,7 +623,7 @@ def main():
             "limb": "each fp32 operand as three bf16 limbs (hi + mid + lo == x exactly), the six limb products of weight >= 2^-16 "
                     "on v_mfma_f32_32x32x16_bf16 (each exact in fp32), fp32 accumulation; dropped terms < 2^-23 of a product. "
                     "Measured against float64 at [36 k, 768] x [768, 256]: 4.0e-6 max abs (exact-fp32 library GEMM: 5.3e-6); "
-                    "C2 layer vs the fp32 oracle 3.8e-6 abs (library route 6.2e-6): profiles/r03_parity_margin_limb.json",
+                    "C2 layer vs the fp32 oracle 3.8e-6 abs (library route 6.2e-6): profiles/r03_parity_margin.json",
             "lib": "exact fp32 (v_mfma_f32_32x32x2_f32 through hipBLASLt): timed in `exact_fp32_gemm_route` below"},
         "data": "synthetic",
         "config": {

@@ -7,6 +7,7 @@
 #      duration of seg_reduce_wave_kernel there must agree with roofline.avg_kernel_ms
 #  (5) kernel trace + stats of the C5 step (GNN-FiLM, VarMisuse-shaped) and of `bench.py --config C5`
 #  (6) matrix-pipe counters of the panel GEMM and of the limb GEMM kernels next to the library GEMM on the C2 layer shapes
+#  (8) counters of the typed K = 128 product kernels (scripts/gpu_pmc_typed.sh)
 #  (7) the limb GEMM against the exact-fp32 products per shape (time + error vs float64); the parity-margin test once more with
 #      RELGNN_GEMM=lib (the default run above is the limb route)
 set -u
@@ -65,4 +66,5 @@ with open(O + "/gemm_pmc.txt", "w") as f:
         f.write("%-72s %-30s n=%3d mean %.4g\n" % (k, c, len(v), sum(v) / len(v)))
 PY
 
+bash scripts/gpu_pmc_typed.sh > /dev/null 2>&1; cp gpurun_out/pmc_typed/summary.txt $O/typed_pmc.txt 2>/dev/null
 tail -3 $O/gpu_tests.txt; head -4 $O/giant_uniform_kernel_stats.csv | cut -c1-200; cat $O/gemm_pmc.txt | head -30; cut -c1-400 $O/bench_c5.json

@@ -39,7 +39,7 @@ def _check_line(d, full):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_b_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_c_bench.json")))
     _check_line(d, full=True)
     r = d["roofline"]
     # the line is quoted on the workload no cache can help; the upper bound on Infinity-Cache hits rides along
