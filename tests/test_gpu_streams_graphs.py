@@ -172,3 +172,37 @@ def test_backward_overlap_on_a_side_stream_gives_the_same_bits(gpu_device, monke
         junk = [torch.empty((V, D), device=gpu_device).normal_() for _ in range(3)]      # churn the allocator between iterations
         del junk
 
+
+
+def test_captured_step_on_the_limb_route_and_eager_code_after_replays(gpu_device):
+    """A batch tall enough for the limb route (>= 4096 nodes: products from weight limb images, weight gradient on the side
+    stream): under capture no image is cached (a replay re-runs kernels, not the host code that would refresh one), and eager
+    code behind a replay must see the replayed update (dense.weights_changed), not an image from before it."""
+    from tf_gnn_samples_amd import dense as DN
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(3, 1, seed=4)
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
+    assert mb.num_nodes >= 4096 and DN._LIMB_GEMM
+
+    def fresh():
+        p = RGCN_Model.default_params()
+        p.update(hidden_size=256, graph_num_layers=2, graph_layer_input_dropout_keep_prob=1.0, random_seed=3)
+        return RGCN_Model(p, task, device=str(gpu_device)), DeviceBatch(mb, gpu_device)
+
+    eager, batch_e = fresh()
+    losses_e = [float(eager.train_step(batch_e)['loss'].detach()) for _ in range(6)]
+    with torch.no_grad():
+        eval_e = float(eager.forward_batch(batch_e, training=False)['loss'])
+    captured, batch_c = fresh()
+    step = captured.capture_train_step(batch_c, warmup_steps=3)
+    with torch.no_grad():
+        captured.forward_batch(batch_c, training=False)                    # fills the image cache from the weights after step 3
+    losses_c = [float(step.replay()['loss']) for _ in range(3)]
+    with torch.no_grad():
+        eval_c = float(captured.forward_batch(batch_c, training=False)['loss'])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses_c, losses_e[3:], rtol=2e-5)
+    np.testing.assert_allclose(eval_c, eval_e, rtol=2e-5)                  # (a stale image would give the loss after step 3)
+    assert abs(eval_e - losses_e[3]) > 1e-3 * abs(eval_e)
