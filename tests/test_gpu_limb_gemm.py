@@ -360,3 +360,15 @@ def test_limb_dense_sel_cut_last_chunk(gpu_device, M, N, K, bias, act):
         assert torch.equal(y, out)
         y.backward(torch.ones_like(y))
         assert float((x.grad.double() - W.double().sum(1)).abs().max()) < 1e-4
+
+
+def test_limb_dense_sel_cut_last_chunk_nt_layout(gpu_device):
+    """The same cut for the NT layout (B given as [N, K] with N = 121 rows)."""
+    from tf_gnn_samples_amd import dense as DN
+    a = _rand((6000, 256), gpu_device, 1)
+    W = _rand((121, 256), gpu_device, 2, 0.1)
+    out = DN.limb_dense_sel(DN.GEMM_NT, a, W)
+    truth = a.double() @ W.double().t()
+    assert out.shape == (6000, 121)
+    e, e32 = float((out.double() - truth).abs().max()), float(((a @ W.t()).double() - truth).abs().max())
+    assert e <= max(3.0 * e32, 8e-7 * max(1.0, float(truth.abs().max()))), (e, e32)
