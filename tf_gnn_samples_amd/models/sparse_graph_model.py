@@ -383,6 +383,8 @@ class Sparse_Graph_Model(ABC):
         (= keep the initial value of) the ones it does not, report saved entries nothing consumed."""
         used = self.variables.load_tf_weights(weights, report_unused=False)
         used |= self.optimizer.load_tf_slots(weights, self._trainable_names())
+        from ..dense import weights_changed
+        weights_changed()                  # (copy_ moves the version counters too; said once more for limb images kept per step)
         for var_name in weights:
             if var_name not in used:
                 print('Saved weights for %s not used by model.' % var_name)
