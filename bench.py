@@ -505,7 +505,14 @@ def main():
     nodes = sorted(len(g.node_features) for g in fold)
     params['max_nodes_in_batch'] = int(sum(nodes) / max(1, len(fold) // cfg["graphs_per_batch"])) + nodes[-1]
     model = model_cls(params, task, device=str(device))
-    reducer = GradientAllReducer(model.optimizer.params) if world > 1 else None
+    # RELGNN_ALLREDUCE=overlap: the gradient all-reduce in buckets that leave during the backward (parallel.py); default: one flat
+    # collective behind the backward (the form every N > 1 number so far was taken with)
+    overlap_reduce = os.environ.get("RELGNN_ALLREDUCE", "flat") == "overlap"
+    if world > 1 and overlap_reduce:
+        from tf_gnn_samples_amd.parallel import OverlappedGradientAllReducer
+        reducer = OverlappedGradientAllReducer(model.optimizer.params)
+    else:
+        reducer = GradientAllReducer(model.optimizer.params) if world > 1 else None
 
     def batch_stream():
         """Shuffled epochs over the HBM-resident fold, forever (models/sparse_graph_model.py:263-311)."""
@@ -533,14 +540,19 @@ def main():
         def hook(_params):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cur_stream)
-            reducer(float(batch.num_nodes))
+            if overlap_reduce:
+                reducer.finish()                  # (what is left of the collective behind the backward)
+            else:
+                reducer(float(batch.num_nodes))
             e1.record(cur_stream)
             marks["reduce"].append((e0, e1))
         return hook
 
     def one_step():
         batch = state["upcoming"]
-        m = model.train_step(batch, grad_hook=reduce_hook(batch) if reducer is not None else None)
+        m = model.train_step(batch, grad_hook=reduce_hook(batch) if reducer is not None else None,
+                             pre_backward=(lambda: reducer.arm(float(batch.num_nodes))) if reducer is not None and overlap_reduce
+                             else None)
         readback = MetricsReadback(m)             # async D2H of this step's metrics into pinned memory
         end = torch.cuda.Event(enable_timing=True)
         end.record(cur_stream)
@@ -657,6 +669,9 @@ def main():
         },
         "step_edge_imbalance_max_over_mean": {"mean": float(imbalance.mean()), "max": float(imbalance.max())},
         "gradient_allreduce_bytes": reducer.nbytes if reducer is not None else 0,
+        "gradient_allreduce": ("none" if reducer is None else
+                               "%d buckets launched from the backward's post-accumulate hooks" % len(reducer.buckets) if overlap_reduce
+                               else "one flat collective behind the backward"),
         "gemm_autotuned": False,
         "final_loss": state["loss"],
         # time rank 0's host spent blocked on the (one step late) metrics copy: ~0 = the host is the bottleneck,

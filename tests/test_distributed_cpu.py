@@ -101,6 +101,64 @@ def test_two_rank_gloo_gradient_equals_union_batch():
             assert np.abs(a - b).max() < 1e-5 * max(1.0, np.abs(b).max())
 
 
+def _overlap_worker(rank, world, port, q):
+    """The bucketed reducer through a real backward: its hooks fire while the autograd engine is still running."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    from tf_gnn_samples_amd.parallel import GradientAllReducer, OverlappedGradientAllReducer, init_distributed
+    init_distributed(backend="gloo")
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(12, 16), (16, 16), (16, 16), (16,), (16, 40), (40,), (7, 3)]       # the last one never receives a gradient
+    init = [torch.randn(*s, generator=gen) * 0.3 for s in shapes]
+    data = torch.Generator().manual_seed(10 + rank)
+    x = torch.randn(50 + 20 * rank, 12, generator=data)
+    out = {}
+    for name, cls, kw in (("flat", GradientAllReducer, {}), ("overlap", OverlappedGradientAllReducer, {"bucket_bytes": 1200})):
+        params = [torch.nn.Parameter(t.clone()) for t in init]
+        reducer = cls(params, **kw)
+        if name == "overlap":
+            assert len(reducer.buckets) >= 3 and sorted(i for _, _, idx in reducer.buckets for i in idx) == list(range(len(params)))
+        for step in range(2):                                                      # (twice: re-arming, .grad as views of the buffer)
+            for p in params:
+                p.grad = None
+            h = torch.tanh(x @ params[0])
+            h = torch.tanh(h @ params[1]) + h @ params[2] + params[3]
+            loss = ((h @ params[4] + params[5]) ** 2).sum() / x.shape[0]
+            if name == "overlap":
+                reducer.arm(float(x.shape[0]))
+                loss.backward()
+                assert any(reducer._sent)                                          # buckets left during the backward
+                reducer.finish()
+            else:
+                loss.backward()
+                reducer(float(x.shape[0]))
+        out[name] = [p.grad.numpy().copy() if p.grad is not None else None for p in params]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_during_the_backward_equals_the_flat_one():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        for a, b in zip(results[rank]["flat"], results[rank]["overlap"]):
+            assert (a is None and b is None) or np.array_equal(a, b)              # two ranks: the same bits
+    for a, b in zip(results[0]["overlap"], results[1]["overlap"]):
+        assert np.array_equal(a, b)                                                # every rank holds the same average
+    assert np.abs(results[0]["overlap"][0]).max() > 0 and np.abs(results[0]["overlap"][6]).max() == 0
+
+
 @pytest.mark.parametrize("config", ["C2", "C5"])
 def test_bench_ranks_build_only_their_own_graphs(config, monkeypatch):
     """bench.py's fold: graph i comes from its own generator stream, so the by-edge sharding is planned from one draw per graph and

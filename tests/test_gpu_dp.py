@@ -58,12 +58,13 @@ def _grads(model, batch):
     return [p.grad.detach().clone() for p in model.optimizer.params]
 
 
-def _worker(rank, world, port, share_gpu, q):
+def _worker(rank, world, port, share_gpu, q, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0" if share_gpu else str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
-    from tf_gnn_samples_amd.parallel import GradientAllReducer, init_distributed, shard_graphs_by_edges
+    from tf_gnn_samples_amd.parallel import (GradientAllReducer, OverlappedGradientAllReducer, init_distributed,
+                                             shard_graphs_by_edges)
     r, local_rank, w = init_distributed(backend="gloo" if share_gpu else "nccl")
     assert (r, w) == (rank, world)
     device = torch.device("cuda", local_rank)
@@ -73,16 +74,28 @@ def _worker(rank, world, port, share_gpu, q):
     shard = shard_graphs_by_edges(counts, world)[rank]
     task, model = _model(device)
     local = _batch(task, [graphs[i] for i in shard], device)
-    reducer = GradientAllReducer(model.optimizer.params)
-    _grads(model, local)
-    reducer(float(local.num_nodes))
+    reducer = (OverlappedGradientAllReducer(model.optimizer.params, bucket_bytes=16 << 10) if overlap
+               else GradientAllReducer(model.optimizer.params))
+    if overlap:                              # buckets leave from the backward's hooks
+        model.optimizer.zero_grad()
+        m = model.forward_batch(local, training=True)
+        reducer.arm(float(local.num_nodes))
+        m['loss'].backward()
+        assert len(reducer.buckets) > 1 and any(reducer._sent)
+        reducer.finish()
+    else:
+        _grads(model, local)
+        reducer(float(local.num_nodes))
     reduced = [p.grad.detach().cpu().numpy().copy() for p in model.optimizer.params]
     union = None
     if rank == 0:   # the single-process answer through the same HIP kernels
         union = [g.cpu().numpy() for g in _grads(model, _batch(task, graphs, device))]
     # one full training step with the hook: parameters must stay identical across ranks
     model.optimizer.zero_grad()
-    model.train_step(local, grad_hook=lambda ps: reducer(float(local.num_nodes)))
+    if overlap:
+        model.train_step(local, pre_backward=lambda: reducer.arm(float(local.num_nodes)), grad_hook=lambda ps: reducer.finish())
+    else:
+        model.train_step(local, grad_hook=lambda ps: reducer(float(local.num_nodes)))
     torch.cuda.synchronize()
     params = [p.detach().cpu().numpy().copy() for p in model.optimizer.params]
     q.put((rank, shard, reduced, union, params, dist.get_backend()))
@@ -91,13 +104,14 @@ def _worker(rank, world, port, share_gpu, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_hip_gradient_equals_union_batch(gpu_device):
+@pytest.mark.parametrize("overlap", [False, True], ids=["flat", "buckets_during_backward"])
+def test_two_ranks_hip_gradient_equals_union_batch(gpu_device, overlap):
     world = 2
     share_gpu = torch.cuda.device_count() < 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, share_gpu, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, share_gpu, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])

@@ -517,10 +517,15 @@ class Sparse_Graph_Model(ABC):
 
     _backward_seed: Dict[Any, torch.Tensor] = {}
 
-    def train_step(self, batch: DeviceBatch, grad_hook=None, device_step_count: bool = False) -> Dict[str, torch.Tensor]:
-        """forward + backward + per-variable clip + optimizer update == one sess.run with train_step (:287-293)."""
+    def train_step(self, batch: DeviceBatch, grad_hook=None, device_step_count: bool = False,
+                   pre_backward=None) -> Dict[str, torch.Tensor]:
+        """forward + backward + per-variable clip + optimizer update == one sess.run with train_step (:287-293).
+        pre_backward(): called between the forward and the backward (a bucketed gradient all-reduce arms its hooks there);
+        grad_hook(params): between the backward and the clipping (the data-parallel reduction)."""
         self.optimizer.zero_grad()
         metrics = self.forward_batch(batch, training=True)
+        if pre_backward is not None:
+            pre_backward()
         # one process drives one GPU: running the backward on the calling thread instead of the autograd engine's
         # device thread saves the hand-off per node (host enqueue 1.56 -> 1.29 ms per C2 step) and a busy CPU thread
         with torch.autograd.set_multithreading_enabled(False):

@@ -114,3 +114,91 @@ class GradientAllReducer:
         # the next backward allocates fresh .grad tensors after zero_grad() and this buffer is overwritten by the pack)
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+
+class OverlappedGradientAllReducer(GradientAllReducer):
+    """The same weighted average, with the collective cut into buckets that leave while the backward is still running
+    (RELGNN_ALLREDUCE=overlap in bench.py; the flat one-collective form stays the default until an N > 1 run has timed both).
+
+    Buckets are contiguous ranges of the same flat buffer, filled from its END (the backward produces the last layers'
+    gradients first): a parameter's post-accumulate hook counts its bucket down, a complete bucket is packed (one
+    multi-tensor copy + one scale by the local weight) and all-reduced asynchronously.  The local weight n_r — known before the
+    backward — is reduced by its own tiny collective at arm() time; finish() (the training step's grad_hook) launches what
+    is left (parameters that received no gradient count as zeros), waits, divides by sum_r n_r and points every .grad at its
+    slice, exactly like the flat form.  For two ranks the result is bit-identical to the flat form (a sum of two values has
+    one order); for more ranks the reduction order of an element may depend on where the library cuts its buffer."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 1 << 20, group=None):
+        super().__init__(params, group)
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += p.numel()
+        self.buckets = []                       # (lo, hi, [param indices]) in the order the backward completes them
+        members, hi = [], off
+        for i in reversed(range(len(self.params))):
+            members.append(i)
+            if (hi - offs[i]) * 4 >= bucket_bytes or i == 0:
+                self.buckets.append((offs[i], hi, members[::-1]))
+                members, hi = [], offs[i]
+        self.bucket_of = {}
+        for b, (_, _, idx) in enumerate(self.buckets):
+            for i in idx:
+                self.bucket_of[i] = b
+        self._armed = False
+        self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if self._armed:
+                b = self.bucket_of[i]
+                self._left[b] -= 1
+                if self._left[b] == 0:
+                    self._launch(b)
+        return hook
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    @torch.no_grad()
+    def arm(self, local_weight: float) -> None:
+        """Call before the backward of the step."""
+        if not self._active():
+            return
+        self._w = float(local_weight)
+        self._left = [len(idx) for _, _, idx in self.buckets]
+        self._sent = [False] * len(self.buckets)
+        self.flat[-1] = self._w
+        self._works = [dist.all_reduce(self.flat[-1:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        self._armed = True
+
+    @torch.no_grad()
+    def _launch(self, b: int) -> None:
+        lo, hi, idx = self.buckets[b]
+        grads = [self.params[i].grad if self.params[i].grad is not None else torch.zeros_like(self.params[i]) for i in idx]
+        torch._foreach_copy_([self.views[i] for i in idx], grads)
+        self.flat[lo:hi].mul_(self._w)
+        self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._sent[b] = True
+
+    @torch.no_grad()
+    def finish(self) -> None:
+        """The training step's grad_hook: after the backward, before clipping."""
+        if not self._armed:
+            return
+        self._armed = False
+        for b in range(len(self.buckets)):
+            if not self._sent[b]:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self.flat[:-1].div_(self.flat[-1])
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def __call__(self, local_weight: float):
+        """Without arm() before the backward this is the flat form's call: everything at once."""
+        if not self._armed:
+            self.arm(local_weight)
+        self.finish()
