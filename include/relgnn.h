@@ -237,6 +237,17 @@ int relgnn_seg_reduce_acc64_fwd(int32_t mode, const float* X, int64_t num_rows_x
                                 int64_t ldo, void* stream);
 
 /*
+ * relgnn_seg_reduce_fwd_rowmax — relgnn_seg_reduce_fwd (sum / mean / sqrt_n) that also writes rowmax[s] = the largest magnitude of
+ * output row s: what the consumer of these rows needs when it evaluates its product from two fp16 limbs per value
+ * (relgnn_limb16_gemm_xf32: the row's power-of-two scale).  The wave that reduces a bucket holds the whole row, so the maximum costs
+ * a wave reduction and one store.  Rows of 132 .. 1024 floats, 16-byte aligned (RELGNN_EUNSUPPORTED otherwise).
+ */
+int relgnn_seg_reduce_fwd_rowmax(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                                 const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                                 const int32_t* col, const float* w, int32_t act, float* out,
+                                 int64_t ldo, float* rowmax, void* stream);
+
+/*
  * Per-MESSAGE activation before the reduction (gnns/gnn_edge_mlp.py:104-116, rgin.py:127-133: scale, activation,
  * segment reduce on the materialised message tensor) without an elementwise pass over [M, D]:
  *   relgnn_seg_reduce_msgact_fwd : out[s,:] = finalize_mode( REDUCE_p msg_act( w[p] * X[col[p],:] ) )
@@ -757,6 +768,26 @@ int relgnn_limb_gemm_f32(int32_t act, const uint16_t* A, const uint16_t* B, cons
                          int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,
                           float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* The same products from TWO fp16 limbs per operand behind exact power-of-two scales: x * 2^j = hi + lo (+ a remainder <= 2^-22 of
+ * it), three MFMA products (hi hi, hi lo, lo hi: each exact in fp32) instead of the six of the bf16 triple.  fp16's exponent range is
+ * what the scales are for:
+ *   weights   relgnn_limb16_split_multi_f32 writes n matrices into n_images images (image[d]: the image matrix d belongs to — the
+ *             matrices of one product; laid out like relgnn_limb_split_multi_f32's, two 1 KiB blocks per tile:
+ *             relgnn_limb16_elements), each image scaled by the power of two that puts ITS largest magnitude into [2^14, 2^15);
+ *             the magnitudes are left in wmax[0 .. n_images) (device memory; the product is handed wmax + its image's index)
+ *   left rows relgnn_limb16_gemm_xf32 scales row m by the power of two of max_g xmax[m * xgroups + g] — per-row magnitudes the
+ *             PRODUCER of A wrote (relgnn_seg_reduce_fwd_rowmax: one value per (node, type) bucket = xgroups per row of the
+ *             [V, L * D] operand of gnns/rgcn.py:96-98 in the aggregate-first order); a row's scale factors out of its output row,
+ *             the epilogue removes it together with the weights' (both exact)
+ * Same shape requirements as relgnn_limb_gemm_xf32.  Not an exact split like the bf16 triple: the representation error is
+ * <= 2^-22 of an element, of the order of one fp32 rounding (tests: against float64 next to the exact-fp32 product). */
+int64_t relgnn_limb16_elements(int64_t rows, int64_t cols);
+int relgnn_limb16_split_multi_f32(int32_t n, const float* const* X, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
+                                  const int32_t* transpose, uint16_t* const* out, const int32_t* kt_offset, const int32_t* kt_total,
+                                  const int32_t* image, int32_t n_images, float* wmax, void* stream);
+int relgnn_limb16_gemm_xf32(int32_t act, const float* A, int64_t lda, const float* xmax, int32_t xgroups, const uint16_t* B,
+                            const float* wmax, const float* bias, const void* zeros, float* C, int64_t ldc, int32_t M, int32_t N,
+                            int32_t K, void* stream);
 /* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need
  * (gnns/gnn_film.py:92-106; the limb counterpart of relgnn_panel_gemm_f32's a_rows / b_select for the forward product and the input
  * gradient; K = 128 there):

@@ -372,3 +372,48 @@ def test_limb_dense_sel_cut_last_chunk_nt_layout(gpu_device):
     assert out.shape == (6000, 121)
     e, e32 = float((out.double() - truth).abs().max()), float(((a @ W.t()).double() - truth).abs().max())
     assert e <= max(3.0 * e32, 8e-7 * max(1.0, float(truth.abs().max()))), (e, e32)
+
+
+@pytest.mark.parametrize("agg,scale", [("sum", 1.0), ("mean", 1.0), ("sum", 1e-4)])
+def test_two_fp16_limb_products_of_the_aggregate_first_layer(gpu_device, monkeypatch, agg, scale):
+    """RELGNN_LIMB=pair: the gather writes every bucket's largest magnitude, the products of the aggregate-first layer (forward and
+    input gradient) run from two fp16 limbs per value behind power-of-two row scales.  Output and gradients against float64,
+    next to the bf16-triple route's errors; rows of zeros (isolated nodes) and tiny inputs included."""
+    from helpers import random_relational_graph
+    from tf_gnn_samples_amd import dense as DN, ops
+    from tf_gnn_samples_amd.graph import RelGraph
+    rng = np.random.default_rng(3)
+    V, L, D = 9000, 3, 256
+    adj = random_relational_graph(rng, V, L, [70000, 9000, 70000])
+    adj = [a[(a[:, 1] % 17) != 0] for a in adj]                      # every 17th node receives nothing: rows of zeros
+    g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)
+    w = g.degree_scale(torch.as_tensor(np.stack([np.bincount(a[:, 1], minlength=V) for a in adj]).astype(np.float32),
+                                       device=gpu_device)) if agg == "mean" else None
+    H0 = torch.as_tensor((np.maximum(rng.standard_normal((V, D)), 0) * scale).astype(np.float32), device=gpu_device)
+    W0 = [torch.as_tensor((rng.standard_normal((D, D)) * 0.06).astype(np.float32), device=gpu_device) for _ in range(L)]
+    gout = torch.as_tensor((rng.standard_normal((V, D)) * np.exp(rng.uniform(-6, 2, (V, 1)))).astype(np.float32), device=gpu_device)
+
+    def run(pair):
+        monkeypatch.setattr(DN, "_LIMB_PAIR", pair)
+        H = H0.clone().requires_grad_(True)
+        Ws = [x.clone().requires_grad_(True) for x in W0]
+        out = ops.aggregate_then_transform(H, Ws, g, w, "sum", "relu")
+        out.backward(gout)
+        return [out.detach(), H.grad] + [x.grad for x in Ws]
+
+    triple, pair = run(False), run(True)
+    if w is None:                                                    # float64 truth through the same function in plain torch
+        Hd = H0.double().requires_grad_(True)
+        Wd = [x.double().requires_grad_(True) for x in W0]
+        acc = 0
+        for l in range(L):
+            src, tgt = (torch.as_tensor(adj[l][:, i].astype(np.int64), device=gpu_device) for i in (0, 1))
+            acc = acc + torch.zeros((V, D), dtype=torch.float64, device=gpu_device).index_add_(0, tgt, Hd[src]) @ Wd[l]
+        truth_out = torch.relu(acc)
+        truth_out.backward(gout.double())
+        truth = [truth_out.detach(), Hd.grad] + [x.grad for x in Wd]
+        for name, t, a, b in zip(["out", "dH", "dW0", "dW1", "dW2"], truth, triple, pair):
+            et, ep = float((a.double() - t).abs().max()), float((b.double() - t).abs().max())
+            assert ep <= max(2.0 * et, 4e-6 * max(float(t.abs().max()), 1e-30)), (name, ep, et)
+    for name, a, b in zip(["out", "dH", "dW0", "dW1", "dW2"], triple, pair):
+        assert float((a - b).abs().max()) <= 8e-6 * max(float(a.abs().max()), 1e-30), name

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "relgnn_segment_counts_scale": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_seg_reduce_fwd": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_seg_reduce_acc64_fwd": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr]),
+    "relgnn_seg_reduce_fwd_rowmax": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_seg_reduce_msgact_fwd": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr]),
     "relgnn_msg_act_bwd": (ctypes.c_int, [_c_i32, _ptr, _c_i32, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
     "relgnn_seg_max_count": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr]),
@@ -90,6 +91,10 @@ _SIGNATURES = {
     "relgnn_limb_gemm_xf32": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_limb_gemm_tn_chunks": (_c_i64, [_c_i32, _c_i32, _c_i32]),
     "relgnn_limb_gemm_tn_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i32, _c_i32, _c_i32, _ptr]),
+    "relgnn_limb16_elements": (_c_i64, [_c_i64, _c_i64]),
+    "relgnn_limb16_split_multi_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _ptr]),
+    "relgnn_limb16_gemm_xf32": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32,
+                                               _c_i32, _ptr]),
     "relgnn_limb_split_multi_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_limb_split_batch_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr]),
     "relgnn_limb_dense_sel_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i64, _ptr, _c_i32, _ptr, _ptr,

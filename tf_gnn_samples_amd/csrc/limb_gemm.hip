@@ -59,13 +59,44 @@ struct LimbArgs {
   int32_t M, N, K, act;
   int32_t units_base, units_rem;       // panel q covers 32-row units [q*base + min(q, rem), +base + (q < rem))
   int32_t panels, chunks;              // row panels x 256-column chunks = logical workgroups
+  // two-fp16-limb arithmetic (NL = 2): per-row magnitudes of the left operand (xmax[m * xgroups + g], the row's scale comes from
+  // their maximum) and the magnitude the right operand's limbs were scaled by (wmax[0]); both in device memory
+  const float* xmax; int32_t xgroups; const float* wmax;
 #ifdef RELGNN_LIMB_TIMING
   unsigned long long* timing;          // [workgroup][wave][8] cycle totals per loop segment (diagnostic build only)
 #endif
 };
 
-// ---- fp32 -> three bf16 limbs ----------------------------------------------------------------------------------------
+// ---- fp32 -> two fp16 limbs behind an exact power-of-two scale ----------------------------------------------------------
+// x * s = hi + lo + r with hi = fp16(x s), lo = fp16(x s - hi), |r| <= 2^-22 |x s|; s = 2^j puts the largest magnitude of the
+// row (of the matrix, for weights) into [2^14, 2^15): fp16's mantissa is enough for two limbs, its exponent range is what the
+// scale is for.  Three products per fp32 product (hi hi, hi lo, lo hi: each exact in fp32) instead of the six of the bf16 triple.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t limb16_scale_bits(float mx) {          // exponent field of s (s = 1 for 0 / denormal / inf / nan)
+  const uint32_t e = (__float_as_uint(mx) >> 23) & 0xFFu;
+  if (e == 0u || e == 255u) return 127u;
+  const uint32_t f = 268u - e;                                              // 2^(141 - e): mx * s in [2^14, 2^15)
+  return f > 253u ? 253u : f;
+}
+__device__ __forceinline__ float limb16_scale(float mx) { return __uint_as_float(limb16_scale_bits(mx) << 23); }
+__device__ __forceinline__ float limb16_unscale(float mx) { return __uint_as_float((254u - limb16_scale_bits(mx)) << 23); }
+__device__ __forceinline__ void split_pair16(float x0, float x1, uint32_t& h, uint32_t& l) {
+  const f16x2 hh = __builtin_convertvector(f32x2{x0, x1}, f16x2);          // round to nearest even
+  const f32x2 hf = __builtin_convertvector(hh, f32x2);
+  const f16x2 ll = __builtin_convertvector(f32x2{x0 - hf[0], x1 - hf[1]}, f16x2);
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, ll);
+}
+__device__ __forceinline__ void split8_16(const float* v, float s, uint4& h, uint4& l) {
+  split_pair16(v[0] * s, v[1] * s, h.x, l.x);
+  split_pair16(v[2] * s, v[3] * s, h.y, l.y);
+  split_pair16(v[4] * s, v[5] * s, h.z, l.z);
+  split_pair16(v[6] * s, v[7] * s, h.w, l.w);
+}
+
+// ---- fp32 -> three bf16 limbs ----------------------------------------------------------------------------------------
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // two fp32 -> two bf16 (round to nearest even), packed
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));      // v_cvt_pk_bf16_f32
@@ -95,10 +126,12 @@ __device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m, uint4
 //               48 us for [36 k, 768], profiles/r03_limb_gemm.jsonl).
 // ABL (experiments only, results wrong when != 0): bit 0 no DMA after the prologue, bit 1 no fragment reads in the loop,
 // bit 2 no waits / barrier in the loop.
-template <int T32, bool XF32, int ABL = 0>
+// NL = 3: three bf16 limbs per operand, six products; NL = 2 (XF32 only): two fp16 limbs behind power-of-two scales, three products.
+template <int T32, bool XF32, int ABL = 0, int NL = 3>
 __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
+  static_assert(NL == 3 || (NL == 2 && XF32), "two limbs: the in-flight form only");
   constexpr int NC = 256;
-  constexpr int PA = 3 * T32, PB = 3 * (NC / 32), P = PA + PB;     // 1 KiB blocks per k-tile
+  constexpr int PA = NL * T32, PB = NL * (NC / 32), P = PA + PB;   // 1 KiB blocks per k-tile
   constexpr int STAGE_BYTES = P * 1024;
   // DMA: XF32: the W blocks only, by the last 4 (T32 <= 4) or 3 waves; else everything, by waves 0-3 (one per SIMD)
   constexpr int LOADERS = XF32 ? (T32 <= 4 ? 4 : 3) : 4;
@@ -127,7 +160,7 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
   const uint16_t* src[G];
   int step[G];
   int piece[G];
-  constexpr int TILE = 3 * 512;                       // bf16 elements of one limb tile
+  constexpr int TILE = NL * 512;                      // 16-bit elements of one limb tile
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     // wave-uniform; past the end: a duplicate of the last block
@@ -135,13 +168,13 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     const int c = (XF32 ? PA : 0) + min(lw + LOADERS * g, PD - 1);
     piece[g] = c;
     if (c < PA) {
-      const int tm = c / 3, pl = c % 3;
+      const int tm = c / NL, pl = c % NL;
       const bool ok = tm < nu;                        // a tile row of this panel (rows past M inside it are stored zeros)
       src[g] = ok ? a.A + ((int64_t)(u0 + tm) * ntiles) * TILE + pl * 512 + 8 * lane : a.zeros + 8 * lane;
       step[g] = ok ? TILE : 0;
     } else {
       const int cb = c - PA;
-      const int wn_ = cb / 3, pl = cb % 3;
+      const int wn_ = cb / NL, pl = cb % NL;
       src[g] = a.B + ((int64_t)(n0 / 32 + wn_) * ntiles) * TILE + pl * 512 + 8 * lane;
       step[g] = TILE;
     }
@@ -175,7 +208,14 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
   const int xr = tid >> 1, xhf = tid & 1;
   const bool xrow_ok = xwave && xr < rows_here;
   const float* xsrc = XF32 ? a.Ax + (int64_t)(m0 + (xrow_ok ? xr : 0)) * a.lda + 16 * xhf : nullptr;
-  const int xblock = (3 * (xr >> 5)) * 1024 + (xr & 31) * 16;      // byte offset of (tile row, row) inside a stage, chunk 0, plane hi
+  const int xblock = (NL * (xr >> 5)) * 1024 + (xr & 31) * 16;     // byte offset of (tile row, row) inside a stage, chunk 0, plane hi
+  float xscale = 1.f;                                              // NL = 2: the power of two that lifts my row into fp16's range
+  if constexpr (NL == 2) {
+    float mx = 0.f;
+    if (xrow_ok)
+      for (int g = 0; g < a.xgroups; ++g) mx = fmaxf(mx, a.xmax[(int64_t)(m0 + xr) * a.xgroups + g]);
+    xscale = limb16_scale(mx);
+  }
   f32x4 xv[4];                                                     // the super-tile in flight
   float xh[8];                                                     // second chunk of the super-tile being stored
   // The loads are issued by EVERY wave, outside any branch, from an address that is always valid (a wave or row that has nothing to
@@ -195,12 +235,19 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     float z[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) z[i] = xrow_ok ? v[i] : 0.f;      // rows past M inside the panel
-    uint4 h, m, l;
-    split8(z, h, m, l);
     unsigned char* p = lds + ((2 * S + xhf) % STAGES) * STAGE_BYTES + xblock + half * 512;
-    *reinterpret_cast<uint4*>(p) = h;
-    *reinterpret_cast<uint4*>(p + 1024) = m;
-    *reinterpret_cast<uint4*>(p + 2048) = l;
+    if constexpr (NL == 2) {
+      uint4 h, l;
+      split8_16(z, xscale, h, l);
+      *reinterpret_cast<uint4*>(p) = h;
+      *reinterpret_cast<uint4*>(p + 1024) = l;
+    } else {
+      uint4 h, m, l;
+      split8(z, h, m, l);
+      *reinterpret_cast<uint4*>(p) = h;
+      *reinterpret_cast<uint4*>(p + 1024) = m;
+      *reinterpret_cast<uint4*>(p + 2048) = l;
+    }
   };
   auto x_first = [&](int S) {                                      // chunk 0 now, chunk 1 kept for the next k-tile
     float v[8];
@@ -211,22 +258,20 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
 
   // ---- fragments -----------------------------------------------------------------------------------------------------
   struct Limbs { bf16x8 hi, mid, lo; };
-  auto read_x = [&](int stage, int tm) {
-    const unsigned char* p = lds + stage * STAGE_BYTES + (3 * tm) * 1024 + 16 * lane;
+  auto read_planes = [&](const unsigned char* p) {          // (NL = 2: hi, lo; `mid` stays unused)
     Limbs f;
     f.hi = *reinterpret_cast<const bf16x8*>(p);
-    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
-    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    if constexpr (NL == 3) {
+      f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+      f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    } else {
+      f.lo = *reinterpret_cast<const bf16x8*>(p + 1024);
+      f.mid = f.lo;
+    }
     return f;
   };
-  auto read_w = [&](int stage) {
-    const unsigned char* p = lds + stage * STAGE_BYTES + (PA + 3 * wave) * 1024 + 16 * lane;
-    Limbs f;
-    f.hi = *reinterpret_cast<const bf16x8*>(p);
-    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
-    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
-    return f;
-  };
+  auto read_x = [&](int stage, int tm) { return read_planes(lds + stage * STAGE_BYTES + (NL * tm) * 1024 + 16 * lane); };
+  auto read_w = [&](int stage) { return read_planes(lds + stage * STAGE_BYTES + (PA + NL * wave) * 1024 + 16 * lane); };
   f32x16 acc[T32];
 #pragma unroll
   for (int tm = 0; tm < T32; ++tm)
@@ -234,13 +279,22 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
   // small terms first: the three 2^-16 products, then the two 2^-8 ones, then the leading one
   auto products = [&](f32x16 c, const Limbs& w, const Limbs& x) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, c, 0, 0, 0);
-    return c;
+    if constexpr (NL == 2) {
+      const f16x8 wh = __builtin_bit_cast(f16x8, w.hi), wl = __builtin_bit_cast(f16x8, w.lo);
+      const f16x8 xh_ = __builtin_bit_cast(f16x8, x.hi), xl = __builtin_bit_cast(f16x8, x.lo);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh_, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh_, c, 0, 0, 0);
+      return c;
+    } else {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, c, 0, 0, 0);
+      return c;
+    }
   };
 
   // ---- pipeline ------------------------------------------------------------------------------------------------------
@@ -382,10 +436,17 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     const int r = tm * 32 + i32;
     if (r < rows_here) {
       float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
+      float unscale = 1.f;
+      if constexpr (NL == 2) {                          // the row's and the weights' powers of two leave: exact
+        float mx = 0.f;
+        for (int g = 0; g < a.xgroups; ++g) mx = fmaxf(mx, a.xmax[(int64_t)(m0 + r) * a.xgroups + g]);
+        unscale = limb16_unscale(mx) * limb16_unscale(a.wmax[0]);
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int col = colw + 8 * c + 4 * h32;
-        const f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+        f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+        if constexpr (NL == 2) v *= unscale;
         *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
       }
     }
@@ -1102,6 +1163,7 @@ constexpr int SPLIT_MULTI_MAX = 24;
 struct SplitItem {
   const float* X; int64_t ldx; uint16_t* out;
   int32_t rows, cols, transpose, kt_off, kt_total, gx, block_end;
+  int32_t image;                       // (two-limb images: which scale / magnitude slot the matrix belongs to)
 };
 struct SplitMultiArgs { SplitItem it[SPLIT_MULTI_MAX]; int32_t n; };
 
@@ -1115,14 +1177,83 @@ __global__ __launch_bounds__(256) void limb_split_multi_kernel(const SplitMultiA
   else limb_split_tile<false>(it.X, it.ldx, it.rows, it.cols, it.out, it.kt_total, it.kt_off, bx, rb);
 }
 
-template <int T32, bool XF32, int ABL = 0>
+// ---- two fp16 limbs: the weight images (all matrices of an image share ONE scale: they are summed over in one product) -------------
+// block = the 32 x 64 tile of the OUTPUT matrix limb_split_tile takes; first pass: the largest magnitude of the image (atomicMax on
+// the bit pattern: magnitudes order like unsigned integers), second pass: the limbs of x * 2^j, j from that magnitude.
+__device__ __forceinline__ void limb16_item_of_block(const SplitMultiArgs& a, int& d, int& bx, int& rb) {
+  d = 0;
+  while (d + 1 < a.n && (int)blockIdx.x >= a.it[d].block_end) ++d;
+  const int local = (int)blockIdx.x - (d ? a.it[d - 1].block_end : 0);
+  bx = local % a.it[d].gx; rb = local / a.it[d].gx;
+}
+
+template <bool TRANSPOSE>
+__device__ __forceinline__ bool limb16_load8(const SplitItem& it, int bx, int rb, float (&v)[8], int& i, int& g8) {
+  const int R = TRANSPOSE ? it.cols : it.rows, C = TRANSPOSE ? it.rows : it.cols;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  i = 8 * wave + (lane & 7);
+  g8 = bx * 8 + (lane >> 3);
+  if (g8 * 8 >= C) return false;
+  const int r = rb * 32 + i;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  if (r < R) {
+    if constexpr (TRANSPOSE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = it.X[(int64_t)(8 * g8 + j) * it.ldx + r];
+    } else {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(it.X + (int64_t)r * it.ldx + 8 * g8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(it.X + (int64_t)r * it.ldx + 8 * g8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void limb16_absmax_multi_kernel(const SplitMultiArgs a, float* __restrict__ wmax) {
+  int d, bx, rb, i, g8;
+  limb16_item_of_block(a, d, bx, rb);
+  float v[8];
+  const bool ok = a.it[d].transpose ? limb16_load8<true>(a.it[d], bx, rb, v, i, g8) : limb16_load8<false>(a.it[d], bx, rb, v, i, g8);
+  float m = 0.f;
+  if (ok)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wave_max[4];                      // one atomic per block (every wave on one address measured 26 us for 18 matrices)
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(wmax + a.it[d].image), __float_as_uint(m));
+  }
+}
+
+__global__ __launch_bounds__(256) void limb16_split_multi_kernel(const SplitMultiArgs a, const float* __restrict__ wmax) {
+  int d, bx, rb, i, g8;
+  limb16_item_of_block(a, d, bx, rb);
+  const SplitItem& it = a.it[d];
+  float v[8];
+  const bool ok = it.transpose ? limb16_load8<true>(it, bx, rb, v, i, g8) : limb16_load8<false>(it, bx, rb, v, i, g8);
+  if (!ok) return;
+  uint4 h, l;
+  split8_16(v, limb16_scale(wmax[it.image]), h, l);
+  const int kt = it.kt_off + (g8 >> 1), hh = g8 & 1;
+  uint16_t* o = it.out + ((int64_t)rb * it.kt_total + kt) * 1024 + hh * 256 + i * 8;
+  *reinterpret_cast<uint4*>(o) = h;
+  *reinterpret_cast<uint4*>(o + 512) = l;
+}
+
+template <int T32, bool XF32, int ABL = 0, int NL = 3>
 int launch_limb(const LimbArgs& a, hipStream_t st) {
   const int64_t logical = (int64_t)a.panels * a.chunks;
-  limb_gemm_kernel<T32, XF32, ABL><<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, st>>>(a);
+  limb_gemm_kernel<T32, XF32, ABL, NL><<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, st>>>(a);
   return launch_status();
 }
 
-template <bool XF32>
+template <bool XF32, int NL = 3>
 int dispatch_limb(LimbArgs a, hipStream_t st) {
   a.chunks = a.N / 256;
 #ifdef RELGNN_LIMB_TIMING
@@ -1158,11 +1289,11 @@ int dispatch_limb(LimbArgs a, hipStream_t st) {
   }
 #endif
   switch (best_cap) {
-    case 1: return launch_limb<1, XF32>(a, st);
-    case 2: return launch_limb<2, XF32>(a, st);
-    case 3: return launch_limb<3, XF32>(a, st);
-    case 4: return launch_limb<4, XF32>(a, st);
-    default: return launch_limb<5, XF32>(a, st);
+    case 1: return launch_limb<1, XF32, 0, NL>(a, st);
+    case 2: return launch_limb<2, XF32, 0, NL>(a, st);
+    case 3: return launch_limb<3, XF32, 0, NL>(a, st);
+    case 4: return launch_limb<4, XF32, 0, NL>(a, st);
+    default: return launch_limb<5, XF32, 0, NL>(a, st);
   }
 }
 
@@ -1258,6 +1389,61 @@ int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16
   a.Ax = A; a.lda = lda; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M;
   a.N = N; a.K = K; a.act = act;
   return dispatch_limb<true>(a, as_stream(stream));
+}
+
+// ---- two fp16 limbs -------------------------------------------------------------------------------------------------------------
+int64_t relgnn_limb16_elements(int64_t rows, int64_t cols) { return ((rows + 31) / 32) * (cols / 16) * 1024; }
+
+int relgnn_limb16_split_multi_f32(int32_t n, const float* const* X, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
+                                  const int32_t* transpose, uint16_t* const* out, const int32_t* kt_offset, const int32_t* kt_total,
+                                  const int32_t* image, int32_t n_images, float* wmax, void* stream) {
+  if (n < 0 || n_images < 0 || (n_images > 0 && !wmax) ||
+      (n > 0 && (!X || !ldx || !rows || !cols || !transpose || !out || !kt_offset || !kt_total || !image)))
+    return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  for (int32_t d = 0; d < n; ++d) {
+    const int C = transpose[d] ? rows[d] : cols[d];
+    if (rows[d] < 0 || cols[d] < 0 || C % 16 != 0 || kt_offset[d] < 0 || kt_offset[d] + C / 16 > kt_total[d] || image[d] < 0 ||
+        image[d] >= n_images)
+      return RELGNN_EINVAL;
+    if (rows[d] == 0 || cols[d] == 0) continue;
+    if (!X[d] || !out[d]) return RELGNN_EINVAL;
+    if (!aligned16(out[d]) || (!transpose[d] && (!aligned16(X[d]) || ldx[d] % 4)) || ldx[d] < cols[d]) return RELGNN_EUNSUPPORTED;
+  }
+  if (n_images > 0 && hipMemsetAsync(wmax, 0, sizeof(float) * n_images, st) != hipSuccess) return RELGNN_EHIP;
+  // pass 0: every image's largest magnitude; pass 1: the limbs (both in launches of up to SPLIT_MULTI_MAX matrices)
+  for (int pass = 0; pass < 2; ++pass)
+    for (int32_t first = 0; first < n; first += SPLIT_MULTI_MAX) {
+      SplitMultiArgs a{};
+      int blocks = 0;
+      for (int32_t d = first; d < n && d < first + SPLIT_MULTI_MAX; ++d) {
+        const int R = transpose[d] ? cols[d] : rows[d], C = transpose[d] ? rows[d] : cols[d];
+        if (R == 0 || C == 0) continue;
+        SplitItem& it = a.it[a.n++];
+        it.X = X[d]; it.ldx = ldx[d]; it.out = out[d]; it.rows = rows[d]; it.cols = cols[d]; it.transpose = transpose[d];
+        it.kt_off = kt_offset[d]; it.kt_total = kt_total[d]; it.gx = (C + 63) / 64; it.image = image[d];
+        blocks += it.gx * ((R + 31) / 32);
+        it.block_end = blocks;
+      }
+      if (!a.n) continue;
+      if (pass == 0) limb16_absmax_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(a, wmax);
+      else limb16_split_multi_kernel<<<(unsigned)blocks, 256, 0, st>>>(a, wmax);
+      const int rc = launch_status();
+      if (rc != RELGNN_OK) return rc;
+    }
+  return RELGNN_OK;
+}
+
+int relgnn_limb16_gemm_xf32(int32_t act, const float* A, int64_t lda, const float* xmax, int32_t xgroups, const uint16_t* B,
+                            const float* wmax, const float* bias, const void* zeros, float* C, int64_t ldc, int32_t M, int32_t N,
+                            int32_t K, void* stream) {
+  const int rc = limb_common_checks(act, A, B, bias, zeros, C, ldc, M, N, K);
+  if (rc >= 0) return rc;
+  if (lda % 4 || lda < K || !xmax || !wmax || xgroups < 1) return RELGNN_EUNSUPPORTED;
+  LimbArgs a{};
+  a.Ax = A; a.lda = lda; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M;
+  a.N = N; a.K = K; a.act = act; a.xmax = xmax; a.xgroups = xgroups; a.wmax = wmax;
+  return dispatch_limb<true, 2>(a, as_stream(stream));
 }
 
 // rows per chunk (% 32 == 0) and number of chunks for the V - V % 32 rows the kernel takes

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
     const float4* __restrict__ X, int64_t ldx4, int32_t D4, const int32_t* __restrict__ rowptr,
     int64_t num_segments, int32_t stride, const int32_t* __restrict__ col,
     const float* __restrict__ w, int32_t mode, int32_t act, float4* __restrict__ out, int64_t ldo4,
-    int64_t n_logical_blocks, int32_t col_block0, int32_t msg_act) {
+    int64_t n_logical_blocks, int32_t col_block0, int32_t msg_act, float* __restrict__ rowmax) {
   const int64_t lb = XCD ? xcd_logical_block(n_logical_blocks)
                          : ((int64_t)blockIdx.x < n_logical_blocks ? (int64_t)blockIdx.x : -1);
   if (lb < 0) return;
@@ -187,10 +187,12 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
   }
 
   float4* orow = out + s * ldo4 + c0;
+  float mx = 0.f;                      // the largest magnitude of the row as it is written (rowmax: relgnn_seg_reduce_fwd_rowmax)
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
     if (on[c]) {
       const float4 r = finalize(mode, act, acc[c], end - beg);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
       if constexpr (NT) {  // streamed output: do not displace gathered rows from L2
         float* o = reinterpret_cast<float*>(orow + 64 * c);
         __builtin_nontemporal_store(r.x, o); __builtin_nontemporal_store(r.y, o + 1);
@@ -199,6 +201,11 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
         orow[64 * c] = r;
       }
     }
+  if (rowmax) {                        // (wave-uniform; the wave holds the whole row: one column block)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) rowmax[s] = mx;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -482,6 +489,9 @@ __global__ __launch_bounds__(256) void msg_act_bwd_kernel(int32_t act, const flo
   }
 }
 
+// set by relgnn_seg_reduce_fwd_rowmax around its call (the wave kernels write one magnitude per output row there)
+thread_local float* tl_rowmax = nullptr;
+
 template <int NCH, bool IS_MAX>
 int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_t* rowptr,
                 int64_t S, int32_t stride, const int32_t* col, const float* w, int32_t mode,
@@ -496,11 +506,11 @@ int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_
       if (has_w)
         seg_reduce_wave_kernel<NCH, false, true, kUnroll, false, true, false, true><<<grid, 256, 0, st>>>(
             reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-            reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+            reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act, tl_rowmax);
       else
         seg_reduce_wave_kernel<NCH, false, false, kUnroll, false, true, false, true><<<grid, 256, 0, st>>>(
             reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-            reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+            reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act, tl_rowmax);
       return launch_status();
     }
   }
@@ -511,7 +521,7 @@ int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_
   case ID:                                                                                             \
     seg_reduce_wave_kernel<1, false, true, U, N, X_><<<grid, 256, 0, st>>>(                            \
         reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,         \
-        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);                                     \
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act, tl_rowmax);                                     \
     return launch_status();
       switch (var) {
         RELGNN_VARIANT_CASE(1, 16, false, true)
@@ -531,21 +541,21 @@ int launch_wave(bool has_w, const float* X, int64_t ldx, int32_t D, const int32_
     if (has_w)
       seg_reduce_wave_kernel<NCH, IS_MAX, true, kUnroll, false, true, true><<<grid, 256, 0, st>>>(
           reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-          reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+          reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act, tl_rowmax);
     else
       seg_reduce_wave_kernel<NCH, IS_MAX, false, kUnroll, false, true, true><<<grid, 256, 0, st>>>(
           reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-          reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+          reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act, tl_rowmax);
     return launch_status();
   }
   if (has_w)
     seg_reduce_wave_kernel<NCH, IS_MAX, true><<<grid, 256, 0, st>>>(
         reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act, tl_rowmax);
   else
     seg_reduce_wave_kernel<NCH, IS_MAX, false><<<grid, 256, 0, st>>>(
         reinterpret_cast<const float4*>(X), ldx / 4, D4, rowptr, S, stride, col, w, mode, act,
-        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act);
+        reinterpret_cast<float4*>(out), ldo / 4, nlb, 0, msg_act, tl_rowmax);
   return launch_status();
 }
 
@@ -629,6 +639,22 @@ int relgnn_seg_reduce_fwd(int32_t mode, const float* X, int64_t num_rows_x, int6
                           void* stream) {
   return seg_reduce_any(mode, RELGNN_ACT_LINEAR, X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, act,
                         out, ldo, stream);
+}
+
+int relgnn_seg_reduce_fwd_rowmax(int32_t mode, const float* X, int64_t num_rows_x, int64_t ldx, int32_t D,
+                                 const int32_t* rowptr, int64_t num_segments, int32_t seg_stride,
+                                 const int32_t* col, const float* w, int32_t act, float* out, int64_t ldo,
+                                 float* rowmax, void* stream) {
+  if (!rowmax) return RELGNN_EINVAL;
+  // the one-wave-per-row kernels with the whole row in one wave: 128 < D <= 1024, 16-byte aligned rows
+  if (mode == RELGNN_AGG_MAX || D % 4 != 0 || D <= 128 || D > 1024 || ldx % 4 != 0 || ldo % 4 != 0 || !aligned16(X) || !aligned16(out) ||
+      num_rows_x * (ldx / 4) >= ((int64_t)1 << 32))
+    return RELGNN_EUNSUPPORTED;
+  tl_rowmax = rowmax;
+  const int rc = seg_reduce_any(mode, RELGNN_ACT_LINEAR, X, num_rows_x, ldx, D, rowptr, num_segments, seg_stride, col, w, act,
+                                out, ldo, stream);
+  tl_rowmax = nullptr;
+  return rc;
 }
 
 int relgnn_seg_reduce_msgact_fwd(int32_t mode, int32_t msg_act, const float* X, int64_t num_rows_x, int64_t ldx,

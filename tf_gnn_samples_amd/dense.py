@@ -33,6 +33,10 @@ _CACHED_LIB_GEMM = _GEMM_MODE != "torch"
 _PANEL_GEMM = _GEMM_MODE == "panel"
 _LIMB_GEMM = _GEMM_MODE == "limb"
 _LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
+# RELGNN_LIMB=pair: where the producer of the left operand supplies per-row magnitudes (the gather in front of the aggregate-first
+# layer's products), the product is evaluated from TWO fp16 limbs per value behind exact power-of-two scales — three MFMA products
+# instead of the six of the bf16 triple (csrc/limb_gemm.hip, NL = 2); `triple` keeps the exact split everywhere.
+_LIMB_PAIR = os.environ.get("RELGNN_LIMB", "triple") == "pair"
 _LIMB_CUT = os.environ.get("RELGNN_LIMB_CUT", "1") == "1"       # N % 128 >= 96 on the 128-column panels (last chunk cut at N)
 _LIMB_WS = {}
 _STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
@@ -286,7 +290,8 @@ def weights_changed() -> None:
 
 
 class _WeightImage:
-    __slots__ = ("refs", "items", "versions", "gen", "used_gen", "buf")     # (no strong reference to the weights)
+    # (no strong reference to the weights; pair: two fp16 limbs, `wmax` = the device float the image's scale comes from)
+    __slots__ = ("refs", "items", "versions", "gen", "used_gen", "buf", "pair", "wmax")
 
 
 def _weight_matrices(w):
@@ -329,17 +334,39 @@ def _split_weight_images(images) -> None:
     import ctypes
     from . import _lib
     lib = _lib.load_library()
-    items = [it for im in images for it in im.items]
-    n = len(items)
-    cols = list(zip(*items))
-    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
-    _lib.check(lib.relgnn_limb_split_multi_f32(n, vp(*cols[0]), i64(*cols[1]), i32(*cols[2]), i32(*cols[3]), i32(*cols[4]),
-                                               vp(*cols[5]), i32(*cols[6]), i32(*cols[7]), _lib.current_stream()),
-               "relgnn_limb_split_multi_f32")
+    triples = [im for im in images if not im.pair]
+    pairs = [im for im in images if im.pair]
+    if triples:
+        items = [it for im in triples for it in im.items]
+        n = len(items)
+        cols = list(zip(*items))
+        vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+        _lib.check(lib.relgnn_limb_split_multi_f32(n, vp(*cols[0]), i64(*cols[1]), i32(*cols[2]), i32(*cols[3]), i32(*cols[4]),
+                                                   vp(*cols[5]), i32(*cols[6]), i32(*cols[7]), _lib.current_stream()),
+                   "relgnn_limb_split_multi_f32")
+    if pairs:           # two fp16 limbs: one magnitude per image first (its power-of-two scale), then the limbs — three launches
+        wm = torch.empty(len(pairs), dtype=torch.float32, device=pairs[0].buf.device)
+        items, image = [], []
+        for i, im in enumerate(pairs):
+            im.wmax = wm[i:i + 1]
+            items += im.items
+            image += [i] * len(im.items)
+        n = len(items)
+        cols = list(zip(*items))
+        vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+        _lib.check(lib.relgnn_limb16_split_multi_f32(n, vp(*cols[0]), i64(*cols[1]), i32(*cols[2]), i32(*cols[3]), i32(*cols[4]),
+                                                     vp(*cols[5]), i32(*cols[6]), i32(*cols[7]), i32(*image), len(pairs),
+                                                     wm.data_ptr(), _lib.current_stream()), "relgnn_limb16_split_multi_f32")
 
 
 def weight_limbs(w, kind: str) -> torch.Tensor:
-    """The limb image (flat bf16 buffer) of a weight operand as the right operand B [N, K] of relgnn_limb_gemm_xf32; w: a matrix, a
+    """The bf16-triple limb image (flat buffer) of a weight operand: weight_image(w, kind).buf."""
+    return weight_image(w, kind).buf
+
+
+def weight_image(w, kind: str, pair: bool = False) -> "_WeightImage":
+    """The limb image of a weight operand as the right operand B [N, K] of relgnn_limb_gemm_xf32 (pair: of relgnn_limb16_gemm_xf32:
+    two fp16 limbs, .wmax = the device float its scale comes from); .buf is the flat 16-bit buffer.  w: a matrix, a
     [L, ., .] stack or a sequence of matrices (laid side by side along k):
       WEIGHT_NN  w_l [K_l, N]:  [x_0 | x_1 | ..] @ [w_0; w_1; ..] = sum_l x_l @ w_l     (Dense forward; gnns/rgcn.py:96-98 summed over
                                                                                           the edge types in one product)
@@ -350,15 +377,17 @@ def weight_limbs(w, kind: str) -> torch.Tensor:
     ws = _weight_matrices(w)
     rows, cols = _weight_image_shape(ws, kind)
     dev = ws[0].device
+    elements = int(lib.relgnn_limb16_elements(rows, cols) if pair else lib.relgnn_limb_elements(rows, cols))
     if torch.cuda.is_current_stream_capturing() or not _WEIGHT_LIMB_CACHE:
         im = _WeightImage()
-        im.buf = torch.empty(int(lib.relgnn_limb_elements(rows, cols)), dtype=torch.bfloat16, device=dev)
+        im.pair, im.wmax = pair, None
+        im.buf = torch.empty(elements, dtype=torch.bfloat16, device=dev)
         im.items = _weight_image_items(ws, kind, im.buf)
         _split_weight_images([im])
-        return im.buf
+        return im
     import weakref
     table = _WEIGHT_LIMBS.setdefault((dev, torch.cuda.current_stream(dev).cuda_stream), {})
-    key = (kind,) + tuple((m.data_ptr(), m.shape[0], m.shape[1], m.stride(0)) for m in ws)
+    key = (kind, pair) + tuple((m.data_ptr(), m.shape[0], m.shape[1], m.stride(0)) for m in ws)
     gen = _WEIGHT_GEN[0]
     im = table.get(key)
     bases = [m._base if m._base is not None else m for m in ws]
@@ -366,11 +395,12 @@ def weight_limbs(w, kind: str) -> torch.Tensor:
         im = None                                        # another tensor lives at that address now
     if im is not None and im.gen == gen and im.versions == [m._version for m in ws]:
         im.used_gen = gen
-        return im.buf
+        return im
     if im is None:
         im = table[key] = _WeightImage()
         im.refs, im.gen, im.versions, im.used_gen = [weakref.ref(b) for b in bases], -1, None, gen
-        im.buf = torch.empty(int(lib.relgnn_limb_elements(rows, cols)), dtype=torch.bfloat16, device=dev)
+        im.pair, im.wmax = pair, None
+        im.buf = torch.empty(elements, dtype=torch.bfloat16, device=dev)
         im.items = _weight_image_items(ws, kind, im.buf)
     todo = [im]
     for k, other in list(table.items()):
@@ -385,20 +415,30 @@ def weight_limbs(w, kind: str) -> torch.Tensor:
     for t in todo:
         t.gen, t.versions = gen, [r()._version for r in t.refs]
     im.used_gen = gen
-    return im.buf
+    return im
 
 
 def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, act: int = 0,
-                     out: torch.Tensor = None) -> torch.Tensor:
-    """act(bias + a @ B^T) with B = weight_limbs(w, kind), a fp32 [M, K] split inside the kernel (relgnn_limb_gemm_xf32)."""
+                     out: torch.Tensor = None, xmax: torch.Tensor = None, xgroups: int = 0) -> torch.Tensor:
+    """act(bias + a @ B^T) with B = weight_limbs(w, kind), a fp32 [M, K] split inside the kernel (relgnn_limb_gemm_xf32).
+    xmax [M * xgroups] (per-row magnitudes of `a` from its producer, ops._seg_reduce_raw(rowmax=)): the two-fp16-limb form
+    (relgnn_limb16_gemm_xf32)."""
     from . import _lib
     lib = _lib.load_library()
     n, k = _weight_image_shape(_weight_matrices(w), kind)
     if a.shape[1] != k:
         raise ValueError("limb_gemm_weight: a is [%d, %d], the weight operand has K = %d" % (a.shape[0], a.shape[1], k))
-    buf = weight_limbs(w, kind)
     if out is None:
         out = torch.empty((a.shape[0], n), dtype=torch.float32, device=a.device)
+    if xmax is not None:
+        if xmax.numel() != a.shape[0] * xgroups or xmax.dtype != torch.float32 or not xmax.is_contiguous():
+            raise ValueError("limb_gemm_weight: xmax must be a contiguous float32 [%d * %d]" % (a.shape[0], xgroups))
+        im = weight_image(w, kind, pair=True)
+        _lib.check(lib.relgnn_limb16_gemm_xf32(act, a.data_ptr(), a.stride(0), xmax.data_ptr(), int(xgroups), im.buf.data_ptr(),
+                                               im.wmax.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)), out.data_ptr(),
+                                               out.stride(0), a.shape[0], n, k, _lib.current_stream()), "relgnn_limb16_gemm_xf32")
+        return out
+    buf = weight_limbs(w, kind)
     _lib.check(lib.relgnn_limb_gemm_xf32(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
                                          out.data_ptr(), out.stride(0), a.shape[0], n, k, _lib.current_stream()),
                "relgnn_limb_gemm_xf32")
@@ -412,22 +452,22 @@ def _limb_group_ok(a: torch.Tensor, ws, kind: str) -> bool:
     return a.shape[1] == k and n % 256 == 0 and 16 <= k <= _LIMB_MAX_K
 
 
-def grouped_nn_gemm(a: torch.Tensor, kernels, relu: bool = False) -> torch.Tensor:
+def grouped_nn_gemm(a: torch.Tensor, kernels, relu: bool = False, xmax: torch.Tensor = None, xgroups: int = 0) -> torch.Tensor:
     """(relu of) sum_l a[:, block l] @ kernels[l] for a [V, sum_l K_l], kernels[l] [K_l, N]: gnns/rgcn.py:96-98 summed over the
     edge types in one product (the aggregate-first layer's forward)."""
     from . import _lib
     kernels = list(kernels)
     if _limb_group_ok(a, kernels, WEIGHT_NN):
-        return limb_gemm_weight(a, kernels, WEIGHT_NN, None, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
+        return limb_gemm_weight(a, kernels, WEIGHT_NN, None, _lib.ACT_RELU if relu else _lib.ACT_LINEAR, xmax=xmax, xgroups=xgroups)
     return lib_gemm(GEMM_NN, a, torch.cat(kernels, dim=0) if len(kernels) > 1 else kernels[0], relu=relu)
 
 
-def grouped_nt_gemm(g: torch.Tensor, kernels) -> torch.Tensor:
+def grouped_nt_gemm(g: torch.Tensor, kernels, xmax: torch.Tensor = None, xgroups: int = 0) -> torch.Tensor:
     """sum_l g[:, block l] @ kernels[l]^T for g [V, sum_l K_l], kernels[l] [N, K_l]: the input gradient of grouped_nn_gemm's layer
     (dH = sum_l dT_l @ W_l^T)."""
     kernels = list(kernels)
     if _limb_group_ok(g, kernels, WEIGHT_NT):
-        return limb_gemm_weight(g, kernels, WEIGHT_NT)
+        return limb_gemm_weight(g, kernels, WEIGHT_NT, xmax=xmax, xgroups=xgroups)
     # (the stacked [sum K_l, N] right operand is W_l^T row blocks, 0.8 MB re-laid per call at C2)
     return lib_gemm(GEMM_NN, g, torch.cat([k.t() for k in kernels], dim=0))
 

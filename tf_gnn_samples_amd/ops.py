@@ -100,15 +100,30 @@ def acc64_supported(D: int) -> bool:
     return D % 4 == 0 and 128 < D <= 1024
 
 
-def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEAR, acc64: bool = False):
+def rowmax_supported(X, rowptr, stride, acc64: bool = False) -> bool:
+    """relgnn_seg_reduce_fwd_rowmax takes this gather (one wave holds a whole output row; not the hub-split route)."""
+    split = getattr(rowptr, "_relgnn_split", None)
+    D = X.shape[1]
+    return (not acc64 and not (split is not None and stride in split) and X.is_cuda and D % 4 == 0 and 128 < D <= 1024
+            and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0)
+
+
+def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEAR, acc64: bool = False, rowmax=None):
     """acc64: float64 bucket accumulators (relgnn_seg_reduce_acc64_fwd) — for sums that feed a GEMM, never for values that
-    stand for the reference's own segment sums.  Split (hub) plans keep the float32 two-pass route."""
+    stand for the reference's own segment sums.  Split (hub) plans keep the float32 two-pass route.
+    rowmax: a [num_out] float32 tensor that receives the largest magnitude of every output row (rowmax_supported)."""
     split = getattr(rowptr, "_relgnn_split", None)
     if split is not None and stride in split:
         return _seg_reduce_split(mode, X, split[stride], col, w, num_out, act)
     lib = _lib.load_library()
     D = X.shape[1]
     out = torch.empty((num_out, D), dtype=torch.float32, device=X.device)
+    if rowmax is not None:
+        _lib.check(lib.relgnn_seg_reduce_fwd_rowmax(
+            mode, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), D, _lib.ptr(rowptr), num_out, stride,
+            _lib.ptr(col), _lib.ptr(w), act, _lib.ptr(out), D, _lib.ptr(rowmax), _lib.current_stream()),
+            "relgnn_seg_reduce_fwd_rowmax")
+        return out
     if acc64 and mode != _lib.AGG_MAX and acc64_supported(D) and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0:
         _lib.check(lib.relgnn_seg_reduce_acc64_fwd(
             mode, _lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0), D, _lib.ptr(rowptr), num_out, stride,
@@ -779,6 +794,17 @@ def _side_stream(device):
     return st
 
 
+def _pair_products(X, rowptr, stride, V, k, n, kernels, kind) -> bool:
+    """The two-fp16-limb form for this gather + product pair (dense.RELGNN_LIMB=pair): the gather can write the per-bucket
+    magnitudes and the product takes the limb route."""
+    from . import dense as DN
+    if not (DN._LIMB_PAIR and DN._LIMB_GEMM and X.is_cuda and V >= DN._LIMB_MIN_ROWS and n % 256 == 0 and k % 16 == 0
+            and 16 <= k <= DN._LIMB_MAX_K):
+        return False
+    return (rowmax_supported(X, rowptr, stride, aggregate_acc64())
+            and DN.weight_image_ok(list(kernels), DN.WEIGHT_NN if kind == "nn" else DN.WEIGHT_NT))
+
+
 class _AggregateThenTransform(torch.autograd.Function):
     """out = act(f_mode(sum_l A_l @ W_l)),  A_l[v] = sum_{p in (v,l)} w_p H[src_p]   (W: [L, Din, Dout]).
 
@@ -796,11 +822,15 @@ class _AggregateThenTransform(torch.autograd.Function):
         L = len(kernels)                                # kernels[l]: [Din, Dout], the per-edge-type variables themselves
         d_in, d_out = kernels[0].shape
         V = graph.V
+        # RELGNN_LIMB=pair: the gather also writes every bucket's largest magnitude — the row scales of the two-fp16-limb product
+        amax = None
+        if _pair_products(H, graph.rowptr_t, 1, V, L * d_in, d_out, kernels, "nn"):
+            amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
         agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
-                              acc64=aggregate_acc64()).view(V, L * d_in)
+                              acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
         f = _mode_factor(graph, mode)
         fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the product's epilogue
-        out = grouped_nn_gemm(agg, kernels, relu=fused_relu)
+        out = grouped_nn_gemm(agg, kernels, relu=fused_relu, xmax=amax, xgroups=L)
         if f is not None:
             out.mul_(f.unsqueeze(1))
         if act == _lib.ACT_RELU:
@@ -848,9 +878,13 @@ class _AggregateThenTransform(torch.autograd.Function):
                 t.record_stream(side)
         if ctx.needs_input_grad[0]:
             plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
+            gmax = None
+            if (plan.num_rows_x == V * L and
+                    _pair_products(gout, plan.rowptr_b, plan.stride_b, V, L * d_out, d_in, kernels, "nt")):
+                gmax = torch.empty(V * L, dtype=torch.float32, device=gout.device)
             gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
-                                 plan.num_rows_x, acc64=aggregate_acc64()).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
-            gH = grouped_nt_gemm(gT, kernels)           # dH = sum_l dT_l @ W_l^T
+                                 plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
+            gH = grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=L)           # dH = sum_l dT_l @ W_l^T
         if side is not None:
             torch.cuda.current_stream(gout.device).wait_stream(side)
             gW.record_stream(torch.cuda.current_stream(gout.device))
