@@ -632,6 +632,12 @@ def main():
         # fp32 values everywhere in HBM and in every result; how the tall node-side Dense products are evaluated:
         "dense_products": {
             "route": os.environ.get("RELGNN_GEMM", "limb"),
+            "limbs": os.environ.get("RELGNN_LIMB", "pair"),
+            "pair": "the aggregate-first layer's products (forward, input gradient, weight gradient: K = 768) from TWO fp16 limbs per "
+                    "value (22 significant bits) behind exact power-of-two scales — per row of the streamed operand, from the "
+                    "magnitudes the gather writes with its rows; per operand for the weight gradient — three "
+                    "v_mfma_f32_32x32x16_f16 products per fp32 product; against float64 at least as close as the bf16 triple "
+                    "(RELGNN_LIMB=triple) and closer than the exact-fp32 library product on these shapes",
             "limb": "each fp32 operand as three bf16 limbs (hi + mid + lo == x exactly), the six limb products of weight >= 2^-16 "
                     "on v_mfma_f32_32x32x16_bf16 (each exact in fp32), fp32 accumulation; dropped terms < 2^-23 of a product. "
                     "Measured against float64 at [36 k, 768] x [768, 256]: 4.0e-6 max abs (exact-fp32 library GEMM: 5.3e-6); "

@@ -788,6 +788,12 @@ int relgnn_limb16_split_multi_f32(int32_t n, const float* const* X, const int64_
 int relgnn_limb16_gemm_xf32(int32_t act, const float* A, int64_t lda, const float* xmax, int32_t xgroups, const uint16_t* B,
                             const float* wmax, const float* bias, const void* zeros, float* C, int64_t ldc, int32_t M, int32_t N,
                             int32_t K, void* stream);
+/* The weight gradient from two fp16 limbs: relgnn_limb_gemm_tn_f32's partial products with ONE power-of-two scale per operand
+ * (amax[0], gmax[0]: the operands' largest magnitudes in device memory, e.g. from relgnn_absmax_f32; the reduction runs over the
+ * rows of both operands, so a row's scale would not factor out).  relgnn_absmax_f32: out[0] = max |x[i]| (x 16-byte aligned). */
+int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax, float* P,
+                              int32_t V, int32_t J, int32_t C, void* stream);
+int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream);
 /* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need
  * (gnns/gnn_film.py:92-106; the limb counterpart of relgnn_panel_gemm_f32's a_rows / b_select for the forward product and the input
  * gradient; K = 128 there):

@@ -417,3 +417,19 @@ def test_two_fp16_limb_products_of_the_aggregate_first_layer(gpu_device, monkeyp
             assert ep <= max(2.0 * et, 4e-6 * max(float(t.abs().max()), 1e-30)), (name, ep, et)
     for name, a, b in zip(["out", "dH", "dW0", "dW1", "dW2"], triple, pair):
         assert float((a - b).abs().max()) <= 8e-6 * max(float(a.abs().max()), 1e-30), name
+
+
+@pytest.mark.parametrize("V,J,C", [(36096, 768, 256), (5000, 128, 256), (9001, 256, 512)])
+def test_limb16_gemm_tn_matches_float64(gpu_device, V, J, C):
+    """The weight gradient from two fp16 limbs behind one power-of-two scale per operand, against float64 next to the bf16 triple;
+    operands whose rows span four decades (what gradients look like)."""
+    from tf_gnn_samples_amd import dense as DN
+    g = torch.Generator(device="cpu").manual_seed(V + J)
+    a = (torch.relu(torch.randn((V, J), generator=g)) * torch.distributions.Gamma(2.0, 0.125).sample((V, 1))).to(gpu_device)
+    b = (torch.randn((V, C), generator=g) * 1e-4 * torch.exp(torch.empty(V, 1).uniform_(-4.6, 4.6))).to(gpu_device)
+    truth = a.double().t() @ b.double()
+    pair = DN.limb_gemm_tn(a, b, DN.absmax(a), DN.absmax(b))
+    triple = DN.limb_gemm_tn(a, b)
+    e2, e3 = float((pair.double() - truth).abs().max()), float((triple.double() - truth).abs().max())
+    assert e2 <= max(2.0 * e3, 2e-6 * float(truth.abs().max())), (e2, e3)
+    assert float(DN.absmax(b)) == float(b.abs().max()) and float(DN.absmax(a[:7, :3].contiguous())) == float(a[:7, :3].abs().max())

@@ -923,12 +923,16 @@ struct LimbTnArgs {
   int32_t V, J, C;
   int32_t rows_per_chunk;              // % 32 == 0
   int32_t panels, chunks, Z;
+  const float* amax; const float* gmax;   // NL = 2: the largest magnitude of A / of G (device floats): one power-of-two scale per operand
 };
 
-template <int T32>
+// NL = 3: bf16 triples, six products; NL = 2: fp16 pairs behind ONE power-of-two scale per operand (the reduction runs over the rows
+// of both operands, so a row's scale would not factor out; an element 2^-18 below its operand's largest loses low bits of a term
+// that is 2^-18 of the largest terms of the sum), three products.
+template <int T32, int NL = 3>
 __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   constexpr int NC = 256, PR = 32 * T32;
-  constexpr int PA = 3 * T32, PB = 3 * (NC / 32), P = PA + PB;
+  constexpr int PA = NL * T32, PB = NL * (NC / 32), P = PA + PB;
   constexpr int STAGE_BYTES = P * 1024;
   constexpr int XG = PR / 4;                          // 4-column groups of the panel's rows
   constexpr int ITEMS = 256 + 4 * XG;                 // per 32-row super-tile: G: 64 groups x 4 row octets, A: XG x 4
@@ -962,7 +966,9 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   // LDS blocks of THIS kernel keep row i of a tile at slot i ^ ((i >> 3) & 3) (16 B each): the fragment reads stay conflict-free
   // (the XOR permutes inside aligned groups of four slots) and the limb stores — 8 lanes = 8 column groups = rows 4 a + c — hit
   // 8 different bank quads instead of two (4-way conflicts: 114 -> 9x us at [36 k, 768]^T x [36 k, 256])
-  const int blk = ((is_g ? PA : 0) + 3 * (col >> 5)) * 1024 + (oct & 1) * 512 + (col & 31) * 16;
+  const int blk = ((is_g ? PA : 0) + NL * (col >> 5)) * 1024 + (oct & 1) * 512 + (col & 31) * 16;
+  float pscale = 1.f;
+  if constexpr (NL == 2) pscale = limb16_scale(is_g ? a.gmax[0] : a.amax[0]);
   const int cswz = ((col & 31) >> 3) & 3;                          // column c of my patch goes to slot (col & 31) + (c ^ cswz)
   const int dump = DUMP + lane * 16;
   f32x4 pv[8];                                                      // the patch in flight: pv[m][c]
@@ -974,12 +980,19 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
     for (int m = 0; m < 8; ++m) pv[m] = *reinterpret_cast<const f32x4*>(base + (int64_t)min(r0 + m, a.V - 1) * ld);
   };
   auto p_store = [&](int S, int c, const float* v) {                // 8 reduction values of column c -> one chunk per plane
-    uint4 h, m, l;
-    split8(v, h, m, l);
     const int off = (active && S < nsuper) ? ((2 * S + (oct >> 1)) % STAGES) * STAGE_BYTES + blk + (c ^ cswz) * 16 : dump;
-    *reinterpret_cast<uint4*>(lds + off) = h;
-    *reinterpret_cast<uint4*>(lds + off + 1024) = m;
-    *reinterpret_cast<uint4*>(lds + off + 2048) = l;
+    if constexpr (NL == 2) {
+      uint4 h, l;
+      split8_16(v, pscale, h, l);
+      *reinterpret_cast<uint4*>(lds + off) = h;
+      *reinterpret_cast<uint4*>(lds + off + 1024) = l;
+    } else {
+      uint4 h, m, l;
+      split8(v, h, m, l);
+      *reinterpret_cast<uint4*>(lds + off) = h;
+      *reinterpret_cast<uint4*>(lds + off + 1024) = m;
+      *reinterpret_cast<uint4*>(lds + off + 2048) = l;
+    }
   };
   // step 0 .. 3 of a super-tile's split: columns 0 (+ keep columns 2, 3 aside: the next load reuses pv), 1 | 2, 3
   auto p_step = [&](int S, auto step_c) {
@@ -1002,21 +1015,23 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
 
   // ---- fragments / products (as in limb_gemm_kernel) ------------------------------------------------------------------
   struct Limbs { bf16x8 hi, mid, lo; };
-  auto read_x = [&](int stage, int tm) {
-    const unsigned char* p = lds + stage * STAGE_BYTES + (3 * tm) * 1024 + 16 * (lane ^ ((lane >> 3) & 3));
+  auto read_planes = [&](const unsigned char* p) {
     Limbs f;
     f.hi = *reinterpret_cast<const bf16x8*>(p);
-    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
-    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    if constexpr (NL == 3) {
+      f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
+      f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
+    } else {
+      f.lo = *reinterpret_cast<const bf16x8*>(p + 1024);
+      f.mid = f.lo;
+    }
     return f;
   };
+  auto read_x = [&](int stage, int tm) {
+    return read_planes(lds + stage * STAGE_BYTES + (NL * tm) * 1024 + 16 * (lane ^ ((lane >> 3) & 3)));
+  };
   auto read_w = [&](int stage) {
-    const unsigned char* p = lds + stage * STAGE_BYTES + (PA + 3 * wave) * 1024 + 16 * (lane ^ ((lane >> 3) & 3));
-    Limbs f;
-    f.hi = *reinterpret_cast<const bf16x8*>(p);
-    f.mid = *reinterpret_cast<const bf16x8*>(p + 1024);
-    f.lo = *reinterpret_cast<const bf16x8*>(p + 2048);
-    return f;
+    return read_planes(lds + stage * STAGE_BYTES + (PA + NL * wave) * 1024 + 16 * (lane ^ ((lane >> 3) & 3)));
   };
   f32x16 acc[T32];
 #pragma unroll
@@ -1024,13 +1039,22 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
   auto products = [&](f32x16 c, const Limbs& w, const Limbs& x) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, c, 0, 0, 0);
-    return c;
+    if constexpr (NL == 2) {
+      const f16x8 wh = __builtin_bit_cast(f16x8, w.hi), wl = __builtin_bit_cast(f16x8, w.lo);
+      const f16x8 xh_ = __builtin_bit_cast(f16x8, x.hi), xl = __builtin_bit_cast(f16x8, x.lo);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh_, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh_, c, 0, 0, 0);
+      return c;
+    } else {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, c, 0, 0, 0);
+      return c;
+    }
   };
 
   // ---- pipeline: super-tile S is loaded during k-tile 2S-4, split and stored during k-tiles 2S-2 (columns 0, 1) and 2S-1
@@ -1103,13 +1127,37 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   const int i32 = lane & 31, h32 = lane >> 5;
   const int colw = n0 + wave * 32;
   float* slab = a.P + (int64_t)z * a.J * a.C;
+  float unscale = 1.f;
+  if constexpr (NL == 2) unscale = limb16_unscale(a.amax[0]) * limb16_unscale(a.gmax[0]);      // (powers of two: exact)
 #pragma unroll
   for (int tm = 0; tm < T32; ++tm) {
     float* crow = slab + (int64_t)(j0 + tm * 32 + i32) * a.C;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      *reinterpret_cast<f32x4*>(crow + colw + 8 * c + 4 * h32) =
-          f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+    for (int c = 0; c < 4; ++c) {
+      f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
+      if constexpr (NL == 2) v *= unscale;
+      *reinterpret_cast<f32x4*>(crow + colw + 8 * c + 4 * h32) = v;
+    }
+  }
+}
+
+// the largest magnitude of n floats (atomicMax on the bit pattern; the caller zeroes *out first)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ out) {
+  float m = 0.f;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - 4 * n4)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wave_max[4];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
   }
 }
 
@@ -1471,8 +1519,37 @@ int64_t relgnn_limb_gemm_tn_chunks(int32_t V, int32_t J, int32_t C) {
 // P [chunks][J][C] = per-chunk partial products of A^T G over the first V - V % 32 rows (A [V, J], G [V, C], fp32 row-major;
 // J % 32 == 0, C % 256 == 0, V >= 32); chunks = relgnn_limb_gemm_tn_chunks(V, J, C).  The caller sums the slabs in order and adds
 // the last V % 32 rows' product: relgnn_sum_slabs_tail_f32 does both in one pass.
+static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax, float* P,
+                       int32_t V, int32_t J, int32_t C, void* stream);
+
 int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* P, int32_t V, int32_t J, int32_t C,
                             void* stream) {
+  return limb_tn_any(A, lda, G, ldg, nullptr, nullptr, P, V, J, C, stream);
+}
+
+int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax, float* P,
+                              int32_t V, int32_t J, int32_t C, void* stream) {
+  if (!amax || !gmax) return RELGNN_EINVAL;
+  return limb_tn_any(A, lda, G, ldg, amax, gmax, P, V, J, C, stream);
+}
+
+int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
+  if (n < 0 || !out) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return RELGNN_EHIP;
+  if (n == 0) return RELGNN_OK;
+  if (!x) return RELGNN_EINVAL;
+  if (!aligned16(x)) return RELGNN_EUNSUPPORTED;
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  absmax_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, n4, n, out);
+  return launch_status();
+}
+
+static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax, float* P,
+                       int32_t V, int32_t J, int32_t C, void* stream) {
   if (V < 0 || J < 0 || C < 0) return RELGNN_EINVAL;
   if (J == 0 || C == 0) return RELGNN_OK;
   if (V < 32) return RELGNN_EUNSUPPORTED;
@@ -1480,13 +1557,21 @@ int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t
   if (J % 32 != 0 || C % 256 != 0 || lda % 4 || ldg % 4 || lda < J || ldg < C || !aligned16(A) || !aligned16(G) || !aligned16(P))
     return RELGNN_EUNSUPPORTED;
   LimbTnArgs a{};
-  a.A = A; a.lda = lda; a.G = G; a.ldg = ldg; a.P = P; a.V = V - V % 32; a.J = J; a.C = C;
+  a.A = A; a.lda = lda; a.G = G; a.ldg = ldg; a.P = P; a.V = V - V % 32; a.J = J; a.C = C; a.amax = amax; a.gmax = gmax;
   int t32, rows, Z;
   limb_tn_geometry(V, J, C, &t32, &rows, &Z);
   a.panels = (J / 32) / t32; a.chunks = C / 256; a.rows_per_chunk = rows; a.Z = Z;
   const int64_t logical = (int64_t)a.panels * a.chunks * a.Z;
   const unsigned grid = (unsigned)(8 * ((logical + 7) / 8));
   hipStream_t st = as_stream(stream);
+  if (amax) {
+    switch (t32) {
+      case 4: limb_gemm_tn_kernel<4, 2><<<grid, 512, 0, st>>>(a); break;
+      case 2: limb_gemm_tn_kernel<2, 2><<<grid, 512, 0, st>>>(a); break;
+      default: limb_gemm_tn_kernel<1, 2><<<grid, 512, 0, st>>>(a); break;
+    }
+    return launch_status();
+  }
   switch (t32) {
     case 4: limb_gemm_tn_kernel<4><<<grid, 512, 0, st>>>(a); break;
     case 2: limb_gemm_tn_kernel<2><<<grid, 512, 0, st>>>(a); break;

@@ -33,10 +33,12 @@ _CACHED_LIB_GEMM = _GEMM_MODE != "torch"
 _PANEL_GEMM = _GEMM_MODE == "panel"
 _LIMB_GEMM = _GEMM_MODE == "limb"
 _LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
-# RELGNN_LIMB=pair: where the producer of the left operand supplies per-row magnitudes (the gather in front of the aggregate-first
-# layer's products), the product is evaluated from TWO fp16 limbs per value behind exact power-of-two scales — three MFMA products
-# instead of the six of the bf16 triple (csrc/limb_gemm.hip, NL = 2); `triple` keeps the exact split everywhere.
-_LIMB_PAIR = os.environ.get("RELGNN_LIMB", "triple") == "pair"
+# RELGNN_LIMB=pair (default): where the producer of the left operand supplies per-row magnitudes (the gather in front of the
+# aggregate-first layer's products), the product is evaluated from TWO fp16 limbs per value behind exact power-of-two scales — three
+# MFMA products instead of the six of the bf16 triple (csrc/limb_gemm.hip, NL = 2; its weight gradient: one scale per operand).
+# Against float64 on the C2 shapes it is at least as close as the triple and closer than the exact-fp32 library product
+# (scripts/bench_limb16.py, tests/test_gpu_limb_gemm.py); `triple` keeps the exact split everywhere.
+_LIMB_PAIR = os.environ.get("RELGNN_LIMB", "pair") == "pair"
 _LIMB_CUT = os.environ.get("RELGNN_LIMB_CUT", "1") == "1"       # N % 128 >= 96 on the 128-column panels (last chunk cut at N)
 _LIMB_WS = {}
 _STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
@@ -548,8 +550,18 @@ def limb_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
             and b.shape[1] % 256 == 0)
 
 
-def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T @ b for a [V, J], b [V, C] (weight gradient) through relgnn_limb_gemm_tn_f32 + the in-order slab sum."""
+def absmax(x: torch.Tensor) -> torch.Tensor:
+    """[1] float32 on the device: max |x| (relgnn_absmax_f32; no host round trip)."""
+    from . import _lib
+    x = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load_library().relgnn_absmax_f32(_lib.ptr(x), x.numel(), out.data_ptr(), _lib.current_stream()), "relgnn_absmax_f32")
+    return out
+
+
+def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor, amax: torch.Tensor = None, bmax: torch.Tensor = None) -> torch.Tensor:
+    """a^T @ b for a [V, J], b [V, C] (weight gradient) through relgnn_limb_gemm_tn_f32 + the in-order slab sum.
+    amax, bmax ([1] device floats: the operands' largest magnitudes, e.g. absmax()): the two-fp16-limb form."""
     from . import _lib
     lib = _lib.load_library()
     V, J = a.shape
@@ -558,8 +570,12 @@ def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     if Z <= 0:
         raise ValueError("limb_gemm_tn: unsupported shape [%d, %d]^T @ [%d, %d]" % (V, J, V, C))
     parts = torch.empty((Z, J, C), dtype=torch.float32, device=a.device)
-    _lib.check(lib.relgnn_limb_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), parts.data_ptr(), V, J, C,
-                                           _lib.current_stream()), "relgnn_limb_gemm_tn_f32")
+    if amax is not None:
+        _lib.check(lib.relgnn_limb16_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), amax.data_ptr(), bmax.data_ptr(),
+                                                 parts.data_ptr(), V, J, C, _lib.current_stream()), "relgnn_limb16_gemm_tn_f32")
+    else:
+        _lib.check(lib.relgnn_limb_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), parts.data_ptr(), V, J, C,
+                                               _lib.current_stream()), "relgnn_limb_gemm_tn_f32")
     # the slabs in chunk order + the last V % 32 rows (exact fp32), one pass
     R = V % 32
     out = torch.empty((J, C), dtype=torch.float32, device=a.device)

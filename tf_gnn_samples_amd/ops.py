@@ -794,12 +794,24 @@ def _side_stream(device):
     return st
 
 
+def _weight_gradient(agg, gsc, amax):
+    """agg^T @ gsc; with the buckets' magnitudes from the forward gather (RELGNN_LIMB=pair) from two fp16 limbs behind one
+    power-of-two scale per operand (their largest magnitudes: two small reductions, on whatever stream this runs on)."""
+    from . import dense as DN
+    if (amax is not None and DN._LIMB_PAIR and DN.limb_tn_supported(agg, gsc) and agg.shape[1] * gsc.shape[1] > 256 * 256
+            and "tn" in os.environ.get("RELGNN_LIMB_PAIR_PARTS", "nn,nt,tn").split(",")):
+        return DN.limb_gemm_tn(agg, gsc, DN.absmax(amax), DN.absmax(gsc))
+    return DN.matmul_tn_splitk(agg, gsc)
+
+
 def _pair_products(X, rowptr, stride, V, k, n, kernels, kind) -> bool:
     """The two-fp16-limb form for this gather + product pair (dense.RELGNN_LIMB=pair): the gather can write the per-bucket
     magnitudes and the product takes the limb route."""
     from . import dense as DN
     if not (DN._LIMB_PAIR and DN._LIMB_GEMM and X.is_cuda and V >= DN._LIMB_MIN_ROWS and n % 256 == 0 and k % 16 == 0
             and 16 <= k <= DN._LIMB_MAX_K):
+        return False
+    if kind not in os.environ.get("RELGNN_LIMB_PAIR_PARTS", "nn,nt,tn").split(","):      # (diagnostics: which products take the form)
         return False
     return (rowmax_supported(X, rowptr, stride, aggregate_acc64())
             and DN.weight_image_ok(list(kernels), DN.WEIGHT_NN if kind == "nn" else DN.WEIGHT_NT))
@@ -843,7 +855,8 @@ class _AggregateThenTransform(torch.autograd.Function):
             out = apply_activation(get_activation(act_name), out)
         ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L = graph, w, mode, act, L
         want_w = any(k.requires_grad for k in kernels)
-        ctx.save_for_backward(agg if want_w else None, out if act != _lib.ACT_LINEAR else None, *kernels)
+        ctx.save_for_backward(agg if want_w else None, out if act != _lib.ACT_LINEAR else None,
+                              amax if want_w else None, *kernels)
         return out
 
     @staticmethod
@@ -851,7 +864,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         from .dense import grouped_nt_gemm, matmul_tn_splitk
         lib = _lib.load_library()
         graph, w, mode, act, L = ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L
-        agg, out, *kernels = ctx.saved_tensors
+        agg, out, amax, *kernels = ctx.saved_tensors
         d_in, d_out = kernels[0].shape
         V = graph.V
         gout = gout.contiguous()
@@ -873,8 +886,8 @@ class _AggregateThenTransform(torch.autograd.Function):
             with torch.cuda.stream(side):
                 f = _mode_factor(graph, mode)
                 gsc = gout if f is None else gout * f.unsqueeze(1)
-                gW = matmul_tn_splitk(agg, gsc)
-            for t in (agg, gout, gsc):
+                gW = _weight_gradient(agg, gsc, amax)
+            for t in (agg, gout, gsc) + ((amax,) if amax is not None else ()):
                 t.record_stream(side)
         if ctx.needs_input_grad[0]:
             plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
@@ -891,7 +904,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         elif want_w:
             f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
             gsc = gout if f is None else gout * f.unsqueeze(1)
-            gW = matmul_tn_splitk(agg, gsc)
+            gW = _weight_gradient(agg, gsc, amax)
         gWs = tuple(gW[l * d_in:(l + 1) * d_in] if ctx.needs_input_grad[6 + l] else None for l in range(L)) \
             if gW is not None else (None,) * L           # dW_l = A_l^T @ dOut: row block l of [L*Din, Dout]
         return (gH, None, None, None, None, None) + gWs
