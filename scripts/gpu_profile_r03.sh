@@ -25,6 +25,8 @@ timeout 600 python scripts/bench_limb_gemm.py > $O/limb_gemm.jsonl 2> $O/limb_ge
 timeout 600 python scripts/bench_limb_typed.py > $O/limb_typed.jsonl 2>> $O/limb_gemm.err
 ( time timeout 900 python bench.py 2>$O/bench.err >$O/bench.json ) 2>&1 | tail -3
 timeout 300 python bench.py --config C5 --steps 10 --warmup 3 --no-roofline --no-extras --no-cpu-baseline > $O/bench_c5.json 2>> $O/bench.err
+RELGNN_LIMB=triple timeout 300 python bench.py --steps 60 --warmup 12 --no-roofline --no-extras --no-cpu-baseline > $O/bench_limb_triple.json 2>> $O/bench.err
+timeout 300 python scripts/bench_limb16.py > $O/limb16.jsonl 2>> $O/limb_gemm.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bench -o bench -- \
     python $R/bench.py --steps 40 --warmup 10 --no-roofline --no-extras --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
