@@ -60,6 +60,12 @@ def parse_args():
                          "configs[4], GNN-FiLM on VarMisuse-shaped batches (23 edge types, h=128, 10 layers), ~1.2 M edges per rank "
                          "and step, sharded by graph with ONE all-reduce of the ~46 MB FiLM gradient per step")
     ap.add_argument("--cpu-sample-graphs", type=int, default=4)
+    ap.add_argument("--model-param-overrides", default=None,
+                    help="JSON dict of model hyper-parameters laid over the config's (the reference's train.py:38-59 layering: class "
+                         "defaults -> the config's values -> this), e.g. '{\"graph_num_layers\": 4}'.  A run with overrides is NOT "
+                         "the BASELINE workload any more: the line says so in config.model_param_overrides")
+    ap.add_argument("--task-param-overrides", default=None,
+                    help="JSON dict laid over the synthetic fold's generator parameters (graphs_per_rank, mean_nodes, ...)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     return ap.parse_args()
 
@@ -100,7 +106,7 @@ CONFIGS = {
 }
 
 
-def build_local_fold(rank, world, config="C2"):
+def build_local_fold(rank, world, config="C2", overrides=None):
     """This rank's shard of the fold: graphs_per_rank * world synthetic graphs, graph i drawn from its own generator stream
     default_rng([seed, i]) (tasks/synthetic.py), sharded over ranks by edge count (LPT).  The sizes of ALL graphs cost one
     draw each (the node count is the stream's first draw), so a rank builds only the graphs it owns — at 8 ranks that is 1/8 of
@@ -108,10 +114,16 @@ def build_local_fold(rank, world, config="C2"):
     from tf_gnn_samples_amd.parallel import shard_graphs_by_edges
     from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
     from tf_gnn_samples_amd.tasks import synthetic as S
-    n_graphs = CONFIGS[config]["graphs_per_rank"] * world
-    seed = 0
+    overrides = dict(overrides or {})
+    n_graphs = int(overrides.pop("graphs_per_rank", CONFIGS[config]["graphs_per_rank"])) * world
+    seed = int(overrides.pop("seed", 0))
     if config == "C2":
         gen = S.ppi_shaped_generator_params(num_graphs=n_graphs, seed=seed)
+        unknown = sorted(k for k in overrides if k not in gen)
+        if unknown:
+            raise SystemExit("--task-param-overrides: unknown generator parameter(s) %s (known: graphs_per_rank, seed, %s)"
+                             % (unknown, ", ".join(sorted(gen))))
+        gen.update(overrides)
         size_of, make = S.ppi_shaped_graph_size, S.make_ppi_shaped_graph
         kw = {k: gen[k] for k in ("mean_nodes", "std_nodes", "min_nodes", "max_nodes", "fwd_edges_per_node")}
         make_kw = dict(kw, feature_size=gen["feature_size"], num_labels=gen["num_labels"],
@@ -120,6 +132,8 @@ def build_local_fold(rank, world, config="C2"):
         gen = {"num_graphs": n_graphs, "seed": seed, "shape": "VarMisuse-like program graphs: 23 edge types (11 base types x "
                "fwd/bkwd + self loops, tasks/varmisuse_task.py:22-28,244-247), ~2500 nodes, 4.7 forward edges per node, two "
                "chain-like types carry 60 % of the edges", "feature_size": 128}
+        if overrides:
+            raise SystemExit("--task-param-overrides: the C5 generator takes graphs_per_rank and seed only")
         size_of, make, kw, make_kw = S.varmisuse_shaped_graph_size, S.make_varmisuse_shaped_graph, {}, {}
     gen["per_graph_streams"] = "numpy default_rng([seed, graph_index])"
     edge_counts = [size_of(seed, i, **kw)[1] for i in range(n_graphs)]
@@ -293,13 +307,14 @@ def roofline_section(device, iters, with_pmc):
     return roof
 
 
-def exact_fp32_leg(steps, warmup, timeout_s=180):
-    """The same timed loop in a child process with RELGNN_GEMM=lib: the node-side Dense products on the exact-fp32 matrix pipe
-    through the library (v_mfma_f32_32x32x2_f32, an fmaf chain bit for bit) instead of the default six-bf16-products-per-fp32-
-    product route (csrc/limb_gemm.hip).  Reported next to `value` so that the gain of the limb arithmetic is a driver-observable
-    number and anybody who rules the limb route out has the figure without it."""
+def route_leg(route_env, what, steps, warmup, timeout_s=180):
+    """The same timed loop in a child process on another arithmetic of the node-side Dense products (RELGNN_GEMM / RELGNN_LIMB are
+    the initial values of tf_gnn_samples_amd.config.settings): reported next to `value` so that the gain of each limb arithmetic
+    is a driver-observable number and anybody who rules one of them out has the figure without it.
+      RELGNN_GEMM=lib      exact fp32 through the library (v_mfma_f32_32x32x2_f32, an fmaf chain bit for bit)
+      RELGNN_LIMB=triple   every limb product from three bf16 limbs per value (the EXACT split: hi + mid + lo == x), six products"""
     env = dict(os.environ)
-    env["RELGNN_GEMM"] = "lib"
+    env.update(route_env)
     env.setdefault("LOCAL_RANK", "0")
     for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
         env.pop(k, None)
@@ -309,8 +324,8 @@ def exact_fp32_leg(steps, warmup, timeout_s=180):
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
-        return {"what": "the same loop with RELGNN_GEMM=lib (exact-fp32 library GEMMs for every Dense product)",
-                "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "final_loss": d.get("final_loss")}
+        return {"what": what, "switches": route_env, "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                "final_loss": d.get("final_loss")}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -379,18 +394,18 @@ def time_native_batch(task, graphs, device, iters=11):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(sample_graphs, params):
+def cpu_baseline(batch_graphs, sample_n, params):
     """Reference-order CPU restatement (oracle/torch_ref.py: gather -> per-edge [E,D]@[D,D] -> 1/deg scale
-    -> concat -> index_add -> ReLU) on a bounded sample of the bench batch, host cores of this box: a forward-only
-    leg (the reference's validation pass) and a full training step (fwd + bwd through autograd)."""
+    -> concat -> index_add -> ReLU) on this box's host cores, SURVEY.md 8d's protocol:
+      forward-only leg (the reference's validation pass): the WHOLE bench batch (all GRAPHS_PER_BATCH graphs = C2),
+      training leg (fwd + bwd through autograd): a bounded sample, the first `sample_n` graphs of that batch (the whole batch is
+      ~11 s per step here; the default bench run has to stay within minutes) — nothing is scaled, each leg's value = its own edges
+      / its own median step time.  The thread count is the fastest of {quota, quota / 2, quota / 4} on a short probe."""
     from oracle import torch_ref as R
     from tf_gnn_samples_amd.parallel import effective_cpu_count
     from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
-    cores = effective_cpu_count()          # the cgroup quota, not the host's hardware threads
-    torch.set_num_threads(cores)
+    quota = effective_cpu_count()          # the cgroup quota, not the host's hardware threads
     task = PPI_Task(PPI_Task.default_params())
-    mb = next(PPI_Task.make_minibatch_iterator(task, list(sample_graphs), DataFold.VALIDATION, 10 ** 9))
-    fd = mb.feed_dict
     h = params['hidden_size']
     gen = torch.Generator().manual_seed(0)
 
@@ -398,34 +413,35 @@ def cpu_baseline(sample_graphs, params):
         lim = (6.0 / (i + o)) ** 0.5
         return ((torch.rand((i, o), generator=gen) * 2 - 1) * lim).requires_grad_(True)
 
-    F = fd['initial_node_features'].shape[1]
-    W = {"in": glorot(F, h), "dense0": glorot(h, h), "out": glorot(h, fd['target_labels'].shape[1]),
-         "bias": torch.zeros(fd['target_labels'].shape[1], requires_grad=True)}
-    layers = [{"Edge_%i_Weight/kernel" % l: glorot(h, h) for l in range(3)} for _ in range(params['graph_num_layers'])]
-    x = torch.as_tensor(fd['initial_node_features'], dtype=torch.float32)
-    full_adj = [torch.as_tensor(a) for a in fd['adjacency_lists']]
-    deg = torch.as_tensor(fd['type_to_num_incoming_edges'], dtype=torch.float32)
-    labels = torch.as_tensor(fd['target_labels'])
-    state = {"adj": full_adj}
+    def load(graphs):
+        mb = next(PPI_Task.make_minibatch_iterator(task, list(graphs), DataFold.VALIDATION, 10 ** 9))
+        fd = mb.feed_dict
+        return {"mb": mb, "x": torch.as_tensor(fd['initial_node_features'], dtype=torch.float32),
+                "adj": [torch.as_tensor(a) for a in fd['adjacency_lists']],
+                "deg": torch.as_tensor(fd['type_to_num_incoming_edges'], dtype=torch.float32),
+                "labels": torch.as_tensor(fd['target_labels'])}
 
-    def forward():
-        cur = torch.tanh(x @ W["in"])
+    sample, full = load(batch_graphs[:sample_n]), load(batch_graphs)
+    F, n_labels = sample["x"].shape[1], sample["labels"].shape[1]
+    W = {"in": glorot(F, h), "dense0": glorot(h, h), "out": glorot(h, n_labels), "bias": torch.zeros(n_labels, requires_grad=True)}
+    layers = [{"Edge_%i_Weight/kernel" % l: glorot(h, h) for l in range(3)} for _ in range(params['graph_num_layers'])]
+
+    def forward(d):
+        cur = torch.tanh(d["x"] @ W["in"])
         for i, lw in enumerate(layers):
-            cur = R.sparse_rgcn_layer(cur, state["adj"], deg, h, 1, "ReLU", "sum", weights=lw)
+            cur = R.sparse_rgcn_layer(cur, d["adj"], d["deg"], h, 1, "ReLU", "sum", weights=lw)
             if i == 0:
                 cur = torch.tanh(cur @ W["dense0"])
         logits = cur @ W["out"] + W["bias"]
-        return torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction='sum') / labels.shape[0]
+        return torch.nn.functional.binary_cross_entropy_with_logits(logits, d["labels"], reduction='sum') / d["labels"].shape[0]
 
     def train_step():
-        forward().backward()
+        forward(sample).backward()
 
-    def fwd_step():
+    def fwd_step(d):
         with torch.no_grad():
-            forward()
+            forward(d)
 
-    # SURVEY.md 8d / BASELINE.md 3 protocol: fixed thread count = the CPU quota of this process, 2 warm-ups, median of 5,
-    # a forward-only leg (the reference's validation pass) and a training leg; bounded to ~60 s of host time in total.
     def timed(fn, warmups, reps, budget_s):
         t_begin = time.time()
         for _ in range(warmups):
@@ -439,19 +455,31 @@ def cpu_baseline(sample_graphs, params):
                 break
         return float(np.median(ts)), len(ts)
 
-    dt_fwd, n_fwd = timed(fwd_step, 2, 5, 20.0)
-    dt, n = timed(train_step, 2, 5, 40.0)
-    torch.set_num_threads(max(1, effective_cpu_count() // 2))
-    return {"value": mb.num_edges / dt, "unit": "edges/sec", "cores": cores, "kind": "port",
-            "host": "%d hardware threads visible, cgroup CPU quota %d" % (os.cpu_count() or 1, effective_cpu_count()),
-            "sample": "the first %d of the bench batch's %d graphs (%d edges, %d nodes; the whole batch would take ~4x as long per "
-                      "step — the default bench run has to stay within minutes — and nothing is scaled: value = the sample's edges / "
-                      "the sample's median step time); torch-CPU fp32 restatement of gnns/rgcn.py op order incl. the per-edge "
-                      "matmul, %d threads (= the CPU quota); training leg: full step fwd+bwd, median of %d after 2 warm-ups; "
-                      "forward-only leg: median of %d after 2 warm-ups"
-                      % (len(sample_graphs), GRAPHS_PER_BATCH, mb.num_edges, mb.num_nodes, cores, n, n_fwd),
+    # thread-count probe (an oversubscribed OpenMP pool can be slower than half of it): forward pass of the sample, one warm-up +
+    # one timed run per setting
+    probe = {}
+    for n in sorted({quota, max(1, quota // 2), max(1, quota // 4)}, reverse=True):
+        torch.set_num_threads(n)
+        probe[n] = timed(lambda: fwd_step(sample), 1, 1, 0.0)[0]
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
+    dt_fwd, n_fwd = timed(lambda: fwd_step(full), 1, 3, 40.0)          # the whole batch
+    dt, n = timed(train_step, 2, 5, 40.0)                              # the sample
+    torch.set_num_threads(max(1, quota // 2))
+    smb, fmb = sample["mb"], full["mb"]
+    return {"value": smb.num_edges / dt, "unit": "edges/sec", "cores": cores, "kind": "port",
+            "host": "%d hardware threads visible, cgroup CPU quota %d" % (os.cpu_count() or 1, quota),
+            "thread_probe_forward_sample_s": {str(k): round(v, 3) for k, v in probe.items()},
+            "sample": "training leg (`value`): the first %d of the bench batch's %d graphs (%d edges, %d nodes), full step fwd + bwd, "
+                      "median of %d after 2 warm-ups; forward-only leg (`forward_only_value`): the WHOLE batch (%d edges, %d nodes = "
+                      "C2), median of %d after 1 warm-up.  Nothing is scaled: each value = that leg's edges / that leg's median step "
+                      "time.  torch-CPU fp32 restatement of gnns/rgcn.py op order incl. the per-edge matmul, %d threads (the fastest "
+                      "of the probed counts; the CPU quota is %d)"
+                      % (sample_n, len(batch_graphs), smb.num_edges, smb.num_nodes, n, fmb.num_edges, fmb.num_nodes, n_fwd, cores,
+                         quota),
             "ms_per_step": dt * 1e3,
-            "forward_only_value": mb.num_edges / dt_fwd, "forward_only_ms": dt_fwd * 1e3}
+            "forward_only_value": fmb.num_edges / dt_fwd, "forward_only_ms": dt_fwd * 1e3,
+            "forward_only_sample": "whole batch"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -487,8 +515,13 @@ def main():
     from tf_gnn_samples_amd.models import RGCN_Model, name_to_model_class
     from tf_gnn_samples_amd.models.sparse_graph_model import MetricsReadback
     from tf_gnn_samples_amd.tasks import DataFold
+    from tf_gnn_samples_amd import config as route_config
     cfg = CONFIGS[args.config]
-    task, fold, gen_params = build_local_fold(rank, world, args.config)
+    model_overrides = json.loads(args.model_param_overrides) if args.model_param_overrides else {}
+    task_overrides = json.loads(args.task_param_overrides) if args.task_param_overrides else {}
+    if not isinstance(model_overrides, dict) or not isinstance(task_overrides, dict):
+        raise SystemExit("--model-param-overrides / --task-param-overrides take a JSON object")
+    task, fold, gen_params = build_local_fold(rank, world, args.config, task_overrides)
     if args.config == "C2":
         model_cls = RGCN_Model
         params = model_cls.default_params()
@@ -502,12 +535,16 @@ def main():
         params.update(hidden_size=128, graph_num_layers=10, graph_dense_between_every_num_gnn_layers=1,
                       graph_residual_connection_every_num_layers=2,          # tasks/default_hypers/VarMisuse_GNN-FiLM.json
                       graph_layer_input_dropout_keep_prob=1.0)
+    unknown = sorted(k for k in model_overrides if k not in params)
+    if unknown:
+        raise SystemExit("--model-param-overrides: unknown hyper-parameter(s) %s (known: %s)" % (unknown, sorted(params)))
+    params.update(model_overrides)
     nodes = sorted(len(g.node_features) for g in fold)
     params['max_nodes_in_batch'] = int(sum(nodes) / max(1, len(fold) // cfg["graphs_per_batch"])) + nodes[-1]
     model = model_cls(params, task, device=str(device))
     # RELGNN_ALLREDUCE=overlap: the gradient all-reduce in buckets that leave during the backward (parallel.py); default: one flat
     # collective behind the backward (the form every N > 1 number so far was taken with)
-    overlap_reduce = os.environ.get("RELGNN_ALLREDUCE", "flat") == "overlap"
+    overlap_reduce = route_config.settings.allreduce == "overlap"
     if world > 1 and overlap_reduce:
         from tf_gnn_samples_amd.parallel import OverlappedGradientAllReducer
         reducer = OverlappedGradientAllReducer(model.optimizer.params)
@@ -631,18 +668,22 @@ def main():
         "dtype": "f32",
         # fp32 values everywhere in HBM and in every result; how the tall node-side Dense products are evaluated:
         "dense_products": {
-            "route": os.environ.get("RELGNN_GEMM", "limb"),
-            "limbs": os.environ.get("RELGNN_LIMB", "pair"),
+            "route": route_config.settings.gemm,
+            "limbs": route_config.settings.limb,
+            "switches": route_config.current(),
             "pair": "the aggregate-first layer's products (forward, input gradient, weight gradient: K = 768) from TWO fp16 limbs per "
-                    "value (22 significant bits) behind exact power-of-two scales — per row of the streamed operand, from the "
-                    "magnitudes the gather writes with its rows; per operand for the weight gradient — three "
-                    "v_mfma_f32_32x32x16_f16 products per fp32 product; against float64 at least as close as the bf16 triple "
-                    "(RELGNN_LIMB=triple) and closer than the exact-fp32 library product on these shapes",
+                    "value (22 significant bits per operand instead of 24) behind exact power-of-two scales — per row of the "
+                    "streamed operand, from the magnitudes the gather writes with its rows; per column of each operand for the "
+                    "weight gradient — three v_mfma_f32_32x32x16_f16 products per fp32 product.  Measured against float64 "
+                    "(tests/test_gpu_baseline_size.py over five model draws, profiles/r04_gradient_parity_by_seed.json; "
+                    "profiles/r04_trajectory_routes.json): within the same 1e-5 budget as the bf16 triple and the fp32 library, "
+                    "neither systematically closer; the triple and exact-fp32 legs of the same loop are timed below",
             "limb": "each fp32 operand as three bf16 limbs (hi + mid + lo == x exactly), the six limb products of weight >= 2^-16 "
                     "on v_mfma_f32_32x32x16_bf16 (each exact in fp32), fp32 accumulation; dropped terms < 2^-23 of a product. "
                     "Measured against float64 at [36 k, 768] x [768, 256]: 4.0e-6 max abs (exact-fp32 library GEMM: 5.3e-6); "
                     "C2 layer vs the fp32 oracle 3.8e-6 abs (library route 6.2e-6): profiles/r03_parity_margin.json",
-            "lib": "exact fp32 (v_mfma_f32_32x32x2_f32 through hipBLASLt): timed in `exact_fp32_gemm_route` below"},
+            "lib": "exact fp32 (v_mfma_f32_32x32x2_f32 through hipBLASLt): timed in `exact_fp32_gemm_route` below; the bf16-triple "
+                   "leg in `bf16_triple_limb_route`"},
         "data": "synthetic",
         "config": {
             "workload": ("C2: RGCN on synthetic PPI-shaped batches (~%d graphs, ~%.2f M edges, ~%d k nodes each), 3 edge types "
@@ -657,6 +698,7 @@ def main():
             "graphs_per_rank": len(fold), "max_nodes_in_batch": params['max_nodes_in_batch'],
             "input_pipeline": pipeline, "generator": gen_params, "parallelism": "dp%d-by-graph" % world,
             "edges_all_ranks_timed_region": int(total_edges), "nodes_all_ranks_timed_region": int(total_nodes),
+            "model_param_overrides": model_overrides, "task_param_overrides": task_overrides,
         },
         "world_size": world,
         "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none (1 rank)",
@@ -740,14 +782,19 @@ def main():
             result["roofline"] = roofline_section(device, args.kernel_iters, not args.no_pmc)
         except Exception as e:
             result["roofline"] = {"error": repr(e)}
-    if (rank == 0 and world == 1 and not args.no_extras and args.config == "C2"
-            and os.environ.get("RELGNN_GEMM", "limb") == "limb"):
-        result["exact_fp32_gemm_route"] = exact_fp32_leg(args.steps, args.warmup)
+    if (rank == 0 and world == 1 and not args.no_extras and args.config == "C2" and not model_overrides and not task_overrides
+            and route_config.settings.limb_pair):
+        result["exact_fp32_gemm_route"] = route_leg(
+            {"RELGNN_GEMM": "lib"}, "the same loop with RELGNN_GEMM=lib (exact-fp32 library GEMMs for every Dense product)",
+            args.steps, args.warmup)
+        result["bf16_triple_limb_route"] = route_leg(
+            {"RELGNN_LIMB": "triple"}, "the same loop with RELGNN_LIMB=triple (every limb product from three bf16 limbs per value: "
+            "the exact split, six MFMA products per fp32 product)", args.steps, args.warmup)
     if rank == 0 and world == 1 and not args.no_extras:
         result["other_configs"] = other_configs_section()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C2":
         try:
-            result["cpu_baseline"] = cpu_baseline(fold[:args.cpu_sample_graphs], params)
+            result["cpu_baseline"] = cpu_baseline(fold[:GRAPHS_PER_BATCH], args.cpu_sample_graphs, params)
         except Exception as e:  # the baseline is reporting only; never lose the GPU number over it
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

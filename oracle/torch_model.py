@@ -40,16 +40,23 @@ def graph_propagation(initial_node_features, adjacency_lists, type_to_num_incomi
     return cur
 
 
-def rgcn_apply(params, lean=False):
+def rgcn_apply(params, lean=False, relu_masks=None, pre_activations=None):
     """models/rgcn_model.py:31-44 (normalize_by_num_incoming not passed: the layer default True).  lean=True: the
-    BASELINE-size float64 evaluation of oracle/torch_ref.py:sparse_rgcn_layer_lean."""
+    BASELINE-size float64 evaluation of oracle/torch_ref.py:sparse_rgcn_layer_lean; relu_masks (lean only): per layer the
+    [V, D] bool branch of every ReLU unit as the run under test took it (see sparse_rgcn_layer_lean), pre_activations: a list
+    that receives every layer's float64 pre-activation."""
     layer = R.sparse_rgcn_layer_lean if lean else R.sparse_rgcn_layer
 
     def apply(layer_idx, h, adj, deg, timesteps, w):
+        extra = {}
+        if lean and relu_masks is not None:
+            extra["relu_mask"] = relu_masks[layer_idx]
+        if lean and pre_activations is not None:
+            extra["pre_activations"] = pre_activations
         return layer(h, adj, deg, params['hidden_size'], num_timesteps=timesteps,
                      activation_function=params['graph_activation_function'],
                      message_aggregation_function=params['message_aggregation_function'],
-                     weights={k: v for k, v in w.items() if k.startswith("Edge_")})
+                     weights={k: v for k, v in w.items() if k.startswith("Edge_")}, **extra)
     return apply
 
 

@@ -259,17 +259,31 @@ def sparse_rgdcn_layer(h, adj, deg, num_channels=8, channel_dim=16, num_timestep
 
 
 def sparse_rgcn_layer_lean(h, adj, deg, state_dim, num_timesteps=1, activation_function="tanh",
-                           message_aggregation_function="sum", normalize_by_num_incoming=True, *, weights):
+                           message_aggregation_function="sum", normalize_by_num_incoming=True, *, weights,
+                           relu_mask=None, pre_activations=None):
     """BASELINE-size variant of sparse_rgcn_layer above for REFERENCE GRADIENTS in float64 (sum aggregation, source-only
     inputs): the same function, evaluated as  act(sum_l A_l (h W_l))  with A_l the sparse [V, V] matrix holding
     1/(c_{l,v} + 1e-7) at (v, u) for every edge (u, v) of type l (duplicates summed).  Op for op the chain above keeps two
     [M, D] float64 tensors per layer alive for autograd (7.6 GB per layer at the C2 batch); this one keeps [V, D] tensors.
     In float64 the association of the sums is immaterial at the 1e-12 level (tests/test_oracle_crosscheck_cpu.py checks it
     against the op-for-op path); the 1/(c + 1e-7) scale is evaluated in float32 like the reference's and then widened, so
-    that both sides multiply by the same number."""
+    that both sides multiply by the same number.
+
+    relu_mask ([V, D] bool, ReLU layers with one timestep only): the layer is evaluated as  mask * pre-activation  — the ReLU with
+    the BRANCH of every unit prescribed from outside (the float32 run under test) instead of decided by the sign of the float64
+    pre-activation.  A unit whose pre-activation lies within the float32 forward error of zero takes the other branch in the two
+    arithmetics, and its whole gradient path (a rank-one term of every weight gradient upstream) then exists in one run and not in
+    the other: a difference that measures where a knife edge fell, not the accuracy of any product.  With the branches prescribed
+    the two runs differentiate the SAME piecewise-linear function.  pre_activations (a list): the float64 pre-activation is
+    appended, so that the caller can count the units whose branch differs."""
     if _KINDS.get(message_aggregation_function) != "sum":
         raise ValueError("sparse_rgcn_layer_lean: sum aggregation only")
     act = activation(activation_function)
+    if relu_mask is not None:
+        if activation_function.lower() != "relu" or num_timesteps != 1:
+            raise ValueError("sparse_rgcn_layer_lean: relu_mask needs a ReLU layer with one timestep")
+        gate = relu_mask.to(h.dtype)
+        act = lambda z: z * gate
     V = h.shape[0]
     mats = []
     for l, a in enumerate(adj):
@@ -285,5 +299,7 @@ def sparse_rgcn_layer_lean(h, adj, deg, state_dim, num_timesteps=1, activation_f
         for l, A in enumerate(mats):
             part = torch.sparse.mm(A, cur @ weights["Edge_%i_Weight/kernel" % l])
             total = part if total is None else total + part
+        if pre_activations is not None:
+            pre_activations.append(total.detach())
         cur = act(total)
     return cur

@@ -5,28 +5,20 @@ import json, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
-from tf_gnn_samples_amd import dense as DN
+from tf_gnn_samples_amd import config, dense as DN
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(0)
 
 
 def exact_lib_gemm(layout, a, b):
     """the exact-fp32 library GEMM whatever RELGNN_GEMM says"""
-    keep = DN._LIMB_GEMM
-    DN._LIMB_GEMM = False
-    try:
+    with config.override(gemm="lib"):
         return DN.lib_gemm(layout, a, b)
-    finally:
-        DN._LIMB_GEMM = keep
 
 
 def exact_tn(a, b):
-    keep = DN._LIMB_GEMM
-    DN._LIMB_GEMM = False
-    try:
+    with config.override(gemm="lib"):
         return DN.matmul_tn_splitk(a, b)
-    finally:
-        DN._LIMB_GEMM = keep
 
 
 def timed(fn, reps=7, inner=10):
@@ -82,6 +74,17 @@ for name, V, J, C in [("dW   A[V,768]^T @ G[V,256]", 36096, 768, 256), ("dW   V=
     truth = a.double().t() @ g.double()
     t_limb = timed(lambda: DN.limb_gemm_tn(a, g))
     t_lib = timed(lambda: exact_tn(a, g))
+    # two fp16 limbs: one scale per column of each operand (two column-maximum passes in front) / one per operand (round 3's form)
+    ca, cg = DN.col_absmax(a), DN.col_absmax(g)
+    t_pair_cols = timed(lambda: DN.limb_gemm_tn(a, g, ca, cg))
+    t_colmax = timed(lambda: (DN.col_absmax(a), DN.col_absmax(g)))
+    ma, mg = DN.absmax(a), DN.absmax(g)
+    t_pair_op = timed(lambda: DN.limb_gemm_tn(a, g, ma, mg))
+    t_absmax = timed(lambda: (DN.absmax(a), DN.absmax(g)))
+    pair = DN.limb_gemm_tn(a, g, ca, cg)
     print(json.dumps({"shape": name, "V": V, "J": J, "C": C, "limb_tn_us": round(t_limb, 1), "f32_route_us": round(t_lib, 1),
+                      "pair_column_scales_us": round(t_pair_cols, 1), "col_absmax_both_us": round(t_colmax, 1),
+                      "pair_operand_scale_us": round(t_pair_op, 1), "absmax_both_us": round(t_absmax, 1),
+                      "err_pair_columns_vs_f64": float((pair.double() - truth).abs().max()),
                       "max_abs_out": round(float(truth.abs().max()), 3), "err_limb_vs_f64": float((out.double() - truth).abs().max()),
                       "err_f32_vs_f64": float((ref.double() - truth).abs().max())}), flush=True)

@@ -81,3 +81,11 @@ def layer_norm_weights(D, num_timesteps=2, rng=None):
         w[s + "/gamma"] = np.ones(D, np.float32) if rng is None else (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
         w[s + "/beta"] = np.zeros(D, np.float32) if rng is None else (0.1 * rng.standard_normal(D)).astype(np.float32)
     return w
+
+
+def set_switch(monkeypatch, env_name: str, value):
+    """Set the route switch that `env_name` (RELGNN_*) initialises — tf_gnn_samples_amd.config.settings, read at call time —
+    for the rest of the test (value None: back to its default).  The environment itself is read once, at import."""
+    from tf_gnn_samples_amd import config
+    name = config.attribute_of(env_name)
+    monkeypatch.setattr(config.settings, name, config.default_of(name) if value is None else value)

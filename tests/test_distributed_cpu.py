@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo processes.  Data parallelism by graph must reproduce the
+"""N > 1 path on CPU: world_size-2 and -4 gloo processes.  Data parallelism by graph must reproduce the
 single-batch objective: the all-reduced, node-weighted gradient of the two shards equals the gradient of
 the union batch.  The compute here is the oracle's torch-CPU mirror (the HIP path needs a GPU); what is
 under test is the package's sharding + GradientAllReducer logic and its loss scaling."""
@@ -78,9 +78,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_two_rank_gloo_gradient_equals_union_batch():
-    world = 2
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_ranks_gradient_equals_union_batch(world):
+    """world_size 2 and 4 (6 graphs: with 4 ranks two of them hold two graphs, two hold one — unequal shards): the node-weighted
+    all-reduced gradient on every rank equals the gradient of the union batch computed by one process."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -109,7 +111,8 @@ def _overlap_worker(rank, world, port, q):
     from tf_gnn_samples_amd.parallel import GradientAllReducer, OverlappedGradientAllReducer, init_distributed
     init_distributed(backend="gloo")
     gen = torch.Generator().manual_seed(0)
-    shapes = [(12, 16), (16, 16), (16, 16), (16,), (16, 40), (40,), (7, 3)]       # the last one never receives a gradient
+    shapes = [(7, 3), (12, 16), (16, 16), (16, 16), (16,), (16, 40), (40,)]       # the first one never receives a gradient (it sits in
+                                                                                  # the LAST bucket: buckets are cut from the end)
     init = [torch.randn(*s, generator=gen) * 0.3 for s in shapes]
     data = torch.Generator().manual_seed(10 + rank)
     x = torch.randn(50 + 20 * rank, 12, generator=data)
@@ -122,13 +125,13 @@ def _overlap_worker(rank, world, port, q):
         for step in range(2):                                                      # (twice: re-arming, .grad as views of the buffer)
             for p in params:
                 p.grad = None
-            h = torch.tanh(x @ params[0])
-            h = torch.tanh(h @ params[1]) + h @ params[2] + params[3]
-            loss = ((h @ params[4] + params[5]) ** 2).sum() / x.shape[0]
+            h = torch.tanh(x @ params[1])
+            h = torch.tanh(h @ params[2]) + h @ params[3] + params[4]
+            loss = ((h @ params[5] + params[6]) ** 2).sum() / x.shape[0]
             if name == "overlap":
                 reducer.arm(float(x.shape[0]))
                 loss.backward()
-                assert any(reducer._sent)                                          # buckets left during the backward
+                assert reducer._next > 0                                           # buckets left during the backward
                 reducer.finish()
             else:
                 loss.backward()
@@ -156,7 +159,73 @@ def test_bucketed_allreduce_during_the_backward_equals_the_flat_one():
             assert (a is None and b is None) or np.array_equal(a, b)              # two ranks: the same bits
     for a, b in zip(results[0]["overlap"], results[1]["overlap"]):
         assert np.array_equal(a, b)                                                # every rank holds the same average
-    assert np.abs(results[0]["overlap"][0]).max() > 0 and np.abs(results[0]["overlap"][6]).max() == 0
+    assert np.abs(results[0]["overlap"][1]).max() > 0 and np.abs(results[0]["overlap"][0]).max() == 0
+
+
+def _diverging_order_worker(rank, world, port, q):
+    """Two ranks whose autograd graphs differ (on real batches the route — hub / pair-table / typed-panel — is picked per
+    batch and per rank): rank 0 runs the chain A -> B -> C -> D and completes D's gradient first, rank 1 runs D -> C -> B -> A and
+    completes A's first, and rank 1's graph does not contain E at all.  Launched as they complete, bucket collectives would pair
+    A's bucket on one rank with D's on the other (same size: a silently wrong sum).  In index order they cannot."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    from tf_gnn_samples_amd.parallel import GradientAllReducer, OverlappedGradientAllReducer, init_distributed
+    init_distributed(backend="gloo")
+    gen = torch.Generator().manual_seed(0)
+    init = [torch.randn(16, 16, generator=gen) * 0.3 for _ in range(5)]           # A, B, C, D, E: equal sizes, one bucket each
+    x = torch.randn(40 + 10 * rank, 16, generator=torch.Generator().manual_seed(20 + rank))
+    out, launch_order = {}, []
+    for name, cls, kw in (("flat", GradientAllReducer, {}), ("overlap", OverlappedGradientAllReducer, {"bucket_bytes": 1024})):
+        params = [torch.nn.Parameter(t.clone()) for t in init]
+        reducer = cls(params, **kw)
+        if name == "overlap":
+            assert len(reducer.buckets) == 5
+            real = reducer._launch
+            reducer._launch = lambda b, real=real: (launch_order.append(b), real(b))[1]
+        for p in params:
+            p.grad = None
+        order = [0, 1, 2, 3] if rank == 0 else [3, 2, 1, 0]
+        h = x
+        for i in order:
+            h = torch.tanh(h @ params[i])
+        loss = (h ** 2).sum() / x.shape[0]
+        if rank == 0:
+            loss = loss + (torch.tanh(x @ params[4]) ** 2).sum() / x.shape[0]
+        if name == "overlap":
+            reducer.arm(float(x.shape[0]))
+            loss.backward()
+            reducer.finish()
+        else:
+            loss.backward()
+            reducer(float(x.shape[0]))
+        out[name] = [p.grad.numpy().copy() for p in params]
+    q.put((rank, out, launch_order))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_when_the_ranks_complete_their_buckets_in_different_orders():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diverging_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results = {r: o for r, o, _ in got}
+    for r, _, launched in got:
+        assert launched == sorted(launched) == list(range(5)), (r, launched)       # every rank: bucket 0, 1, 2, 3, 4
+    for rank in range(world):
+        for a, b in zip(results[rank]["flat"], results[rank]["overlap"]):
+            assert np.array_equal(a, b)
+    for a, b in zip(results[0]["overlap"], results[1]["overlap"]):
+        assert np.array_equal(a, b)
+    assert np.abs(results[1]["overlap"][4]).max() > 0                              # E: rank 0's gradient alone, averaged
 
 
 @pytest.mark.parametrize("config", ["C2", "C5"])

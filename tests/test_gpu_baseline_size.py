@@ -10,6 +10,7 @@ node states for the normalised layers; max-abs and max-rel recorded for all):
   C3  sparse_ggnn_layer (GRU, mean / max) on one 50 000-node batch of real QM9 molecules (153 206 messages, 5 edge types)
 
 The oracle needs a few seconds per layer at these sizes (host BLAS + the sequential C fold)."""
+import json
 import os
 
 import numpy as np
@@ -102,72 +103,115 @@ def test_c2_full_batch_rgcn_layer_against_the_op_for_op_oracle(gpu_device, c2):
     assert_parity(out, ref, strict_abs=True, what="C2 full batch rgcn layer vs op-for-op oracle (per-edge matmul order)")
 
 
-def test_c2_full_batch_model_gradients(gpu_device, c2):
+GRADIENT_ROUTES = {"pair": dict(gemm="limb", limb="pair"), "triple": dict(gemm="limb", limb="triple"), "lib": dict(gemm="lib")}
+_GRADIENT_ROWS = []
+
+
+@pytest.mark.parametrize("route", list(GRADIENT_ROUTES))
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])
+def test_c2_full_batch_model_gradients(gpu_device, c2, monkeypatch, seed, route):
     """d loss / d (every variable) and d loss / d (input features) of the 3-layer RGCN + PPI head on the FULL C2 batch:
     the HIP path's backward (by-source gather-reduce, GEMMs with the stacked kernels, streaming / split-K weight
     gradients, fused loss) against float64 autograd through the torch mirror of the driver (oracle/torch_model.py) with
     the layer evaluated as sparse products (oracle/torch_ref.py:sparse_rgcn_layer_lean, pinned to the op-for-op mirror
-    in tests/test_oracle_crosscheck_cpu.py)."""
+    in tests/test_oracle_crosscheck_cpu.py) — for five model initialisations on each arithmetic of the Dense products
+    (two fp16 limbs, three bf16 limbs, exact fp32).
+
+    FLIP-AWARE: the float64 mirror evaluates every ReLU with the branch the HIP forward took (oracle/torch_ref.py:
+    sparse_rgcn_layer_lean, relu_mask).  A ReLU unit whose float32 pre-activation lies within the forward error (~3e-6) of
+    zero takes the other branch than in float64 — a few of the 25 M units, which ones is chance — and its gradient path (a
+    rank-one term ~1e-6 .. 1e-5 in every weight gradient upstream) then exists in one run and not in the other: round 3's
+    comparison sat at 9.4e-6 of its 1e-5 bar for some draws on either arithmetic for that reason alone
+    (profiles/r03_c_gradient_parity_by_seed.txt).  With the branches prescribed both runs differentiate the same
+    piecewise-linear function and the assert measures arithmetic: bar 5e-6 abs, half the north-star tolerance.  The number of
+    units whose branch differs, the largest |pre-activation| among them (must be within the forward error: otherwise it is a
+    bug, not a knife edge) and the plain comparison's numbers are recorded next to it (profiles/r04_gradient_parity_by_seed.json)."""
     from oracle import torch_model as TM
+    from tf_gnn_samples_amd import config, ops
     from tf_gnn_samples_amd.models import RGCN_Model
     from tf_gnn_samples_amd.tasks import DeviceBatch
     task, mb = c2
+    for name, value in GRADIENT_ROUTES[route].items():
+        monkeypatch.setattr(config.settings, name, value)
     p = RGCN_Model.default_params()
     p.update(hidden_size=256, graph_num_layers=3, graph_activation_function="ReLU", message_aggregation_function="sum",
-             graph_layer_input_dropout_keep_prob=1.0,
-             random_seed=int(os.environ.get("RELGNN_TEST_SEED", "0")))      # (other initialisations: which ReLU units flip is chance)
+             graph_layer_input_dropout_keep_prob=1.0, random_seed=seed)
     model = RGCN_Model(p, task, device=str(gpu_device))
     batch = DeviceBatch(mb, gpu_device)
     batch.wait_ready()
     x_hip = batch.initial_node_features.detach().clone().requires_grad_(True)
     batch.initial_node_features = x_hip
     model.optimizer.zero_grad()
+    layer_outputs = []                                        # the HIP forward's post-ReLU states, layer by layer
+    real = ops.aggregate_then_transform
+
+    def recording(*args, **kwargs):
+        out = real(*args, **kwargs)
+        layer_outputs.append(out.detach())
+        return out
+    monkeypatch.setattr(ops, "aggregate_then_transform", recording)
     metrics = model.forward_batch(batch, training=True)
+    monkeypatch.setattr(ops, "aggregate_then_transform", real)
     metrics['loss'].backward()
     torch.cuda.synchronize()
+    assert len(layer_outputs) == 3
+    masks = [(o > 0).cpu() for o in layer_outputs]
 
     names = list(model.variables.names())
-    W = {n[len("graph_model/"):]: model.variables[n].detach().cpu().double().requires_grad_(True)
-         for n in names if n.startswith("graph_model/")}
-    head = {n: model.variables[n].detach().cpu().double().requires_grad_(True) for n in names if not n.startswith("graph_model/")}
     fd = mb.feed_dict
     adj = [torch.as_tensor(a) for a in fd['adjacency_lists']]
     deg = torch.as_tensor(fd['type_to_num_incoming_edges'].astype(np.float32))
-    x = torch.as_tensor(fd['initial_node_features']).double().requires_grad_(True)
-    final = TM.graph_propagation(x, adj, deg, p, W, TM.rgcn_apply(p, lean=True))
-    kernel = next(v for k, v in head.items() if k.endswith("kernel"))
-    bias = next(v for k, v in head.items() if k.endswith("bias"))
-    loss = TM.ppi_loss(final, torch.as_tensor(fd['target_labels']).double(), kernel, bias)
-    loss.backward()
-    assert abs(float(metrics['loss']) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
 
-    # Criterion: 1e-5 ABSOLUTE on every entry of every gradient (north star), max-abs and max-rel recorded; plus the relative
-    # Frobenius error as a whole-tensor sanity bound.  Why not a tight relative bound per entry: a ReLU unit whose float32
-    # pre-activation lies within the forward error (~3e-6) of zero takes the other branch than in float64 — about one unit in
-    # a million of the 25 M here — and its gradient path (~1e-6 absolute, a rank-one update x_v (x) delta_v of the input
-    # projection's gradient) exists in one run and not in the other; that is 1e-4 .. 5e-3 of the SMALL gradients (the
-    # input-feature gradient peaks at 2.7e-4) and 1e-7 of the large ones.
-    def check(got, ref, what):
-        assert_parity(got, ref, strict_abs=True, what=what)
-        diff = got.detach().cpu().numpy().astype(np.float64) - ref
-        fro = float(np.linalg.norm(diff) / max(np.linalg.norm(ref), 1e-300))
-        assert fro <= 2e-3, (what, fro)
-        return fro
+    def float64_gradients(relu_masks):
+        W = {n[len("graph_model/"):]: model.variables[n].detach().cpu().double().requires_grad_(True)
+             for n in names if n.startswith("graph_model/")}
+        head = {n: model.variables[n].detach().cpu().double().requires_grad_(True) for n in names if not n.startswith("graph_model/")}
+        x = torch.as_tensor(fd['initial_node_features']).double().requires_grad_(True)
+        pre = []
+        final = TM.graph_propagation(x, adj, deg, p, W, TM.rgcn_apply(p, lean=True, relu_masks=relu_masks, pre_activations=pre))
+        kernel = next(v for k, v in head.items() if k.endswith("kernel"))
+        bias = next(v for k, v in head.items() if k.endswith("bias"))
+        loss = TM.ppi_loss(final, torch.as_tensor(fd['target_labels']).double(), kernel, bias)
+        loss.backward()
+        grads = {n: (W[n[len("graph_model/"):]] if n.startswith("graph_model/") else head[n]).grad.numpy() for n in names}
+        grads["initial_node_features"] = x.grad.numpy()
+        return float(loss), grads, pre
 
-    bulk = {}
-    for n in names:
-        ref = (W[n[len("graph_model/"):]] if n.startswith("graph_model/") else head[n]).grad.numpy()
-        got = model.variables[n].grad
-        assert got is not None, n
-        bulk[n] = check(got, ref, "C2 full batch d loss / d %s" % n)
-    bulk["initial_node_features"] = check(x_hip.grad, x.grad.numpy(), "C2 full batch d loss / d initial_node_features")
-    print("relative Frobenius error per gradient:", {k: "%.1e" % v for k, v in bulk.items()})
-    worst = {}
-    for n in list(names) + ["initial_node_features"]:
-        got = (model.variables[n].grad if n in names else x_hip.grad).detach().cpu().numpy().astype(np.float64)
-        ref = ((W[n[len("graph_model/"):]] if n.startswith("graph_model/") else head[n]).grad if n in names else x.grad).numpy()
-        worst[n.split("/", 1)[-1]] = "%.1e" % float(np.abs(got - ref).max())
-    print("max abs error per gradient:", worst)
+    loss64, ref, pre = float64_gradients(masks)
+    assert abs(float(metrics['loss']) - loss64) <= 1e-5 * max(1.0, abs(loss64))
+    # the units whose branch differs between the two arithmetics: how many, and how far from zero the float64 pre-activation is
+    flipped, knife = 0, 0.0
+    for z, m in zip(pre, masks):
+        diff = (z > 0) != m
+        flipped += int(diff.sum())
+        if bool(diff.any()):
+            knife = max(knife, float(z[diff].abs().max()))
+    assert knife <= 2e-5, "a ReLU unit %g away from zero took the other branch: not a rounding knife edge" % knife
+
+    got = {n: model.variables[n].grad.detach().cpu().numpy().astype(np.float64) for n in names}
+    got["initial_node_features"] = x_hip.grad.detach().cpu().numpy().astype(np.float64)
+    aware = {n: float(np.abs(got[n] - ref[n]).max()) for n in ref}
+    fro = {n: float(np.linalg.norm(got[n] - ref[n]) / max(np.linalg.norm(ref[n]), 1e-300)) for n in ref}
+    row = {"seed": seed, "route": route, "relu_units_with_other_branch": flipped, "largest_abs_preactivation_among_them": knife,
+           "flip_aware_max_abs": max(aware.values()), "flip_aware_worst_gradient": max(aware, key=aware.get),
+           "flip_aware_max_rel_frobenius": max(fro.values()),
+           "flip_aware_max_abs_per_gradient": {k.split("/", 1)[-1]: "%.1e" % v for k, v in aware.items()}}
+    if flipped:          # the plain comparison (float64 decides its own branches), for the record: what round 3 asserted on
+        _, plain_ref, _ = float64_gradients(None)
+        plain = {n: float(np.abs(got[n] - plain_ref[n]).max()) for n in plain_ref}
+        row["plain_max_abs"], row["plain_worst_gradient"] = max(plain.values()), max(plain, key=plain.get)
+    else:
+        row["plain_max_abs"], row["plain_worst_gradient"] = row["flip_aware_max_abs"], row["flip_aware_worst_gradient"]
+    _GRADIENT_ROWS.append(row)
+    print(row)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/gradient_parity_by_seed.json", "w") as f:
+        json.dump({"what": "C2 full batch, 3-layer RGCN + PPI head: max |HIP gradient - float64 gradient| over every variable and "
+                           "the input features; flip_aware = the float64 mirror takes the HIP forward's ReLU branches",
+                   "bar_flip_aware": 5e-6, "rows": _GRADIENT_ROWS}, f, indent=1)
+    for n, e in aware.items():
+        assert e <= 5e-6, ("C2 full batch d loss / d %s (%s, seed %d)" % (n, route, seed), e)
+    assert max(fro.values()) <= 2e-3
 
 
 def test_c4_rgat_on_the_c2_batch(gpu_device, c2):

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import gnns as G, model as OM, torch_ref as R
-from helpers import assert_parity, degree_table, glorot, layer_norm_weights, random_relational_graph, rgcn_weights
+from helpers import assert_parity, degree_table, glorot, layer_norm_weights, random_relational_graph, rgcn_weights, set_switch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -451,7 +451,7 @@ def test_edge_backward_regather_variant_matches(gpu_device, monkeypatch, layer, 
     adj_d, deg_d = _dev(adj, gpu_device), _dev(deg, gpu_device)
     grads = []
     for flag in ("emit", "regather"):
-        monkeypatch.setenv("RELGNN_EDGE_BWD", flag)
+        set_switch(monkeypatch, "RELGNN_EDGE_BWD", flag)
         hd = torch.as_tensor(h, device=gpu_device).requires_grad_(True)
         wd = {k: torch.as_tensor(v, device=gpu_device).requires_grad_(True) for k, v in w.items()}
         out = fn(hd, wd, adj_d, deg_d)
@@ -476,7 +476,7 @@ def test_edge_free_batch_through_every_rgcn_order(gpu_device, monkeypatch):
     deg = torch.zeros((L, V), device=gpu_device)
     w = {k: torch.as_tensor(v, device=gpu_device).requires_grad_(True) for k, v in rgcn_weights(rng, L, D, D).items()}
     for order in ("aggregate_first", "transform_first"):
-        monkeypatch.setenv("RELGNN_RGCN_ORDER", order)
+        set_switch(monkeypatch, "RELGNN_RGCN_ORDER", order)
         for norm in (True, False):
             clear_graph_cache()
             h = torch.randn((V, D), device=gpu_device, requires_grad=True)
@@ -508,7 +508,7 @@ def test_film_sign_mask_route_matches_recompute(gpu_device, monkeypatch, act, D)
                       ("recompute", {"RELGNN_EDGE_BWD": "regather", "RELGNN_EDGE_SIGN_MASK": "0"}),
                       ("emit", {"RELGNN_EDGE_BWD": "emit", "RELGNN_EDGE_SIGN_MASK": "0"})):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            set_switch(monkeypatch, k, v)
         hd = torch.as_tensor(h, device=gpu_device).requires_grad_(True)
         wd = {k: torch.as_tensor(v, device=gpu_device).requires_grad_(True) for k, v in w.items()}
         out = sparse_gnn_film_layer(hd, adj_d, deg_d, D, 1, act, "sum", True, weights=wd)

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import gnns as G, torch_ref as R
-from helpers import degree_table, glorot, layer_norm_weights, random_relational_graph, rgcn_weights
+from helpers import degree_table, glorot, layer_norm_weights, random_relational_graph, rgcn_weights, set_switch
 
 pytestmark = pytest.mark.gpu
 
@@ -125,7 +125,7 @@ def test_film_layer_compact_vs_oracle_and_dense(gpu_device, monkeypatch, agg, no
     adj_d, deg_d = [dev(a) for a in adj], dev(deg)
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("RELGNN_PAIR_TABLES", flag)
+        set_switch(monkeypatch, "RELGNN_PAIR_TABLES", flag)
         clear_graph_cache()
         hd = dev(h).requires_grad_(True)
         wd = {k: dev(v).requires_grad_(True) for k, v in w.items()}
@@ -160,9 +160,9 @@ def test_film_model_trains_with_pair_tables(gpu_device, monkeypatch):
     losses = {}
     for flag in (None, "0"):
         if flag is None:
-            monkeypatch.delenv("RELGNN_PAIR_TABLES", raising=False)
+            set_switch(monkeypatch, "RELGNN_PAIR_TABLES", None)
         else:
-            monkeypatch.setenv("RELGNN_PAIR_TABLES", flag)
+            set_switch(monkeypatch, "RELGNN_PAIR_TABLES", flag)
         clear_graph_cache()
         task = PPI_Task(PPI_Task.default_params())
         task._PPI_Task__num_edge_types = 23; task._PPI_Task__initial_node_feature_size = 128; task._PPI_Task__num_labels = 1
@@ -192,7 +192,7 @@ def test_rgcn_layer_compact_vs_oracle(gpu_device, monkeypatch, agg):
     adj_d, deg_d = [dev(a) for a in adj], dev(deg)
     grads = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("RELGNN_PAIR_TABLES", flag)
+        set_switch(monkeypatch, "RELGNN_PAIR_TABLES", flag)
         clear_graph_cache()
         hd = dev(h).requires_grad_(True)
         wd = {k: dev(v).requires_grad_(True) for k, v in w.items()}
@@ -226,7 +226,7 @@ def test_ggnn_layer_compact_vs_oracle(gpu_device, monkeypatch, agg):
     ref = G.sparse_ggnn_layer(h, adj, D, 2, "gru", "tanh", agg, weights=w)
     dev = lambda x: torch.as_tensor(x, device=gpu_device)
     for flag in ("1", "0"):
-        monkeypatch.setenv("RELGNN_PAIR_TABLES", flag)
+        set_switch(monkeypatch, "RELGNN_PAIR_TABLES", flag)
         clear_graph_cache()
         out = sparse_ggnn_layer(dev(h), [dev(a) for a in adj], D, 2, "gru", "tanh", agg, weights={k: dev(v) for k, v in w.items()})
         assert np.abs(out.cpu().numpy() - ref).max() < 1e-5, flag

@@ -24,7 +24,8 @@ import pytest
 import torch
 
 from oracle import gnns as G
-from helpers import PARITY_TOL, parity_errors, rgcn_weights
+from helpers import PARITY_TOL, parity_errors, rgcn_weights, set_switch
+from tf_gnn_samples_amd import config
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +86,7 @@ def _run_case(monkeypatch, dev, name, adj, deg, V, h, w, normalize, bounded):
     h_d, adj_d, deg_d, w_d = _dev(h, dev), _dev(adj, dev), _dev(deg, dev), _dev(w, dev)
     for vname, env in VARIANTS.items():
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            set_switch(monkeypatch, k, v)
         out = sparse_rgcn_layer(h_d, adj_d, deg_d, D, 1, "ReLU", "sum", normalize, weights=w_d).cpu().numpy()
         a, r = parity_errors(out, ref32)
         row["variants"][vname] = {"abs_vs_oracle_f32": a, "rel_vs_oracle_f32": r, "abs_vs_f64_truth": parity_errors(out, truth)[0]}
@@ -147,5 +148,5 @@ def test_zz_write_margin_report():
                                                                                 e["abs_vs_f64_truth"]))
     if os.path.isdir("gpurun_out"):
         with open("gpurun_out/parity_margin.json", "w") as f:
-            json.dump({"tolerance_abs": PARITY_TOL, "default_variant": DEFAULT, "dense_product_route": os.environ.get("RELGNN_GEMM", "limb"),
+            json.dump({"tolerance_abs": PARITY_TOL, "default_variant": DEFAULT, "dense_product_route": config.settings.gemm + "/" + config.settings.limb,
                    "cases": _ROWS}, f, indent=1)

@@ -147,7 +147,7 @@ def test_backward_overlap_on_a_side_stream_gives_the_same_bits(gpu_device, monke
     """RELGNN_BWD_OVERLAP: the aggregate-first layer's weight gradient on a side stream next to the input gradient's gather is the
     same kernels on the same operands — gradients must be bit-identical to the single-stream order, run after run, and the caching
     allocator must not hand the side stream's buffers out early (many iterations, fresh tensors every time)."""
-    from tf_gnn_samples_amd import ops
+    from tf_gnn_samples_amd import config, ops
     from tf_gnn_samples_amd.graph import RelGraph
     rng = np.random.default_rng(5)
     V, L, D = 6000, 3, 256
@@ -159,7 +159,7 @@ def test_backward_overlap_on_a_side_stream_gives_the_same_bits(gpu_device, monke
     gout = torch.as_tensor(rng.standard_normal((V, D)).astype(np.float32), device=gpu_device)
 
     def grads(overlap):
-        monkeypatch.setattr(ops, "_BWD_OVERLAP", overlap)
+        monkeypatch.setattr(config.settings, "bwd_overlap", "1" if overlap else "0")
         H, W = H0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
         out = ops.aggregate_then_transform(H, W, g, w, "sum", "relu")
         out.backward(gout)
@@ -184,7 +184,8 @@ def test_captured_step_on_the_limb_route_and_eager_code_after_replays(gpu_device
     task = PPI_Task(PPI_Task.default_params())
     task.load_synthetic(3, 1, seed=4)
     mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
-    assert mb.num_nodes >= 4096 and DN._LIMB_GEMM
+    from tf_gnn_samples_amd import config
+    assert mb.num_nodes >= 4096 and config.settings.limb_gemm
 
     def fresh():
         p = RGCN_Model.default_params()

@@ -1,0 +1,142 @@
+"""Every route switch of the package in ONE place.
+
+The reference has no such switches: each one here selects between two implementations of the SAME function (same results up to
+the rounding stated in DESIGN.md), kept because both were measured.  `settings` is read at call time, so a value can be changed
+for a region of code in one process:
+
+    from tf_gnn_samples_amd import config
+    with config.override(gemm="lib"):
+        ...
+
+The RELGNN_* environment variables only supply the initial values (read once, when this module is imported); nothing else in the
+package reads the environment.  `describe()` returns the table that README.md / INTEGRATION.md print and that
+tests/test_config_cpu.py checks against this file.
+"""
+import contextlib
+import os
+from typing import Dict, Iterator, List, Tuple
+
+# attribute -> (environment variable, default, allowed values or None, what it selects)
+_SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
+    "gemm": ("RELGNN_GEMM", "limb", ("limb", "lib", "panel", "torch"),
+             "route of the node-side Dense products: fp32 from bf16 / fp16 limbs on the 16-bit matrix pipe (csrc/limb_gemm.hip) | "
+             "exact fp32 through hipBLASLt with cached solutions | the exact-fp32 row-panel MFMA kernel | torch.mm"),
+    "limb": ("RELGNN_LIMB", "pair", ("pair", "triple"),
+             "limb arithmetic of the aggregate-first layer's three products: two fp16 limbs behind power-of-two scales | three "
+             "bf16 limbs (exact split) everywhere"),
+    "limb_pair_parts": ("RELGNN_LIMB_PAIR_PARTS", "nn,nt,tn", None,
+                        "which of the aggregate-first layer's products take the two-limb form (diagnostic): forward nn, input "
+                        "gradient nt, weight gradient tn"),
+    "limb_cut": ("RELGNN_LIMB_CUT", "1", ("0", "1"),
+                 "N % 128 >= 96 products (the 121 logits of the PPI head) on the 128-column limb panels with the last chunk cut at N"),
+    "weight_limb_cache": ("RELGNN_WEIGHT_LIMB_CACHE", "1", ("0", "1"),
+                          "limb images of the weights kept across the products of a step (re-split once after the optimizer's update)"),
+    "tn": ("RELGNN_TN", "stream", ("stream", "lib"),
+           "weight gradients with outputs up to 256 x 256: the streaming MFMA kernel (csrc/gemm_tn_stream.hip) | library split-K"),
+    "rgcn_order": ("RELGNN_RGCN_ORDER", "aggregate_first", ("aggregate_first", "transform_first"),
+                   "sum / mean / sqrt_n RGCN layers: gather raw states into the (target, type) buckets, then one K = L*D product | "
+                   "the reference's order (per-type transform, then gather)"),
+    "agg_acc": ("RELGNN_AGG_ACC", "f32", ("f32", "f64"),
+                "accumulator width of the bucket sums in front of the aggregate-first product"),
+    "bwd_overlap": ("RELGNN_BWD_OVERLAP", "auto", ("auto", "0", "1"),
+                    "aggregate-first backward: the weight gradient on a side stream next to the input gradient's gather "
+                    "(auto: on with gemm=limb, off otherwise)"),
+    "edge_bwd": ("RELGNN_EDGE_BWD", "auto", ("auto", "emit", "regather"),
+                 "FiLM / pair kernels, gradient of the gathered rows: per-message gradients written and gather-reduced | the "
+                 "by-source pass re-gathers (auto: emit on compact pair tables or D <= 128)"),
+    "edge_sign_mask": ("RELGNN_EDGE_SIGN_MASK", "0", ("0", "1"),
+                       "FiLM regather backward: pass A leaves one sign bit per message and feature for pass B"),
+    "typed": ("RELGNN_TYPED", "panel", ("panel", "bmm"),
+              "per-(node, type) transforms of many-type graphs: one gathered-row MFMA launch | index_select + torch.bmm"),
+    "pair_tables": ("RELGNN_PAIR_TABLES", "auto", ("auto", "0", "1"),
+                    "compact tables over the non-empty (node, type) buckets (auto: L >= 8 and < 60 % of the buckets non-empty)"),
+    "rgat_fused_sums": ("RELGNN_RGAT_FUSED_SUMS", "1", ("0", "1"),
+                        "RGAT backward: the two score-table gradients carried along by the dz pass and the by-source gather"),
+    "assemble_stream": ("RELGNN_ASSEMBLE_STREAM", "main", ("main", "side"),
+                        "resident folds: the next batch's assembly on the caller's stream | on a side stream under the step"),
+    "allreduce": ("RELGNN_ALLREDUCE", "flat", ("flat", "overlap"),
+                  "data-parallel gradient all-reduce: one flat collective after the backward | buckets launched during the backward"),
+}
+
+
+class _Settings:
+    __slots__ = tuple(_SPEC)
+
+    def __init__(self):
+        for name, (env, default, allowed, _) in _SPEC.items():
+            value = os.environ.get(env, default)
+            if name == "edge_bwd" and env not in os.environ and os.environ.get("RELGNN_EDGE_BWD_REGATHER") is not None:
+                value = "regather"                       # (the older spelling of RELGNN_EDGE_BWD=regather)
+            _check(name, value)
+            object.__setattr__(self, name, value)
+
+    def __setattr__(self, name, value):
+        _check(name, value)
+        object.__setattr__(self, name, value)
+
+    # ---- derived ----
+    @property
+    def limb_gemm(self) -> bool:
+        return self.gemm == "limb"
+
+    @property
+    def limb_pair(self) -> bool:
+        return self.gemm == "limb" and self.limb == "pair"
+
+    @property
+    def bwd_overlap_on(self) -> bool:
+        return self.bwd_overlap == "1" or (self.bwd_overlap == "auto" and self.gemm == "limb")
+
+    def pair_part(self, kind: str) -> bool:
+        return kind in self.limb_pair_parts.split(",")
+
+
+def _check(name: str, value: str) -> None:
+    if name not in _SPEC:
+        raise AttributeError("tf_gnn_samples_amd.config: no switch %r (known: %s)" % (name, ", ".join(_SPEC)))
+    env, _, allowed, _ = _SPEC[name]
+    if not isinstance(value, str):
+        raise ValueError("%s: switch values are strings (got %r)" % (env, value))
+    if allowed is not None and value not in allowed:
+        raise ValueError("%s must be one of %s (got %r)" % (env, ", ".join(allowed), value))
+
+
+settings = _Settings()
+
+
+@contextlib.contextmanager
+def override(**values: str) -> Iterator[_Settings]:
+    """Set switches for the duration of a `with` block (validated; restored on exit, also on exceptions).  Limb images of weights
+    cached under one arithmetic are keyed by it, so switching needs no cache flush."""
+    old = {}
+    try:
+        for name, value in values.items():
+            _check(name, value)
+            old[name] = getattr(settings, name)
+            setattr(settings, name, value)
+        yield settings
+    finally:
+        for name, value in old.items():
+            setattr(settings, name, value)
+
+
+def describe() -> List[Tuple[str, str, str, str, str]]:
+    """(environment variable, attribute, default, allowed values, meaning) per switch."""
+    return [(env, name, default, " | ".join(allowed) if allowed else "comma-separated subset of nn,nt,tn", doc)
+            for name, (env, default, allowed, doc) in _SPEC.items()]
+
+
+def attribute_of(env: str) -> str:
+    """'RELGNN_GEMM' -> 'gemm'."""
+    for name, spec in _SPEC.items():
+        if spec[0] == env:
+            return name
+    raise KeyError("no switch reads %s" % env)
+
+
+def default_of(name: str) -> str:
+    return _SPEC[name][1]
+
+
+def current() -> Dict[str, str]:
+    return {name: getattr(settings, name) for name in _SPEC}

@@ -109,11 +109,52 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint
   const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
   l = cvt_pk_bf16(s0, s1);
 }
+// |x| >= 0x7F7F8000 (3.3962e38 .. FLT_MAX, and inf) rounds to a bf16 INFINITY: hi = +-inf, mid = x - hi = -+inf, lo = NaN — and the
+// float32 lowest that tf.unsorted_segment_max writes for an empty segment (utils/utils.py:23-33) is such a value: it came
+// out of a Dense product as NaN where fp32 arithmetic gives a finite number.  For those values hi saturates at the largest finite
+// bf16 (0x7F7F); the remainder x - hi is then at most 16 significant bits at 2^104 .. 2^120 and mid, lo hold it exactly as before,
+// so hi + mid + lo == x still holds bit for bit for EVERY finite x.  inf / NaN inputs keep producing non-finite limbs (inf: hi = inf
+// -> mid = NaN), i.e. a non-finite output row, as the fp32 product does.
+// Detection costs four v_max3_f32 per eight values (written as asm: hipcc's fmaxf() first canonicalises every operand, one more
+// VALU instruction per value) and one compare; the saturating split itself sits behind a branch that normal data never takes.
+// (A signalling NaN among the eight makes the maximum a NaN and hides a huge finite neighbour from the compare — the eight values
+// share one output row, which that NaN makes non-finite anyway.)
+__device__ __forceinline__ float max3_abs(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ bool bf16_hi_overflows(const float* v) {       // any of v[0..7] rounds to a bf16 infinity
+  float m = max3_abs(v[0], v[1], v[2]);
+  m = max3_abs(m, v[3], v[4]);
+  m = max3_abs(m, v[5], v[6]);
+  m = max3_abs(m, v[7], v[7]);
+  return m >= __uint_as_float(0x7F7F8000u);
+}
+__device__ __forceinline__ uint32_t bf16_sat_bits(float x) {              // bf16(x), round to nearest even; a finite x stays finite
+  uint32_t h = cvt_pk_bf16(x, x) & 0xFFFFu;
+  if ((h & 0x7FFFu) == 0x7F80u && (__float_as_uint(x) & 0x7FFFFFFFu) < 0x7F800000u) h -= 1u;      // 0x7F80 -> 0x7F7F, sign kept
+  return h;
+}
+__device__ __forceinline__ void split_pair_sat(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const uint32_t h0 = bf16_sat_bits(x0), h1 = bf16_sat_bits(x1);
+  h = h0 | (h1 << 16);
+  const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h1 << 16);
+  m = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  l = cvt_pk_bf16(s0, s1);
+}
 __device__ __forceinline__ void split8(const float* v, uint4& h, uint4& m, uint4& l) {
   split_pair(v[0], v[1], h.x, m.x, l.x);
   split_pair(v[2], v[3], h.y, m.y, l.y);
   split_pair(v[4], v[5], h.z, m.z, l.z);
   split_pair(v[6], v[7], h.w, m.w, l.w);
+  if (__builtin_expect(bf16_hi_overflows(v), 0)) {
+    split_pair_sat(v[0], v[1], h.x, m.x, l.x);
+    split_pair_sat(v[2], v[3], h.y, m.y, l.y);
+    split_pair_sat(v[4], v[5], h.z, m.z, l.z);
+    split_pair_sat(v[6], v[7], h.w, m.w, l.w);
+  }
 }
 
 // XF32 = false: both operands arrive as limb tiles (DMA for everything).
@@ -923,12 +964,16 @@ struct LimbTnArgs {
   int32_t V, J, C;
   int32_t rows_per_chunk;              // % 32 == 0
   int32_t panels, chunks, Z;
-  const float* amax; const float* gmax;   // NL = 2: the largest magnitude of A / of G (device floats): one power-of-two scale per operand
+  // NL = 2: magnitudes the power-of-two scales come from (device floats): of A, amax[j * astride] for column j (astride 1: one per
+  // column, 0: one for the operand), and of G likewise.  A column's scale factors out of its row / column of the product.
+  const float* amax; const float* gmax; int32_t astride, gstride;
 };
 
-// NL = 3: bf16 triples, six products; NL = 2: fp16 pairs behind ONE power-of-two scale per operand (the reduction runs over the rows
-// of both operands, so a row's scale would not factor out; an element 2^-18 below its operand's largest loses low bits of a term
-// that is 2^-18 of the largest terms of the sum), three products.
+// NL = 3: bf16 triples, six products; NL = 2: fp16 pairs behind one power-of-two scale per COLUMN of each operand (the reduction
+// runs over the rows of both operands, so a row's scale would not factor out, a column's does: out[j][c] carries sa[j] * sg[c]).
+// An element 2^-18 below its column's largest loses low bits of a term that is 2^-18 of the largest terms of ITS sum; with one
+// scale per operand (astride = gstride = 0, the first form) that was 2^-18 of the operand's largest, and a column of small
+// gradients lost relative precision (measured: tests/test_gpu_limb_gemm.py, column magnitudes 1 .. 1e-10).  Three products.
 template <int T32, int NL = 3>
 __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   constexpr int NC = 256, PR = 32 * T32;
@@ -967,8 +1012,12 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   // (the XOR permutes inside aligned groups of four slots) and the limb stores — 8 lanes = 8 column groups = rows 4 a + c — hit
   // 8 different bank quads instead of two (4-way conflicts: 114 -> 9x us at [36 k, 768]^T x [36 k, 256])
   const int blk = ((is_g ? PA : 0) + NL * (col >> 5)) * 1024 + (oct & 1) * 512 + (col & 31) * 16;
-  float pscale = 1.f;
-  if constexpr (NL == 2) pscale = limb16_scale(is_g ? a.gmax[0] : a.amax[0]);
+  float pscale[4] = {1.f, 1.f, 1.f, 1.f};                         // NL = 2: the scales of my four columns
+  if constexpr (NL == 2) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      pscale[c] = limb16_scale(is_g ? a.gmax[(int64_t)(n0 + col + c) * a.gstride] : a.amax[(int64_t)(j0 + col + c) * a.astride]);
+  }
   const int cswz = ((col & 31) >> 3) & 3;                          // column c of my patch goes to slot (col & 31) + (c ^ cswz)
   const int dump = DUMP + lane * 16;
   f32x4 pv[8];                                                      // the patch in flight: pv[m][c]
@@ -983,7 +1032,7 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
     const int off = (active && S < nsuper) ? ((2 * S + (oct >> 1)) % STAGES) * STAGE_BYTES + blk + (c ^ cswz) * 16 : dump;
     if constexpr (NL == 2) {
       uint4 h, l;
-      split8_16(v, pscale, h, l);
+      split8_16(v, pscale[c], h, l);
       *reinterpret_cast<uint4*>(lds + off) = h;
       *reinterpret_cast<uint4*>(lds + off + 1024) = l;
     } else {
@@ -1127,29 +1176,46 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   const int i32 = lane & 31, h32 = lane >> 5;
   const int colw = n0 + wave * 32;
   float* slab = a.P + (int64_t)z * a.J * a.C;
-  float unscale = 1.f;
-  if constexpr (NL == 2) unscale = limb16_unscale(a.amax[0]) * limb16_unscale(a.gmax[0]);      // (powers of two: exact)
+  f32x4 ug[4];                                                      // NL = 2: 1 / scale of my output columns (powers of two: exact)
+  if constexpr (NL == 2) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ug[c][e] = limb16_unscale(a.gmax[(int64_t)(colw + 8 * c + 4 * h32 + e) * a.gstride]);
+  }
 #pragma unroll
   for (int tm = 0; tm < T32; ++tm) {
-    float* crow = slab + (int64_t)(j0 + tm * 32 + i32) * a.C;
+    const int j = j0 + tm * 32 + i32;
+    float* crow = slab + (int64_t)j * a.C;
+    float ua = 1.f;
+    if constexpr (NL == 2) ua = limb16_unscale(a.amax[(int64_t)j * a.astride]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
-      if constexpr (NL == 2) v *= unscale;
+      if constexpr (NL == 2) v = (v * ua) * ug[c];
       *reinterpret_cast<f32x4*>(crow + colw + 8 * c + 4 * h32) = v;
     }
   }
 }
 
-// the largest magnitude of n floats (atomicMax on the bit pattern; the caller zeroes *out first)
+// |x| as its bit pattern if x is finite, 0 for inf / NaN: magnitudes order like unsigned integers, and a scale derived from the
+// largest FINITE magnitude keeps every finite element of the operand representable — a non-finite element then spoils the sums it
+// takes part in (as it does in fp32) and nothing else
+__device__ __forceinline__ uint32_t finite_mag_bits(float x) {
+  const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu;
+  return u < 0x7F800000u ? u : 0u;
+}
+__device__ __forceinline__ float finite_mag(float x) { return __uint_as_float(finite_mag_bits(x)); }
+
+// the largest finite magnitude of n floats (atomicMax on the bit pattern; the caller zeroes *out first)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ out) {
   float m = 0.f;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const f32x4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    m = fmaxf(fmaxf(m, fmaxf(finite_mag(v[0]), finite_mag(v[1]))), fmaxf(finite_mag(v[2]), finite_mag(v[3])));
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n - 4 * n4)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
+  if (blockIdx.x == 0 && threadIdx.x < (n - 4 * n4)) m = fmaxf(m, finite_mag(x[4 * n4 + threadIdx.x]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   __shared__ float wave_max[4];
@@ -1158,6 +1224,36 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
     if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+
+// The largest finite magnitude of every COLUMN of X [rows, cols] (cols % 4 == 0): the per-column scales of the two-fp16-limb weight
+// gradient.  A workgroup = 64 column quads x 4 row lanes over a range of rows; the four row lanes meet in LDS, then one atomicMax per
+// column on the bit pattern (max does not depend on the order: deterministic; the caller zeroes out[] first).
+__global__ __launch_bounds__(256) void col_absmax_kernel(const float* __restrict__ X, int64_t ldx, int32_t rows, int32_t cols,
+                                                         int32_t rows_per_block, float* __restrict__ out) {
+  const int q = blockIdx.x * 64 + (threadIdx.x & 63);             // column quad
+  const int y = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  uint32_t m[4] = {0u, 0u, 0u, 0u};
+  if (4 * q < cols) {
+    const float* p = X + 4 * q;
+    for (int r = r0 + y; r < r1; r += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)r * ldx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = max(m[e], finite_mag_bits(v[e]));
+    }
+  }
+  __shared__ uint32_t part[4][64][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[y][threadIdx.x & 63][e] = m[e];
+  __syncthreads();
+  if (y == 0 && 4 * q < cols) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t v = max(max(m[e], part[1][threadIdx.x][e]), max(part[2][threadIdx.x][e], part[3][threadIdx.x][e]));
+      if (v) atomicMax(reinterpret_cast<unsigned int*>(out) + 4 * q + e, v);
+    }
   }
 }
 
@@ -1267,7 +1363,7 @@ __global__ __launch_bounds__(256) void limb16_absmax_multi_kernel(const SplitMul
   float m = 0.f;
   if (ok)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, finite_mag(v[j]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   __shared__ float wave_max[4];                      // one atomic per block (every wave on one address measured 26 us for 18 matrices)
@@ -1519,18 +1615,34 @@ int64_t relgnn_limb_gemm_tn_chunks(int32_t V, int32_t J, int32_t C) {
 // P [chunks][J][C] = per-chunk partial products of A^T G over the first V - V % 32 rows (A [V, J], G [V, C], fp32 row-major;
 // J % 32 == 0, C % 256 == 0, V >= 32); chunks = relgnn_limb_gemm_tn_chunks(V, J, C).  The caller sums the slabs in order and adds
 // the last V % 32 rows' product: relgnn_sum_slabs_tail_f32 does both in one pass.
-static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax, float* P,
-                       int32_t V, int32_t J, int32_t C, void* stream);
+static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
+                       int32_t per_column, float* P, int32_t V, int32_t J, int32_t C, void* stream);
 
 int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* P, int32_t V, int32_t J, int32_t C,
                             void* stream) {
-  return limb_tn_any(A, lda, G, ldg, nullptr, nullptr, P, V, J, C, stream);
+  return limb_tn_any(A, lda, G, ldg, nullptr, nullptr, 0, P, V, J, C, stream);
 }
 
-int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax, float* P,
-                              int32_t V, int32_t J, int32_t C, void* stream) {
+int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
+                              int32_t per_column, float* P, int32_t V, int32_t J, int32_t C, void* stream) {
   if (!amax || !gmax) return RELGNN_EINVAL;
-  return limb_tn_any(A, lda, G, ldg, amax, gmax, P, V, J, C, stream);
+  return limb_tn_any(A, lda, G, ldg, amax, gmax, per_column, P, V, J, C, stream);
+}
+
+int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* stream) {
+  if (rows < 0 || cols < 0 || (cols > 0 && !out)) return RELGNN_EINVAL;
+  if (cols == 0) return RELGNN_OK;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(out, 0, sizeof(float) * cols, st) != hipSuccess) return RELGNN_EHIP;
+  if (rows == 0) return RELGNN_OK;
+  if (!X) return RELGNN_EINVAL;
+  if (cols % 4 != 0 || ldx % 4 != 0 || ldx < cols || !aligned16(X)) return RELGNN_EUNSUPPORTED;
+  const int gx = (cols / 4 + 63) / 64;
+  int per = 128;                                       // rows per workgroup: ~1024 workgroups at most
+  while ((int64_t)gx * ((rows + per - 1) / per) > 1024) per *= 2;
+  dim3 grid((unsigned)gx, (unsigned)((rows + per - 1) / per));
+  col_absmax_kernel<<<grid, 256, 0, st>>>(X, ldx, rows, cols, per, out);
+  return launch_status();
 }
 
 int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
@@ -1548,8 +1660,8 @@ int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
   return launch_status();
 }
 
-static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax, float* P,
-                       int32_t V, int32_t J, int32_t C, void* stream) {
+static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
+                       int32_t per_column, float* P, int32_t V, int32_t J, int32_t C, void* stream) {
   if (V < 0 || J < 0 || C < 0) return RELGNN_EINVAL;
   if (J == 0 || C == 0) return RELGNN_OK;
   if (V < 32) return RELGNN_EUNSUPPORTED;
@@ -1558,6 +1670,7 @@ static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg,
     return RELGNN_EUNSUPPORTED;
   LimbTnArgs a{};
   a.A = A; a.lda = lda; a.G = G; a.ldg = ldg; a.P = P; a.V = V - V % 32; a.J = J; a.C = C; a.amax = amax; a.gmax = gmax;
+  a.astride = a.gstride = per_column ? 1 : 0;
   int t32, rows, Z;
   limb_tn_geometry(V, J, C, &t32, &rows, &Z);
   a.panels = (J / 32) / t32; a.chunks = C / 256; a.rows_per_chunk = rows; a.Z = Z;

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-# RELGNN_GEMM selects the route of the node-side Dense products (forward / input gradient / weight gradient):
+# The route of the node-side Dense products (forward / input gradient / weight gradient) is config.settings.gemm (RELGNN_GEMM):
 #   limb  (default) tall operands (>= _LIMB_MIN_ROWS rows; N % 256 == 0, K % 16 == 0, K <= _LIMB_MAX_K; weight gradients with
 #         J % 32 == 0, C % 256 == 0 and more than 256 x 256 outputs) through csrc/limb_gemm.hip: every fp32 value as three bf16
 #         limbs (exact), six bf16 MFMA products per fp32 product, fp32 accumulation.  Against float64 at [36 k, 768] x [768, 256]:
@@ -26,22 +26,16 @@ import torch
 #         constraints hold (N % 64 == 0, K % 4 == 0); the weight gradients keep their `lib` routes
 #   torch library GEMMs through torch.mm (a hipBLASLt solution lookup per call: ~70 us of host time for every node count not
 #         seen before, i.e. for every batch of a shuffled epoch)
-_GEMM_MODE = os.environ.get("RELGNN_GEMM", "limb")
-if _GEMM_MODE not in ("limb", "lib", "panel", "torch"):
-    raise ValueError("RELGNN_GEMM must be one of limb, lib, panel, torch (got %r)" % _GEMM_MODE)
-_CACHED_LIB_GEMM = _GEMM_MODE != "torch"
-_PANEL_GEMM = _GEMM_MODE == "panel"
-_LIMB_GEMM = _GEMM_MODE == "limb"
+# config.settings.limb (RELGNN_LIMB) = pair (default): where the producer of the left operand supplies per-row magnitudes (the
+# gather in front of the aggregate-first layer's products), the product is evaluated from TWO fp16 limbs per value behind exact
+# power-of-two scales — three MFMA products instead of the six of the bf16 triple (csrc/limb_gemm.hip, NL = 2; its weight gradient:
+# one scale per column of each operand).  Per product its operands carry 22 instead of 24 significant bits; measured against
+# float64 on the C2 shapes neither arithmetic is systematically closer end to end (profiles/r04_*);
+# `triple` keeps the exact split everywhere.
+from .config import settings as _cfg
+
 _LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
-# RELGNN_LIMB=pair (default): where the producer of the left operand supplies per-row magnitudes (the gather in front of the
-# aggregate-first layer's products), the product is evaluated from TWO fp16 limbs per value behind exact power-of-two scales — three
-# MFMA products instead of the six of the bf16 triple (csrc/limb_gemm.hip, NL = 2; its weight gradient: one scale per operand).
-# Against float64 on the C2 shapes it is at least as close as the triple and closer than the exact-fp32 library product
-# (scripts/bench_limb16.py, tests/test_gpu_limb_gemm.py); `triple` keeps the exact split everywhere.
-_LIMB_PAIR = os.environ.get("RELGNN_LIMB", "pair") == "pair"
-_LIMB_CUT = os.environ.get("RELGNN_LIMB_CUT", "1") == "1"       # N % 128 >= 96 on the 128-column panels (last chunk cut at N)
 _LIMB_WS = {}
-_STREAM_TN = os.environ.get("RELGNN_TN", "stream") == "stream"
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 _WORKSPACE = {}
 _WARNED_UNSUPPORTED = False
@@ -70,7 +64,7 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
     """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
     Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU).
     weight=True: b is a parameter (or a view of one) — the limb route keeps its limb image across the step (weight_limbs)."""
-    if _LIMB_GEMM and layout != GEMM_TN and out is None and not accumulate:
+    if _cfg.limb_gemm and layout != GEMM_TN and out is None and not accumulate:
         from . import _lib
         if _limb_route_ok(layout, a, b, bias):
             return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR, weight=weight)
@@ -78,11 +72,11 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
             return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
         if layout == GEMM_NN and _limb_cut_route_ok(a, b, bias):   # N just short of a multiple of 128 (the 121 labels of the PPI head)
             return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
-    if (_PANEL_GEMM and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
+    if ((_cfg.gemm == "panel") and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
         from . import _lib
         return panel_gemm(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
-    if not (_CACHED_LIB_GEMM and _lib_rows_ok(a) and _lib_rows_ok(b) and (bias is None or (bias.is_cuda and bias.is_contiguous()
+    if not ((_cfg.gemm != "torch") and _lib_rows_ok(a) and _lib_rows_ok(b) and (bias is None or (bias.is_cuda and bias.is_contiguous()
                                                                                           and bias.dtype == torch.float32))):
         if layout == GEMM_NN:
             res = torch.addmm(bias, a, b) if bias is not None else a @ b
@@ -280,7 +274,6 @@ def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias, columns:
 # [L*Din, Dout] operand of the forward product nor the stacked W^T of the input gradient is ever formed in fp32.
 # C2: 8 split launches + 3 stacks + 3 re-layouts per step -> 1 launch.  Under stream capture nothing is cached (a replay re-runs
 # kernels, not this code): the image is split on every request.
-_WEIGHT_LIMB_CACHE = os.environ.get("RELGNN_WEIGHT_LIMB_CACHE", "1") == "1"
 _WEIGHT_LIMBS = {}
 _WEIGHT_GEN = [0]
 WEIGHT_NN, WEIGHT_NT = "nn", "nt"
@@ -380,7 +373,7 @@ def weight_image(w, kind: str, pair: bool = False) -> "_WeightImage":
     rows, cols = _weight_image_shape(ws, kind)
     dev = ws[0].device
     elements = int(lib.relgnn_limb16_elements(rows, cols) if pair else lib.relgnn_limb_elements(rows, cols))
-    if torch.cuda.is_current_stream_capturing() or not _WEIGHT_LIMB_CACHE:
+    if torch.cuda.is_current_stream_capturing() or _cfg.weight_limb_cache != "1":
         im = _WeightImage()
         im.pair, im.wmax = pair, None
         im.buf = torch.empty(elements, dtype=torch.bfloat16, device=dev)
@@ -448,7 +441,7 @@ def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, a
 
 
 def _limb_group_ok(a: torch.Tensor, ws, kind: str) -> bool:
-    if not (_LIMB_GEMM and _rows_ok(a) and a.shape[0] >= _LIMB_MIN_ROWS and weight_image_ok(ws, kind)):
+    if not (_cfg.limb_gemm and _rows_ok(a) and a.shape[0] >= _LIMB_MIN_ROWS and weight_image_ok(ws, kind)):
         return False
     n, k = _weight_image_shape(ws, kind)
     return a.shape[1] == k and n % 256 == 0 and 16 <= k <= _LIMB_MAX_K
@@ -477,7 +470,7 @@ def grouped_nt_gemm(g: torch.Tensor, kernels, xmax: torch.Tensor = None, xgroups
 def _limb_cut_route_ok(a: torch.Tensor, b: torch.Tensor, bias) -> bool:
     """a @ b (+ bias) with b [K, N], N % 128 >= 96: the 128-column panels with the last one cut at N (library pick for
     [36 k, 256] @ [256, 121]: 59-65 us; this route: measured in profiles/)."""
-    if not _LIMB_CUT or not _rows_ok(a) or a.shape[0] < _LIMB_MIN_ROWS:
+    if not (_cfg.limb_cut == "1") or not _rows_ok(a) or a.shape[0] < _LIMB_MIN_ROWS:
         return False
     K, N = a.shape[1], b.shape[1]
     return (b.is_cuda and b.dtype == torch.float32 and b.dim() == 2 and b.is_contiguous() and b.shape[0] == K and b.data_ptr() % 16 == 0
@@ -511,7 +504,7 @@ def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
 def mm_into(layout: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out[:] = a @ b (GEMM_NN) | a @ b^T (GEMM_NT) into a preallocated row block: the limb route when the shapes allow
     (RELGNN_GEMM=limb), else the library through torch.mm.  For the per-edge-type row blocks of an edge MLP (ops._BlockedLinear)."""
-    if _LIMB_GEMM and _limb_route_ok(layout, a, b, None) and _rows_ok(out):
+    if _cfg.limb_gemm and _limb_route_ok(layout, a, b, None) and _rows_ok(out):
         return limb_dense(layout, a, b, out=out)
     return torch.mm(a, b if layout == GEMM_NN else b.t(), out=out)
 
@@ -550,8 +543,19 @@ def limb_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
             and b.shape[1] % 256 == 0)
 
 
+def col_absmax(x: torch.Tensor) -> torch.Tensor:
+    """[cols] float32 on the device: the largest finite magnitude of every column of x [rows, cols] (relgnn_col_absmax_f32)."""
+    from . import _lib
+    if not _rows_ok(x):
+        x = x.contiguous()
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load_library().relgnn_col_absmax_f32(_lib.ptr(x), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(),
+                                                         _lib.current_stream()), "relgnn_col_absmax_f32")
+    return out
+
+
 def absmax(x: torch.Tensor) -> torch.Tensor:
-    """[1] float32 on the device: max |x| (relgnn_absmax_f32; no host round trip)."""
+    """[1] float32 on the device: max |x| over the finite elements (relgnn_absmax_f32; no host round trip)."""
     from . import _lib
     x = x if x.is_contiguous() else x.contiguous()
     out = torch.empty(1, dtype=torch.float32, device=x.device)
@@ -561,7 +565,8 @@ def absmax(x: torch.Tensor) -> torch.Tensor:
 
 def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor, amax: torch.Tensor = None, bmax: torch.Tensor = None) -> torch.Tensor:
     """a^T @ b for a [V, J], b [V, C] (weight gradient) through relgnn_limb_gemm_tn_f32 + the in-order slab sum.
-    amax, bmax ([1] device floats: the operands' largest magnitudes, e.g. absmax()): the two-fp16-limb form."""
+    amax, bmax (device floats): the two-fp16-limb form — [J] / [C] magnitudes per column (col_absmax(): one power-of-two scale
+    per column of each operand) or [1] / [1] (absmax(): one scale per operand)."""
     from . import _lib
     lib = _lib.load_library()
     V, J = a.shape
@@ -571,8 +576,12 @@ def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor, amax: torch.Tensor = None, bm
         raise ValueError("limb_gemm_tn: unsupported shape [%d, %d]^T @ [%d, %d]" % (V, J, V, C))
     parts = torch.empty((Z, J, C), dtype=torch.float32, device=a.device)
     if amax is not None:
+        per_column = amax.numel() == J and bmax.numel() == C and (J, C) != (1, 1)
+        if not per_column and (amax.numel() != 1 or bmax.numel() != 1):
+            raise ValueError("limb_gemm_tn: magnitudes must be [%d] and [%d] (per column) or [1] and [1]" % (J, C))
         _lib.check(lib.relgnn_limb16_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), amax.data_ptr(), bmax.data_ptr(),
-                                                 parts.data_ptr(), V, J, C, _lib.current_stream()), "relgnn_limb16_gemm_tn_f32")
+                                                 1 if per_column else 0, parts.data_ptr(), V, J, C, _lib.current_stream()),
+                   "relgnn_limb16_gemm_tn_f32")
     else:
         _lib.check(lib.relgnn_limb_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), parts.data_ptr(), V, J, C,
                                                _lib.current_stream()), "relgnn_limb_gemm_tn_f32")
@@ -643,9 +652,9 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     # small outputs (every Dense of the path except the stacked per-type transforms): the streaming kernel — measured at
     # V = 36 k: [256 x 256] 59 us vs 171 us for the library's strided-batched split-K, [256 x 121] 43 vs 114, [50 x 256]
     # 33 vs 57, [128 x 128] 30 vs 56; the library wins for [768 x 256] (131 vs 223) and for V ~ 1e6 (scripts/exp_tn_stream.py)
-    if _STREAM_TN and M * N <= 256 * 256 and 0 < V <= (1 << 18) and _lib_rows_ok(a) and _lib_rows_ok(b):
+    if (_cfg.tn == "stream") and M * N <= 256 * 256 and 0 < V <= (1 << 18) and _lib_rows_ok(a) and _lib_rows_ok(b):
         return tn_stream_gemm(a, b)
-    if _LIMB_GEMM and limb_tn_supported(a, b):
+    if _cfg.limb_gemm and limb_tn_supported(a, b):
         return limb_gemm_tn(a, b)
     S = _split_count(V, M, N)
     if S <= 1:
@@ -656,7 +665,7 @@ def matmul_tn_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     head = c * S
     # (outputs narrower than one 64-wide tile — the [50, 256] gradient of the input projection — keep torch.bmm: hipBLASLt's
     # strided-batched pick for them measured 148 us against 52 us, scripts/exp_cached_gemm_quality.py)
-    if _CACHED_LIB_GEMM and min(M, N) >= 64 and _lib_rows_ok(a) and _lib_rows_ok(b) and a.is_contiguous() and b.is_contiguous():
+    if (_cfg.gemm != "torch") and min(M, N) >= 64 and _lib_rows_ok(a) and _lib_rows_ok(b) and a.is_contiguous() and b.is_contiguous():
         # one strided-batched library call: chunk z = rows [z*c, (z+1)*c) of both operands
         from . import _lib
         lib = _lib.load_library()
@@ -757,6 +766,6 @@ class _DenseReluFn(torch.autograd.Function):
 def dense_relu(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
     """relu(dense(x, kernel, bias)) as one GEMM with a ReLU epilogue (CUDA fp32 operands; anything else takes the two-step
     route)."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _CACHED_LIB_GEMM):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and (_cfg.gemm != "torch")):
         return torch.relu(dense(x, kernel, bias))
     return _DenseReluFn.apply(x, kernel, bias)

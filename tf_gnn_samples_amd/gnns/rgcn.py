@@ -28,7 +28,8 @@ def aggregate_first_enabled() -> bool:
     """Default order for sum / mean / sqrt_n: gather + reduce the raw states into the (target, type) buckets, then ONE
     GEMM with the stacked kernels (ops.aggregate_then_transform).  RELGNN_RGCN_ORDER=transform_first restores
     transform-then-aggregate."""
-    return os.environ.get("RELGNN_RGCN_ORDER", "aggregate_first") != "transform_first"
+    from ..config import settings
+    return settings.rgcn_order != "transform_first"
 
 
 def rgcn_layer_variables(num_edge_types: int, in_dim: int, state_dim: int,

@@ -512,9 +512,9 @@ class RelGraph:
         """Node-side per-type transforms over all V*L (node,type) rows waste work when most buckets are empty
         (VarMisuse-shaped graphs: 23 edge types, ~2/3 of the buckets empty).  Few-type graphs (PPI: every bucket
         non-empty) keep the dense [V*L, D] tables and one big GEMM.  RELGNN_PAIR_TABLES=0/1 overrides."""
-        force = os.environ.get("RELGNN_PAIR_TABLES")
-        if force is not None:
-            return force not in ("0", "", "false")
+        from .config import settings
+        if settings.pair_tables != "auto":
+            return settings.pair_tables == "1"
         if self.L < 8 or self.M == 0:
             return False
         pt = self.pair_tables()
@@ -530,7 +530,7 @@ class RelGraph:
 
 
 # rows per GEMM batch entry of the compact tables; every type's row block is padded to a multiple
-PAIR_CHUNK = int(os.environ.get("RELGNN_PAIR_CHUNK", "512"))
+PAIR_CHUNK = 512
 
 
 class SidePairs:

@@ -5,12 +5,12 @@ get_aggregation_function (utils/utils.py:23-33), same argument names and meaning
 `seg_gather_reduce` is the fused form the layer functions use: the gather
 (tf.nn.embedding_lookup), the per-message scale and the segment reduction in ONE kernel.
 """
-import os
 from typing import Optional
 
 import torch
 
 from . import _lib
+from .config import settings as _cfg
 from .graph import GatherReducePlan, build_segment_plan
 
 _MODE_IDS = {
@@ -340,8 +340,7 @@ class _FusedEdgeMessages(torch.autograd.Function):
         # Measured on MI355X (scripts/bench_configs.py): the wave kernels (D > 128) on dense tables win with regather
         # (FiLM on the C2 batch: 833 + 426 us -> 330 + 536 us per layer, step 9.06 -> 7.66 ms); the lane-group kernels on
         # compact pair tables (C5: D = 128, 23 types) with emit (47.4 vs 52.9 ms).
-        choice = os.environ.get("RELGNN_EDGE_BWD") or ("emit" if os.environ.get("RELGNN_EDGE_BWD_REGATHER") is None
-                                                       and (pairs is not None or D <= 128) else "regather")
+        choice = _cfg.edge_bwd if _cfg.edge_bwd != "auto" else ("emit" if (pairs is not None or D <= 128) else "regather")
         emit = choice == "emit"
         dmsg = torch.empty((graph.M, D), dtype=torch.float32, device=T.device) if emit else None
         # RELGNN_EDGE_SIGN_MASK=1 (opt-in; regather + piecewise-linear activation + wave kernels with one float4 per lane):
@@ -351,7 +350,7 @@ class _FusedEdgeMessages(torch.autograd.Function):
         smask = None
         if (not emit and kind == "film" and pairs is None and act in (_lib.ACT_LINEAR, _lib.ACT_RELU, _lib.ACT_LEAKY_RELU)
                 and 128 < D <= 256 and L <= 63 and V * L * (D // 4) < 2 ** 32 and graph.M > 0
-                and os.environ.get("RELGNN_EDGE_SIGN_MASK", "0") == "1"):
+                and _cfg.edge_sign_mask == "1"):
             smask = torch.empty((graph.M, 4), dtype=torch.int64, device=T.device)
         if kind == "film":
             col = graph.col_t if pairs is None else pairs.col_t
@@ -554,13 +553,13 @@ class _TypedLinearPanel(torch.autograd.Function):
 def _typed_limb_ok(k: int, n: int) -> bool:
     """The limb route (relgnn_limb_dense_sel_f32) for a typed product with reduction length k and n output columns."""
     from . import dense
-    return dense._LIMB_GEMM and n % 128 == 0 and k % 16 == 0 and 16 <= k <= dense._LIMB_MAX_K
+    return _cfg.limb_gemm and n % 128 == 0 and k % 16 == 0 and 16 <= k <= dense._LIMB_MAX_K
 
 
 def _typed_panel_ok(H, side, weights) -> bool:
     Din, Dout = weights[0].shape
     # (forward: N = Dout; input gradient: N = Din; both must be panel widths)
-    return (os.environ.get("RELGNN_TYPED", "panel") == "panel" and H.is_cuda and side.chunk == 512 and Din % 64 == 0
+    return (_cfg.typed == "panel" and H.is_cuda and side.chunk == 512 and Din % 64 == 0
             and Dout % 64 == 0 and side.P > 0 and H.data_ptr() % 16 == 0)
 
 
@@ -602,7 +601,7 @@ class _PairMaterialize(torch.autograd.Function):
         M, D = graph.M, P.shape[1]
         ghidden = ghidden.contiguous()
         S = graph.V * graph.L
-        if (ctx.has_q and os.environ.get("RELGNN_EDGE_BWD") != "emit" and D % 4 == 0 and 128 < D <= 1024
+        if (ctx.has_q and _cfg.edge_bwd != "emit" and D % 4 == 0 and 128 < D <= 1024
                 and M * (D // 4) < 2 ** 32 and S > 0):
             # No [M, D] gradient of the pre-activation is written and re-read twice: the by-(source,type) pass of the pair
             # kernels sums g_m * act'(P[r] + Q[f_m]) per bucket r straight from ghidden's rows (its "target gradient row" is
@@ -679,7 +678,7 @@ class _RgatAttention(torch.autograd.Function):
         # the two score-table gradients are sums of dz over the (target, type) and the (source, type) buckets: the dz
         # pass keeps the first in registers and the by-source gather of the gT pass carries the second along
         # (RELGNN_RGAT_FUSED_SUMS=0: two separate gather-reduces over dz, 70 + 60 us per layer at the C2 shape)
-        fuse = os.environ.get("RELGNN_RGAT_FUSED_SUMS", "1") != "0"
+        fuse = _cfg.rgat_fused_sums != "0"
         if ctx.fast and _rgat_dz_fast_ok(D, K):
             fuse_t = fuse and L * K <= 64
             gs_tgt = torch.empty((V * L, K), dtype=torch.float32, device=T.device) if fuse_t else None
@@ -771,19 +770,14 @@ def aggregate_acc64() -> bool:
     Measured at the full C2 batch (profiles/r03_parity_margin.json): float64 accumulators change the distance to the oracle from
     6.2e-6 to 6.0e-6 and the distance to the float64 truth from 4.8e-6 to 5.1e-6 — the bucket sums are NOT where the
     aggregate-first order spends its error budget (the K = 768 dot products are), so the default stays the float32 kernel."""
-    return os.environ.get("RELGNN_AGG_ACC", "f32") == "f64"
+    return _cfg.agg_acc == "f64"
 
 
-# RELGNN_BWD_OVERLAP=1 (default on the limb route): the weight gradient of the aggregate-first RGCN layer on a side stream next to the input gradient's
+# config.settings.bwd_overlap (RELGNN_BWD_OVERLAP; auto = on with the limb route): the weight gradient of the aggregate-first RGCN layer on a side stream next to the input gradient's
 # gather.  Measured on the C2 step, alternated twice in one process group: 2.006 / 2.014 ms without, 1.955 / 1.955 ms with (round 2
 # measured the opposite, 3.08 vs 2.94 ms, with the library's split-K GEMM in that place: it wanted the same CUs and the same L2 as the
 # gather; the limb kernel is one 147 KB-LDS workgroup per CU that leaves registers and the L2 path to the gather's waves).
 # With the exact-fp32 routes (RELGNN_GEMM=lib / panel) the default is off: 2.45 vs 2.22 ms.
-def _bwd_overlap_default() -> str:
-    return "1" if os.environ.get("RELGNN_GEMM", "limb") == "limb" else "0"
-
-
-_BWD_OVERLAP = os.environ.get("RELGNN_BWD_OVERLAP", _bwd_overlap_default()) == "1"
 _SIDE_STREAMS = {}
 
 
@@ -795,12 +789,12 @@ def _side_stream(device):
 
 
 def _weight_gradient(agg, gsc, amax):
-    """agg^T @ gsc; with the buckets' magnitudes from the forward gather (RELGNN_LIMB=pair) from two fp16 limbs behind one
-    power-of-two scale per operand (their largest magnitudes: two small reductions, on whatever stream this runs on)."""
+    """agg^T @ gsc; on the two-fp16-limb route (RELGNN_LIMB=pair: `amax`, the forward gather's bucket magnitudes, says the layer
+    took it) behind one power-of-two scale per COLUMN of each operand (two column-maximum passes on whatever stream this runs on)."""
     from . import dense as DN
-    if (amax is not None and DN._LIMB_PAIR and DN.limb_tn_supported(agg, gsc) and agg.shape[1] * gsc.shape[1] > 256 * 256
-            and "tn" in os.environ.get("RELGNN_LIMB_PAIR_PARTS", "nn,nt,tn").split(",")):
-        return DN.limb_gemm_tn(agg, gsc, DN.absmax(amax), DN.absmax(gsc))
+    if (amax is not None and _cfg.limb_pair and DN.limb_tn_supported(agg, gsc) and agg.shape[1] * gsc.shape[1] > 256 * 256
+            and _cfg.pair_part("tn")):
+        return DN.limb_gemm_tn(agg, gsc, DN.col_absmax(agg), DN.col_absmax(gsc))
     return DN.matmul_tn_splitk(agg, gsc)
 
 
@@ -808,10 +802,10 @@ def _pair_products(X, rowptr, stride, V, k, n, kernels, kind) -> bool:
     """The two-fp16-limb form for this gather + product pair (dense.RELGNN_LIMB=pair): the gather can write the per-bucket
     magnitudes and the product takes the limb route."""
     from . import dense as DN
-    if not (DN._LIMB_PAIR and DN._LIMB_GEMM and X.is_cuda and V >= DN._LIMB_MIN_ROWS and n % 256 == 0 and k % 16 == 0
+    if not (_cfg.limb_pair and X.is_cuda and V >= DN._LIMB_MIN_ROWS and n % 256 == 0 and k % 16 == 0
             and 16 <= k <= DN._LIMB_MAX_K):
         return False
-    if kind not in os.environ.get("RELGNN_LIMB_PAIR_PARTS", "nn,nt,tn").split(","):      # (diagnostics: which products take the form)
+    if not _cfg.pair_part(kind):                         # (diagnostics: which products take the form)
         return False
     return (rowmax_supported(X, rowptr, stride, aggregate_acc64())
             and DN.weight_image_ok(list(kernels), DN.WEIGHT_NN if kind == "nn" else DN.WEIGHT_NT))
@@ -879,7 +873,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         # gradient's gather (L2-latency bound, no LDS, few registers): it runs on a side stream next to it (fork / join by events,
         # capturable in a hipGraph; the result is the same bits, the kernels are the same).
         side = None
-        if want_w and ctx.needs_input_grad[0] and _BWD_OVERLAP and gout.is_cuda:
+        if want_w and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and gout.is_cuda:
             side = _side_stream(gout.device)
             cur = torch.cuda.current_stream(gout.device)
             side.wait_stream(cur)

@@ -126,7 +126,14 @@ class OverlappedGradientAllReducer(GradientAllReducer):
     backward — is reduced by its own tiny collective at arm() time; finish() (the training step's grad_hook) launches what
     is left (parameters that received no gradient count as zeros), waits, divides by sum_r n_r and points every .grad at its
     slice, exactly like the flat form.  For two ranks the result is bit-identical to the flat form (a sum of two values has
-    one order); for more ranks the reduction order of an element may depend on where the library cuts its buffer."""
+    one order); for more ranks the reduction order of an element may depend on where the library cuts its buffer.
+
+    Collectives must be issued in the SAME sequence on every rank, and the order in which autograd completes buckets is not a
+    property of the model: which parameters get a gradient at all, and when, follows the autograd graph of THIS rank's batch
+    (hub routes, pair tables and typed panels are picked per batch).  So buckets leave strictly in index order, as in DDP: a
+    complete bucket is launched only when every bucket before it has been — otherwise it waits for a later hook or for finish(),
+    which launches whatever is left, again in index order.  Two ranks whose backward passes complete their buckets in different
+    orders (tests/test_distributed_cpu.py) therefore still pair bucket b with bucket b."""
 
     def __init__(self, params: Sequence[torch.nn.Parameter], bucket_bytes: int = 1 << 20, group=None):
         super().__init__(params, group)
@@ -151,11 +158,14 @@ class OverlappedGradientAllReducer(GradientAllReducer):
     def _make_hook(self, i):
         def hook(_param):
             if self._armed:
-                b = self.bucket_of[i]
-                self._left[b] -= 1
-                if self._left[b] == 0:
-                    self._launch(b)
+                self._left[self.bucket_of[i]] -= 1
+                self._launch_ready_prefix()
         return hook
+
+    def _launch_ready_prefix(self) -> None:
+        while self._next < len(self.buckets) and self._left[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -167,7 +177,7 @@ class OverlappedGradientAllReducer(GradientAllReducer):
             return
         self._w = float(local_weight)
         self._left = [len(idx) for _, _, idx in self.buckets]
-        self._sent = [False] * len(self.buckets)
+        self._next = 0                          # buckets [0, _next) have been launched: strictly in index order on every rank
         self.flat[-1] = self._w
         self._works = [dist.all_reduce(self.flat[-1:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
         self._armed = True
@@ -179,7 +189,6 @@ class OverlappedGradientAllReducer(GradientAllReducer):
         torch._foreach_copy_([self.views[i] for i in idx], grads)
         self.flat[lo:hi].mul_(self._w)
         self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._sent[b] = True
 
     @torch.no_grad()
     def finish(self) -> None:
@@ -187,9 +196,9 @@ class OverlappedGradientAllReducer(GradientAllReducer):
         if not self._armed:
             return
         self._armed = False
-        for b in range(len(self.buckets)):
-            if not self._sent[b]:
-                self._launch(b)
+        while self._next < len(self.buckets):   # what the hooks left: incomplete buckets (parameters without a gradient) included
+            self._launch(self._next)
+            self._next += 1
         for w in self._works:
             w.wait()
         self._works = []

@@ -227,11 +227,11 @@ class ResidentDataset:
         RELGNN_ASSEMBLE_STREAM=side each batch is assembled on a side stream under step i's kernels and the consumer's
         stream waits for the batch's event (DeviceBatch.wait_ready / RelGraph.wait_ready) before its first kernel touches
         the tensors."""
-        import os
+        from ..config import settings
         # Default: assemble on the CALLER's stream.  The lean assembly is ~85 us of streaming kernels; run on a side stream
         # under the previous step they stretched whichever GEMM they met from 113 to 229 us (kernel timeline,
         # scripts/gpu_step_timeline.sh) — 2.38 vs 2.44 ms per step in one A/B.  RELGNN_ASSEMBLE_STREAM=side keeps the overlap.
-        if os.environ.get("RELGNN_ASSEMBLE_STREAM", "main") != "side":
+        if settings.assemble_stream != "side":
             for ids in self.store.split_batches(graph_ids, max_nodes_per_batch):
                 yield self.assemble(ids)
             return
