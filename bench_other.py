@@ -74,11 +74,30 @@ def _time_kernel(fn, iters=10):
     return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
 
-def _line(name, mb, train_ms, fwd_ms, kernel):
-    print(json.dumps({"config": name, "nodes": mb.num_nodes, "edges": mb.num_edges, "graphs": mb.num_graphs,
-                      "train_ms": round(train_ms, 3), "train_edges_per_s": round(mb.num_edges / train_ms * 1e3),
-                      "fwd_ms": round(fwd_ms, 3), "fwd_edges_per_s": round(mb.num_edges / fwd_ms * 1e3),
-                      "dominant_gather_kernel": kernel}), flush=True)
+def _time_captured_step(model, batch, steps):
+    """The same training step (fixed resident batch, its bucketing part of the batch) recorded as ONE hipGraph and replayed:
+    what a launch-bound config costs without the host's ~150 enqueues per step (models/sparse_graph_model.py: capture_train_step)."""
+    try:
+        cap = model.capture_train_step(batch)
+        for _ in range(3):
+            cap.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cap.replay()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / steps * 1e3, 3)
+    except Exception as e:                 # the eager number stands on its own
+        return "capture failed: %r" % (e,)
+
+
+def _line(name, mb, train_ms, fwd_ms, kernel, **extra):
+    row = {"config": name, "nodes": mb.num_nodes, "edges": mb.num_edges, "graphs": mb.num_graphs,
+           "train_ms": round(train_ms, 3), "train_edges_per_s": round(mb.num_edges / train_ms * 1e3),
+           "fwd_ms": round(fwd_ms, 3), "fwd_edges_per_s": round(mb.num_edges / fwd_ms * 1e3),
+           "dominant_gather_kernel": kernel}
+    row.update(extra)
+    print(json.dumps(row), flush=True)
 
 
 def _kernel_record(what, alg_bytes, ms):
@@ -108,12 +127,18 @@ def run_c3(dev):
         p = cls.default_params(); p.update(hidden_size=D, graph_num_layers=6, graph_rnn_cell="GRU", message_aggregation_function=agg)
         model = _quiet(lambda: cls(p, task, device=str(dev)))
         train_ms, fwd_ms = _time_steps(model, batch, 4, 8)
+        graph_ms = _time_captured_step(model, batch, 20)
         mode = ops.aggregation_mode_id(agg)
         ms = _time_kernel(lambda: ops._seg_reduce_raw(mode, T, plan.rowptr, plan.stride, plan.col, None, plan.num_out))
         k = _kernel_record("seg_reduce_group_kernel<32> (gather rows of the [V*L, 128] transformed table + segment-%s)" % agg,
                            M * (4 * D + 4) + V * 4 * D + 4 * (V * L + 1), ms)
         k["note"] += "; 80 MB per launch: launch-latency bound (SURVEY.md 8d), not a bandwidth statement"
-        _line("C3 GGNN / QM9 (real molecules), GRU, %s aggregation, D=128, 6 layers" % agg, mb, train_ms, fwd_ms, k)
+        extra = {"train_ms_hipgraph": graph_ms,
+                 "train_ms_hipgraph_what": "the same step on the same fixed batch (bucketing kept with the batch) as one captured "
+                                           "hipGraph, replayed 20 times"}
+        if isinstance(graph_ms, float):
+            extra["train_edges_per_s_hipgraph"] = round(mb.num_edges / graph_ms * 1e3)
+        _line("C3 GGNN / QM9 (real molecules), GRU, %s aggregation, D=128, 6 layers" % agg, mb, train_ms, fwd_ms, k, **extra)
         del model
 
 

@@ -789,16 +789,17 @@ int relgnn_limb16_gemm_xf32(int32_t act, const float* A, int64_t lda, const floa
                             const float* wmax, const float* bias, const void* zeros, float* C, int64_t ldc, int32_t M, int32_t N,
                             int32_t K, void* stream);
 /* The weight gradient from two fp16 limbs: relgnn_limb_gemm_tn_f32's partial products behind exact power-of-two scales derived from
- * magnitudes in device memory.  per_column != 0: amax[J], gmax[C] hold one magnitude per COLUMN of A / of G (relgnn_col_absmax_f32)
- * — the reduction runs over the rows of both operands, so a row's scale would not factor out, a column's does (out[j][c] carries
- * sa[j] * sg[c]) and a column of small gradients keeps its relative precision next to a column of large ones; per_column == 0:
- * amax[0], gmax[0] are the operands' largest magnitudes (relgnn_absmax_f32), one scale per operand.  Magnitudes must bound the
+ * magnitudes in device memory.  Column j of A is scaled from amax[j / a_cols_per_scale], column c of G from
+ * gmax[c / g_cols_per_scale]: 1 = one magnitude per COLUMN (relgnn_col_absmax_f32) — the reduction runs over the rows of both
+ * operands, so a row's scale would not factor out, a column's does (out[j][c] carries sa[j] * sg[c]) and a column of small
+ * gradients keeps its relative precision next to a column of large ones; J (resp. C) = one magnitude for the operand
+ * (relgnn_absmax_f32): normwise accuracy only; anything between = per group of consecutive columns.  Magnitudes must bound the
  * finite elements they cover; relgnn_absmax_f32 / relgnn_col_absmax_f32 skip inf / NaN elements, which then spoil exactly the
  * sums they take part in, as in fp32.
  * relgnn_absmax_f32: out[0] = max |x[i]| over the finite x[i] (x 16-byte aligned).
  * relgnn_col_absmax_f32: out[c] = max_r |X[r][c]| over the finite elements (cols % 4 == 0, ldx % 4 == 0, X 16-byte aligned). */
-int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
-                              int32_t per_column, float* P, int32_t V, int32_t J, int32_t C, void* stream);
+int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, int32_t a_cols_per_scale,
+                              const float* gmax, int32_t g_cols_per_scale, float* P, int32_t V, int32_t J, int32_t C, void* stream);
 int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* stream);
 int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream);
 /* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need

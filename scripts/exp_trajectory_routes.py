@@ -46,12 +46,16 @@ def main():
     runs = {}
     for name, switches in ROUTES.items():
         with config.override(**switches):
-            model = RGCN_Model(p, task, device=str(dev))
+            keep, sys.stdout = sys.stdout, sys.stderr           # (the constructor prints the parameter count)
+            try:
+                model = RGCN_Model(p, task, device=str(dev))
+            finally:
+                sys.stdout = keep
             batch = DeviceBatch(mb, dev)
             losses, snaps = [], {}
             for step in range(1, steps + 1):
                 m = model.train_step(batch)
-                losses.append(float(m['loss']))
+                losses.append(float(m['loss'].detach()))
                 if step in MARKS:
                     snaps[step] = {n: model.variables[n].detach().double().cpu().numpy().copy() for n in model.variables.names()}
             runs[name] = (losses, snaps)

@@ -196,11 +196,14 @@ def test_c2_full_batch_model_gradients(gpu_device, c2, monkeypatch, seed, route)
            "flip_aware_max_abs": max(aware.values()), "flip_aware_worst_gradient": max(aware, key=aware.get),
            "flip_aware_max_rel_frobenius": max(fro.values()),
            "flip_aware_max_abs_per_gradient": {k.split("/", 1)[-1]: "%.1e" % v for k, v in aware.items()}}
-    if flipped:          # the plain comparison (float64 decides its own branches), for the record: what round 3 asserted on
+    # the plain comparison (float64 decides its own branches), for the record — what round 3 asserted on; it doubles the host time of
+    # the test, so it runs on request (RELGNN_TEST_PLAIN_GRADIENTS=1: profiles/r04_a_gradient_parity_by_seed.json has all 15 cases:
+    # up to 4.8e-5 on the EXACT-fp32 route, seed 2, where the flip-aware comparison says 1.9e-7)
+    if flipped and os.environ.get("RELGNN_TEST_PLAIN_GRADIENTS") == "1":
         _, plain_ref, _ = float64_gradients(None)
         plain = {n: float(np.abs(got[n] - plain_ref[n]).max()) for n in plain_ref}
         row["plain_max_abs"], row["plain_worst_gradient"] = max(plain.values()), max(plain, key=plain.get)
-    else:
+    elif not flipped:
         row["plain_max_abs"], row["plain_worst_gradient"] = row["flip_aware_max_abs"], row["flip_aware_worst_gradient"]
     _GRADIENT_ROWS.append(row)
     print(row)

@@ -81,7 +81,7 @@ def _worker(rank, world, port, share_gpu, q, overlap=False):
         m = model.forward_batch(local, training=True)
         reducer.arm(float(local.num_nodes))
         m['loss'].backward()
-        assert len(reducer.buckets) > 1 and any(reducer._sent)
+        assert len(reducer.buckets) > 1 and reducer._next > 0      # (buckets left during the backward, in index order)
         reducer.finish()
     else:
         _grads(model, local)

@@ -42,7 +42,15 @@ def test_limbs_stay_exact_and_finite_at_both_ends_of_the_range(gpu_device, trans
     src = x.t().contiguous() if transpose else x
     limbs = DN.limb_split(src, transpose=transpose)
     assert bool(torch.isfinite(limbs.data.float()).all())
-    assert torch.equal(limbs.to_float64(), x.double())
+    got, want = limbs.to_float64(), x.double()
+    # three bf16 limbs reach down to bf16's smallest denormal, 2^-133: hi + mid + lo == x EXACTLY for every float32 whose lowest set
+    # bit is at or above it — every |x| >= 2^-110, and zero — and up to the top of the range (hi saturates at the largest finite
+    # bf16 instead of rounding to infinity); below 2^-110 the low bits of x fall under 2^-133 (and the matrix pipe may flush
+    # denormal limbs): an absolute error of at most 2^-126 = 1.2e-38, eleven orders of magnitude under any tolerance of the path
+    big = want.abs() >= 2.0 ** -110
+    assert torch.equal(got[big], want[big])
+    assert float((got - want).abs().max()) <= 2.0 ** -126
+    assert bool((got[want == 0] == 0).all())
 
 
 def _extreme_left_operand(M, K, dev, seed):

@@ -202,6 +202,28 @@ def test_rgat_layer(gpu_device, D, K):
                 lambda x, ww: R.sparse_rgat_layer(x, adj_c, D, K, 1, "tanh", weights=ww), h, w, gpu_device)
 
 
+def test_rgat_fused_sums_switch(gpu_device, monkeypatch):
+    """RELGNN_RGAT_FUSED_SUMS=0: the two score-table gradients as separate gather-reduces over dz instead of riding along with the
+    dz pass and the by-source gather — the same gradients."""
+    from tf_gnn_samples_amd.gnns import sparse_rgat_layer
+    rng, adj, deg = _graph(12)
+    V, L, D, K = 150, 3, 256, 4
+    w = rgcn_weights(rng, L, D, D)
+    for l in range(L):
+        w["Edge_%i_Attention_Parameters" % l] = (rng.standard_normal(2 * D) * 0.3).astype(np.float32)
+    h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+    gout = torch.as_tensor(rng.standard_normal((V, D)).astype(np.float32), device=gpu_device)
+    grads = []
+    for flag in ("1", "0"):
+        set_switch(monkeypatch, "RELGNN_RGAT_FUSED_SUMS", flag)
+        hd = torch.as_tensor(h, device=gpu_device).requires_grad_(True)
+        wd = {k: torch.as_tensor(v, device=gpu_device).requires_grad_(True) for k, v in w.items()}
+        sparse_rgat_layer(hd, _dev(adj, gpu_device), D, K, 1, "tanh", weights=wd).backward(gout)
+        grads.append([hd.grad] + [wd[k].grad for k in sorted(wd)])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+
+
 def test_rgat_nodes_without_incoming_edges(gpu_device):
     from tf_gnn_samples_amd.gnns import sparse_rgat_layer
     rng = np.random.default_rng(12)

@@ -77,9 +77,12 @@ def test_few_type_graphs_keep_dense_tables(gpu_device):
     assert not g.wants_pair_tables()
 
 
-def test_typed_linear_matches_per_row_matmul(gpu_device):
+@pytest.mark.parametrize("typed", ["panel", "bmm"])
+def test_typed_linear_matches_per_row_matmul(gpu_device, monkeypatch, typed):
+    """RELGNN_TYPED: one gathered-row MFMA launch per product (panel) | index_select + torch.bmm (bmm)."""
     from tf_gnn_samples_amd import ops
     from tf_gnn_samples_amd.graph import RelGraph
+    set_switch(monkeypatch, "RELGNN_TYPED", typed)
     rng, adj, _ = _sparse_many_type_graph(2)
     V, L, Din, Dout = 300, 12, 64, 96
     g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)

@@ -90,6 +90,17 @@ def test_resident_batches_and_plans_are_bit_identical(gpu_device, L):
     got = [x.num_graphs for x in resident.iterate(np.arange(30), 200)]
     want = [x.num_graphs for x in host.iterate(np.arange(30), 200)]
     assert got == want and sum(got) == 30
+    # RELGNN_ASSEMBLE_STREAM=side: every batch assembled on a side stream under the previous step — the same batches
+    from tf_gnn_samples_amd import config
+    with config.override(assemble_stream="side"):
+        side_batches = list(resident.iterate(np.arange(30), 200))
+    for x in side_batches:
+        x.wait_ready()
+    main_batches = list(resident.iterate(np.arange(30), 200))
+    assert len(side_batches) == len(main_batches)
+    for a, b in zip(side_batches, main_batches):
+        assert torch.equal(a.initial_node_features, b.initial_node_features) and torch.equal(a.graph.src_t, b.graph.src_t)
+        assert torch.equal(a.graph.rowptr_t, b.graph.rowptr_t) and torch.equal(a.graph.rowptr_s, b.graph.rowptr_s)
 
 
 def test_resident_qm9_with_per_graph_targets_and_training(gpu_device):

@@ -19,7 +19,7 @@ def cache(monkeypatch):
     monkeypatch.setattr(_lib, "load_library", lambda: Lib())
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: types.SimpleNamespace(cuda_stream=0))
-    monkeypatch.setattr(DN, "_WEIGHT_LIMBS", {})
+    monkeypatch.setattr(DN, "_WEIGHT_LIMBS", DN._PerStream(limit=8))
     from tf_gnn_samples_amd import config
     monkeypatch.setattr(config.settings, "weight_limb_cache", "1")
     return DN, launches

@@ -140,3 +140,10 @@ def default_of(name: str) -> str:
 
 def current() -> Dict[str, str]:
     return {name: getattr(settings, name) for name in _SPEC}
+
+
+if __name__ == "__main__":                     # the markdown table of README.md "Switches"
+    print("| Environment variable | `config.settings.` | default | values | selects |")
+    print("|---|---|---|---|---|")
+    for env, name, default, allowed, doc in describe():
+        print("| `%s` | `%s` | `%s` | %s | %s |" % (env, name, default, allowed.replace(" | ", ", "), doc.replace(" | ", " / ")))

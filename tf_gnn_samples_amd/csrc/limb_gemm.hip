@@ -82,6 +82,10 @@ __device__ __forceinline__ uint32_t limb16_scale_bits(float mx) {          // ex
 }
 __device__ __forceinline__ float limb16_scale(float mx) { return __uint_as_float(limb16_scale_bits(mx) << 23); }
 __device__ __forceinline__ float limb16_unscale(float mx) { return __uint_as_float((254u - limb16_scale_bits(mx)) << 23); }
+// log2 of 1 / scale: scales are removed with ldexpf(x, k_left + k_right) — ONE exact scaling by the sum of the exponents.  Multiplying
+// by the two reciprocal scales one after the other overflows on the way when a huge left operand (scale 2^-113 for float32 lowest:
+// acc * 2^113 = inf) meets a tiny right one (2^-29 would have brought it back): found by tests/test_gpu_extreme_values.py.
+__device__ __forceinline__ int limb16_unscale_exp(float mx) { return 127 - (int)limb16_scale_bits(mx); }
 __device__ __forceinline__ void split_pair16(float x0, float x1, uint32_t& h, uint32_t& l) {
   const f16x2 hh = __builtin_convertvector(f32x2{x0, x1}, f16x2);          // round to nearest even
   const f32x2 hf = __builtin_convertvector(hh, f32x2);
@@ -477,17 +481,17 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
     const int r = tm * 32 + i32;
     if (r < rows_here) {
       float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
-      float unscale = 1.f;
-      if constexpr (NL == 2) {                          // the row's and the weights' powers of two leave: exact
+      int unscale = 0;
+      if constexpr (NL == 2) {                          // the row's and the weights' powers of two leave: exact (one ldexp)
         float mx = 0.f;
         for (int g = 0; g < a.xgroups; ++g) mx = fmaxf(mx, a.xmax[(int64_t)(m0 + r) * a.xgroups + g]);
-        unscale = limb16_unscale(mx) * limb16_unscale(a.wmax[0]);
+        unscale = limb16_unscale_exp(mx) + limb16_unscale_exp(a.wmax[0]);
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int col = colw + 8 * c + 4 * h32;
         f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
-        if constexpr (NL == 2) v *= unscale;
+        if constexpr (NL == 2) v = f32x4{ldexpf(v[0], unscale), ldexpf(v[1], unscale), ldexpf(v[2], unscale), ldexpf(v[3], unscale)};
         *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
       }
     }
@@ -964,9 +968,11 @@ struct LimbTnArgs {
   int32_t V, J, C;
   int32_t rows_per_chunk;              // % 32 == 0
   int32_t panels, chunks, Z;
-  // NL = 2: magnitudes the power-of-two scales come from (device floats): of A, amax[j * astride] for column j (astride 1: one per
-  // column, 0: one for the operand), and of G likewise.  A column's scale factors out of its row / column of the product.
-  const float* amax; const float* gmax; int32_t astride, gstride;
+  // NL = 2: magnitudes the power-of-two scales come from (device floats): column j of A takes amax[j / a_cols] (a_cols = 1: one
+  // scale per column, J: one for the operand, anything between: per group of a_cols consecutive columns — e.g. per edge type of
+  // the aggregate-first layer's [V, L*D] operand), column c of G gmax[c / g_cols].  A column's scale factors out of its row /
+  // column of the product.
+  const float* amax; const float* gmax; int32_t a_cols, g_cols;
 };
 
 // NL = 3: bf16 triples, six products; NL = 2: fp16 pairs behind one power-of-two scale per COLUMN of each operand (the reduction
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   if constexpr (NL == 2) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      pscale[c] = limb16_scale(is_g ? a.gmax[(int64_t)(n0 + col + c) * a.gstride] : a.amax[(int64_t)(j0 + col + c) * a.astride]);
+      pscale[c] = limb16_scale(is_g ? a.gmax[(n0 + col + c) / a.g_cols] : a.amax[(j0 + col + c) / a.a_cols]);
   }
   const int cswz = ((col & 31) >> 3) & 3;                          // column c of my patch goes to slot (col & 31) + (c ^ cswz)
   const int dump = DUMP + lane * 16;
@@ -1176,23 +1182,24 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   const int i32 = lane & 31, h32 = lane >> 5;
   const int colw = n0 + wave * 32;
   float* slab = a.P + (int64_t)z * a.J * a.C;
-  f32x4 ug[4];                                                      // NL = 2: 1 / scale of my output columns (powers of two: exact)
+  int ug[4][4];                                                     // NL = 2: log2(1 / scale) of my output columns
   if constexpr (NL == 2) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ug[c][e] = limb16_unscale(a.gmax[(int64_t)(colw + 8 * c + 4 * h32 + e) * a.gstride]);
+      for (int e = 0; e < 4; ++e) ug[c][e] = limb16_unscale_exp(a.gmax[(colw + 8 * c + 4 * h32 + e) / a.g_cols]);
   }
 #pragma unroll
   for (int tm = 0; tm < T32; ++tm) {
     const int j = j0 + tm * 32 + i32;
     float* crow = slab + (int64_t)j * a.C;
-    float ua = 1.f;
-    if constexpr (NL == 2) ua = limb16_unscale(a.amax[(int64_t)j * a.astride]);
+    int ua = 0;
+    if constexpr (NL == 2) ua = limb16_unscale_exp(a.amax[j / a.a_cols]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
-      if constexpr (NL == 2) v = (v * ua) * ug[c];
+      if constexpr (NL == 2)          // (one exact scaling by the sum of the two exponents: no overflow on the way, see limb16_unscale_exp)
+        v = f32x4{ldexpf(v[0], ua + ug[c][0]), ldexpf(v[1], ua + ug[c][1]), ldexpf(v[2], ua + ug[c][2]), ldexpf(v[3], ua + ug[c][3])};
       *reinterpret_cast<f32x4*>(crow + colw + 8 * c + 4 * h32) = v;
     }
   }
@@ -1228,7 +1235,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }
 
 // The largest finite magnitude of every COLUMN of X [rows, cols] (cols % 4 == 0): the per-column scales of the two-fp16-limb weight
-// gradient.  A workgroup = 64 column quads x 4 row lanes over a range of rows; the four row lanes meet in LDS, then one atomicMax per
+// gradient.  A workgroup = 64 column quads x 4 row lanes over a range of rows, four independent 16-byte loads in flight per thread
+// (a streaming read: 110 MB for the [36 k, 768] bucket sums of a C2 layer); the four row lanes meet in LDS, then one atomicMax per
 // column on the bit pattern (max does not depend on the order: deterministic; the caller zeroes out[] first).
 __global__ __launch_bounds__(256) void col_absmax_kernel(const float* __restrict__ X, int64_t ldx, int32_t rows, int32_t cols,
                                                          int32_t rows_per_block, float* __restrict__ out) {
@@ -1238,7 +1246,17 @@ __global__ __launch_bounds__(256) void col_absmax_kernel(const float* __restrict
   uint32_t m[4] = {0u, 0u, 0u, 0u};
   if (4 * q < cols) {
     const float* p = X + 4 * q;
-    for (int r = r0 + y; r < r1; r += 4) {
+    int r = r0 + y;
+    for (; r + 12 < r1; r += 16) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (int64_t)(r + 4 * u) * ldx));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = max(m[e], finite_mag_bits(v[u][e]));
+    }
+    for (; r < r1; r += 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)r * ldx);
 #pragma unroll
       for (int e = 0; e < 4; ++e) m[e] = max(m[e], finite_mag_bits(v[e]));
@@ -1616,17 +1634,17 @@ int64_t relgnn_limb_gemm_tn_chunks(int32_t V, int32_t J, int32_t C) {
 // J % 32 == 0, C % 256 == 0, V >= 32); chunks = relgnn_limb_gemm_tn_chunks(V, J, C).  The caller sums the slabs in order and adds
 // the last V % 32 rows' product: relgnn_sum_slabs_tail_f32 does both in one pass.
 static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
-                       int32_t per_column, float* P, int32_t V, int32_t J, int32_t C, void* stream);
+                       int32_t a_cols, int32_t g_cols, float* P, int32_t V, int32_t J, int32_t C, void* stream);
 
 int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* P, int32_t V, int32_t J, int32_t C,
                             void* stream) {
-  return limb_tn_any(A, lda, G, ldg, nullptr, nullptr, 0, P, V, J, C, stream);
+  return limb_tn_any(A, lda, G, ldg, nullptr, nullptr, 1, 1, P, V, J, C, stream);
 }
 
-int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
-                              int32_t per_column, float* P, int32_t V, int32_t J, int32_t C, void* stream) {
-  if (!amax || !gmax) return RELGNN_EINVAL;
-  return limb_tn_any(A, lda, G, ldg, amax, gmax, per_column, P, V, J, C, stream);
+int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, int32_t a_cols_per_scale,
+                              const float* gmax, int32_t g_cols_per_scale, float* P, int32_t V, int32_t J, int32_t C, void* stream) {
+  if (!amax || !gmax || a_cols_per_scale < 1 || g_cols_per_scale < 1) return RELGNN_EINVAL;
+  return limb_tn_any(A, lda, G, ldg, amax, gmax, a_cols_per_scale, g_cols_per_scale, P, V, J, C, stream);
 }
 
 int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* stream) {
@@ -1638,8 +1656,8 @@ int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t col
   if (!X) return RELGNN_EINVAL;
   if (cols % 4 != 0 || ldx % 4 != 0 || ldx < cols || !aligned16(X)) return RELGNN_EUNSUPPORTED;
   const int gx = (cols / 4 + 63) / 64;
-  int per = 128;                                       // rows per workgroup: ~1024 workgroups at most
-  while ((int64_t)gx * ((rows + per - 1) / per) > 1024) per *= 2;
+  int per = 64;                                        // rows per workgroup: ~2048 workgroups at most (8 per CU)
+  while ((int64_t)gx * ((rows + per - 1) / per) > 2048) per *= 2;
   dim3 grid((unsigned)gx, (unsigned)((rows + per - 1) / per));
   col_absmax_kernel<<<grid, 256, 0, st>>>(X, ldx, rows, cols, per, out);
   return launch_status();
@@ -1661,7 +1679,7 @@ int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
 }
 
 static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
-                       int32_t per_column, float* P, int32_t V, int32_t J, int32_t C, void* stream) {
+                       int32_t a_cols, int32_t g_cols, float* P, int32_t V, int32_t J, int32_t C, void* stream) {
   if (V < 0 || J < 0 || C < 0) return RELGNN_EINVAL;
   if (J == 0 || C == 0) return RELGNN_OK;
   if (V < 32) return RELGNN_EUNSUPPORTED;
@@ -1670,7 +1688,7 @@ static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg,
     return RELGNN_EUNSUPPORTED;
   LimbTnArgs a{};
   a.A = A; a.lda = lda; a.G = G; a.ldg = ldg; a.P = P; a.V = V - V % 32; a.J = J; a.C = C; a.amax = amax; a.gmax = gmax;
-  a.astride = a.gstride = per_column ? 1 : 0;
+  a.a_cols = a_cols; a.g_cols = g_cols;
   int t32, rows, Z;
   limb_tn_geometry(V, J, C, &t32, &rows, &Z);
   a.panels = (J / 32) / t32; a.chunks = C / 256; a.rows_per_chunk = rows; a.Z = Z;

@@ -187,12 +187,16 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
   }
 
   float4* orow = out + s * ldo4 + c0;
-  float mx = 0.f;                      // the largest magnitude of the row as it is written (rowmax: relgnn_seg_reduce_fwd_rowmax)
+  // the largest FINITE magnitude of the row as it is written (rowmax: relgnn_seg_reduce_fwd_rowmax; as a bit pattern: magnitudes
+  // order like unsigned integers).  inf / NaN elements are skipped: a scale derived from the finite ones keeps those representable,
+  // and the non-finite element spoils its row of the product, as it does in fp32
+  uint32_t mxb = 0u;
+  auto mag = [](float x) { const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu; return u < 0x7F800000u ? u : 0u; };
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
     if (on[c]) {
       const float4 r = finalize(mode, act, acc[c], end - beg);
-      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+      mxb = max(max(mxb, max(mag(r.x), mag(r.y))), max(mag(r.z), mag(r.w)));
       if constexpr (NT) {  // streamed output: do not displace gathered rows from L2
         float* o = reinterpret_cast<float*>(orow + 64 * c);
         __builtin_nontemporal_store(r.x, o); __builtin_nontemporal_store(r.y, o + 1);
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
     }
   if (rowmax) {                        // (wave-uniform; the wave holds the whole row: one column block)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if (lane == 0) rowmax[s] = mx;
+    for (int o = 32; o > 0; o >>= 1) mxb = max(mxb, (uint32_t)__shfl_xor((int)mxb, o, 64));
+    if (lane == 0) rowmax[s] = __uint_as_float(mxb);
   }
 }
 

@@ -35,10 +35,47 @@ import torch
 from .config import settings as _cfg
 
 _LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
-_LIMB_WS = {}
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
-_WORKSPACE = {}
 _WARNED_UNSUPPORTED = False
+
+
+class _PerStream(dict):
+    """Scratch keyed by (device, raw stream handle): products issued on different streams may run concurrently and must not
+    share it.  Bounded: at most `limit` streams per cache are remembered, the least recently used entry goes first (a process
+    that keeps creating streams — graph captures, user streams — would otherwise pin 64 MB per stream for its lifetime, and a
+    recycled stream handle would find another stream's entry).  Dropping an entry only returns its memory to torch's caching
+    allocator, which hands it out again in stream order of the stream it was allocated on; clear_caches() empties all of them."""
+
+    def __init__(self, limit: int = 4):
+        super().__init__()
+        self.limit = limit
+
+    def lookup(self, key):
+        v = self.get(key)
+        if v is not None:                      # move to the back: most recently used
+            del self[key]
+            self[key] = v
+        return v
+
+    def store(self, key, value):
+        self.pop(key, None)
+        while len(self) >= self.limit:
+            del self[next(iter(self))]
+        self[key] = value
+        return value
+
+
+_LIMB_WS = _PerStream()
+_WORKSPACE = _PerStream()
+
+
+def clear_caches() -> None:
+    """Drop every per-stream scratch buffer and every cached limb image of a weight (dense.weight_image re-splits on the next
+    request).  For callers that retire streams or devices; never needed for correctness."""
+    _LIMB_WS.clear()
+    _WORKSPACE.clear()
+    _WEIGHT_LIMBS.clear()
+    _ZEROS.clear()
 
 
 def _lib_rows_ok(t: torch.Tensor) -> bool:
@@ -53,9 +90,9 @@ def _workspace(device):
     GEMMs issued on different streams may run concurrently and must not share it.  The library checks the size it is handed
     against the solution's need on every call (a cached solution that wants more fails and is re-queried, blaslt_gemm.hip)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _WORKSPACE.get(key)
+    ws = _WORKSPACE.lookup(key)
     if ws is None:
-        ws = _WORKSPACE[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        ws = _WORKSPACE.store(key, torch.empty(64 << 20, dtype=torch.uint8, device=device))
     return ws
 
 
@@ -274,13 +311,19 @@ def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias, columns:
 # [L*Din, Dout] operand of the forward product nor the stacked W^T of the input gradient is ever formed in fp32.
 # C2: 8 split launches + 3 stacks + 3 re-layouts per step -> 1 launch.  Under stream capture nothing is cached (a replay re-runs
 # kernels, not this code): the image is split on every request.
-_WEIGHT_LIMBS = {}
+_WEIGHT_LIMBS = _PerStream(limit=8)      # (device, stream) -> {operand key: _WeightImage}
 _WEIGHT_GEN = [0]
 WEIGHT_NN, WEIGHT_NT = "nn", "nt"
 
 
 def weights_changed() -> None:
-    """Parameters were rewritten in place through raw pointers (models/sparse_graph_model.py: the fused clip + Adam launch)."""
+    """Tell the limb-image cache that parameters were rewritten in place by something torch's version counters do not see:
+    a kernel that writes through raw pointers (models/sparse_graph_model.py: the fused clip + Adam launch; a hipGraph replay of
+    it), `p.data.copy_()` / `p.data.mul_()`, a third-party optimizer that updates `.data`, a parameter broadcast.  Ordinary
+    in-place tensor operations on the parameter itself (`p.add_()`, `p.copy_()` under no_grad) move its version and are noticed
+    without this call.  PUBLIC CONTRACT of the default route (config gemm=limb, weight_limb_cache=1): whoever writes weights
+    behind torch's back calls tf_gnn_samples_amd.dense.weights_changed() (cheap: a counter) — or runs with
+    RELGNN_WEIGHT_LIMB_CACHE=0, which re-splits on every product."""
     _WEIGHT_GEN[0] += 1
 
 
@@ -381,7 +424,10 @@ def weight_image(w, kind: str, pair: bool = False) -> "_WeightImage":
         _split_weight_images([im])
         return im
     import weakref
-    table = _WEIGHT_LIMBS.setdefault((dev, torch.cuda.current_stream(dev).cuda_stream), {})
+    skey = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    table = _WEIGHT_LIMBS.lookup(skey)
+    if table is None:
+        table = _WEIGHT_LIMBS.store(skey, {})
     key = (kind, pair) + tuple((m.data_ptr(), m.shape[0], m.shape[1], m.stride(0)) for m in ws)
     gen = _WEIGHT_GEN[0]
     im = table.get(key)
@@ -489,10 +535,7 @@ def limb_dense(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
     M, K = a.shape
     N = b.shape[1] if layout == GEMM_NN else b.shape[0]
     need = int(lib.relgnn_limb_elements(N, K))
-    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
-    ws = _LIMB_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _LIMB_WS[key] = torch.empty(max(need, 1 << 20), dtype=torch.bfloat16, device=a.device)
+    ws = _limb_ws(a.device, need)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _lib.check(lib.relgnn_limb_dense_f32(layout, act, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _lib.ptr(bias),
@@ -511,9 +554,9 @@ def mm_into(layout: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) ->
 
 def _limb_ws(device, need: int) -> torch.Tensor:
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _LIMB_WS.get(key)
+    ws = _LIMB_WS.lookup(key)
     if ws is None or ws.numel() < need:
-        ws = _LIMB_WS[key] = torch.empty(max(need, 1 << 20), dtype=torch.bfloat16, device=device)
+        ws = _LIMB_WS.store(key, torch.empty(max(need, 1 << 20), dtype=torch.bfloat16, device=device))
     return ws
 
 
@@ -549,7 +592,7 @@ def col_absmax(x: torch.Tensor) -> torch.Tensor:
     if not _rows_ok(x):
         x = x.contiguous()
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load_library().relgnn_col_absmax_f32(_lib.ptr(x), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(),
+    _lib.check(_lib.load_library().relgnn_col_absmax_f32(_lib.ptr(x, rows_strided=True), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(),
                                                          _lib.current_stream()), "relgnn_col_absmax_f32")
     return out
 
@@ -566,7 +609,8 @@ def absmax(x: torch.Tensor) -> torch.Tensor:
 def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor, amax: torch.Tensor = None, bmax: torch.Tensor = None) -> torch.Tensor:
     """a^T @ b for a [V, J], b [V, C] (weight gradient) through relgnn_limb_gemm_tn_f32 + the in-order slab sum.
     amax, bmax (device floats): the two-fp16-limb form — [J] / [C] magnitudes per column (col_absmax(): one power-of-two scale
-    per column of each operand) or [1] / [1] (absmax(): one scale per operand)."""
+    per column of each operand), [1] / [1] (absmax(): one scale per operand), or any count that divides the operand's width (one
+    per group of consecutive columns)."""
     from . import _lib
     lib = _lib.load_library()
     V, J = a.shape
@@ -576,11 +620,11 @@ def limb_gemm_tn(a: torch.Tensor, b: torch.Tensor, amax: torch.Tensor = None, bm
         raise ValueError("limb_gemm_tn: unsupported shape [%d, %d]^T @ [%d, %d]" % (V, J, V, C))
     parts = torch.empty((Z, J, C), dtype=torch.float32, device=a.device)
     if amax is not None:
-        per_column = amax.numel() == J and bmax.numel() == C and (J, C) != (1, 1)
-        if not per_column and (amax.numel() != 1 or bmax.numel() != 1):
-            raise ValueError("limb_gemm_tn: magnitudes must be [%d] and [%d] (per column) or [1] and [1]" % (J, C))
-        _lib.check(lib.relgnn_limb16_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), amax.data_ptr(), bmax.data_ptr(),
-                                                 1 if per_column else 0, parts.data_ptr(), V, J, C, _lib.current_stream()),
+        na, nb = amax.numel(), bmax.numel()
+        if na < 1 or nb < 1 or J % na or C % nb or amax.dtype != torch.float32 or bmax.dtype != torch.float32:
+            raise ValueError("limb_gemm_tn: the magnitude counts (%d, %d) must divide the operand widths (%d, %d)" % (na, nb, J, C))
+        _lib.check(lib.relgnn_limb16_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), amax.data_ptr(), J // na,
+                                                 bmax.data_ptr(), C // nb, parts.data_ptr(), V, J, C, _lib.current_stream()),
                    "relgnn_limb16_gemm_tn_f32")
     else:
         _lib.check(lib.relgnn_limb_gemm_tn_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), parts.data_ptr(), V, J, C,
