@@ -458,7 +458,10 @@ def test_limb16_gemm_tn_columns_over_ten_decades(gpu_device):
         fp32 = DN.matmul_tn_splitk(a, b)
     outs = {"fp32_library_split_k": fp32, "bf16_triple": DN.limb_gemm_tn(a, b),
             "fp16_pair_column_scales": DN.limb_gemm_tn(a, b, DN.col_absmax(a), DN.col_absmax(b)),
-            "fp16_pair_operand_scale": DN.limb_gemm_tn(a, b, DN.absmax(a), DN.absmax(b))}
+            "fp16_pair_operand_scale": DN.limb_gemm_tn(a, b, DN.absmax(a), DN.absmax(b)),
+            # what the aggregate-first layer passes (ops._weight_gradient): one scale per 256-column group (edge type) of the
+            # bucket sums, one per column of the gradient — on THESE operands (A's columns ten decades apart inside a group) recorded only
+            "fp16_pair_layer_form_on_these_operands": DN.limb_gemm_tn(a, b, a.abs().view(V, 3, 256).amax(2).amax(0), DN.col_absmax(b))}
     rep = {}
     outer = (sa.double()[:, None] * sb.double()[None, :]).to(gpu_device)      # entry (j, c) is a sum of terms of size sa[j] * sb[c]
     for name, o in outs.items():
@@ -475,3 +478,20 @@ def test_limb16_gemm_tn_columns_over_ten_decades(gpu_device):
     assert pc["worst_row_rel"] <= 4.0 * f32["worst_row_rel"] and pc["worst_col_rel"] <= 4.0 * f32["worst_col_rel"], rep
     assert pc["worst_entry_over_its_column_scales"] <= 4.0 * f32["worst_entry_over_its_column_scales"], rep
     assert rep["bf16_triple"]["worst_row_rel"] <= 4.0 * f32["worst_row_rel"], rep
+    # the layer's form where it is used: gradient columns ten decades apart, the bucket sums' columns within two decades of each
+    # other inside an edge type (sums of post-activation states), the three edge types three decades apart
+    sa2 = (10.0 ** (-2 * torch.rand(J, generator=g))) * torch.tensor([1.0, 1e-3, 30.0]).repeat_interleave(256)
+    a2 = (torch.relu(torch.randn((V, J), generator=g)) * sa2).to(gpu_device)
+    truth2 = a2.double().t() @ b.double()
+    with config.override(gemm="lib"):
+        f2 = DN.matmul_tn_splitk(a2, b)
+    l2 = DN.limb_gemm_tn(a2, b, a2.abs().view(V, 3, 256).amax(2).amax(0), DN.col_absmax(b))
+    outer2 = (sa2.double()[:, None] * sb.double()[None, :]).to(gpu_device)
+    e_f, e_l = ((x.double() - truth2).abs() / outer2 for x in (f2, l2))
+    rep2 = {"fp32_library_split_k": float(e_f.max()), "fp16_pair_layer_form": float(e_l.max())}
+    with open("gpurun_out/limb16_tn_column_range.json", "w") as f:
+        json.dump({"shape": [V, J, C], "columns_scaled": "1e0 .. 1e-10 (log-spaced, shuffled), both operands", "errors": rep,
+                   "layer_form_regime": {"what": "worst entry error over the scales of its row and column; A's columns within two "
+                                                 "decades inside an edge type, edge types three decades apart, G's columns ten decades",
+                                         "errors": rep2}}, f, indent=1)
+    assert rep2["fp16_pair_layer_form"] <= 4.0 * rep2["fp32_library_split_k"], rep2

@@ -788,20 +788,20 @@ def _side_stream(device):
     return st
 
 
-def _pair_weight_gradient_ok(agg, d_out: int) -> bool:
-    """The two-fp16-limb weight gradient applies to agg^T @ dOut (RELGNN_LIMB=pair, its kernel's shape constraints, an output larger
-    than the streaming kernel's 256 x 256)."""
+def _weight_gradient(agg, gsc, amax, L: int):
+    """agg^T @ gsc (agg [V, L*Din]: the bucket sums, gsc [V, Dout]).  On the two-fp16-limb route (RELGNN_LIMB=pair: `amax`, the
+    forward gather's per-bucket magnitudes [V*L], says the layer took it) the operands go behind exact power-of-two scales that
+    factor out of the product: gsc one per COLUMN (gradient columns differ by decades and Adam normalises every weight by its own
+    history: relgnn_col_absmax_f32, one streaming pass over [V, Dout]), agg one per EDGE TYPE — the largest of that type's bucket
+    magnitudes, a reduction over the [V, L] table the gather already wrote.  (One magnitude per column of agg as well would cost a
+    pass over the [V, L*Din] sums — 110 MB at C2, measured +50 us per layer even on a side stream, more than the two-limb
+    arithmetic gains; within an edge type an element keeps all 22 bits down to 4e-6 of the type's largest bucket entry, and the
+    columns of one type's bucket sums are sums of the same post-activation states.  The kernel and the C ABI take any grouping:
+    tests/test_gpu_limb_gemm.py measures per-column scales on both sides.)"""
     from . import dense as DN
-    return (_cfg.limb_pair and _cfg.pair_part("tn") and agg.is_cuda and agg.shape[0] >= DN._LIMB_MIN_ROWS and agg.shape[1] % 32 == 0
-            and d_out % 256 == 0 and agg.shape[1] * d_out > 256 * 256)
-
-
-def _weight_gradient(agg, gsc, acol):
-    """agg^T @ gsc; on the two-fp16-limb route (`acol`: the column magnitudes of agg, taken next to the forward product) behind one
-    power-of-two scale per COLUMN of each operand (gsc's column maxima: one streaming pass on whatever stream this runs on)."""
-    from . import dense as DN
-    if acol is not None and DN.limb_tn_supported(agg, gsc):
-        return DN.limb_gemm_tn(agg, gsc, acol, DN.col_absmax(gsc))
+    if (amax is not None and _cfg.limb_pair and _cfg.pair_part("tn") and DN.limb_tn_supported(agg, gsc)
+            and agg.shape[1] * gsc.shape[1] > 256 * 256):
+        return DN.limb_gemm_tn(agg, gsc, amax.view(-1, L).amax(0), DN.col_absmax(gsc))
     return DN.matmul_tn_splitk(agg, gsc)
 
 
@@ -841,23 +841,10 @@ class _AggregateThenTransform(torch.autograd.Function):
             amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
         agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
                               acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
-        # the column magnitudes of the bucket sums (the per-column scales of the two-limb weight gradient, _weight_gradient): one
-        # streaming pass over agg on the side stream, next to the product that reads the same rows (training only)
-        acol = None
         want_w = any(ctx.needs_input_grad[6:])
-        if amax is not None and want_w and _pair_weight_gradient_ok(agg, d_out):
-            from . import dense as DN
-            side, cur = _side_stream(H.device), torch.cuda.current_stream(H.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                acol = DN.col_absmax(agg)
-            agg.record_stream(side)
         f = _mode_factor(graph, mode)
         fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the product's epilogue
         out = grouped_nn_gemm(agg, kernels, relu=fused_relu, xmax=amax, xgroups=L)
-        if acol is not None:
-            cur.wait_stream(side)
-            acol.record_stream(cur)
         if f is not None:
             out.mul_(f.unsqueeze(1))
         if act == _lib.ACT_RELU:
@@ -869,7 +856,8 @@ class _AggregateThenTransform(torch.autograd.Function):
             from .utils import apply_activation, get_activation
             out = apply_activation(get_activation(act_name), out)
         ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L = graph, w, mode, act, L
-        ctx.save_for_backward(agg if want_w else None, out if act != _lib.ACT_LINEAR else None, acol, *kernels)
+        ctx.save_for_backward(agg if want_w else None, out if act != _lib.ACT_LINEAR else None,
+                              amax if want_w else None, *kernels)
         return out
 
     @staticmethod
@@ -877,7 +865,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         from .dense import grouped_nt_gemm, matmul_tn_splitk
         lib = _lib.load_library()
         graph, w, mode, act, L = ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L
-        agg, out, acol, *kernels = ctx.saved_tensors
+        agg, out, amax, *kernels = ctx.saved_tensors
         d_in, d_out = kernels[0].shape
         V = graph.V
         gout = gout.contiguous()
@@ -899,8 +887,8 @@ class _AggregateThenTransform(torch.autograd.Function):
             with torch.cuda.stream(side):
                 f = _mode_factor(graph, mode)
                 gsc = gout if f is None else gout * f.unsqueeze(1)
-                gW = _weight_gradient(agg, gsc, acol)
-            for t in (agg, gout, gsc) + ((acol,) if acol is not None else ()):
+                gW = _weight_gradient(agg, gsc, amax, L)
+            for t in (agg, gout, gsc) + ((amax,) if amax is not None else ()):
                 t.record_stream(side)
         if ctx.needs_input_grad[0]:
             plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
@@ -917,7 +905,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         elif want_w:
             f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
             gsc = gout if f is None else gout * f.unsqueeze(1)
-            gW = _weight_gradient(agg, gsc, acol)
+            gW = _weight_gradient(agg, gsc, amax, L)
         gWs = tuple(gW[l * d_in:(l + 1) * d_in] if ctx.needs_input_grad[6 + l] else None for l in range(L)) \
             if gW is not None else (None,) * L           # dW_l = A_l^T @ dOut: row block l of [L*Din, Dout]
         return (gH, None, None, None, None, None) + gWs
