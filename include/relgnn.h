@@ -797,10 +797,15 @@ int relgnn_limb16_gemm_xf32(int32_t act, const float* A, int64_t lda, const floa
  * finite elements they cover; relgnn_absmax_f32 / relgnn_col_absmax_f32 skip inf / NaN elements, which then spoil exactly the
  * sums they take part in, as in fp32.
  * relgnn_absmax_f32: out[0] = max |x[i]| over the finite x[i] (x 16-byte aligned).
- * relgnn_col_absmax_f32: out[c] = max_r |X[r][c]| over the finite elements (cols % 4 == 0, ldx % 4 == 0, X 16-byte aligned). */
+ * relgnn_col_absmax_f32: out[c] = max_r |X[r][c]| over the finite elements.  cols <= 16: any layout (the [V, L] bucket magnitudes
+ * of the gather -> one magnitude per edge type), no workspace.  cols > 16: cols % 4 == 0, ldx % 4 == 0, X 16-byte aligned, and a
+ * 16-byte aligned workspace of relgnn_col_absmax_workspace_bytes(rows, cols) bytes (per-workgroup partial maxima: two stages, no
+ * atomics). */
 int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, int32_t a_cols_per_scale,
                               const float* gmax, int32_t g_cols_per_scale, float* P, int32_t V, int32_t J, int32_t C, void* stream);
-int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* stream);
+int64_t relgnn_col_absmax_workspace_bytes(int32_t rows, int32_t cols);
+int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream);
 /* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need
  * (gnns/gnn_film.py:92-106; the limb counterpart of relgnn_panel_gemm_f32's a_rows / b_select for the forward product and the input

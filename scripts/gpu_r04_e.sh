@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 4, trip e: two-stage column maxima, narrow variant for the per-edge-type magnitudes, DPP row maxima in the gather:
+# full GPU suite, A/B pair / triple, kernel trace of the pair loop
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04e; rm -rf $O; mkdir -p $O; cd $R
+timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -30 > $O/gpu_tests.txt; tail -8 $O/gpu_tests.txt
+cp gpurun_out/gradient_parity_by_seed.json gpurun_out/limb16_tn_column_range.json gpurun_out/parity_*.json $O/ 2>/dev/null
+for i in 1 2; do
+  for v in pair triple; do
+    RELGNN_LIMB=$v timeout 300 python bench.py --steps 60 --warmup 12 --no-roofline --no-extras --no-cpu-baseline > $O/bench_${v}_$i.json 2>> $O/err.txt
+    python -c "import json;d=json.load(open('$O/bench_${v}_$i.json'));print('$v run $i', round(d['ms_per_step'],4), round(d['value']/1e6,1), d['final_loss'])"
+  done
+done
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -o bench -- \
+    python $R/bench.py --steps 50 --warmup 10 --no-roofline --no-extras --no-cpu-baseline > $O/bench_traced.json 2> $O/bench_traced.err
+f=$(find $O/t -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_pair.csv; rm -rf $O/t
+python - "$O/kernel_stats_pair.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:16]:
+    print("%5.1f%% %7.1f us x %5s  %s" % (100 * float(r["TotalDurationNs"]) / tot, float(r["AverageNs"]) / 1e3, r["Calls"],
+                                         r["Name"].replace("(anonymous namespace)::", "")[:100]))
+PY

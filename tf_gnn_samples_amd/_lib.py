@@ -92,7 +92,8 @@ _SIGNATURES = {
     "relgnn_limb_gemm_tn_chunks": (_c_i64, [_c_i32, _c_i32, _c_i32]),
     "relgnn_limb_gemm_tn_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_limb16_gemm_tn_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i32, _ptr, _c_i32, _ptr, _c_i32, _c_i32, _c_i32, _ptr]),
-    "relgnn_col_absmax_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr]),
+    "relgnn_col_absmax_workspace_bytes": (ctypes.c_int64, [_c_i32, _c_i32]),
+    "relgnn_col_absmax_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _c_i64, _ptr]),
     "relgnn_absmax_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _ptr]),
     "relgnn_limb16_elements": (_c_i64, [_c_i64, _c_i64]),
     "relgnn_limb16_split_multi_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _ptr]),

@@ -1234,12 +1234,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   }
 }
 
-// The largest finite magnitude of every COLUMN of X [rows, cols] (cols % 4 == 0): the per-column scales of the two-fp16-limb weight
-// gradient.  A workgroup = 64 column quads x 4 row lanes over a range of rows, four independent 16-byte loads in flight per thread
-// (a streaming read: 110 MB for the [36 k, 768] bucket sums of a C2 layer); the four row lanes meet in LDS, then one atomicMax per
-// column on the bit pattern (max does not depend on the order: deterministic; the caller zeroes out[] first).
-__global__ __launch_bounds__(256) void col_absmax_kernel(const float* __restrict__ X, int64_t ldx, int32_t rows, int32_t cols,
-                                                         int32_t rows_per_block, float* __restrict__ out) {
+// The largest finite magnitude of every COLUMN of X [rows, cols]: the per-column / per-group scales of the two-fp16-limb weight
+// gradient.  Two stages, no atomics (564 workgroups x 256 atomicMax on 256 addresses measured 44 us for the [36 k, 256] gradient
+// of a C2 layer, inside a step: the contention, not the 37 MB read): stage 1, a workgroup = 64 column quads x 4 row lanes over a
+// range of rows with four independent 16-byte loads in flight per thread, writes its 256 column maxima to part[block]; stage 2
+// takes the maximum over the blocks.  Magnitudes as bit patterns (they order like unsigned integers): deterministic.
+__global__ __launch_bounds__(256) void col_absmax_part_kernel(const float* __restrict__ X, int64_t ldx, int32_t rows, int32_t cols,
+                                                              int32_t rows_per_block, uint32_t* __restrict__ part) {
   const int q = blockIdx.x * 64 + (threadIdx.x & 63);             // column quad
   const int y = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -1262,16 +1263,54 @@ __global__ __launch_bounds__(256) void col_absmax_kernel(const float* __restrict
       for (int e = 0; e < 4; ++e) m[e] = max(m[e], finite_mag_bits(v[e]));
     }
   }
-  __shared__ uint32_t part[4][64][4];
+  __shared__ uint32_t sh[4][64][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) part[y][threadIdx.x & 63][e] = m[e];
+  for (int e = 0; e < 4; ++e) sh[y][threadIdx.x & 63][e] = m[e];
   __syncthreads();
   if (y == 0 && 4 * q < cols) {
+    uint4 v;
+    v.x = max(max(m[0], sh[1][threadIdx.x][0]), max(sh[2][threadIdx.x][0], sh[3][threadIdx.x][0]));
+    v.y = max(max(m[1], sh[1][threadIdx.x][1]), max(sh[2][threadIdx.x][1], sh[3][threadIdx.x][1]));
+    v.z = max(max(m[2], sh[1][threadIdx.x][2]), max(sh[2][threadIdx.x][2], sh[3][threadIdx.x][2]));
+    v.w = max(max(m[3], sh[1][threadIdx.x][3]), max(sh[2][threadIdx.x][3], sh[3][threadIdx.x][3]));
+    *reinterpret_cast<uint4*>(part + (int64_t)blockIdx.y * cols + 4 * q) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void col_absmax_final_kernel(const uint32_t* __restrict__ part, int32_t blocks, int32_t cols,
+                                                               float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  uint32_t m = 0u;
+  for (int b = 0; b < blocks; ++b) m = max(m, part[(int64_t)b * cols + c]);
+  out[c] = __uint_as_float(m);
+}
+
+// the same for a NARROW matrix (cols <= 16, any cols: the [V, L] bucket magnitudes of the gather -> one magnitude per edge type): a
+// thread walks whole rows, one workgroup reduces in LDS, out[] (zeroed by the caller) takes one atomicMax per column and block
+template <int MAXC>
+__global__ __launch_bounds__(256) void col_absmax_narrow_kernel(const float* __restrict__ X, int64_t ldx, int32_t rows, int32_t cols,
+                                                                float* __restrict__ out) {
+  uint32_t m[MAXC];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t v = max(max(m[e], part[1][threadIdx.x][e]), max(part[2][threadIdx.x][e], part[3][threadIdx.x][e]));
-      if (v) atomicMax(reinterpret_cast<unsigned int*>(out) + 4 * q + e, v);
+  for (int c = 0; c < MAXC; ++c) m[c] = 0u;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < cols) m[c] = max(m[c], finite_mag_bits(X[r * ldx + c]));
+  __shared__ uint32_t sh[256];
+  for (int c = 0; c < cols; ++c) {
+    uint32_t v = 0u;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) if (k == c) v = m[k];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + o]);
+      __syncthreads();
     }
+    if (threadIdx.x == 0 && sh[0]) atomicMax(reinterpret_cast<unsigned int*>(out) + c, sh[0]);
+    __syncthreads();
   }
 }
 
@@ -1647,34 +1686,45 @@ int relgnn_limb16_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64
   return limb_tn_any(A, lda, G, ldg, amax, gmax, a_cols_per_scale, g_cols_per_scale, P, V, J, C, stream);
 }
 
-int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* stream) {
+static void col_absmax_geometry(int32_t rows, int32_t cols, int* gx, int* per, int* nb) {
+  *gx = (cols / 4 + 63) / 64;
+  *per = 64;                                           // rows per workgroup: ~1024 workgroups at most (4 per CU)
+  while ((int64_t)*gx * ((rows + *per - 1) / *per) > 1024) *per *= 2;
+  *nb = (rows + *per - 1) / *per;
+}
+
+int64_t relgnn_col_absmax_workspace_bytes(int32_t rows, int32_t cols) {
+  if (rows <= 0 || cols <= 16 || cols % 4 != 0) return 0;
+  int gx, per, nb;
+  col_absmax_geometry(rows, cols, &gx, &per, &nb);
+  return (int64_t)nb * cols * 4;
+}
+
+int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
   if (rows < 0 || cols < 0 || (cols > 0 && !out)) return RELGNN_EINVAL;
   if (cols == 0) return RELGNN_OK;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(out, 0, sizeof(float) * cols, st) != hipSuccess) return RELGNN_EHIP;
-  if (rows == 0) return RELGNN_OK;
+  if (rows == 0 || cols <= 16) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * cols, st) != hipSuccess) return RELGNN_EHIP;
+    if (rows == 0) return RELGNN_OK;
+    if (!X || ldx < cols) return RELGNN_EINVAL;
+    int64_t blocks = ((int64_t)rows + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    if (cols <= 4) col_absmax_narrow_kernel<4><<<(unsigned)blocks, 256, 0, st>>>(X, ldx, rows, cols, out);
+    else col_absmax_narrow_kernel<16><<<(unsigned)blocks, 256, 0, st>>>(X, ldx, rows, cols, out);
+    return launch_status();
+  }
   if (!X) return RELGNN_EINVAL;
   if (cols % 4 != 0 || ldx % 4 != 0 || ldx < cols || !aligned16(X)) return RELGNN_EUNSUPPORTED;
-  const int gx = (cols / 4 + 63) / 64;
-  int per = 64;                                        // rows per workgroup: ~2048 workgroups at most (8 per CU)
-  while ((int64_t)gx * ((rows + per - 1) / per) > 2048) per *= 2;
-  dim3 grid((unsigned)gx, (unsigned)((rows + per - 1) / per));
-  col_absmax_kernel<<<grid, 256, 0, st>>>(X, ldx, rows, cols, per, out);
-  return launch_status();
-}
-
-int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
-  if (n < 0 || !out) return RELGNN_EINVAL;
-  hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return RELGNN_EHIP;
-  if (n == 0) return RELGNN_OK;
-  if (!x) return RELGNN_EINVAL;
-  if (!aligned16(x)) return RELGNN_EUNSUPPORTED;
-  const int64_t n4 = n / 4;
-  int64_t blocks = (n4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  absmax_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, n4, n, out);
+  int gx, per, nb;
+  col_absmax_geometry(rows, cols, &gx, &per, &nb);
+  if (!workspace || workspace_bytes < (int64_t)nb * cols * 4 || !aligned16(workspace)) return RELGNN_EINVAL;
+  dim3 grid((unsigned)gx, (unsigned)nb);
+  col_absmax_part_kernel<<<grid, 256, 0, st>>>(X, ldx, rows, cols, per, static_cast<uint32_t*>(workspace));
+  int rc = launch_status();
+  if (rc != RELGNN_OK) return rc;
+  col_absmax_final_kernel<<<(unsigned)((cols + 255) / 256), 256, 0, st>>>(static_cast<const uint32_t*>(workspace), nb, cols, out);
   return launch_status();
 }
 

@@ -59,6 +59,20 @@ __device__ __forceinline__ float msg_act_apply(int act, float x) {
   }
 }
 
+// maximum over the 64 lanes of a wave on the DPP network (six VALU instructions, no LDS round trips: __shfl_xor compiles to
+// ds_bpermute, six dependent ~100-cycle LDS accesses at the end of every wave of the gather: measured +5 us per C2 launch).
+// quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: every 16-lane row holds its maximum in all lanes; row_bcast15 into
+// rows 1 and 3, row_bcast31 into rows 2 and 3: lane 63 holds the wave's.  (Masked-out lanes read `old` = 0: neutral for an unsigned maximum.)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <bool IS_MAX, bool MSGACT = false>
 __device__ __forceinline__ void combine(float4& acc, float w, const float4& v, int msg_act = RELGNN_ACT_LINEAR) {
   // product and add are rounded separately (file is built with -ffp-contract=off):
@@ -187,16 +201,23 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
   }
 
   float4* orow = out + s * ldo4 + c0;
-  // the largest FINITE magnitude of the row as it is written (rowmax: relgnn_seg_reduce_fwd_rowmax; as a bit pattern: magnitudes
-  // order like unsigned integers).  inf / NaN elements are skipped: a scale derived from the finite ones keeps those representable,
-  // and the non-finite element spoils its row of the product, as it does in fp32
-  uint32_t mxb = 0u;
-  auto mag = [](float x) { const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu; return u < 0x7F800000u ? u : 0u; };
+  // the largest FINITE magnitude of the row as it is written (rowmax: relgnn_seg_reduce_fwd_rowmax), as a bit pattern (magnitudes
+  // order like unsigned integers; inf / NaN patterns are the largest of all).  inf / NaN elements do not count: a scale derived
+  // from the finite ones keeps those representable, and the non-finite element spoils its row of the product, as it does in fp32.
+  // Cheap path: one AND per value and unsigned maxima; only a row that holds a non-finite value (its maximum says so) is walked
+  // again with the filter.
+  uint32_t mxb = 0u, mxf = 0u;
+  auto absb = [](float x) { return __float_as_uint(x) & 0x7FFFFFFFu; };
+  auto finb = [](float x) { const uint32_t u = __float_as_uint(x) & 0x7FFFFFFFu; return u < 0x7F800000u ? u : 0u; };
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
     if (on[c]) {
       const float4 r = finalize(mode, act, acc[c], end - beg);
-      mxb = max(max(mxb, max(mag(r.x), mag(r.y))), max(mag(r.z), mag(r.w)));
+      mxb = max(max(mxb, max(absb(r.x), absb(r.y))), max(absb(r.z), absb(r.w)));
+      if (__builtin_expect(mxb >= 0x7F800000u, 0))
+        mxf = max(max(mxf, max(finb(r.x), finb(r.y))), max(finb(r.z), finb(r.w)));
+      else
+        mxf = mxb;
       if constexpr (NT) {  // streamed output: do not displace gathered rows from L2
         float* o = reinterpret_cast<float*>(orow + 64 * c);
         __builtin_nontemporal_store(r.x, o); __builtin_nontemporal_store(r.y, o + 1);
@@ -206,9 +227,8 @@ __global__ __launch_bounds__(256) void seg_reduce_wave_kernel(
       }
     }
   if (rowmax) {                        // (wave-uniform; the wave holds the whole row: one column block)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mxb = max(mxb, (uint32_t)__shfl_xor((int)mxb, o, 64));
-    if (lane == 0) rowmax[s] = __uint_as_float(mxb);
+    const uint32_t m = wave_max_u32(mxf);
+    if (lane == 0) rowmax[s] = __uint_as_float(m);
   }
 }
 

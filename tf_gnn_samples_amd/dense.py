@@ -589,11 +589,17 @@ def limb_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
 def col_absmax(x: torch.Tensor) -> torch.Tensor:
     """[cols] float32 on the device: the largest finite magnitude of every column of x [rows, cols] (relgnn_col_absmax_f32)."""
     from . import _lib
-    if not _rows_ok(x):
+    lib = _lib.load_library()
+    if x.shape[1] > 16 and not _rows_ok(x):
+        x = x.contiguous()
+    if x.shape[1] <= 16 and not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         x = x.contiguous()
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load_library().relgnn_col_absmax_f32(_lib.ptr(x, rows_strided=True), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(),
-                                                         _lib.current_stream()), "relgnn_col_absmax_f32")
+    nbytes = int(lib.relgnn_col_absmax_workspace_bytes(x.shape[0], x.shape[1]))
+    ws = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device) if nbytes else None
+    _lib.check(lib.relgnn_col_absmax_f32(_lib.ptr(x, rows_strided=True), x.stride(0) if x.shape[0] > 1 else x.shape[1], x.shape[0],
+                                         x.shape[1], out.data_ptr(), _lib.ptr(ws), nbytes, _lib.current_stream()),
+               "relgnn_col_absmax_f32")
     return out
 
 

@@ -801,7 +801,7 @@ def _weight_gradient(agg, gsc, amax, L: int):
     from . import dense as DN
     if (amax is not None and _cfg.limb_pair and _cfg.pair_part("tn") and DN.limb_tn_supported(agg, gsc)
             and agg.shape[1] * gsc.shape[1] > 256 * 256):
-        return DN.limb_gemm_tn(agg, gsc, amax.view(-1, L).amax(0), DN.col_absmax(gsc))
+        return DN.limb_gemm_tn(agg, gsc, DN.col_absmax(amax.view(-1, L)), DN.col_absmax(gsc))
     return DN.matmul_tn_splitk(agg, gsc)
 
 
