@@ -1728,6 +1728,21 @@ int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t col
   return launch_status();
 }
 
+int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
+  if (n < 0 || !out) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return RELGNN_EHIP;
+  if (n == 0) return RELGNN_OK;
+  if (!x) return RELGNN_EINVAL;
+  if (!aligned16(x)) return RELGNN_EUNSUPPORTED;
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  absmax_kernel<<<(unsigned)blocks, 256, 0, st>>>(x, n4, n, out);
+  return launch_status();
+}
+
 static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg, const float* amax, const float* gmax,
                        int32_t a_cols, int32_t g_cols, float* P, int32_t V, int32_t J, int32_t C, void* stream) {
   if (V < 0 || J < 0 || C < 0) return RELGNN_EINVAL;
