@@ -1277,29 +1277,32 @@ __global__ __launch_bounds__(256) void col_absmax_part_kernel(const float* __res
   }
 }
 
-// stage 2: 64 columns x 16 block lanes per workgroup, four loads in flight per thread, the 16 lanes meet in LDS (one thread
-// walking all ~500 partial rows of a column is 500 dependent loads: measured 177 us)
+// stage 2: 16 columns x 64 block lanes per workgroup — every thread issues its <= 16 loads at once (one memory latency), the 64
+// lanes of a column meet in LDS.  (One thread per column walking all ~500 partial rows: 500 dependent loads, measured 177 us;
+// 16 lanes per column, four loads in flight: 38 us inside a step, next to the gather.)
 __global__ __launch_bounds__(1024) void col_absmax_final_kernel(const uint32_t* __restrict__ part, int32_t blocks, int32_t cols,
                                                                 float* __restrict__ out) {
-  const int cl = threadIdx.x & 63, y = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 15, y = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   uint32_t m = 0u;
   if (c < cols) {
-    int b = y;
-    for (; b + 48 < blocks; b += 64) {
-      uint32_t v[4];
+    for (int b0 = y; b0 < blocks; b0 += 64 * 16) {
+      uint32_t v[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = part[(int64_t)(b + 16 * u) * cols + c];
-      m = max(max(m, max(v[0], v[1])), max(v[2], v[3]));
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + 64 * u;
+        v[u] = b < blocks ? part[(int64_t)b * cols + c] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) m = max(m, v[u]);
     }
-    for (; b < blocks; b += 16) m = max(m, part[(int64_t)b * cols + c]);
   }
-  __shared__ uint32_t sh[16][64];
+  __shared__ uint32_t sh[64][16];
   sh[y][cl] = m;
   __syncthreads();
   if (y == 0 && c < cols) {
-#pragma unroll
-    for (int k = 1; k < 16; ++k) m = max(m, sh[k][cl]);
+#pragma unroll 8
+    for (int k = 1; k < 64; ++k) m = max(m, sh[k][cl]);
     out[c] = __uint_as_float(m);
   }
 }
@@ -1742,7 +1745,7 @@ int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t col
   col_absmax_part_kernel<<<grid, 256, 0, st>>>(X, ldx, rows, cols, per, static_cast<uint32_t*>(workspace));
   int rc = launch_status();
   if (rc != RELGNN_OK) return rc;
-  col_absmax_final_kernel<<<(unsigned)((cols + 63) / 64), 1024, 0, st>>>(static_cast<const uint32_t*>(workspace), nb, cols, out);
+  col_absmax_final_kernel<<<(unsigned)((cols + 15) / 16), 1024, 0, st>>>(static_cast<const uint32_t*>(workspace), nb, cols, out);
   return launch_status();
 }
 
