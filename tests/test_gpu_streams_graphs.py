@@ -185,7 +185,9 @@ def test_captured_step_on_the_limb_route_and_eager_code_after_replays(gpu_device
     task.load_synthetic(3, 1, seed=4)
     mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
     from tf_gnn_samples_amd import config
-    assert mb.num_nodes >= 4096 and config.settings.limb_gemm
+    if not config.settings.limb_gemm:
+        pytest.skip("the limb route is what this test is about (RELGNN_GEMM is set to another route in this run)")
+    assert mb.num_nodes >= 4096
 
     def fresh():
         p = RGCN_Model.default_params()
