@@ -233,7 +233,9 @@ def test_weight_limb_images_equal_single_splits(gpu_device):
 def test_weight_limb_cache_follows_the_weights(gpu_device):
     """A cached image is replaced after an in-place write (version counter), after weights_changed() (writes through raw
     pointers, as the fused optimizer launch does), and when another tensor takes the address."""
-    from tf_gnn_samples_amd import dense as DN
+    from tf_gnn_samples_amd import config, dense as DN
+    if not config.settings.limb_gemm:
+        pytest.skip("the public Dense entry takes another route in this run (RELGNN_GEMM)")
     DN._WEIGHT_LIMBS.clear()
     x = _rand((4608, 256), gpu_device, 3)
     w = _rand((256, 256), gpu_device, 4, 0.1)
@@ -353,7 +355,8 @@ def test_limb_dense_sel_cut_last_chunk(gpu_device, M, N, K, bias, act):
     e, e32 = float((out.double() - truth).abs().max()), float((f32.double() - truth).abs().max())
     assert e <= max(3.0 * e32, 8e-7 * max(1.0, float(truth.abs().max()))), (e, e32)
     # the route the Dense layers take, and its gradients through the library routes
-    if act == "linear" and N == 121:
+    from tf_gnn_samples_amd import config
+    if act == "linear" and N == 121 and config.settings.limb_gemm:
         x = a.clone().requires_grad_(True)
         k = W.clone().requires_grad_(True)
         bb = b.clone().requires_grad_(True)

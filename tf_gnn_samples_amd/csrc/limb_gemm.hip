@@ -1277,13 +1277,15 @@ __global__ __launch_bounds__(256) void col_absmax_part_kernel(const float* __res
   }
 }
 
-// stage 2: 16 columns x 64 block lanes per workgroup — every thread issues its <= 16 loads at once (one memory latency), the 64
-// lanes of a column meet in LDS.  (One thread per column walking all ~500 partial rows: 500 dependent loads, measured 177 us;
-// 16 lanes per column, four loads in flight: 38 us inside a step, next to the gather.)
-__global__ __launch_bounds__(1024) void col_absmax_final_kernel(const uint32_t* __restrict__ part, int32_t blocks, int32_t cols,
-                                                                float* __restrict__ out) {
-  const int cl = threadIdx.x & 15, y = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+// stage 2: 4 columns x 64 block lanes per workgroup of 256 threads — every thread issues its <= 16 loads at once (one memory
+// latency), the 64 lanes of a column meet in LDS.  Small workgroups on purpose: this kernel runs on the side stream next to the
+// gather, whose 27 k four-wave workgroups keep every wave slot and register of the chip taken; a 1024-thread workgroup needs 16
+// free slots on ONE CU at the same moment and starved for 38-50 us (measured), a four-wave one slips in as soon as one retires.
+// (One thread per column walking all ~500 partial rows: 500 dependent loads, measured 177 us.)
+__global__ __launch_bounds__(256) void col_absmax_final_kernel(const uint32_t* __restrict__ part, int32_t blocks, int32_t cols,
+                                                               float* __restrict__ out) {
+  const int cl = threadIdx.x & 3, y = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   uint32_t m = 0u;
   if (c < cols) {
     for (int b0 = y; b0 < blocks; b0 += 64 * 16) {
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(1024) void col_absmax_final_kernel(const uint32_t* 
       for (int u = 0; u < 16; ++u) m = max(m, v[u]);
     }
   }
-  __shared__ uint32_t sh[64][16];
+  __shared__ uint32_t sh[64][4];
   sh[y][cl] = m;
   __syncthreads();
   if (y == 0 && c < cols) {
@@ -1745,7 +1747,7 @@ int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t col
   col_absmax_part_kernel<<<grid, 256, 0, st>>>(X, ldx, rows, cols, per, static_cast<uint32_t*>(workspace));
   int rc = launch_status();
   if (rc != RELGNN_OK) return rc;
-  col_absmax_final_kernel<<<(unsigned)((cols + 15) / 16), 1024, 0, st>>>(static_cast<const uint32_t*>(workspace), nb, cols, out);
+  col_absmax_final_kernel<<<(unsigned)((cols + 3) / 4), 256, 0, st>>>(static_cast<const uint32_t*>(workspace), nb, cols, out);
   return launch_status();
 }
 
