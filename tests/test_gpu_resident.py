@@ -65,6 +65,26 @@ def _same_scales(batch):
     assert torch.equal(g.w_by_source(w), fresh.w_by_source(w_ref))
 
 
+def _same_pair_tables(graph, adjacency_lists, V):
+    """A resident fold counts the non-empty (node, type) buckets of every graph once; a batch's RelGraph carries their sums
+    (pair_counts) and graph.PairTables then builds the compact numbering without reading anything back from the device: the same
+    tables, array for array, as the ones built from counts read back."""
+    from tf_gnn_samples_amd.graph import PairTables, RelGraph
+    fresh = RelGraph(adjacency_lists, V)
+    assert getattr(fresh, "pair_counts", None) is None and graph.pair_counts is not None
+    want, got = PairTables(fresh), PairTables(graph)
+    for side in ("tgt", "src"):
+        w, g_ = getattr(want, side), getattr(got, side)
+        assert list(graph.pair_counts[0 if side == "tgt" else 1]) == w.type_counts == g_.type_counts
+        assert (w.P, w.num_pairs, w.offsets, w.chunk_counts) == (g_.P, g_.num_pairs, g_.offsets, g_.chunk_counts)
+        for name in ("bucket_row", "node", "node_col", "node_rowptr", "pad_rows", "chunk_type"):
+            assert torch.equal(getattr(w, name), getattr(g_, name)), (side, name)
+        for a_, b_ in zip(w.weight_grad_plan(4), g_.weight_grad_plan(4)):
+            assert torch.equal(a_, b_)
+    assert torch.equal(want.col_t, got.col_t) and torch.equal(want.frow_s, got.frow_s)
+    assert fresh.wants_pair_tables() == graph.wants_pair_tables()
+
+
 PAYLOADS = {"initial_node_features": ("node_features", np.float32), "target_labels": ("node_labels", np.float32)}
 
 
@@ -87,6 +107,8 @@ def test_resident_batches_and_plans_are_bit_identical(gpu_device, L):
             _same_batch(a, b)
             _same_plan(a.graph, b.adjacency_lists, b.num_nodes)
             _same_scales(a)
+            if L >= 8 and lean:
+                _same_pair_tables(a.graph, b.adjacency_lists, b.num_nodes)
     got = [x.num_graphs for x in resident.iterate(np.arange(30), 200)]
     want = [x.num_graphs for x in host.iterate(np.arange(30), 200)]
     assert got == want and sum(got) == 30

@@ -517,6 +517,9 @@ class RelGraph:
             return settings.pair_tables == "1"
         if self.L < 8 or self.M == 0:
             return False
+        known = getattr(self, "pair_counts", None)
+        if known is not None:                      # (a resident fold counted them per graph: decided without building anything)
+            return (sum(known[0]) + sum(known[1])) < 0.6 * (2 * self.V * self.L)
         pt = self.pair_tables()
         return (pt.tgt.num_pairs + pt.src.num_pairs) < 0.6 * (2 * self.V * self.L)
 
@@ -531,6 +534,43 @@ class RelGraph:
 
 # rows per GEMM batch entry of the compact tables; every type's row block is padded to a multiple
 PAIR_CHUNK = 512
+
+
+# Small index tables that are computed on the host (numpy) go to the device through a ring of pinned staging buffers with an
+# asynchronous copy: torch.as_tensor(numpy, device=...) copies from pageable memory and blocks the host until everything queued on
+# the stream has run — one such call per batch is enough to stop the host from running ahead of the GPU (C5: host-bound, 45 ms).
+_UPLOAD_SLOTS, _UPLOAD_BYTES = 8, 1 << 20
+_upload_ring = {"bufs": [None] * _UPLOAD_SLOTS, "done": [None] * _UPLOAD_SLOTS, "at": 0}
+
+
+def _upload(arr, device, dtype=None) -> torch.Tensor:
+    """numpy array -> device tensor without a host / stream synchronisation (small arrays; larger ones: a plain copy)."""
+    import numpy as np
+    arr = np.ascontiguousarray(arr)
+    device = torch.device(device)
+    if device.type != "cuda" or arr.nbytes > _UPLOAD_BYTES or arr.nbytes == 0:
+        t = torch.as_tensor(arr, device=device)
+        return t if dtype is None else t.to(dtype)
+    k = _upload_ring["at"]
+    _upload_ring["at"] = (k + 1) % _UPLOAD_SLOTS
+    if _upload_ring["done"][k] is not None:
+        _upload_ring["done"][k].synchronize()          # (the copy that read this slot eight uploads ago: long done)
+    if _upload_ring["bufs"][k] is None:
+        _upload_ring["bufs"][k] = torch.empty(_UPLOAD_BYTES, dtype=torch.uint8).pin_memory()
+    stage = _upload_ring["bufs"][k][:arr.nbytes]
+    stage.numpy()[:] = arr.view(np.uint8).reshape(-1)
+    out = stage.to(device, non_blocking=True).view(torch.from_numpy(arr[:0]).dtype).view(arr.shape)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _upload_ring["done"][k] = ev
+    return out if dtype is None else out.to(dtype)
+
+
+def _nonzero_known(mask: torch.Tensor, size: int) -> torch.Tensor:
+    """torch.nonzero(mask).view(-1) for a 1-D mask whose number of set entries the HOST already knows: no device -> host round trip."""
+    if hasattr(torch, "nonzero_static"):
+        return torch.nonzero_static(mask, size=int(size)).view(-1)
+    return torch.nonzero(mask).view(-1)
 
 
 class SidePairs:
@@ -550,6 +590,8 @@ class SidePairs:
                  into the node in ascending type order, the order the dense GEMM would add them)"""
 
     def __init__(self, rowptr: torch.Tensor, V: int, L: int, chunk: int = PAIR_CHUNK):
+        """(counts per type are read back by PairTables — one host sync — unless the producer of the graph knows them: a resident
+        fold counts the non-empty buckets of every graph once, tasks/resident.py -> RelGraph.pair_counts)"""
         dev = rowptr.device
         self.V, self.L, self.chunk = V, L, chunk
         nonempty = (rowptr[1:] > rowptr[:-1]).view(V, L)
@@ -561,11 +603,10 @@ class SidePairs:
         ids = torch.where(by_type, rank + starts.unsqueeze(1), torch.full_like(rank, -1))
         self.bucket_row = ids.t().contiguous().view(-1)                       # [V*L], node-major
         self._counts_dev = torch.stack([counts, padded])                      # read once by PairTables (one sync)
-        self._by_type, self._ids = by_type, ids
+        self._by_type, self._ids, self._nonempty = by_type, ids, nonempty
         per_node = nonempty.sum(1, dtype=torch.int32)
         self.node_rowptr = torch.zeros(V + 1, dtype=torch.int32, device=dev)
         torch.cumsum(per_node, 0, dtype=torch.int32, out=self.node_rowptr[1:])
-        self.node_col = self.bucket_row[nonempty.view(-1)].contiguous()       # node-major order
         self._dw_plans = {}
 
     def _finish(self, counts: List[int], padded: List[int]):
@@ -576,16 +617,18 @@ class SidePairs:
         self.P = self.offsets[-1]
         self.num_pairs = int(sum(counts))
         self.type_counts = [int(c) for c in counts]
+        import numpy as np
+        # (every size below is known on the host: no device -> host round trip, no pageable copy)
+        self.node_col = self.bucket_row[_nonzero_known(self._nonempty.view(-1), self.num_pairs)].contiguous()   # node-major order
         node = torch.full((self.P,), self.V, dtype=torch.int64, device=dev)
-        where = torch.nonzero(self._by_type.view(-1)).view(-1)                # type-major positions of real pairs
+        where = _nonzero_known(self._by_type.view(-1), self.num_pairs)        # type-major positions of real pairs
         node[self._ids.view(-1)[where].long()] = where % max(self.V, 1)
         self.node = node
-        self.pad_rows = torch.nonzero(node == self.V).view(-1)               # <= L * chunk rows
-        chunks = [p // self.chunk for p in padded]
+        self.pad_rows = _nonzero_known(node == self.V, self.P - self.num_pairs)   # <= L * chunk rows
+        chunks = [int(p) // self.chunk for p in padded]
         self.chunk_counts = chunks
-        self.chunk_type = torch.repeat_interleave(torch.arange(self.L, device=dev),
-                                                  torch.tensor(chunks, device=dev, dtype=torch.int64))
-        del self._by_type, self._ids
+        self.chunk_type = _upload(np.repeat(np.arange(self.L, dtype=np.int64), chunks), dev)
+        del self._by_type, self._ids, self._nonempty
 
     def panel_indices(self):
         """(row -> node as int32 with -1 for padding rows, tile -> edge type as int32): the index operands of
@@ -614,7 +657,7 @@ class SidePairs:
                 cols.append((tiles[None, :] * K + np.arange(K)[:, None]).reshape(-1))
             col = np.concatenate(cols) if cols else np.zeros(0, np.int64)
             dev = self.bucket_row.device
-            plan = (torch.as_tensor(rowptr.astype(np.int32), device=dev), torch.as_tensor(col.astype(np.int32), device=dev))
+            plan = (_upload(rowptr.astype(np.int32), dev), _upload(col.astype(np.int32), dev))
             self._dw_plans[num_sub_rows] = plan
         return plan
 
@@ -630,7 +673,12 @@ class PairTables:
     def __init__(self, g: "RelGraph"):
         self.tgt = SidePairs(g.rowptr_t, g.V, g.L)
         self.src = SidePairs(g.rowptr_s, g.V, g.L)
-        counts = torch.stack([self.tgt._counts_dev, self.src._counts_dev]).tolist()   # the one host sync
+        known = getattr(g, "pair_counts", None)      # (non-empty buckets per type, by target / by source) from the graph's producer
+        if known is not None:
+            chunk = self.tgt.chunk
+            counts = [[list(c), [(int(x) + chunk - 1) // chunk * chunk for x in c]] for c in known]
+        else:
+            counts = torch.stack([self.tgt._counts_dev, self.src._counts_dev]).tolist()   # the one host sync
         self.tgt._finish(*counts[0])
         self.src._finish(*counts[1])
         self.P_t, self.P_s = self.tgt.P, self.src.P
