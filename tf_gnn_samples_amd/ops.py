@@ -781,6 +781,36 @@ def aggregate_acc64() -> bool:
 _SIDE_STREAMS = {}
 
 
+# The join of the side stream (main stream waits for the weight gradient) normally sits at the end of the layer's backward: whatever
+# reads the gradient next finds it complete.  A training step that owns the whole backward can do better: nothing reads a weight
+# gradient before the optimizer, and next to the gather the side stream's workgroups starve (the gather's 27 k four-wave workgroups
+# hold every wave slot and register), so its kernels really start at the gather's tail and finish AFTER the input-gradient product
+# — the main stream then idled at every layer's join.  deferred_weight_gradient_join() (models/sparse_graph_model.py: train_step)
+# moves the joins to join_deferred(), called once behind the backward.
+_DEFER = {"on": False, "pending": []}
+
+
+class deferred_weight_gradient_join:
+    def __enter__(self):
+        self._old = _DEFER["on"]
+        _DEFER["on"] = True
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER["on"] = self._old
+        return False
+
+
+def join_deferred() -> None:
+    """Make the current stream wait for every side stream whose join was deferred (no host synchronisation)."""
+    pending, _DEFER["pending"] = _DEFER["pending"], []
+    done = set()
+    for device, side in pending:
+        if id(side) not in done:
+            torch.cuda.current_stream(device).wait_stream(side)
+            done.add(id(side))
+
+
 def _side_stream(device):
     st = _SIDE_STREAMS.get(device)
     if st is None:
@@ -900,7 +930,10 @@ class _AggregateThenTransform(torch.autograd.Function):
                                  plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
             gH = grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=L)           # dH = sum_l dT_l @ W_l^T
         if side is not None:
-            torch.cuda.current_stream(gout.device).wait_stream(side)
+            if _DEFER["on"]:
+                _DEFER["pending"].append((gout.device, side))
+            else:
+                torch.cuda.current_stream(gout.device).wait_stream(side)
             gW.record_stream(torch.cuda.current_stream(gout.device))
         elif want_w:
             f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
