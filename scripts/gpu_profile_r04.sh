@@ -12,6 +12,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04_profile
 rm -rf $O; mkdir -p $O
 cd $R
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1; echo "gpu tests rc=$?" >> $O/gpu_tests.txt
 cp gpurun_out/parity_margin.json gpurun_out/parity_baseline_size.json gpurun_out/gradient_parity_by_seed.json gpurun_out/limb16_tn_column_range.json $O/ 2>/dev/null
 RELGNN_LIMB=triple timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_tests_limb_triple.txt 2>&1; echo "gpu tests rc=$?" >> $O/gpu_tests_limb_triple.txt
