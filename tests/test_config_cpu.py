@@ -68,3 +68,23 @@ def test_the_documented_switch_table_is_the_code_s_table():
     assert in_code <= documented, sorted(in_code - documented)
     for env, name, default, allowed, doc in config.describe():
         assert config.attribute_of(env) == name and config.default_of(name) == default and doc
+
+
+def test_driver_entry_points_reference_only_names_that_exist():
+    """smoke() and the bench scripts run on the GPU box only: a module attribute renamed under them (round 4: dense._LIMB_GEMM ->
+    config.settings.limb_gemm) must fail HERE, not at the end of a round."""
+    import importlib
+    aliases = {"DN": "tf_gnn_samples_amd.dense", "ops": "tf_gnn_samples_amd.ops", "config": "tf_gnn_samples_amd.config",
+               "route_config": "tf_gnn_samples_amd.config", "_lib": "tf_gnn_samples_amd._lib"}
+    missing = []
+    for name in ("__graft_entry__.py", "bench.py", "bench_other.py", "bench_roofline.py", "scripts/exp_trajectory_routes.py",
+                 "scripts/bench_limb_gemm.py", "scripts/exp_gemm_after_gather.py"):
+        text = (ROOT / name).read_text()
+        for alias, module in aliases.items():
+            if alias == "config" and name.startswith("bench"):       # (bench.py imports it as route_config; "config.x" there is JSON prose)
+                continue
+            mod = importlib.import_module(module)
+            for attr in set(re.findall(r"(?<![\w.])%s\.([A-Za-z_]\w*)" % alias, text)):
+                if not hasattr(mod, attr):
+                    missing.append("%s: %s.%s" % (name, alias, attr))
+    assert not missing, missing
