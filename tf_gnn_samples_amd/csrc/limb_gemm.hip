@@ -86,18 +86,20 @@ __device__ __forceinline__ float limb16_unscale(float mx) { return __uint_as_flo
 // by the two reciprocal scales one after the other overflows on the way when a huge left operand (scale 2^-113 for float32 lowest:
 // acc * 2^113 = inf) meets a tiny right one (2^-29 would have brought it back): found by tests/test_gpu_extreme_values.py.
 __device__ __forceinline__ int limb16_unscale_exp(float mx) { return 127 - (int)limb16_scale_bits(mx); }
-__device__ __forceinline__ void split_pair16(float x0, float x1, uint32_t& h, uint32_t& l) {
-  const f16x2 hh = __builtin_convertvector(f32x2{x0, x1}, f16x2);          // round to nearest even
+// (vector-typed on purpose: hipcc then issues the scale and the subtraction as v_pk_mul_f32 / v_pk_add_f32 — two values per VALU
+//  instruction, 24 instead of 32 per eight values; the split's issue slots are what gates these kernels, LABNOTES 7.4)
+__device__ __forceinline__ void split_pair16(f32x2 xs, uint32_t& h, uint32_t& l) {
+  const f16x2 hh = __builtin_convertvector(xs, f16x2);                     // round to nearest even
   const f32x2 hf = __builtin_convertvector(hh, f32x2);
-  const f16x2 ll = __builtin_convertvector(f32x2{x0 - hf[0], x1 - hf[1]}, f16x2);
+  const f16x2 ll = __builtin_convertvector(xs - hf, f16x2);
   h = __builtin_bit_cast(uint32_t, hh);
   l = __builtin_bit_cast(uint32_t, ll);
 }
 __device__ __forceinline__ void split8_16(const float* v, float s, uint4& h, uint4& l) {
-  split_pair16(v[0] * s, v[1] * s, h.x, l.x);
-  split_pair16(v[2] * s, v[3] * s, h.y, l.y);
-  split_pair16(v[4] * s, v[5] * s, h.z, l.z);
-  split_pair16(v[6] * s, v[7] * s, h.w, l.w);
+  split_pair16(f32x2{v[0], v[1]} * s, h.x, l.x);
+  split_pair16(f32x2{v[2], v[3]} * s, h.y, l.y);
+  split_pair16(f32x2{v[4], v[5]} * s, h.z, l.z);
+  split_pair16(f32x2{v[6], v[7]} * s, h.w, l.w);
 }
 
 // ---- fp32 -> three bf16 limbs ----------------------------------------------------------------------------------------
@@ -108,10 +110,10 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // tw
 // (x0, x1) -> the packed limbs; each subtraction is exact, so hi + mid + lo == x bit for bit
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
   h = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
-  m = cvt_pk_bf16(r0, r1);
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
-  l = cvt_pk_bf16(s0, s1);
+  const f32x2 r = f32x2{x0, x1} - f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xFFFF0000u)};     // (v_pk_add_f32)
+  m = cvt_pk_bf16(r[0], r[1]);
+  const f32x2 t = r - f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xFFFF0000u)};
+  l = cvt_pk_bf16(t[0], t[1]);
 }
 // |x| >= 0x7F7F8000 (3.3962e38 .. FLT_MAX, and inf) rounds to a bf16 INFINITY: hi = +-inf, mid = x - hi = -+inf, lo = NaN — and the
 // float32 lowest that tf.unsorted_segment_max writes for an empty segment (utils/utils.py:23-33) is such a value: it came
@@ -277,9 +279,9 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
   };
   auto x_store = [&](int S, int half, const float* v) {            // 8 values -> chunk `half` of k-tile 2 S + xhf
     if (2 * S + xhf >= ntiles || xr >= 32 * nu) return;           // (a tile row the panel does not have is never multiplied)
-    float z[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = xrow_ok ? v[i] : 0.f;      // rows past M inside the panel
+    // (rows past M inside the panel were LOADED from the zero block, xbase: nothing to mask here — eight v_cndmask per eight values
+    //  went with that, a fifth of the split's instructions)
+    const float* z = v;
     unsigned char* p = lds + ((2 * S + xhf) % STAGES) * STAGE_BYTES + xblock + half * 512;
     if constexpr (NL == 2) {
       uint4 h, l;
