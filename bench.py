@@ -673,8 +673,9 @@ def main():
             "switches": route_config.current(),
             "pair": "the aggregate-first layer's products (forward, input gradient, weight gradient: K = 768) from TWO fp16 limbs per "
                     "value (22 significant bits per operand instead of 24) behind exact power-of-two scales — per row of the "
-                    "streamed operand, from the magnitudes the gather writes with its rows; per column of each operand for the "
-                    "weight gradient — three v_mfma_f32_32x32x16_f16 products per fp32 product.  Measured against float64 "
+                    "streamed operand, from the magnitudes the gather writes with its rows; in the weight gradient per column of "
+                    "the gradient operand and per edge type of the bucket sums — three v_mfma_f32_32x32x16_f16 products per fp32 "
+                    "product.  Measured against float64 "
                     "(tests/test_gpu_baseline_size.py over five model draws, profiles/r04_gradient_parity_by_seed.json; "
                     "profiles/r04_trajectory_routes.json): within the same 1e-5 budget as the bf16 triple and the fp32 library, "
                     "neither systematically closer; the triple and exact-fp32 legs of the same loop are timed below",
