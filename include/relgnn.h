@@ -866,37 +866,6 @@ int relgnn_rgdcn_apply_bwd(int32_t weight_act, const float* A, const float* P, i
                            int64_t p_channel_stride, int32_t num_nodes, int32_t num_edge_types, int32_t num_channels,
                            int32_t channel_dim, const float* G, float* gA, float* gP, void* stream);
 
-/* ========================================================================== *
- * 13. The aggregate-first gather with the gathered table tiled through LDS (csrc/slab_gather.hip)
- * ========================================================================== *
- * Replaces, like relgnn_seg_reduce_fwd(RELGNN_AGG_SUM): tf.nn.embedding_lookup gnns/rgcn.py:87-89 + the 1/(num_incoming + 1e-7)
- * multiply :100-104 + tf.concat :108 + tf.unsorted_segment_sum :109-112 — for a batch that is a disjoint union of graphs whose
- * message lists exist in sliced-ELL form (graph-local 16-bit row ids; tasks/ppi_task.py:220-233: no edge crosses graphs).
- *   out[bucket_stride * node0_j + b, :] = sum over the messages p of local bucket b of graph slot j, in bucket order, of
- *                                          w_p * X[node0_j + id_p, :]        (product and sum rounded separately)
- * — the same floating-point operations in the same order as relgnn_seg_reduce_fwd on the batch's bucketed CSR: bit-identical.
- *   desc [num_graphs][3] (int64)   fold graph index f, first node of the graph in the batch, nodes; heaviest graph first
- *   slice_base [G+1]               ELL slices of fold graph f: [slice_base[f], slice_base[f+1]) — 64 buckets each, buckets in
- *                                  order of decreasing length
- *   slice_len, slice_off [S]       steps (= longest bucket, rounded up to relgnn_slab_gather_chunk()) and first entry of a slice;
- *                                  entry k of lane i at slice_off + 64 k + i
- *   slice_bucket [64 S]            graph-local bucket id (-1: none) per lane
- *   ell_id (uint16), ell_w (nullable: weights 1)  row id / weight per entry; entries past a bucket's end: id = the graph's node
- *                                  count (a row of zeros the kernel keeps behind the slab), weight 0
- *   max_nodes                      largest `nodes` of desc (<= relgnn_slab_gather_max_nodes(): the slice of a graph's slab,
- *                                  32 bytes per node, must fit the LDS of one workgroup)
- *   rowmax (nullable)              [buckets * D / 8]: largest finite magnitude of every 8-float piece written
- *   ticket                         relgnn_slab_gather_ticket_ints() int32 in device memory, zero before the first launch and private
- *                                  to the stream: the kernel's work queues (persistent workgroups); the kernel leaves them zero
- * Requirements: D % 8 == 0, rows of X and out 16-byte aligned (RELGNN_EUNSUPPORTED otherwise). */
-int32_t relgnn_slab_gather_max_nodes(void);
-int32_t relgnn_slab_gather_chunk(void);
-int32_t relgnn_slab_gather_ticket_ints(void);
-int relgnn_slab_gather_f32(const float* X, int64_t ldx, int32_t D, const int64_t* desc, int32_t num_graphs, int32_t max_nodes,
-                           const int32_t* slice_base, const int32_t* slice_len, const int64_t* slice_off,
-                           const int32_t* slice_bucket, const uint16_t* ell_id, const float* ell_w,
-                           int32_t bucket_stride, float* out, int64_t ldo, float* rowmax, int32_t* ticket, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -94,11 +94,6 @@ _SIGNATURES = {
     "relgnn_limb16_gemm_tn_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i32, _ptr, _c_i32, _ptr, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_col_absmax_workspace_bytes": (ctypes.c_int64, [_c_i32, _c_i32]),
     "relgnn_col_absmax_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _c_i64, _ptr]),
-    "relgnn_slab_gather_max_nodes": (ctypes.c_int32, []),
-    "relgnn_slab_gather_chunk": (ctypes.c_int32, []),
-    "relgnn_slab_gather_ticket_ints": (ctypes.c_int32, []),
-    "relgnn_slab_gather_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                               _c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr]),
     "relgnn_absmax_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _ptr]),
     "relgnn_limb16_elements": (_c_i64, [_c_i64, _c_i64]),
     "relgnn_limb16_split_multi_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _ptr]),

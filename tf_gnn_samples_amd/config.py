@@ -33,10 +33,6 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                           "limb images of the weights kept across the products of a step (re-split once after the optimizer's update)"),
     "tn": ("RELGNN_TN", "stream", ("stream", "lib"),
            "weight gradients with outputs up to 256 x 256: the streaming MFMA kernel (csrc/gemm_tn_stream.hip) | library split-K"),
-    "gather": ("RELGNN_GATHER", "l2", ("l2", "lds"),
-               "gather + segment-sum of the aggregate-first layer on batches of a resident fold: one 1 KiB row load per message "
-               "through L1 / L2 (csrc/seg_reduce.hip) | 8-column slices of every graph's slab staged in LDS, sliced-ELL message "
-               "lists (csrc/slab_gather.hip); same bits"),
     "rgcn_order": ("RELGNN_RGCN_ORDER", "aggregate_first", ("aggregate_first", "transform_first"),
                    "sum / mean / sqrt_n RGCN layers: gather raw states into the (target, type) buckets, then one K = L*D product | "
                    "the reference's order (per-type transform, then gather)"),

@@ -291,8 +291,7 @@ class RelGraph:
         cur.wait_event(ev)
         d = self.__dict__                     # (deferred arrays of a lean graph are not touched: they do not exist yet)
         for t in (self._key_t, self._key_s, self.rowptr_t, self.rowptr_s, self.tgt_s, self._err_flag,
-                  *[d.get(k) for k in RelGraph._LAZY_ARRAYS], *d.get("adjacency_lists", ()), *d.get("_preset", ()),
-                  getattr(d.get("slab"), "desc", None)):
+                  *[d.get(k) for k in RelGraph._LAZY_ARRAYS], *d.get("adjacency_lists", ()), *d.get("_preset", ())):
             if t is not None:
                 t.record_stream(cur)
         return self

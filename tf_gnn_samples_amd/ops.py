@@ -136,55 +136,6 @@ def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEA
     return out
 
 
-def slab_route(graph, X, w, by_source: bool):
-    """The LDS-tiled gather (csrc/slab_gather.hip) for  out[(node, type) bucket] = sum_p w_p X[row_p]  into the V*L buckets by
-    target (forward of the aggregate-first layer) or by source (its input gradient): the batch's graph carries sliced-ELL lists
-    of its fold (tasks/resident.py -> tasks/slab.py), `w` is None or exactly the scale tensor those lists hold, the table is a
-    dense fp32 [V, D] with D % 8 == 0.  Returns the SlabDirection to use or None (the L2 kernel takes the gather)."""
-    slab = getattr(graph, "slab", None)
-    if slab is None or _cfg.gather != "lds" or aggregate_acc64():
-        return None
-    if not (X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.is_contiguous() and X.shape[0] == graph.V
-            and X.shape[1] % 8 == 0 and X.shape[1] > 0 and X.data_ptr() % 16 == 0):
-        return None
-    if w is not None and w is not (slab.w_s if by_source else slab.w_t):
-        return None
-    return slab.fold.by_source if by_source else slab.fold.by_target
-
-
-_SLAB_TICKETS = None
-
-
-def _slab_ticket(device):
-    """The work queue of relgnn_slab_gather_f32's persistent workgroups: two zeroed int32 per (device, stream) — launches on
-    different streams may overlap and must not share it; the kernel leaves it zero."""
-    global _SLAB_TICKETS
-    from . import dense as DN
-    if _SLAB_TICKETS is None:
-        _SLAB_TICKETS = DN._PerStream(limit=8)
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    t = _SLAB_TICKETS.lookup(key)
-    if t is None:
-        t = _SLAB_TICKETS.store(key, torch.zeros(int(_lib.load_library().relgnn_slab_gather_ticket_ints()), dtype=torch.int32, device=device))
-    return t
-
-
-def slab_gather(graph, X, direction, weighted: bool, want_rowmax: bool):
-    """relgnn_slab_gather_f32: (out [V*L, D], rowmax [V*L*D/8] or None).  Same bits as _seg_reduce_raw(AGG_SUM, ...)."""
-    lib = _lib.load_library()
-    slab = graph.slab
-    V, L, D = graph.V, graph.L, X.shape[1]
-    out = torch.empty((V * L, D), dtype=torch.float32, device=X.device)
-    rowmax = torch.empty(V * L * (D // 8), dtype=torch.float32, device=X.device) if want_rowmax else None
-    d = direction
-    _lib.check(lib.relgnn_slab_gather_f32(
-        _lib.ptr(X), X.stride(0), D, _lib.ptr(slab.desc), slab.num_graphs, slab.max_nodes, _lib.ptr(d.slice_base),
-        _lib.ptr(d.slice_len), _lib.ptr(d.slice_off), _lib.ptr(d.slice_bucket), _lib.ptr(d.ell_id),
-        _lib.ptr(d.ell_w) if weighted else None, L, _lib.ptr(out), D, _lib.ptr(rowmax), _lib.ptr(_slab_ticket(X.device)),
-        _lib.current_stream()), "relgnn_slab_gather_f32")
-    return out, rowmax
-
-
 class _SegGatherReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, plan: GatherReducePlan, mode: int, act: int):
@@ -880,8 +831,7 @@ def _weight_gradient(agg, gsc, amax, L: int):
     from . import dense as DN
     if (amax is not None and _cfg.limb_pair and _cfg.pair_part("tn") and DN.limb_tn_supported(agg, gsc)
             and agg.shape[1] * gsc.shape[1] > 256 * 256):
-        # (amax: one magnitude per bucket, or one per 8-column piece of a bucket from the LDS-tiled gather)
-        return DN.limb_gemm_tn(agg, gsc, DN.col_absmax(amax.view(-1, L * (amax.numel() // (agg.shape[0] * L)))), DN.col_absmax(gsc))
+        return DN.limb_gemm_tn(agg, gsc, DN.col_absmax(amax.view(-1, L)), DN.col_absmax(gsc))
     return DN.matmul_tn_splitk(agg, gsc)
 
 
@@ -894,8 +844,7 @@ def _pair_products(X, rowptr, stride, V, k, n, kernels, kind) -> bool:
         return False
     if not _cfg.pair_part(kind):                         # (diagnostics: which products take the form)
         return False
-    # (rowptr None: the LDS-tiled gather writes the magnitudes itself)
-    return ((rowptr is None or rowmax_supported(X, rowptr, stride, aggregate_acc64()))
+    return (rowmax_supported(X, rowptr, stride, aggregate_acc64())
             and DN.weight_image_ok(list(kernels), DN.WEIGHT_NN if kind == "nn" else DN.WEIGHT_NT))
 
 
@@ -917,21 +866,15 @@ class _AggregateThenTransform(torch.autograd.Function):
         d_in, d_out = kernels[0].shape
         V = graph.V
         # RELGNN_LIMB=pair: the gather also writes every bucket's largest magnitude — the row scales of the two-fp16-limb product
-        amax, xgroups = None, L
-        lds = slab_route(graph, H, w, by_source=False)
-        if lds is not None:                              # the table tiled through LDS: same bits, magnitudes per 8-column piece
-            pair = _pair_products(H, None, 1, V, L * d_in, d_out, kernels, "nn")
-            agg, amax = slab_gather(graph, H, lds, w is not None, pair)
-            agg, xgroups = agg.view(V, L * d_in), L * (d_in // 8)
-        else:
-            if _pair_products(H, graph.rowptr_t, 1, V, L * d_in, d_out, kernels, "nn"):
-                amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
-            agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
-                                  acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
+        amax = None
+        if _pair_products(H, graph.rowptr_t, 1, V, L * d_in, d_out, kernels, "nn"):
+            amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
+        agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
+                              acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
         want_w = any(ctx.needs_input_grad[6:])
         f = _mode_factor(graph, mode)
         fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the product's epilogue
-        out = grouped_nn_gemm(agg, kernels, relu=fused_relu, xmax=amax, xgroups=xgroups)
+        out = grouped_nn_gemm(agg, kernels, relu=fused_relu, xmax=amax, xgroups=L)
         if f is not None:
             out.mul_(f.unsqueeze(1))
         if act == _lib.ACT_RELU:
@@ -979,20 +922,13 @@ class _AggregateThenTransform(torch.autograd.Function):
                 t.record_stream(side)
         if ctx.needs_input_grad[0]:
             plan = graph.plan_transformed(w)            # by-source buckets; weights carry the mean / sqrt_n factor
-            gmax, ggroups = None, L
-            wb = plan.w_bwd(mode)
-            lds = slab_route(graph, gout, wb, by_source=True) if plan.num_rows_x == V * L else None
-            if lds is not None:
-                pair = _pair_products(gout, None, 1, V, L * d_out, d_in, kernels, "nt")
-                gT, gmax = slab_gather(graph, gout, lds, wb is not None, pair)
-                gT, ggroups = gT.view(V, L * d_out), L * (d_out // 8)
-            else:
-                if (plan.num_rows_x == V * L and
-                        _pair_products(gout, plan.rowptr_b, plan.stride_b, V, L * d_out, d_in, kernels, "nt")):
-                    gmax = torch.empty(V * L, dtype=torch.float32, device=gout.device)
-                gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, wb,
-                                     plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
-            gH = grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=ggroups)           # dH = sum_l dT_l @ W_l^T
+            gmax = None
+            if (plan.num_rows_x == V * L and
+                    _pair_products(gout, plan.rowptr_b, plan.stride_b, V, L * d_out, d_in, kernels, "nt")):
+                gmax = torch.empty(V * L, dtype=torch.float32, device=gout.device)
+            gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
+                                 plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
+            gH = grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=L)           # dH = sum_l dT_l @ W_l^T
         if side is not None:
             if _DEFER["on"]:
                 _DEFER["pending"].append((gout.device, side))

@@ -27,10 +27,6 @@ from .batcher import GraphStore
 from .sparse_graph_task import DeviceBatch
 
 
-def M_batch_nonempty(edges) -> bool:
-    return bool(edges.size) and int(edges.sum()) > 0
-
-
 def _dev_i64(a, device):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64), device=device)
 
@@ -79,7 +75,6 @@ class ResidentDataset:
                     key = gidx.astype(np.int64) * (N + 1) + a[:, 1 - side].astype(np.int64) + self.node_off[gidx]
                     cnt[side, :, l] = np.bincount(np.unique(key) // (N + 1), minlength=G)
             self.pair_counts = cnt
-        self._fold_graph, self._slab = g, None       # (sliced-ELL lists for the LDS-tiled gather: built on first use, slab_fold())
         self.plan_d = dict(rowptr_t=g.rowptr_t, perm_t=g.perm_t, col_t=g.col_t, rowptr_s=g.rowptr_s, perm_s=g.perm_s,
                            frow_s=g.frow_s, pos_t_of_s=g.pos_t_of_s)
         # per-message 1/(in-degree + 1e-7) of the whole fold, by-target and by-source order: graph properties, copied
@@ -98,18 +93,6 @@ class ResidentDataset:
         self._stage_done = [None] * 4
         self._stage_at = 0
         self._side = None
-
-    def slab_fold(self):
-        """tasks/slab.SlabFold of this fold (config gather=lds), or None when a graph does not fit the LDS slice / a bucket is
-        long enough for the hub route / there is nothing to gather."""
-        if self._slab is None:
-            from .slab import SlabFold
-            lib = _lib.load_library()
-            nodes = np.diff(self.node_off)
-            ok = (len(nodes) > 0 and int(self.msg_off[-1]) > 0 and not self._has_hubs
-                  and int(nodes.max()) <= int(lib.relgnn_slab_gather_max_nodes()))
-            self._slab = SlabFold(self._fold_graph, self.node_off, self.w_t_d, self.w_s_d, self.device) if ok else False
-        return self._slab or None
 
     def _staging(self, n: int) -> torch.Tensor:
         k = self._stage_at
@@ -142,19 +125,13 @@ class ResidentDataset:
         msg_off_b = np.concatenate([[0], np.cumsum(edges.sum(0))])
         type_off_b = np.concatenate([[0], np.cumsum(edge_off_b[:, -1])])
         V, M = int(node_off_b[-1]), int(msg_off_b[-1])
-        # ONE small H2D: [ids | node_off_b | msg_off_b | type_off_b | edge_off_b | graph table of the LDS-tiled gather]
-        from ..config import settings
-        slab = self.slab_fold() if settings.gather == "lds" and K > 0 and M_batch_nonempty(edges) else None
-        slab_desc = None
-        if slab is not None:
-            from .slab import batch_table
-            slab_desc = batch_table(ids, node_off_b, nodes, edges.sum(0)).reshape(-1)
-        sizes = [K, K + 1, K + 1, L + 1, L * (K + 1)] + ([3 * K] if slab_desc is not None else [])
+        # ONE small H2D: [ids | node_off_b | msg_off_b | type_off_b | edge_off_b]
+        sizes = [K, K + 1, K + 1, L + 1, L * (K + 1)]
         total = sum(sizes)
         host, slot = self._staging(total)
         hn = host.numpy()
         at = 0
-        for part in (ids, node_off_b, msg_off_b, type_off_b, edge_off_b.reshape(-1)) + ((slab_desc,) if slab_desc is not None else ()):
+        for part in (ids, node_off_b, msg_off_b, type_off_b, edge_off_b.reshape(-1)):
             hn[at:at + part.size] = part
             at += part.size
         tab = host[:total].to(dev, non_blocking=True)
@@ -249,9 +226,6 @@ class ResidentDataset:
         graph.preset_degree_scale(deg, src_t, w_t, w_s)
         if self.pair_counts is not None:
             graph.pair_counts = (self.pair_counts[0, ids].sum(0).tolist(), self.pair_counts[1, ids].sum(0).tolist())
-        if slab_desc is not None:
-            from .slab import SlabBatch
-            graph.slab = SlabBatch(slab, tab[o[5]:o[6]], K, int(nodes.max()), w_t, w_s)
         if self._has_hubs:
             graph.split_long_segments()
         batch = DeviceBatch.from_tensors(
