@@ -112,6 +112,46 @@ def test_typed_linear_matches_per_row_matmul(gpu_device, monkeypatch, typed):
         assert np.abs(Wd[t].grad.cpu().numpy() - gW[t]).max() < 2e-5 * max(1.0, np.abs(gW[t]).max())
 
 
+def test_typed_weight_gradient_on_the_side_stream_is_the_same_bits(gpu_device):
+    """bwd_overlap: the typed products' weight gradient (panel TN + per-type sum of the tile partials) runs on the side stream next to
+    the input gradient — joined inside backward(), or behind it under deferred_weight_gradient_join (train_step).  Same kernels,
+    same operands: the same bits as the one-stream order."""
+    from tf_gnn_samples_amd import config, ops
+    from tf_gnn_samples_amd.graph import RelGraph
+    rng, adj, _ = _sparse_many_type_graph(7)
+    V, L, Din, Dout = 300, 12, 128, 256
+    g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)
+    side = g.pair_tables().tgt
+    H = torch.as_tensor(rng.standard_normal((V, Din)).astype(np.float32), device=gpu_device)
+    Ws = [torch.as_tensor(glorot(rng, (Din, Dout)), device=gpu_device) for _ in range(L)]
+    gY = None
+
+    def grads(overlap, deferred):
+        nonlocal gY
+        Hd = H.clone().requires_grad_(True)
+        Wd = [w.clone().requires_grad_(True) for w in Ws]
+        with config.override(bwd_overlap=overlap):
+            assert ops._typed_panel_ok(Hd, side, Wd)
+            Y = ops.typed_linear(Hd, side, Wd)
+            if gY is None:
+                gY = torch.as_tensor(rng.standard_normal(tuple(Y.shape)).astype(np.float32), device=gpu_device)
+            if deferred:
+                with ops.deferred_weight_gradient_join():
+                    Y.backward(gY)
+                ops.join_deferred()
+            else:
+                Y.backward(gY)
+        torch.cuda.synchronize()
+        return [Hd.grad.clone()] + [w.grad.clone() for w in Wd]
+
+    want = grads("0", False)
+    for overlap, deferred in (("1", False), ("1", True), ("auto", True)):
+        got = grads(overlap, deferred)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b), (overlap, deferred)
+    assert float(want[1].abs().max()) > 0
+
+
 @pytest.mark.parametrize("agg,norm,act,D", [("sum", False, "ReLU", 128), ("mean", True, "tanh", 64), ("sqrt_n", False, "elu", 256)])
 def test_film_layer_compact_vs_oracle_and_dense(gpu_device, monkeypatch, agg, norm, act, D):
     from tf_gnn_samples_amd.gnns import sparse_gnn_film_layer

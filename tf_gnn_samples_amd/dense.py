@@ -755,6 +755,30 @@ def column_sum(g: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _on_side_stream(run, operands):
+    """A Dense layer's weight and bias gradient on the weight-gradient side stream (ops._side_stream) — only while train_step defers
+    the joins behind the whole backward (ops.deferred_weight_gradient_join): the gradients then leave the main stream's critical
+    path and run under the next layer's gather (C2 step 1.826 -> 1.807 ms).  With the join inside backward() the same move was measured and lost (both
+    products are matrix-pipe kernels: 2.02 vs 1.94 ms per C2 step), so outside train_step everything stays on one stream.
+    Returns run()'s result, or None when not applicable."""
+    from . import ops
+    if not (ops._DEFER["on"] and _cfg.bwd_overlap_on and all(t.is_cuda for t in operands)):
+        return None
+    device = operands[0].device
+    side = ops._side_stream(device)
+    cur = torch.cuda.current_stream(device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = run()
+    for t in operands:
+        t.record_stream(side)
+    for t in out:
+        if t is not None:
+            t.record_stream(cur)
+    ops._DEFER["pending"].append((device, side))
+    return out
+
+
 class _DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, bias):
@@ -769,15 +793,16 @@ class _DenseFn(torch.autograd.Function):
             g = g.contiguous()             # (a row-strided gradient, e.g. a column block of the GRU's gate gradients, is
         gx = None                          # read in place: every consumer below takes a leading dimension; an expanded one,
                                            # strides (0, 1), is materialised)
+        def weight_side():
+            gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), g) \
+                if ctx.needs_input_grad[1] else None
+            gb = column_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            return gk, gb
+
+        aside = _on_side_stream(weight_side, (x, g)) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
             gx = lib_gemm(GEMM_NT, g, kernel, weight=True)
-        # (the weight gradient on a side stream next to the input gradient, as ops._AggregateThenTransform does with its gather, was
-        # measured and lost: both are matrix-pipe kernels, 2.02 vs 1.94 ms per C2 step)
-        gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), g) \
-            if ctx.needs_input_grad[1] else None
-        gb = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = column_sum(g)
+        gk, gb = aside if aside is not None else weight_side()
         return gx, gk, gb
 
 
@@ -806,10 +831,15 @@ class _DenseReluFn(torch.autograd.Function):
         _lib.check(_lib.load_library().relgnn_act_bwd_from_output(_lib.ACT_RELU, _lib.ptr(y), _lib.ptr(g), g.numel(),
                                                                   _lib.ptr(gm), _lib.current_stream()),
                    "relgnn_act_bwd_from_output")
+        def weight_side():
+            gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), gm) \
+                if ctx.needs_input_grad[1] else None
+            gb = column_sum(gm) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            return gk, gb
+
+        aside = _on_side_stream(weight_side, (x, gm)) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
         gx = lib_gemm(GEMM_NT, gm, kernel, weight=True) if ctx.needs_input_grad[0] else None
-        gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), gm) \
-            if ctx.needs_input_grad[1] else None
-        gb = column_sum(gm) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gk, gb = aside if aside is not None else weight_side()
         return gx, gk, gb
 
 
