@@ -209,3 +209,48 @@ def test_captured_step_on_the_limb_route_and_eager_code_after_replays(gpu_device
     np.testing.assert_allclose(losses_c, losses_e[3:], rtol=2e-5)
     np.testing.assert_allclose(eval_c, eval_e, rtol=2e-5)                  # (a stale image would give the loss after step 3)
     assert abs(eval_e - losses_e[3]) > 1e-3 * abs(eval_e)
+
+
+def test_deferred_weight_gradients_only_go_aside_where_nothing_reads_them_early(gpu_device):
+    """ops.deferred_weight_gradient_join (train_step): a Dense layer's weight gradient may stay in flight on the side stream until
+    join_deferred() only when it goes straight into a leaf parameter that is seen once in the backward pass.  The gradient of a VIEW
+    of a parameter (the GRU's recurrent_kernel[:, :2u]) is consumed by the view's backward on the main stream at once, and a
+    parameter used twice has its contributions summed there: both must stay on one stream — and give the bits of the plain order."""
+    from tf_gnn_samples_amd import config, dense as DN, ops
+    torch.manual_seed(0)
+    x = torch.randn(6000, 128, device=gpu_device)
+    U0 = torch.randn(128, 384, device=gpu_device) * 0.05
+    b0 = torch.randn(256, device=gpu_device) * 0.1
+
+    def run(deferred, fn):
+        x_ = x.clone().requires_grad_(True)
+        U = U0.clone().requires_grad_(True)
+        b = b0.clone().requires_grad_(True)
+        y = fn(x_, U, b)
+        pend = None
+        with config.override(bwd_overlap="1"):
+            if deferred:
+                with ops.deferred_weight_gradient_join():
+                    y.square().sum().backward()
+                pend = len(ops._DEFER["pending"])
+                ops.join_deferred()
+                assert not ops._DEFER["pending"] and not ops._DEFER["targets"]
+            else:
+                y.square().sum().backward()
+        torch.cuda.synchronize()
+        return pend, [x_.grad.clone(), U.grad.clone(), b.grad.clone()]
+
+    # (1) a leaf kernel seen once: goes aside (one pending join); (2) a view of the parameter: stays; (3) the leaf used twice: the
+    # second sight stays and makes the main stream wait
+    fns = [
+        (lambda x_, U, b: DN.dense(torch.tanh(x_), U, None)[:, :256] + b, 1),
+        (lambda x_, U, b: DN.dense(torch.tanh(x_), U[:, :256], b), 0),
+        (lambda x_, U, b: DN.dense(torch.tanh(DN.dense(torch.tanh(x_), U, None)[:, :128]), U, None)[:, :256] + b, 1),
+    ]
+    for fn, expected_pending in fns:
+        _, want = run(False, fn)
+        for _ in range(3):
+            pend, got = run(True, fn)
+            assert pend == expected_pending
+            for a, b_ in zip(want, got):
+                assert torch.equal(a, b_)

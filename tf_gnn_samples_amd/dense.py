@@ -755,14 +755,24 @@ def column_sum(g: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _on_side_stream(run, operands):
+def _leaf_params(kernel, bias):
+    """(kernel, bias) when both are leaf parameters — their gradients go straight to the accumulator — else None: the gradient of a
+    VIEW of a parameter (the GRU's recurrent_kernel[:, :2u]) is consumed by the view's backward on the main stream at once."""
+    ok = kernel.is_leaf and kernel.requires_grad and (bias is None or (bias.is_leaf and bias.requires_grad))
+    return ((kernel,) if bias is None else (kernel, bias)) if ok else None
+
+
+def _on_side_stream(run, operands, params):
     """A Dense layer's weight and bias gradient on the weight-gradient side stream (ops._side_stream) — only while train_step defers
     the joins behind the whole backward (ops.deferred_weight_gradient_join): the gradients then leave the main stream's critical
     path and run under the next layer's gather (C2 step 1.826 -> 1.807 ms).  With the join inside backward() the same move was measured and lost (both
     products are matrix-pipe kernels: 2.02 vs 1.94 ms per C2 step), so outside train_step everything stays on one stream.
-    Returns run()'s result, or None when not applicable."""
+    `params`: the leaf parameters the gradients go to (ops.deferred_targets_ok: only a parameter that has no gradient yet takes its
+    gradient tensor without launching anything on the main stream), or None.  Returns run()'s result, or None when not applicable."""
     from . import ops
     if not (ops._DEFER["on"] and _cfg.bwd_overlap_on and all(t.is_cuda for t in operands)):
+        return None
+    if not ops.deferred_targets_ok(params, operands[0].device):
         return None
     device = operands[0].device
     side = ops._side_stream(device)
@@ -784,6 +794,7 @@ class _DenseFn(torch.autograd.Function):
     def forward(ctx, x, kernel, bias):
         ctx.save_for_backward(x, kernel)
         ctx.has_bias = bias is not None
+        ctx.leaf_params = _leaf_params(kernel, bias)
         return lib_gemm(GEMM_NN, x, kernel, bias, weight=True)
 
     @staticmethod
@@ -799,7 +810,7 @@ class _DenseFn(torch.autograd.Function):
             gb = column_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return gk, gb
 
-        aside = _on_side_stream(weight_side, (x, g)) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
+        aside = _on_side_stream(weight_side, (x, g), ctx.leaf_params) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
             gx = lib_gemm(GEMM_NT, g, kernel, weight=True)
         gk, gb = aside if aside is not None else weight_side()
@@ -820,6 +831,7 @@ class _DenseReluFn(torch.autograd.Function):
         y = lib_gemm(GEMM_NN, x, kernel, bias, relu=True, weight=True)
         ctx.save_for_backward(x, kernel, y)
         ctx.has_bias = bias is not None
+        ctx.leaf_params = _leaf_params(kernel, bias)
         return y
 
     @staticmethod
@@ -837,7 +849,7 @@ class _DenseReluFn(torch.autograd.Function):
             gb = column_sum(gm) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return gk, gb
 
-        aside = _on_side_stream(weight_side, (x, gm)) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
+        aside = _on_side_stream(weight_side, (x, gm), ctx.leaf_params) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
         gx = lib_gemm(GEMM_NT, gm, kernel, weight=True) if ctx.needs_input_grad[0] else None
         gk, gb = aside if aside is not None else weight_side()
         return gx, gk, gb

@@ -511,8 +511,9 @@ class _TypedLinearPanel(torch.autograd.Function):
                                                    partials summed per type by the gather-reduce kernel (tile order)"""
 
     @staticmethod
-    def forward(ctx, H, side, W):
+    def forward(ctx, H, side, W, leaves):
         from .dense import GEMM_NN, limb_dense_sel, panel_gemm
+        ctx.leaf_params = leaves            # the per-type weights W was stacked from, when every one is a leaf parameter
         L, Din, Dout = W.shape
         node32, tile_type = side.panel_indices()
         if _typed_limb_ok(Din, Dout):
@@ -548,7 +549,8 @@ class _TypedLinearPanel(torch.autograd.Function):
         # kernels that follow on the main stream (the other typed product's row sums, the next layer's fused edge backward); the
         # join is deferred behind the whole backward inside train_step (deferred_weight_gradient_join above).
         side_stream = None
-        if ctx.needs_input_grad[2] and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and gY.is_cuda:
+        if (ctx.needs_input_grad[2] and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and gY.is_cuda
+                and (not _DEFER["on"] or deferred_targets_ok(ctx.leaf_params, gY.device))):
             side_stream = _side_stream(gY.device)
             cur = torch.cuda.current_stream(gY.device)
             side_stream.wait_stream(cur)
@@ -570,7 +572,7 @@ class _TypedLinearPanel(torch.autograd.Function):
             gW.record_stream(torch.cuda.current_stream(gY.device))
         elif ctx.needs_input_grad[2]:
             gW = weight_gradient()
-        return gH, None, gW
+        return gH, None, gW, None
 
 
 def _typed_limb_ok(k: int, n: int) -> bool:
@@ -591,7 +593,9 @@ def typed_linear(H, side, weights):
     _check_f32(H, "H")
     H = H.contiguous()
     if _typed_panel_ok(H, side, weights):
-        return _TypedLinearPanel.apply(H, side, torch.stack(list(weights)))
+        weights = list(weights)
+        leaves = tuple(weights) if all(w.is_leaf and w.requires_grad for w in weights) else None
+        return _TypedLinearPanel.apply(H, side, torch.stack(weights), leaves)
     return _TypedLinear.apply(H, side, *weights)
 
 
@@ -810,7 +814,7 @@ _SIDE_STREAMS = {}
 # hold every wave slot and register), so its kernels really start at the gather's tail and finish AFTER the input-gradient product
 # — the main stream then idled at every layer's join.  deferred_weight_gradient_join() (models/sparse_graph_model.py: train_step)
 # moves the joins to join_deferred(), called once behind the backward.
-_DEFER = {"on": False, "pending": []}
+_DEFER = {"on": False, "pending": [], "targets": set()}
 
 
 class deferred_weight_gradient_join:
@@ -824,9 +828,28 @@ class deferred_weight_gradient_join:
         return False
 
 
+def deferred_targets_ok(params, device) -> bool:
+    """May a weight gradient be left in flight on the side stream until join_deferred()?  Only if nothing on the main stream reads
+    it before: every target must be a LEAF that has no gradient yet and has not been a target in this backward pass — autograd's
+    accumulator then keeps the tensor itself and launches nothing.  A parameter used twice in the graph (the timesteps of a GGNN
+    layer share their weights) has its contributions SUMMED on the main stream (in the engine's input buffer, or `grad += new`),
+    which would read tensors that are still being written: on the second sight of a parameter the main stream is made to wait for
+    the side stream here and the caller computes on one stream."""
+    seen = _DEFER["targets"]
+    if params is not None and all(p.is_leaf and p.grad is None and id(p) not in seen for p in params):
+        seen.update(id(p) for p in params)
+        return True
+    if params is not None and any(id(p) in seen for p in params):     # (a view's or a non-leaf's gradient never went aside: no wait)
+        side = _SIDE_STREAMS.get(device)
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
+    return False
+
+
 def join_deferred() -> None:
     """Make the current stream wait for every side stream whose join was deferred (no host synchronisation)."""
     pending, _DEFER["pending"] = _DEFER["pending"], []
+    _DEFER["targets"].clear()
     done = set()
     for device, side in pending:
         if id(side) not in done:
@@ -913,6 +936,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L = graph, w, mode, act, L
         ctx.save_for_backward(agg if want_w else None, out if act != _lib.ACT_LINEAR else None,
                               amax if want_w else None, *kernels)
+        ctx.leaf_params = tuple(kernels) if all(k.is_leaf for k in kernels) else None
         return out
 
     @staticmethod
@@ -935,7 +959,8 @@ class _AggregateThenTransform(torch.autograd.Function):
         # gradient's gather (L2-latency bound, no LDS, few registers): it runs on a side stream next to it (fork / join by events,
         # capturable in a hipGraph; the result is the same bits, the kernels are the same).
         side = None
-        if want_w and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and gout.is_cuda:
+        if (want_w and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and gout.is_cuda
+                and (not _DEFER["on"] or deferred_targets_ok(ctx.leaf_params, gout.device))):
             side = _side_stream(gout.device)
             cur = torch.cuda.current_stream(gout.device)
             side.wait_stream(cur)
