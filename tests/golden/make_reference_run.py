@@ -1,0 +1,300 @@
+#!/usr/bin/env python
+"""Runs the UNMODIFIED reference sources (/root/reference: gnns/*.py, utils/utils.py, tasks/ppi_task.py, tasks/qm9_task.py) in the
+build container over tests/golden/tf_numpy_shim.py and writes what they return as fixtures:
+
+    tests/golden/reference_run_layers.npz   every sparse_*_layer of the reference on seeded small graphs: inputs, the variables
+                                            the layer created (by TF variable name), the output it returned
+    tests/golden/reference_run_tasks.npz    PPI_Task.load_data on a synthetic DGL-format directory (written by the same seeded
+                                            helper the test re-runs) + its minibatches; QM9_Task.load_data on the committed
+                                            256-molecule file + its minibatches; utils.micro_f1 on seeded logits / labels
+
+Run from the repo root IN THE BUILD CONTAINER (the GPU box has no /root/reference; the tests read the fixtures only):
+
+    python tests/golden/make_reference_run.py
+
+What this pins and what it does not: tf_numpy_shim.py's header.  In one line: the reference's own code decides which ops run on
+what, in which order, under which variable names; the ops themselves are oracle/tf_ops.py's NumPy restatements of TF's.
+"""
+import gzip
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(OUT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import tf_numpy_shim as S  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+
+def small_graph(seed, V, L, edges_per_type):
+    """adjacency lists [E_l, 2] int32 (source, target), the per-type in-degree table [L, V] float32, states [V, D] float32 drawn later."""
+    rng = np.random.default_rng(seed)
+    adj = []
+    for l, e in enumerate(edges_per_type):
+        if e == "self":
+            a = np.stack([np.arange(V), np.arange(V)], 1)
+        else:
+            a = np.stack([rng.integers(0, V, e), rng.integers(0, V, e)], 1)
+        adj.append(a.astype(np.int32).reshape(-1, 2))
+    deg = np.stack([np.bincount(a[:, 1], minlength=V) for a in adj]).astype(np.float32)
+    return rng, adj, deg
+
+
+# (function, positional-after-adjacency builder, keyword arguments) — every branch the reference's layers have
+LAYER_CASES = [
+    ("sparse_rgcn_layer", "deg", dict(state_dim=16, num_timesteps=1, activation_function="tanh", message_aggregation_function="sum",
+                                      normalize_by_num_incoming=True, use_both_source_and_target=False)),
+    ("sparse_rgcn_layer", "deg", dict(state_dim=16, num_timesteps=2, activation_function="ReLU", message_aggregation_function="mean",
+                                      normalize_by_num_incoming=False, use_both_source_and_target=True)),
+    ("sparse_rgcn_layer", "deg", dict(state_dim=24, num_timesteps=1, activation_function="elu", message_aggregation_function="max",
+                                      normalize_by_num_incoming=True, use_both_source_and_target=False)),
+    ("sparse_rgcn_layer", "deg", dict(state_dim=None, num_timesteps=1, activation_function="gelu",
+                                      message_aggregation_function="sqrt_n", normalize_by_num_incoming=True)),
+    ("sparse_ggnn_layer", None, dict(state_dim=16, num_timesteps=2, gated_unit_type="gru", activation_function="tanh",
+                                     message_aggregation_function="sum")),
+    ("sparse_ggnn_layer", None, dict(state_dim=16, num_timesteps=1, gated_unit_type="GRU", activation_function="ReLU",
+                                     message_aggregation_function="max")),
+    ("sparse_ggnn_layer", None, dict(state_dim=16, num_timesteps=2, gated_unit_type="rnn", activation_function="tanh",
+                                     message_aggregation_function="mean")),
+    ("sparse_rgat_layer", None, dict(state_dim=16, num_heads=4, num_timesteps=1, activation_function="tanh")),
+    ("sparse_rgat_layer", None, dict(state_dim=16, num_heads=2, num_timesteps=2, activation_function="leaky_relu")),
+    ("sparse_rgin_layer", None, dict(state_dim=16, num_timesteps=1, activation_function="ReLU", message_aggregation_function="sum",
+                                     use_target_state_as_input=False, num_edge_MLP_hidden_layers=1, num_aggr_MLP_hidden_layers=None)),
+    ("sparse_rgin_layer", None, dict(state_dim=16, num_timesteps=2, activation_function="tanh", message_aggregation_function="mean",
+                                     use_target_state_as_input=True, num_edge_MLP_hidden_layers=2, num_aggr_MLP_hidden_layers=1)),
+    ("sparse_rgin_layer", None, dict(state_dim=16, num_timesteps=1, activation_function="selu", message_aggregation_function="sum",
+                                     use_target_state_as_input=False, num_edge_MLP_hidden_layers=0, num_aggr_MLP_hidden_layers=2)),
+    ("sparse_gnn_film_layer", "deg", dict(state_dim=16, num_timesteps=1, activation_function="ReLU",
+                                          message_aggregation_function="sum", normalize_by_num_incoming=False)),
+    ("sparse_gnn_film_layer", "deg", dict(state_dim=16, num_timesteps=2, activation_function="tanh",
+                                          message_aggregation_function="mean", normalize_by_num_incoming=True)),
+    ("sparse_gnn_edge_mlp_layer", "deg", dict(state_dim=16, num_timesteps=1, activation_function="ReLU",
+                                              message_aggregation_function="sum", normalize_by_num_incoming=False,
+                                              use_target_state_as_input=True, num_edge_hidden_layers=1)),
+    ("sparse_gnn_edge_mlp_layer", "deg", dict(state_dim=16, num_timesteps=2, activation_function="gelu",
+                                              message_aggregation_function="sqrt_n", normalize_by_num_incoming=True,
+                                              use_target_state_as_input=False, num_edge_hidden_layers=0)),
+    ("sparse_gnn_edge_mlp_layer", "deg", dict(state_dim=16, num_timesteps=1, activation_function="elu",
+                                              message_aggregation_function="max", normalize_by_num_incoming=True,
+                                              use_target_state_as_input=True, num_edge_hidden_layers=2)),
+    ("sparse_rgdcn_layer", "deg", dict(num_channels=4, channel_dim=4, num_timesteps=1, use_full_state_for_channel_weights=False,
+                                       tie_channel_weights=False, activation_function="tanh", message_aggregation_function="sum",
+                                       normalize_by_num_incoming=True)),
+    ("sparse_rgdcn_layer", "deg", dict(num_channels=4, channel_dim=4, num_timesteps=2, use_full_state_for_channel_weights=True,
+                                       tie_channel_weights=True, activation_function="ReLU", message_aggregation_function="mean",
+                                       normalize_by_num_incoming=False)),
+]
+
+
+def run_layers(gnns):
+    arrays, manifest = {}, []
+    for i, (fn_name, second, kw) in enumerate(LAYER_CASES):
+        V, D, L = 37, 16, 3
+        rng, adj, deg = small_graph(100 + i, V, L, [90, "self", 25] if i % 2 == 0 else [60, 0, 41])
+        h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+        S.reset(1000 + i)
+        fn = getattr(gnns, fn_name)
+        if fn_name == "sparse_rgdcn_layer":
+            out = fn(h, adj, deg, **kw)
+        elif second == "deg":
+            kw2 = dict(kw)
+            state_dim = kw2.pop("state_dim")
+            out = fn(h, adj, deg, state_dim, **kw2)
+        else:
+            kw2 = dict(kw)
+            state_dim = kw2.pop("state_dim")
+            out = fn(h, adj, state_dim, **kw2)
+        assert isinstance(out, np.ndarray) and out.dtype == np.float32, (fn_name, type(out), getattr(out, "dtype", None))
+        key = "case%02d" % i
+        arrays[key + "/h"], arrays[key + "/deg"], arrays[key + "/out"] = h, deg, out
+        for l, a in enumerate(adj):
+            arrays[key + "/adj%d" % l] = a
+        names = list(S.VARIABLES)
+        for n in names:
+            arrays[key + "/var/" + n] = S.VARIABLES[n]
+        manifest.append(dict(key=key, function=fn_name, kwargs=kw, takes_degrees=second == "deg", num_edge_types=L,
+                             variables=names, variable_shapes=[list(S.VARIABLES[n].shape) for n in names]))
+        print("%-28s %-60s out %s  |out|max %.3f  %d variables" % (fn_name, json.dumps(kw)[:60], out.shape, np.abs(out).max(), len(names)))
+    arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "reference_run_layers.npz", **arrays)
+
+
+def write_ppi_dir(path, seed=11):
+    """A directory in the layout of DGL's ppi.zip (what tasks/ppi_task.py:87-90 reads), seeded; tests re-run this helper."""
+    rng = np.random.default_rng(seed)
+    meta = {}
+    for name, sizes, gids in (("train", [7, 1, 12, 5, 9], [5, 9, 2, 21, 22]), ("valid", [4, 9], [23, 24]), ("test", [6, 3], [1, 30])):
+        n = int(sum(sizes))
+        gid = np.concatenate([np.full(s, g, np.int64) for s, g in zip(sizes, gids)])
+        feats = rng.standard_normal((n, 6)).astype(np.float32)
+        labels = (rng.random((n, 4)) < 0.4).astype(np.int64)
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        links = []
+        for k, s in enumerate(sizes):
+            for _ in range(3 * s):
+                links.append({"source": int(starts[k] + rng.integers(0, s)), "target": int(starts[k] + rng.integers(0, s))})
+        order = rng.permutation(len(links))
+        links = [links[j] for j in order]
+        links.append(dict(links[0]))
+        with open(os.path.join(path, "%s_graph.json" % name), "w") as f:
+            json.dump({"directed": False, "multigraph": False, "links": links, "nodes": [{"id": j} for j in range(n)]}, f)
+        np.save(os.path.join(path, "%s_feats.npy" % name), feats)
+        np.save(os.path.join(path, "%s_labels.npy" % name), labels)
+        np.save(os.path.join(path, "%s_graph_id.npy" % name), gid)
+        meta[name] = dict(sizes=sizes, graph_ids=gids)
+    return meta
+
+
+def _dump_samples(arrays, prefix, samples, payload):
+    arrays[prefix + "/count"] = np.asarray(len(samples))
+    for g, s in enumerate(samples):
+        for l, a in enumerate(s.adjacency_lists):
+            arrays["%s/g%d/adj%d" % (prefix, g, l)] = np.asarray(a)
+        arrays["%s/g%d/deg" % (prefix, g)] = np.asarray(s.type_to_node_to_num_incoming_edges)
+        arrays["%s/g%d/features" % (prefix, g)] = np.asarray(s.node_features)
+        arrays["%s/g%d/%s" % (prefix, g, payload)] = np.asarray(getattr(s, payload))
+
+
+def _dump_batches(arrays, prefix, batches, placeholders, L, payload_key):
+    arrays[prefix + "/count"] = np.asarray(len(batches))
+    for b, mb in enumerate(batches):
+        fd = mb.feed_dict
+        arrays["%s/b%d/sizes" % (prefix, b)] = np.asarray([mb.num_graphs, mb.num_nodes, mb.num_edges])
+        arrays["%s/b%d/features" % (prefix, b)] = np.asarray(fd[placeholders["initial_node_features"]])
+        arrays["%s/b%d/deg" % (prefix, b)] = np.asarray(fd[placeholders["type_to_num_incoming_edges"]])
+        arrays["%s/b%d/graph_nodes_list" % (prefix, b)] = np.asarray(fd[placeholders["graph_nodes_list"]])
+        arrays["%s/b%d/%s" % (prefix, b, payload_key)] = np.asarray(fd[placeholders[payload_key]])
+        arrays["%s/b%d/keep_prob" % (prefix, b)] = np.asarray(fd[placeholders["out_layer_dropout_keep_prob"]])
+        for l in range(L):
+            arrays["%s/b%d/adj%d" % (prefix, b, l)] = np.asarray(fd[placeholders["adjacency_lists"][l]])
+
+
+def run_tasks():
+    from dpu_utils.utils import RichPath
+    from tasks.ppi_task import PPI_Task
+    from tasks.qm9_task import QM9_Task
+    from tasks.sparse_graph_task import DataFold
+    import utils as ref_utils
+    arrays, manifest = {}, {}
+    tmp = tempfile.mkdtemp()
+    try:
+        manifest["ppi_dir_seed"] = 11
+        manifest["ppi_dir"] = write_ppi_dir(tmp, 11)
+        manifest["ppi"] = []
+        for self_loops, tie in ((True, False), (True, True), (False, False), (False, True)):
+            p = PPI_Task.default_params()
+            p.update(add_self_loop_edges=self_loops, tie_fwd_bkwd_edges=tie, out_layer_dropout_keep_prob=0.8)
+            task = PPI_Task(p)
+            stdout, sys.stdout = sys.stdout, io.StringIO()
+            try:
+                task.load_data(RichPath(tmp))
+                test = task.load_eval_data_from_path(RichPath(tmp))
+            finally:
+                sys.stdout = stdout
+            L = task.num_edge_types
+            prefix = "ppi_%d%d" % (int(self_loops), int(tie))
+            folds = {"train": task._loaded_data[DataFold.TRAIN], "valid": task._loaded_data[DataFold.VALIDATION], "test": test}
+            for name, samples in folds.items():
+                _dump_samples(arrays, "%s/%s" % (prefix, name), samples, "node_labels")
+            ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", "target_labels",
+                                         "out_layer_dropout_keep_prob")}
+            ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(L)]
+            entry = dict(prefix=prefix, add_self_loop_edges=self_loops, tie_fwd_bkwd_edges=tie, num_edge_types=L,
+                         initial_node_feature_size=task.initial_node_feature_size, metadata=task.get_metadata(), batches=[])
+            for fold_name, fold, cap in (("valid", DataFold.VALIDATION, 14), ("test", DataFold.TEST, 100), ("train", DataFold.TRAIN, 20)):
+                data = list(folds[fold_name])
+                np.random.seed(5)                      # the TRAIN iterator shuffles its argument in place with np.random.shuffle
+                batches = list(task.make_minibatch_iterator(data, fold, ph, cap))
+                key = "%s/batches_%s_%d" % (prefix, fold_name, cap)
+                _dump_batches(arrays, key, batches, ph, L, "target_labels")
+                order = [int(np.flatnonzero([d is s for s in folds[fold_name]])[0]) for d in data]
+                entry["batches"].append(dict(key=key, fold=fold_name, max_nodes_per_batch=cap, numpy_seed=5, order_after_shuffle=order))
+            manifest["ppi"].append(entry)
+
+        # ---- QM9: the committed 256-molecule file through the reference's loader ----
+        shutil.copy(OUT / "qm9_valid_256.jsonl.gz", os.path.join(tmp, "valid.jsonl.gz"))
+        with gzip.open(OUT / "qm9_valid_256.jsonl.gz", "rt") as f, gzip.open(os.path.join(tmp, "train.jsonl.gz"), "wt") as g:
+            for i, line in enumerate(f):
+                if i < 40:
+                    g.write(line)
+        manifest["qm9"] = []
+        for self_loops, tie, task_ids in ((True, True, [0]), (True, False, [3, 7]), (False, False, [0]), (False, True, [12])):
+            p = QM9_Task.default_params()
+            p.update(add_self_loop_edges=self_loops, tie_fwd_bkwd_edges=tie, task_ids=task_ids)
+            task = QM9_Task(p)
+            prefix = "qm9_%d%d" % (int(self_loops), int(tie))
+            stdout, sys.stdout = sys.stdout, io.StringIO()
+            try:
+                task.load_data(RichPath(tmp))
+            except IndexError as e:
+                # The reference cannot load QM9 with tie_fwd_bkwd_edges=False: tasks/qm9_task.py:140-145 enumerates
+                # type_to_adj_list while appending the backward lists to it, so the loop runs on into the lists it just added and
+                # indexes the in-degree table one type past its end.  Recorded as the reference's behaviour for this configuration.
+                manifest["qm9"].append(dict(prefix=prefix, add_self_loop_edges=self_loops, tie_fwd_bkwd_edges=tie, task_ids=task_ids,
+                                            reference_raises="IndexError", message=str(e), num_edge_types=task.num_edge_types))
+                continue
+            finally:
+                sys.stdout = stdout
+            L = task.num_edge_types
+            train, valid = task._loaded_data[DataFold.TRAIN], task._loaded_data[DataFold.VALIDATION][:48]
+            _dump_samples(arrays, prefix + "/train", train, "target_values")
+            _dump_samples(arrays, prefix + "/valid", valid, "target_values")
+            ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", "target_values",
+                                         "out_layer_dropout_keep_prob")}
+            ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(L)]
+            entry = dict(prefix=prefix, add_self_loop_edges=self_loops, tie_fwd_bkwd_edges=tie, task_ids=task_ids, num_edge_types=L,
+                         initial_node_feature_size=task.initial_node_feature_size, metadata=task.get_metadata(), batches=[])
+            for fold_name, fold, cap, data in (("valid", DataFold.VALIDATION, 200, list(valid)), ("train", DataFold.TRAIN, 150, list(train))):
+                src = list(data)
+                np.random.seed(9)
+                batches = list(task.make_minibatch_iterator(data, fold, ph, cap))
+                key = "%s/batches_%s_%d" % (prefix, fold_name, cap)
+                _dump_batches(arrays, key, batches, ph, L, "target_values")
+                order = [int(np.flatnonzero([d is s for s in src])[0]) for d in data]
+                entry["batches"].append(dict(key=key, fold=fold_name, max_nodes_per_batch=cap, numpy_seed=9, order_after_shuffle=order))
+            manifest["qm9"].append(entry)
+    finally:
+        shutil.rmtree(tmp)
+
+    # ---- utils.micro_f1 (utils/utils.py:60-74) and the activations it hands out (:36-58) ----
+    rng = np.random.default_rng(21)
+    logits = (2.0 * rng.standard_normal((57, 9))).astype(np.float32)
+    logits[0, :3] = [0.0, 1e-8, -1e-8]                 # sigmoid(0) = 0.5 rounds to 0 (half to even)
+    labels = (rng.random((57, 9)) < 0.35).astype(np.float32)
+    arrays["micro_f1/logits"], arrays["micro_f1/labels"] = logits, labels
+    arrays["micro_f1/value"] = np.asarray(ref_utils.micro_f1(logits, labels))
+    x = np.linspace(-4, 4, 161).astype(np.float32).reshape(7, 23)
+    arrays["activations/x"] = x
+    manifest["activations"] = []
+    for name in ("tanh", "ReLU", "leaky_relu", "elu", "selu", "gelu"):
+        arrays["activations/" + name] = ref_utils.get_activation(name)(x)
+        manifest["activations"].append(name)
+    manifest["constants"] = dict(SMALL_NUMBER=ref_utils.SMALL_NUMBER, BIG_NUMBER=ref_utils.BIG_NUMBER)
+    arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "reference_run_tasks.npz", **arrays)
+    print("tasks: %d arrays" % len(arrays))
+
+
+def main():
+    if not os.path.isdir(REFERENCE):
+        raise SystemExit("make_reference_run.py needs %s (the build container)" % REFERENCE)
+    S.install()
+    sys.path.insert(0, REFERENCE)
+    import gnns
+    run_layers(gnns)
+    run_tasks()
+
+
+if __name__ == "__main__":
+    main()
