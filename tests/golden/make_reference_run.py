@@ -4,6 +4,11 @@ build container over tests/golden/tf_numpy_shim.py and writes what they return a
 
     tests/golden/reference_run_layers.npz   every sparse_*_layer of the reference on seeded small graphs: inputs, the variables
                                             the layer created (by TF variable name), the output it returned
+    tests/golden/reference_run_models.npz   Sparse_Graph_Model.__make_model (sparse_graph_model.py:131-202: task input model, input
+                                            projection, the per-layer driver loop with residuals / inter-layer norm / Dense, every
+                                            model adapter's _apply_gnn_layer, the task's output head and metrics — all but the
+                                            optimizer) of every model class on one reference-built minibatch; the variable
+                                            inventory and the "Model has N parameters." line it logs (README.md:29: 699257)
     tests/golden/reference_run_tasks.npz    PPI_Task.load_data on a synthetic DGL-format directory (written by the same seeded
                                             helper the test re-runs) + its minibatches; QM9_Task.load_data on the committed
                                             256-molecule file + its minibatches; utils.micro_f1 on seeded logits / labels
@@ -94,6 +99,22 @@ LAYER_CASES = [
     ("sparse_rgdcn_layer", "deg", dict(num_channels=4, channel_dim=4, num_timesteps=2, use_full_state_for_channel_weights=True,
                                        tie_channel_weights=True, activation_function="ReLU", message_aggregation_function="mean",
                                        normalize_by_num_incoming=False)),
+    # widths that are not multiples of 4 (the edge kernels move 16-byte pieces; the package pads)
+    ("sparse_gnn_film_layer", "deg", dict(state_dim=15, num_timesteps=1, activation_function="ReLU",
+                                          message_aggregation_function="sum", normalize_by_num_incoming=True)),
+    ("sparse_gnn_edge_mlp_layer", "deg", dict(state_dim=10, num_timesteps=1, activation_function="tanh",
+                                              message_aggregation_function="mean", normalize_by_num_incoming=False,
+                                              use_target_state_as_input=True, num_edge_hidden_layers=1)),
+    ("sparse_gnn_edge_mlp_layer", "deg", dict(state_dim=7, num_timesteps=1, activation_function="ReLU",
+                                              message_aggregation_function="sum", normalize_by_num_incoming=True,
+                                              use_target_state_as_input=True, num_edge_hidden_layers=0)),
+    ("sparse_rgin_layer", None, dict(state_dim=6, num_timesteps=1, activation_function="ReLU", message_aggregation_function="sum",
+                                     use_target_state_as_input=True, num_edge_MLP_hidden_layers=1, num_aggr_MLP_hidden_layers=None)),
+    ("sparse_rgcn_layer", "deg", dict(state_dim=7, num_timesteps=1, activation_function="tanh", message_aggregation_function="sum",
+                                      normalize_by_num_incoming=True, use_both_source_and_target=True)),
+    ("sparse_rgat_layer", None, dict(state_dim=12, num_heads=4, num_timesteps=1, activation_function="tanh")),
+    ("sparse_ggnn_layer", None, dict(state_dim=16, num_timesteps=1, gated_unit_type="gru", activation_function="tanh",
+                                     message_aggregation_function="sqrt_n")),
 ]
 
 
@@ -286,6 +307,177 @@ def run_tasks():
     print("tasks: %d arrays" % len(arrays))
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# whole forward models: the reference's Sparse_Graph_Model.__make_model (everything but the optimizer) on one minibatch
+# ---------------------------------------------------------------------------------------------------------------------------------
+MODEL_CASES = [
+    # (model class, task, task params, model params on top of the class defaults)
+    ("RGCN_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=16, graph_num_layers=3)),
+    ("RGCN_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=True),
+     dict(hidden_size=6, graph_num_layers=5, graph_dense_between_every_num_gnn_layers=2, graph_residual_connection_every_num_layers=2,
+          graph_inter_layer_norm=True, message_aggregation_function="mean", graph_num_timesteps_per_layer=2)),
+    ("GGNN_Model", "QM9", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=True, task_ids=[0]),
+     dict(hidden_size=16, graph_num_layers=2, graph_num_timesteps_per_layer=2)),
+    ("GGNN_Model", "PPI", dict(add_self_loop_edges=False, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=12, graph_num_layers=3, graph_rnn_cell="RNN", message_aggregation_function="max",
+          graph_residual_connection_every_num_layers=2)),
+    ("RGAT_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=16, graph_num_layers=2, num_heads=4)),
+    ("RGIN_Model", "QM9", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=True, task_ids=[3, 7]),
+     dict(hidden_size=16, graph_num_layers=4, graph_num_aggr_MLP_hidden_layers=1, use_target_state_as_input=True)),
+    ("GNN_FiLM_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=16, graph_num_layers=4, graph_layer_input_dropout_keep_prob=1.0)),
+    ("GNN_FiLM_Model", "QM9", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=True, task_ids=[12]),
+     dict(hidden_size=15, graph_num_layers=3, normalize_messages_by_num_incoming=True, graph_inter_layer_norm=True,
+          graph_layer_input_dropout_keep_prob=1.0)),
+    ("GNN_Edge_MLP_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=16, graph_num_layers=3, num_edge_hidden_layers=1, graph_layer_input_dropout_keep_prob=1.0)),
+    ("GNN_Edge_MLP_Model", "QM9", dict(add_self_loop_edges=False, tie_fwd_bkwd_edges=True, task_ids=[0]),
+     dict(hidden_size=16, graph_num_layers=2, num_edge_hidden_layers=0, use_target_state_as_input=False,
+          graph_layer_input_dropout_keep_prob=1.0)),
+    ("RGDCN_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=16, graph_num_layers=2, num_channels=4, channel_dim=4, graph_layer_input_dropout_keep_prob=1.0)),
+]
+
+
+def run_models():
+    from dpu_utils.utils import RichPath
+    import models as ref_models
+    from tasks.ppi_task import PPI_Task
+    from tasks.qm9_task import QM9_Task
+    from tasks.sparse_graph_task import DataFold
+    import tensorflow as tf
+    arrays, manifest = {}, []
+    tmp = tempfile.mkdtemp()
+    try:
+        write_ppi_dir(tmp, 11)
+        shutil.copy(OUT / "qm9_valid_256.jsonl.gz", os.path.join(tmp, "valid.jsonl.gz"))
+        with gzip.open(OUT / "qm9_valid_256.jsonl.gz", "rt") as f, gzip.open(os.path.join(tmp, "train.jsonl.gz"), "wt") as g:
+            for i, line in enumerate(f):
+                if i < 40:
+                    g.write(line)
+        for ci, (model_name, task_name, task_params, model_params) in enumerate(MODEL_CASES):
+            task_cls = PPI_Task if task_name == "PPI" else QM9_Task
+            tp = task_cls.default_params()
+            tp.update(task_params)
+            task = task_cls(tp)
+            stdout, sys.stdout = sys.stdout, io.StringIO()
+            try:
+                task.load_data(RichPath(tmp))
+            finally:
+                sys.stdout = stdout
+            L = task.num_edge_types
+            payload = "target_labels" if task_name == "PPI" else "target_values"
+            ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", payload,
+                                         "out_layer_dropout_keep_prob")}
+            ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(L)]
+            data = list(task._loaded_data[DataFold.VALIDATION])[:30]
+            mb = next(iter(task.make_minibatch_iterator(data, DataFold.VALIDATION, ph, 120 if task_name == "QM9" else 40)))
+            fd = mb.feed_dict
+            S.reset(5000 + ci)
+            # the eager session: every placeholder the reference creates evaluates to the minibatch it would be fed
+            S.FEEDS.update({"initial_node_features": fd[ph["initial_node_features"]],
+                            "type_to_num_incoming_edges": fd[ph["type_to_num_incoming_edges"]],
+                            "graph_nodes_list": fd[ph["graph_nodes_list"]], payload: fd[ph[payload]],
+                            "out_layer_dropout_keep_prob": 1.0, "num_graphs": mb.num_graphs})
+            for l in range(L):
+                S.FEEDS["adjacency_e%s" % l] = fd[ph["adjacency_lists"][l]]
+            model_cls = getattr(ref_models, model_name)
+            mp = model_cls.default_params()
+            mp.update(model_params)
+            model = object.__new__(model_cls)             # (the constructor opens a tf.Session; everything it sets is set here)
+            model.params, model.task, model.run_id, model.result_dir = mp, task, "shim", tmp
+            model._Sparse_Graph_Model__placeholders = {}
+            model._Sparse_Graph_Model__ops = {}
+            model._Sparse_Graph_Model__make_train_step = lambda: None      # the optimizer (sparse_graph_model.py:204-243) is not run
+            stdout, sys.stdout = sys.stdout, io.StringIO()
+            try:
+                model._Sparse_Graph_Model__make_model()                    # sparse_graph_model.py:131-160, the reference's code
+                log = sys.stdout.getvalue()
+            finally:
+                sys.stdout = stdout
+            ops = model._Sparse_Graph_Model__ops
+            key = "model%02d" % ci
+            names = [n for n in S.VARIABLES if n not in S.NON_TRAINABLE]
+            for n in names:
+                arrays["%s/var/%s" % (key, n)] = S.VARIABLES[n]
+            arrays[key + "/features"] = np.asarray(S.FEEDS["initial_node_features"], dtype=np.float32)
+            arrays[key + "/deg"] = np.asarray(S.FEEDS["type_to_num_incoming_edges"], dtype=np.float32)
+            arrays[key + "/graph_nodes_list"] = np.asarray(S.FEEDS["graph_nodes_list"], dtype=np.int32)
+            arrays[key + "/" + payload] = np.asarray(S.FEEDS[payload], dtype=np.float32)
+            for l in range(L):
+                arrays["%s/adj%d" % (key, l)] = np.asarray(S.FEEDS["adjacency_e%s" % l], dtype=np.int32)
+            arrays[key + "/final_node_representations"] = np.asarray(ops["final_node_representations"])
+            metrics = {k: float(np.asarray(v)) for k, v in ops["task_metrics"].items()}
+            for k, v in ops["task_metrics"].items():
+                arrays["%s/metric/%s" % (key, k)] = np.asarray(v)
+            manifest.append(dict(key=key, model=model_name, task=task_name, task_params=tp, model_params=mp, num_edge_types=L,
+                                 num_graphs=int(mb.num_graphs), num_nodes=int(mb.num_nodes), num_edges=int(mb.num_edges), payload=payload,
+                                 variables=names, variable_shapes=[list(S.VARIABLES[n].shape) for n in names],
+                                 logged=log.strip().splitlines(), metrics=metrics,
+                                 total_num_graphs=int(np.asarray(ops["total_num_graphs"]))))
+            print("%-20s %-4s V=%d  %3d variables  %s  metrics %s" % (model_name, task_name, mb.num_nodes, len(names), log.strip(),
+                                                                     {k: round(v, 5) for k, v in metrics.items()}))
+
+        # ---- README.md:29: "Model has 699257 parameters." — the reference's own count for RGCN / PPI at the README's hyper-parameters,
+        #      on a PPI-shaped fold (50 features, 121 labels) ----
+        big = tempfile.mkdtemp()
+        try:
+            rng = np.random.default_rng(3)
+            for name in ("train", "valid"):
+                n = 30
+                links = [{"source": int(rng.integers(0, n)), "target": int(rng.integers(0, n))} for _ in range(60)]
+                with open(os.path.join(big, "%s_graph.json" % name), "w") as f:
+                    json.dump({"links": links}, f)
+                np.save(os.path.join(big, "%s_feats.npy" % name), rng.standard_normal((n, 50)).astype(np.float32))
+                np.save(os.path.join(big, "%s_labels.npy" % name), (rng.random((n, 121)) < 0.3).astype(np.int64))
+                np.save(os.path.join(big, "%s_graph_id.npy" % name), np.zeros(n, np.int64))
+            task = PPI_Task(PPI_Task.default_params())
+            stdout, sys.stdout = sys.stdout, io.StringIO()
+            try:
+                task.load_data(RichPath(big))
+            finally:
+                sys.stdout = stdout
+            ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", "target_labels",
+                                         "out_layer_dropout_keep_prob")}
+            ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(task.num_edge_types)]
+            mb = next(iter(task.make_minibatch_iterator(list(task._loaded_data[DataFold.VALIDATION]), DataFold.VALIDATION, ph, 100)))
+            fd = mb.feed_dict
+            S.reset(1)
+            S.FEEDS.update({"initial_node_features": fd[ph["initial_node_features"]], "type_to_num_incoming_edges": fd[ph["type_to_num_incoming_edges"]],
+                            "graph_nodes_list": fd[ph["graph_nodes_list"]], "target_labels": fd[ph["target_labels"]],
+                            "out_layer_dropout_keep_prob": 1.0, "num_graphs": mb.num_graphs})
+            for l in range(task.num_edge_types):
+                S.FEEDS["adjacency_e%s" % l] = fd[ph["adjacency_lists"][l]]
+            # the hyper-parameters README.md prints next to that count (its "Using the following model params" line; the JSON under
+            # tasks/default_hypers/ has since moved to hidden_size 320 / 4 layers = 1 386 041 parameters)
+            readme = open(os.path.join(REFERENCE, "README.md")).read()
+            line = next(l for l in readme.splitlines() if "Using the following model params:" in l and '"hidden_size": 256' in l)
+            mp = ref_models.RGCN_Model.default_params()
+            mp.update(json.loads(line.split("model params:", 1)[1].strip()))
+            model = object.__new__(ref_models.RGCN_Model)
+            model.params, model.task, model.run_id, model.result_dir = mp, task, "shim", big
+            model._Sparse_Graph_Model__placeholders, model._Sparse_Graph_Model__ops = {}, {}
+            model._Sparse_Graph_Model__make_train_step = lambda: None
+            stdout, sys.stdout = sys.stdout, io.StringIO()
+            try:
+                model._Sparse_Graph_Model__make_model()
+                log = sys.stdout.getvalue().strip()
+            finally:
+                sys.stdout = stdout
+            names = [n for n in S.VARIABLES if n not in S.NON_TRAINABLE]
+            manifest.append(dict(key="readme_rgcn_ppi", model="RGCN_Model", task="PPI", model_params=mp, logged=log.splitlines(),
+                                 variables=names, variable_shapes=[list(S.VARIABLES[n].shape) for n in names]))
+            print("README config:", log)
+        finally:
+            shutil.rmtree(big)
+    finally:
+        shutil.rmtree(tmp)
+    arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "reference_run_models.npz", **arrays)
+
+
 def main():
     if not os.path.isdir(REFERENCE):
         raise SystemExit("make_reference_run.py needs %s (the build container)" % REFERENCE)
@@ -294,6 +486,7 @@ def main():
     import gnns
     run_layers(gnns)
     run_tasks()
+    run_models()
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from oracle import model as M
 from oracle import tf_ops as O
 
 VARIABLES = OrderedDict()          # TF variable name -> float32 array, in creation order
@@ -29,13 +30,40 @@ _scope = []                        # tf.variable_scope stack
 _unique = {}                       # (scope prefix, base name) -> how many handed out
 _rng = [np.random.default_rng(0)]
 PLACEHOLDERS = []
+FEEDS = {}                         # placeholder name -> value: an eager "session" — placeholders evaluate to what is fed
+NON_TRAINABLE = set()
+_keras_uid = {}                    # Keras layer base name -> how many handed out (graph-wide, whatever the scope)
 
 
 def reset(seed: int) -> None:
     VARIABLES.clear()
     _scope.clear()
     _unique.clear()
+    _keras_uid.clear()
+    NON_TRAINABLE.clear()
+    FEEDS.clear()
     _rng[0] = np.random.default_rng(seed)
+
+
+class _Tensor(np.ndarray):
+    """tf.Tensor is immutable: `x += y` REBINDS x.  models/sparse_graph_model.py:181-185 keeps `t = cur` and then does `cur += ...;
+    cur /= 2` — on a plain ndarray that would also change t."""
+
+    def __iadd__(self, other):
+        return np.add(self, other)
+
+    def __isub__(self, other):
+        return np.subtract(self, other)
+
+    def __imul__(self, other):
+        return np.multiply(self, other)
+
+    def __itruediv__(self, other):
+        return np.true_divide(self, np.asarray(other, dtype=self.dtype) if np.isscalar(other) else other)
+
+
+def _t(x):
+    return np.asarray(x).view(_Tensor)
 
 
 def _prefix() -> str:
@@ -55,6 +83,10 @@ def _make(name: str, shape, kind: str) -> np.ndarray:
         return VARIABLES[full]
     shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     r = _rng[0]
+    if kind == "zeros_int64":
+        VARIABLES[full] = np.zeros(shape, np.int64)
+        NON_TRAINABLE.add(full)
+        return VARIABLES[full]
     if kind == "gamma":
         v = 1.0 + 0.1 * r.standard_normal(shape)
     elif kind in ("beta", "bias"):
@@ -71,7 +103,7 @@ class _Dense:
 
     def __init__(self, units, use_bias=True, activation=None, name=None, kernel_initializer=None, **unused):
         self.units, self.use_bias, self.activation = int(units), bool(use_bias), activation
-        self.name = name if name is not None else _unique_name("dense")
+        self.name = name if name is not None else self._default_name()
         self.scope = list(_scope)            # (tf.layers capture the variable scope they were made in; the reference's MLP
         self.kernel = self.bias = None       #  re-enters the same scope at call time, so either rule gives the same names)
 
@@ -84,7 +116,24 @@ class _Dense:
                 self.bias = _make(self.name + "/bias", (self.units,), "bias") if self.use_bias else None
             finally:
                 _scope[:] = saved
-        return O.dense(x, self.kernel, self.bias, self.activation)
+        return _t(O.dense(np.asarray(x), self.kernel, self.bias, self.activation))
+
+    @staticmethod
+    def _default_name():
+        # tf.layers.Dense: its variables live under variable_scope(default_name="dense"), uniquified inside the ENCLOSING variable scope
+        # (utils/utils.py MLP: <name>/dense, <name>/dense_1, ... in every MLP's own scope) [TF-internal]
+        return _unique_name("dense")
+
+
+class _KerasDense(_Dense):
+    @staticmethod
+    def _default_name():
+        # tf.keras.layers.Dense: the layer name is uniquified graph-wide (dense, dense_1, ...) whatever scope it is made in; the
+        # variables then sit under the name scopes open at build time (models/sparse_graph_model.py:166 inside "graph_model",
+        # tasks/ppi_task.py:176 outside: graph_model/dense/kernel and dense_1/kernel) [TF-internal]
+        n = _keras_uid.get("dense", 0)
+        _keras_uid["dense"] = n + 1
+        return "dense" if n == 0 else "dense_%d" % n
 
 
 class _Cell:
@@ -131,7 +180,7 @@ def _layer_norm(x, **unused):
     scope = _unique_name("LayerNorm")
     beta = _make(scope + "/beta", (x.shape[-1],), "beta")        # (tf.contrib creates beta before gamma)
     gamma = _make(scope + "/gamma", (x.shape[-1],), "gamma")
-    return O.layer_norm(x, gamma, beta)
+    return _t(O.layer_norm(np.asarray(x), gamma, beta))
 
 
 @contextlib.contextmanager
@@ -143,15 +192,52 @@ def _variable_scope(name, *unused, **unused_kw):
         _scope.pop()
 
 
-def _get_variable(name=None, shape=None, initializer=None, **unused):
+def _zeros_initializer(*a, **k):
+    return "zeros"
+
+
+def _get_variable(name=None, shape=None, initializer=None, dtype=None, trainable=True, **unused):
+    if initializer is _zeros_initializer and dtype is np.int64:
+        return _make(name, shape, "zeros_int64")
     return _make(name, shape, "kernel")
+
+
+class _Dim:
+    def __init__(self, v):
+        self.value = int(v)
+
+
+class _Var:
+    """What tf.trainable_variables() hands to models/sparse_graph_model.py:155-156 (name, get_shape() -> dims with .value)."""
+
+    def __init__(self, name, array):
+        self.name, self._shape = name + ":0", array.shape
+
+    def get_shape(self):
+        return [_Dim(d) for d in self._shape]
+
+
+def _trainable_variables():
+    return [_Var(n, v) for n, v in VARIABLES.items() if n not in NON_TRAINABLE]
 
 
 def _dropout(x, rate=None, keep_prob=None, **unused):
     r = rate if rate is not None else (None if keep_prob is None else 1.0 - keep_prob)
     if r is None or float(r) != 0.0:
         raise NotImplementedError("the shim runs the reference without dropout (rate must be 0)")
-    return x
+    return _t(x)
+
+
+def _reduce_sum(x, axis=None, **unused):
+    if isinstance(x, (list, tuple)):                       # tf.reduce_sum(list of scalars): packed first (tasks/qm9_task.py:196)
+        x = np.stack([np.asarray(v) for v in x])
+    x = np.asarray(x)
+    return np.sum(x, axis=axis, dtype=x.dtype)
+
+
+def _reduce_mean(x, axis=None, **unused):
+    x = np.asarray(x)
+    return np.mean(x, axis=axis, dtype=x.dtype)
 
 
 def _shape(x, out_type=None, **unused):
@@ -179,6 +265,19 @@ class _Placeholder:
 
     def __repr__(self):
         return "<placeholder %s>" % self.name
+
+
+def _placeholder(dtype=None, shape=None, name=None):
+    """Eager session: a placeholder whose name is in FEEDS IS the fed value, converted to the placeholder's dtype as Session.run
+    converts a feed (QM9's float64 features into a float32 placeholder); otherwise a token."""
+    if name in FEEDS:
+        v = np.asarray(FEEDS[name], dtype=dtype)
+        return _t(v) if v.ndim else v[()]
+    return _Placeholder(dtype, shape, name)
+
+
+def _placeholder_with_default(default, shape=None, name=None):
+    return FEEDS.get(name, default)
 
 
 def _module(name, **attrs):
@@ -240,14 +339,15 @@ def install() -> None:
     nn = _module("tensorflow.nn", embedding_lookup=lambda params, ids, **kw: O.embedding_lookup(params, ids),
                  relu=O.relu, leaky_relu=O.leaky_relu, elu=O.elu, selu=O.selu, dropout=_dropout,
                  sigmoid=lambda x: (np.asarray(1.0, x.dtype) / (np.asarray(1.0, x.dtype) + np.exp(-x))),
-                 sigmoid_cross_entropy_with_logits=None)
+                 sigmoid_cross_entropy_with_logits=lambda labels=None, logits=None, **kw: M.sigmoid_cross_entropy_with_logits(
+                     np.asarray(logits), np.asarray(labels, dtype=np.asarray(logits).dtype)))
     layers = _module("tensorflow.layers", Dense=_Dense)
-    keras_layers = _module("tensorflow.keras.layers", Dense=_Dense, GRUCell=_GRUCell, SimpleRNNCell=_SimpleRNNCell,
+    keras_layers = _module("tensorflow.keras.layers", Dense=_KerasDense, GRUCell=_GRUCell, SimpleRNNCell=_SimpleRNNCell,
                            LSTMCell=_LSTMCell)
     keras = _module("tensorflow.keras", layers=keras_layers)
     contrib = _module("tensorflow.contrib", layers=_module("tensorflow.contrib.layers", layer_norm=_layer_norm))
     initializers = _module("tensorflow.initializers", truncated_normal=lambda **kw: ("truncated_normal", kw))
-    summary = _module("tensorflow.summary", scalar=lambda *a, **k: None)
+    summary = _module("tensorflow.summary", scalar=lambda *a, **k: None, merge_all=lambda *a, **k: None, FileWriter=object)
     tf = _module(
         "tensorflow", Tensor=np.ndarray, Variable=np.ndarray, int32=np.int32, int64=np.int64, float32=np.float32, bool=np.bool_,
         nn=nn, layers=layers, keras=keras, contrib=contrib, initializers=initializers, summary=summary,
@@ -260,11 +360,16 @@ def install() -> None:
         count_nonzero=_count_nonzero, einsum=lambda eq, *ops: np.einsum(eq, *ops),
         unsorted_segment_sum=O.unsorted_segment_sum, unsorted_segment_max=O.unsorted_segment_max,
         unsorted_segment_mean=O.unsorted_segment_mean, unsorted_segment_sqrt_n=O.unsorted_segment_sqrt_n,
-        variable_scope=_variable_scope, get_variable=_get_variable, placeholder=_Placeholder)
+        variable_scope=_variable_scope, get_variable=_get_variable, placeholder=_placeholder,
+        placeholder_with_default=_placeholder_with_default, zeros_initializer=_zeros_initializer,
+        zeros_like=lambda x, **kw: _t(np.zeros_like(np.asarray(x))), reduce_sum=_reduce_sum, reduce_mean=_reduce_mean,
+        abs=np.abs, square=np.square, squeeze=lambda x, **kw: np.squeeze(np.asarray(x)),
+        assign_add=lambda ref, value, **kw: ref + value, trainable_variables=_trainable_variables)
     sys.modules["tensorflow"] = tf
     for m in (nn, layers, keras, keras_layers, contrib, initializers, summary):
         sys.modules[m.__name__] = m
-    dpu_utils = _module("dpu_utils.utils", RichPath=RichPath, LocalPath=RichPath)
+    dpu_utils = _module("dpu_utils.utils", RichPath=RichPath, LocalPath=RichPath,
+                        ThreadedIterator=lambda it, *a, **k: iter(it))          # (imported by models/sparse_graph_model.py; never used here)
     tfutils = _module("dpu_utils.tfutils", unsorted_segment_log_softmax=O.unsorted_segment_log_softmax)
 
     def _not_available(*a, **k):

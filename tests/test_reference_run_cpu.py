@@ -243,3 +243,88 @@ def test_micro_f1_and_activation_table_are_the_reference_s():
     x = z["activations/x"]
     for name in manifest["activations"]:
         np.testing.assert_array_equal(T.apply_act(T.get_activation(name), x), z["activations/" + name])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# whole forward models: Sparse_Graph_Model.__make_model of the reference (all but the optimizer) on one minibatch
+# ------------------------------------------------------------------------------------------------------------------------------
+def model_cases():
+    z, manifest = _load("reference_run_models.npz")
+    return z, [m for m in manifest if m["key"].startswith("model")], next(m for m in manifest if m["key"] == "readme_rgcn_ppi")
+
+
+def build_product_task(entry, tmp_path):
+    """The package's task with the fixture's task parameters and the metadata the reference's loader derived from the same files."""
+    import gzip
+    from make_reference_run import write_ppi_dir
+    from tf_gnn_samples_amd.tasks import PPI_Task, QM9_Task
+    cls = PPI_Task if entry["task"] == "PPI" else QM9_Task
+    p = cls.default_params()
+    p.update({k: v for k, v in entry["task_params"].items() if k in p})
+    task = cls(p)
+    if entry["task"] == "PPI":
+        write_ppi_dir(str(tmp_path), 11)
+        task.load_data(str(tmp_path))
+    else:
+        with gzip.open(GOLDEN / "qm9_valid_256.jsonl.gz", "rt") as f:
+            raw = [json.loads(line) for line in f]
+        task.load_raw(raw[:40])
+        task.load_raw(raw)
+    assert task.num_edge_types == entry["num_edge_types"]
+    return task
+
+
+def build_product_model(entry, task, device):
+    from tf_gnn_samples_amd import models
+    cls = getattr(models, entry["model"])
+    p = cls.default_params()
+    p.update(entry["model_params"])
+    return cls(p, task, device=device)
+
+
+MODEL_Z, MODEL_CASES, README_CASE = model_cases()
+
+
+@pytest.mark.parametrize("i", range(len(MODEL_CASES)), ids=["%s-%s-%d" % (m["model"], m["task"], n) for n, m in enumerate(MODEL_CASES)])
+def test_model_variable_inventory_is_the_reference_s(tmp_path, capsys, i):
+    """Names (TF variable names incl. the graph-wide dense / dense_1 numbering and the per-scope LayerNorm / MLP numbering), shapes,
+    creation order and the logged parameter count of every model class, as the reference's own __make_model produced them."""
+    entry = MODEL_CASES[i]
+    task = build_product_task(entry, tmp_path)
+    model = build_product_model(entry, task, "cpu")
+    names = model.variables.names()
+    # (creation order is not part of the contract — checkpoints are dictionaries by name, sparse_graph_model.py:90-126 — and differs
+    #  where TF builds a layer at its first call: e.g. RGAT's attention parameters exist before any Dense kernel)
+    assert {n: list(model.variables[n].shape) for n in names} == dict(zip(entry["variables"], entry["variable_shapes"]))
+    assert len(names) == len(entry["variables"])
+    logged = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Model has")]
+    assert logged == [l for l in entry["logged"] if l.startswith("Model has")]
+
+
+def test_readme_parameter_count_comes_out_of_the_reference_s_own_code(tmp_path, capsys):
+    """README.md:29 'Model has 699257 parameters.': logged by the reference's __make_model run over the shim at the README's
+    hyper-parameters — a known answer of the reference that the shim's variable bookkeeping has to reproduce — and by the package."""
+    from oracle import model as OM
+    assert README_CASE["logged"] == ["Model has 699257 parameters."]
+    assert OM.rgcn_ppi_num_parameters() == 699257
+    shapes = dict(zip(README_CASE["variables"], README_CASE["variable_shapes"]))
+    assert shapes["graph_model/dense/kernel"] == [50, 256] and shapes["dense_1/kernel"] == [256, 121]
+    assert "graph_model/gnn_layer_0/Dense/kernel" in shapes and "graph_model/gnn_layer_1/Dense/kernel" not in shapes
+
+
+@pytest.mark.parametrize("i", [n for n, m in enumerate(MODEL_CASES) if m["model"] == "RGCN_Model"])
+def test_oracle_driver_loop_and_ppi_head_are_the_reference_s(i):
+    from oracle import model as OM
+    entry, z = MODEL_CASES[i], MODEL_Z
+    k = entry["key"]
+    W = {n[len("graph_model/"):]: z["%s/var/%s" % (k, n)] for n in entry["variables"] if n.startswith("graph_model/")}
+    adj = [z["%s/adj%d" % (k, l)] for l in range(entry["num_edge_types"])]
+    final = OM.graph_propagation(z[k + "/features"], adj, z[k + "/deg"], entry["model_params"], W, OM.rgcn_apply(entry["model_params"]))
+    want = z[k + "/final_node_representations"]
+    np.testing.assert_allclose(final, want, rtol=0, atol=2e-7 * max(1.0, float(np.abs(want).max())))
+    # the head is the graph's second unnamed Keras Dense (dense_1) when there is an input projection, the first (dense) when
+    # hidden_size equals the feature size (sparse_graph_model.py:165-172)
+    head = "dense_1" if "graph_model/dense/kernel" in entry["variables"] else "dense"
+    assert (head == "dense") == (entry["model_params"]["hidden_size"] == z[k + "/features"].shape[1])
+    loss, _ = OM.ppi_head_loss(final, z[k + "/target_labels"], z["%s/var/%s/kernel" % (k, head)], z["%s/var/%s/bias" % (k, head)])
+    assert abs(float(loss) - float(z[k + "/metric/loss"])) <= 1e-6 * abs(float(z[k + "/metric/loss"]))

@@ -397,6 +397,12 @@ class _FusedEdgeMessages(torch.autograd.Function):
 def film_messages_reduce(T, film, graph, w, aggregation: str, activation: Optional[str], pairs=None):
     """gnns/gnn_film.py:92-116 in one kernel (sum / mean / sqrt_n; max forward only).  With `pairs`
     (graph.PairTables) T is [P_s, D] and film [P_t, 2D]: rows for the non-empty (node,type) buckets only."""
+    D = T.shape[1]
+    pad = (-D) % 4
+    if pad:                                       # [gamma | beta] halves padded separately (see _pad_columns)
+        film = torch.nn.functional.pad(film.reshape(film.shape[0], 2, D), (0, pad)).reshape(film.shape[0], 2 * (D + pad))
+        return _FusedEdgeMessages.apply(_pad_columns(T, pad), film, graph, w, aggregation_mode_id(aggregation),
+                                        activation_id(activation), "film", pairs)[:, :D]
     return _FusedEdgeMessages.apply(T, film, graph, w, aggregation_mode_id(aggregation), activation_id(activation),
                                     "film", pairs)
 
@@ -600,6 +606,11 @@ def typed_linear(H, side, weights):
 
 
 def pair_messages_reduce_fused(P, Q, graph, w, aggregation: str, activation: Optional[str]):
+    D = P.shape[1]
+    pad = (-D) % 4
+    if pad:
+        return _FusedEdgeMessages.apply(_pad_columns(P, pad), _pad_columns(Q, pad), graph, w, aggregation_mode_id(aggregation),
+                                        activation_id(activation), "pair")[:, :D]
     return _FusedEdgeMessages.apply(P, Q, graph, w, aggregation_mode_id(aggregation), activation_id(activation), "pair")
 
 
@@ -653,7 +664,18 @@ class _PairMaterialize(torch.autograd.Function):
         return gP, gQ, None, None
 
 
+def _pad_columns(X, pad: int):
+    """[rows, D] -> [rows, D + pad] with zero columns: the edge kernels move 16-byte pieces of a row (D % 4 == 0).  A width the
+    reference accepts and they do not (hidden_size 15) runs on padded tables: every message activation maps 0 to 0, so the padded
+    columns stay 0 through product, scale, activation and every aggregation, and are cut off again (differentiable: F.pad / slice)."""
+    return torch.nn.functional.pad(X, (0, pad)) if X is not None else None
+
+
 def pair_materialize(P, Q, graph, activation: Optional[str]):
+    D = P.shape[1]
+    pad = (-D) % 4
+    if pad:
+        return _PairMaterialize.apply(_pad_columns(P, pad), _pad_columns(Q, pad), graph, activation_id(activation))[:, :D]
     return _PairMaterialize.apply(P, Q, graph, activation_id(activation))
 
 
