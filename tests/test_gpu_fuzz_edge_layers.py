@@ -24,12 +24,14 @@ def _random_graph(rng, V, L):
     return adj, degree_table(adj, V)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(30))
 def test_random_film_and_edge_mlp_layers(gpu_device, seed):
     from tf_gnn_samples_amd.gnns import sparse_gnn_edge_mlp_layer, sparse_gnn_film_layer
     from tf_gnn_samples_amd.graph import clear_graph_cache
     rng = np.random.default_rng(9000 + seed)
     D = int(rng.choice([32, 64, 128, 192, 256, 320, 512]))
+    if seed >= 24:           # widths the reference accepts and the edge kernels (16-byte row pieces) take on padded tables
+        D = int(rng.choice([15, 30, 70, 130]))
     V, L = int(rng.integers(40, 260)), int(rng.integers(1, 6))
     act = ACTS[int(rng.integers(0, len(ACTS)))]
     agg = str(rng.choice(["sum", "mean", "sqrt_n", "max"]))
