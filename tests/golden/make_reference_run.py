@@ -474,6 +474,35 @@ def run_models():
             shutil.rmtree(big)
     finally:
         shutil.rmtree(tmp)
+    # ---- default hyper-parameters of every model / task class, model.name(params), and the name tables of utils/model_utils.py ----
+    from utils import model_utils
+    defaults = dict(models={}, tasks={}, model_names={}, task_names={}, display_names={})
+    for cls_name in ("GGNN_Model", "GNN_Edge_MLP_Model", "GNN_FiLM_Model", "RGAT_Model", "RGCN_Model", "RGDCN_Model", "RGIN_Model"):
+        cls = getattr(ref_models, cls_name)
+        defaults["models"][cls_name] = cls.default_params()
+        defaults["display_names"][cls_name] = cls.name(cls.default_params())
+    for cls in (PPI_Task, QM9_Task):
+        defaults["tasks"][cls.__name__] = dict(params=cls.default_params(), name=cls.name(), data_path=cls.default_data_path())
+    for n in ("ggnn", "GGNN_Model", "gnn_edge_mlp", "GNN-Edge-MLP", "gnn_edge_mlp0", "GNN-Edge-MLP0", "gnn_edge_mlp1", "gnn-edge-mlp1",
+              "gnn_edge_mlp1_model", "gnn_film", "GNN-FiLM", "gnn_film_model", "rgat", "RGAT_Model", "rgcn", "rgcn_model", "rgdcn", "rgin",
+              "RGIN_model", "not_a_model"):
+        try:
+            cls, extra = model_utils.name_to_model_class(n)
+            defaults["model_names"][n] = [cls.__name__, extra]
+        except ValueError as e:
+            defaults["model_names"][n] = ["ValueError", str(e)]
+    for n in ("qm9", "QM9", "ppi", "PPI", "not_a_task"):
+        try:
+            cls, extra = model_utils.name_to_task_class(n)
+            defaults["task_names"][n] = [cls.__name__, extra]
+        except ValueError as e:
+            defaults["task_names"][n] = ["ValueError", str(e)]
+    hypers = {}
+    for f in sorted(os.listdir(os.path.join(REFERENCE, "tasks/default_hypers"))):
+        if f.startswith(("PPI_", "QM9_")):
+            hypers[f] = json.load(open(os.path.join(REFERENCE, "tasks/default_hypers", f)))
+    defaults["default_hypers"] = hypers
+    manifest.append(dict(key="defaults", **defaults))
     arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
     np.savez_compressed(OUT / "reference_run_models.npz", **arrays)
 

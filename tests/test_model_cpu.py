@@ -55,7 +55,7 @@ def test_registries_and_unknown_names():
     assert name_to_model_class("RGCN")[0].__name__ == "RGCN_Model"
     assert name_to_model_class("GNN-Edge-MLP0")[1] == {'num_edge_hidden_layers': 0}
     assert name_to_model_class("rgdcn")[0].__name__ == "RGDCN_Model"
-    assert name_to_task_class("qm9").__name__ == "QM9_Task"
+    assert name_to_task_class("qm9")[0].__name__ == "QM9_Task" and name_to_task_class("PPI")[1] == {}      # (class, extra params) as the reference
     with pytest.raises(ValueError):
         name_to_model_class("GCN")
     with pytest.raises(ValueError):

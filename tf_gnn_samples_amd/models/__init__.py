@@ -4,24 +4,32 @@ from .sparse_graph_model import Sparse_Graph_Model
 
 globals().update(ADAPTER_CLASSES)     # RGCN_Model, GGNN_Model, RGAT_Model, RGIN_Model, GNN_FiLM_Model, GNN_Edge_MLP_Model, RGDCN_Model
 
-# name lookup of the reference's CLI (utils/model_utils.py:32-55), lower-cased; "-"/"_" interchangeable
+# name lookup of the reference's CLI (utils/model_utils.py:32-57): exactly its accepted spellings (lower-cased first), its
+# parameter overrides and its error text — tests/test_reference_run_cpu.py compares with the table the reference's own function returns
 MODEL_CLASSES = {
     "ggnn": ADAPTER_CLASSES["GGNN_Model"], "gnn_edge_mlp": ADAPTER_CLASSES["GNN_Edge_MLP_Model"],
     "gnn_film": ADAPTER_CLASSES["GNN_FiLM_Model"], "rgat": ADAPTER_CLASSES["RGAT_Model"],
     "rgcn": ADAPTER_CLASSES["RGCN_Model"], "rgdcn": ADAPTER_CLASSES["RGDCN_Model"], "rgin": ADAPTER_CLASSES["RGIN_Model"],
 }
+_MODEL_NAMES = {
+    "ggnn": ("ggnn", {}), "ggnn_model": ("ggnn", {}),
+    "gnn_edge_mlp": ("gnn_edge_mlp", {}), "gnn-edge-mlp": ("gnn_edge_mlp", {}), "gnn_edge_mlp_model": ("gnn_edge_mlp", {}),
+    "gnn_edge_mlp0": ("gnn_edge_mlp", {'num_edge_hidden_layers': 0}), "gnn-edge-mlp0": ("gnn_edge_mlp", {'num_edge_hidden_layers': 0}),
+    "gnn_edge_mlp0_model": ("gnn_edge_mlp", {'num_edge_hidden_layers': 0}),
+    "gnn_edge_mlp1": ("gnn_edge_mlp", {'num_edge_hidden_layers': 1}), "gnn-edge-mlp1": ("gnn_edge_mlp", {'num_edge_hidden_layers': 1}),
+    "gnn_edge_mlp1_model": ("gnn_edge_mlp", {'num_edge_hidden_layers': 1}),
+    "gnn_film": ("gnn_film", {}), "gnn-film": ("gnn_film", {}), "gnn_film_model": ("gnn_film", {}),
+    "rgat": ("rgat", {}), "rgat_model": ("rgat", {}), "rgcn": ("rgcn", {}), "rgcn_model": ("rgcn", {}),
+    "rgdcn": ("rgdcn", {}), "rgdcn_model": ("rgdcn", {}), "rgin": ("rgin", {}), "rgin_model": ("rgin", {}),
+}
 
 
 def name_to_model_class(name: str):
     """-> (class, extra default overrides).  'GNN-Edge-MLP0' / 'GNN-Edge-MLP1' select the number of hidden layers."""
-    key = name.lower().replace("-", "_")
-    extra = {}
-    if key in ("gnn_edge_mlp0", "gnn_edge_mlp1"):
-        extra = {'num_edge_hidden_layers': int(key[-1])}
-        key = "gnn_edge_mlp"
-    if key not in MODEL_CLASSES:
-        raise ValueError("Unknown model '%s'!" % name)
-    return MODEL_CLASSES[key], extra
+    entry = _MODEL_NAMES.get(name.lower())
+    if entry is None:
+        raise ValueError("Unknown model type '%s'" % name.lower())
+    return MODEL_CLASSES[entry[0]], dict(entry[1])
 
 
 __all__ = ["Sparse_Graph_Model", "MODEL_CLASSES", "name_to_model_class"] + sorted(ADAPTER_CLASSES)

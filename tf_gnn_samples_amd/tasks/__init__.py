@@ -6,7 +6,8 @@ TASK_CLASSES = {"ppi": PPI_Task, "qm9": QM9_Task}   # utils/model_utils.py:12-29
 
 
 def name_to_task_class(name: str):
+    """-> (class, extra task parameters), utils/model_utils.py:12-29 (the citation / VarMisuse names are unknown here)."""
     key = name.lower()
     if key not in TASK_CLASSES:
-        raise ValueError("Unknown task type '%s'" % name)
-    return TASK_CLASSES[key]
+        raise ValueError("Unknown task type '%s'" % key)
+    return TASK_CLASSES[key], {}
