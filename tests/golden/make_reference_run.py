@@ -302,6 +302,20 @@ def run_tasks():
         arrays["activations/" + name] = ref_utils.get_activation(name)(x)
         manifest["activations"].append(name)
     manifest["constants"] = dict(SMALL_NUMBER=ref_utils.SMALL_NUMBER, BIG_NUMBER=ref_utils.BIG_NUMBER)
+    # ---- what the reference raises for names it does not know (utils/utils.py:19-20, 33-34, 57-58) and what it maps to "no activation"
+    errors = {}
+    for fn_name, args in (("get_activation", ("swish",)), ("get_aggregation_function", ("median",)), ("get_aggregation_function", (None,)),
+                          ("get_gated_unit", (8, "xyz", "tanh"))):
+        try:
+            getattr(ref_utils, fn_name)(*args)
+            errors["%s%r" % (fn_name, args)] = None
+        except Exception as e:                                   # noqa: BLE001 (the TYPE is part of what is recorded)
+            errors["%s%r" % (fn_name, args)] = [type(e).__name__, str(e)]
+    manifest["errors"] = errors
+    manifest["no_activation"] = [n for n in (None, "linear", "LINEAR", "Linear") if ref_utils.get_activation(n) is None]
+    manifest["aggregation_aliases"] = {n: ref_utils.get_aggregation_function(n).__name__ for n in
+                                       ("sum", "unsorted_segment_sum", "max", "unsorted_segment_max", "mean", "unsorted_segment_mean",
+                                        "sqrt_n", "unsorted_segment_sqrt_n")}
     arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
     np.savez_compressed(OUT / "reference_run_tasks.npz", **arrays)
     print("tasks: %d arrays" % len(arrays))

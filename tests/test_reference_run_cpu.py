@@ -362,3 +362,30 @@ def test_default_hyper_parameters_and_name_tables_are_the_reference_s():
         else:
             cls, got_extra = tasks.name_to_task_class(name)
             assert cls.__name__ == cls_name and got_extra == extra, name
+
+
+def test_unknown_names_raise_what_the_reference_raises():
+    """utils/utils.py:19-20, 33-34, 57-58 executed: exception types and texts, the spellings of 'no activation', the aliases of the
+    aggregation functions — in the package's utils and in the op layer that picks the kernels."""
+    import torch
+    from tf_gnn_samples_amd import ops, utils
+    _, manifest = _load("reference_run_tasks.npz")
+    e = manifest["errors"]
+    with pytest.raises(ValueError) as err:
+        utils.get_activation("swish")
+    assert [type(err.value).__name__, str(err.value)] == e["get_activation('swish',)"]
+    for arg, key in (("median", "get_aggregation_function('median',)"), (None, "get_aggregation_function(None,)")):
+        with pytest.raises(ValueError) as err:
+            utils.get_aggregation_function(arg)
+        assert [type(err.value).__name__, str(err.value)] == e[key]
+        with pytest.raises(ValueError) as err:
+            ops.aggregation_mode_id(arg)
+        assert str(err.value) == e[key][1]
+    with pytest.raises(Exception) as err:
+        utils.get_gated_unit(8, "xyz", "tanh", {})
+    assert type(err.value) is Exception and str(err.value) == e["get_gated_unit(8, 'xyz', 'tanh')"][1]
+    for n in manifest["no_activation"]:
+        assert utils.get_activation(n) is None
+    for alias, fn in manifest["aggregation_aliases"].items():
+        assert ops.aggregation_mode_id(alias) == ops.aggregation_mode_id(fn.replace("unsorted_segment_", ""))
+        assert utils.get_aggregation_function(alias).__name__ == fn
