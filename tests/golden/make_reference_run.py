@@ -9,6 +9,11 @@ build container over tests/golden/tf_numpy_shim.py and writes what they return a
                                             model adapter's _apply_gnn_layer, the task's output head and metrics — all but the
                                             optimizer) of every model class on one reference-built minibatch; the variable
                                             inventory and the "Model has N parameters." line it logs (README.md:29: 699257)
+    tests/golden/reference_run_autograd.npz the same sources on float64 torch tensors (tf_torch_shim.py): d loss / d (node states, every
+                                            variable) of every layer case, and __make_model INCLUDING __make_train_step
+                                            (sparse_graph_model.py:227-260: compute_gradients, per-variable clip_by_norm, the
+                                            selected optimizer, the learning-rate normalisation) run twice on one minibatch:
+                                            losses, raw and clipped gradients, every variable after each step
     tests/golden/reference_run_tasks.npz    PPI_Task.load_data on a synthetic DGL-format directory (written by the same seeded
                                             helper the test re-runs) + its minibatches; QM9_Task.load_data on the committed
                                             256-molecule file + its minibatches; utils.micro_f1 on seeded logits / labels
@@ -27,6 +32,7 @@ import os
 import shutil
 import sys
 import tempfile
+import types
 from pathlib import Path
 
 import numpy as np
@@ -521,6 +527,152 @@ def run_models():
     np.savez_compressed(OUT / "reference_run_models.npz", **arrays)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the same reference sources under torch.autograd (tf_torch_shim.py): gradients of the layers, and __make_train_step end to end
+# ---------------------------------------------------------------------------------------------------------------------------------
+TRAIN_CASES = [
+    ("RGCN_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=16, graph_num_layers=3)),                                                        # Adam (the default)
+    ("GGNN_Model", "QM9", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=True, task_ids=[0]),
+     dict(hidden_size=16, graph_num_layers=2, optimizer="RMSProp", lr_for_num_graphs_per_batch=4, learning_rate=0.002)),
+    ("GNN_FiLM_Model", "PPI", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=False),
+     dict(hidden_size=16, graph_num_layers=2, optimizer="SGD", learning_rate=0.05, clamp_gradient_norm=0.5,
+          graph_layer_input_dropout_keep_prob=1.0)),
+    ("RGIN_Model", "QM9", dict(add_self_loop_edges=True, tie_fwd_bkwd_edges=True, task_ids=[3, 7]),
+     dict(hidden_size=16, graph_num_layers=2, optimizer="adam", learning_rate=0.002, clamp_gradient_norm=0.05,
+          lr_for_num_graphs_per_batch=12, graph_layer_input_dropout_keep_prob=1.0)),
+]
+
+
+def _purge_reference_modules():
+    for name in list(sys.modules):
+        if name.split(".")[0] in ("gnns", "utils", "tasks", "models"):
+            del sys.modules[name]
+
+
+def run_autograd():
+    import torch
+    import tf_torch_shim as TS
+    layers_np = np.load(OUT / "reference_run_layers.npz")
+    _purge_reference_modules()
+    TS.install()
+    import gnns
+    import models as ref_models
+    from dpu_utils.utils import RichPath
+    from tasks.ppi_task import PPI_Task
+    from tasks.qm9_task import QM9_Task
+    from tasks.sparse_graph_task import DataFold
+    arrays, manifest = {}, dict(layers=[], train=[])
+    # ---- A. gradients of every layer case: loss = sum(out * cotangent), d loss / d (node states, every variable) ----
+    for i, (fn_name, second, kw) in enumerate(LAYER_CASES):
+        V, D, L = 37, 16, 3
+        rng, adj, deg = small_graph(100 + i, V, L, [90, "self", 25] if i % 2 == 0 else [60, 0, 41])
+        h = np.tanh(rng.standard_normal((V, D))).astype(np.float32)
+        TS.reset(1000 + i)
+        ht = torch.tensor(h.astype(np.float64), requires_grad=True)
+        adj_t = [torch.as_tensor(a.astype(np.int64)) for a in adj]
+        deg_t = torch.as_tensor(deg.astype(np.float64))
+        fn = getattr(gnns, fn_name)
+        if fn_name == "sparse_rgdcn_layer":
+            out = fn(ht, adj_t, deg_t, **kw)
+        else:
+            kw2 = dict(kw)
+            state_dim = kw2.pop("state_dim")
+            out = fn(ht, adj_t, deg_t, state_dim, **kw2) if second == "deg" else fn(ht, adj_t, state_dim, **kw2)
+        key = "case%02d" % i
+        want = layers_np[key + "/out"]
+        assert np.abs(out.detach().numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (fn_name, "float64 torch run vs float32 NumPy run")
+        names = [n for n in TS.TVARS]
+        assert names == [n for n in json.loads(bytes(layers_np["manifest"]).decode())[i]["variables"]], fn_name
+        cot = np.random.default_rng(7000 + i).standard_normal(tuple(out.shape))
+        loss = (out * torch.as_tensor(cot)).sum()
+        grads = torch.autograd.grad(loss, [ht] + [TS.TVARS[n] for n in names], allow_unused=True)
+        arrays[key + "/out64"], arrays[key + "/cotangent"] = out.detach().numpy(), cot
+        arrays[key + "/grad/h"] = grads[0].numpy()
+        for n, g in zip(names, grads[1:]):
+            arrays["%s/grad/var/%s" % (key, n)] = np.zeros(tuple(TS.TVARS[n].shape)) if g is None else g.numpy()
+        manifest["layers"].append(dict(key=key, function=fn_name, variables=names, unused=[n for n, g in zip(names, grads[1:]) if g is None]))
+    print("autograd: %d layer cases" % len(LAYER_CASES))
+
+    # ---- B. the reference's own train step: __make_model INCLUDING __make_train_step, twice on the same minibatch ----
+    tmp = tempfile.mkdtemp()
+    try:
+        write_ppi_dir(tmp, 11)
+        shutil.copy(OUT / "qm9_valid_256.jsonl.gz", os.path.join(tmp, "valid.jsonl.gz"))
+        with gzip.open(OUT / "qm9_valid_256.jsonl.gz", "rt") as f, gzip.open(os.path.join(tmp, "train.jsonl.gz"), "wt") as g:
+            for i, line in enumerate(f):
+                if i < 40:
+                    g.write(line)
+        for ci, (model_name, task_name, task_params, model_params) in enumerate(TRAIN_CASES):
+            task_cls = PPI_Task if task_name == "PPI" else QM9_Task
+            tp = task_cls.default_params()
+            tp.update(task_params)
+            task = task_cls(tp)
+            stdout, sys.stdout = sys.stdout, io.StringIO()
+            try:
+                task.load_data(RichPath(tmp))
+            finally:
+                sys.stdout = stdout
+            L = task.num_edge_types
+            payload = "target_labels" if task_name == "PPI" else "target_values"
+            ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", payload,
+                                         "out_layer_dropout_keep_prob")}
+            ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(L)]
+            data = list(task._loaded_data[DataFold.VALIDATION])[:30]
+            mb = next(iter(task.make_minibatch_iterator(data, DataFold.VALIDATION, ph, 120 if task_name == "QM9" else 40)))
+            fd = mb.feed_dict
+            TS.reset(9000 + ci)
+            feeds = {"initial_node_features": fd[ph["initial_node_features"]], "type_to_num_incoming_edges": fd[ph["type_to_num_incoming_edges"]],
+                     "graph_nodes_list": fd[ph["graph_nodes_list"]], payload: fd[ph[payload]], "out_layer_dropout_keep_prob": 1.0,
+                     "num_graphs": mb.num_graphs}
+            for l in range(L):
+                feeds["adjacency_e%s" % l] = fd[ph["adjacency_lists"][l]]
+            model_cls = getattr(ref_models, model_name)
+            mp = model_cls.default_params()
+            mp.update(model_params)
+            key = "train%02d" % ci
+            steps = []
+            for step in range(2):
+                TS.new_graph()
+                TS.N.FEEDS.clear()
+                TS.N.FEEDS.update(feeds)
+                model = object.__new__(model_cls)
+                model.params, model.task, model.run_id, model.result_dir = mp, task, "shim", tmp
+                model._Sparse_Graph_Model__placeholders, model._Sparse_Graph_Model__ops = {}, {}
+                model.sess = types.SimpleNamespace(graph=types.SimpleNamespace(get_collection=lambda which: TS.trainable()))
+                stdout, sys.stdout = sys.stdout, io.StringIO()
+                try:
+                    model._Sparse_Graph_Model__make_model()          # sparse_graph_model.py:131-160 AND :227-260: the update is applied
+                finally:
+                    sys.stdout = stdout
+                ls = TS.LAST_STEP
+                names = [n for n in TS.TVARS if n not in TS.N.NON_TRAINABLE]
+                for n in names:
+                    raw, app = ls["raw_gradients"][n], ls["applied_gradients"][n]
+                    arrays["%s/step%d/raw_gradient/%s" % (key, step, n)] = np.zeros(tuple(TS.TVARS[n].shape)) if raw is None else raw.numpy()
+                    arrays["%s/step%d/applied_gradient/%s" % (key, step, n)] = np.zeros(tuple(TS.TVARS[n].shape)) if app is None else app.numpy()
+                    arrays["%s/step%d/variable_after/%s" % (key, step, n)] = TS.TVARS[n].detach().numpy().copy()
+                steps.append(dict(loss=ls["loss"], learning_rate=ls["learning_rate"], optimizer=ls["optimizer"],
+                                  without_gradient=[n for n in names if ls["raw_gradients"][n] is None]))
+            for n in names:
+                arrays["%s/initial/%s" % (key, n)] = TS.N.VARIABLES[n]
+            arrays[key + "/features"] = np.asarray(feeds["initial_node_features"], dtype=np.float32)
+            arrays[key + "/deg"] = np.asarray(feeds["type_to_num_incoming_edges"], dtype=np.float32)
+            arrays[key + "/graph_nodes_list"] = np.asarray(feeds["graph_nodes_list"], dtype=np.int32)
+            arrays[key + "/" + payload] = np.asarray(feeds[payload], dtype=np.float32)
+            for l in range(L):
+                arrays["%s/adj%d" % (key, l)] = np.asarray(feeds["adjacency_e%s" % l], dtype=np.int32)
+            manifest["train"].append(dict(key=key, model=model_name, task=task_name, task_params=tp, model_params=mp, num_edge_types=L,
+                                          num_graphs=int(mb.num_graphs), num_nodes=int(mb.num_nodes), num_edges=int(mb.num_edges),
+                                          payload=payload, variables=names, steps=steps))
+            print("%-16s %-4s %-18s lr %.6f  loss %.6f -> %.6f" % (model_name, task_name, steps[0]["optimizer"], steps[0]["learning_rate"],
+                                                                  steps[0]["loss"], steps[1]["loss"]))
+    finally:
+        shutil.rmtree(tmp)
+    arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "reference_run_autograd.npz", **arrays)
+
+
 def main():
     if not os.path.isdir(REFERENCE):
         raise SystemExit("make_reference_run.py needs %s (the build container)" % REFERENCE)
@@ -530,6 +682,7 @@ def main():
     run_layers(gnns)
     run_tasks()
     run_models()
+    run_autograd()
 
 
 if __name__ == "__main__":

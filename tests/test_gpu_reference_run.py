@@ -57,3 +57,84 @@ def test_hip_models_reproduce_the_reference_s_forward_model(gpu_device, tmp_path
         got = float(metrics[name])
         tol = 1e-6 if name == "f1_score" else 2e-5 * max(1.0, abs(value), scale * (entry["num_nodes"] if "total" in name or "abs_err" in name else 1))
         assert abs(got - value) <= tol, (name, got, value)
+
+
+from test_reference_run_cpu import AUTOGRAD, AUTOGRAD_Z, NON_SMOOTH  # noqa: E402
+
+
+@pytest.mark.parametrize("i", range(len(CASES)), ids=["%s-%d" % (c[0]["function"], n) for n, c in enumerate(CASES)])
+def test_hip_backward_reproduces_the_gradients_of_the_reference_s_own_code(gpu_device, i):
+    """d sum(out * cotangent) / d (node states, every variable) through the HIP backward kernels against the float64 gradients of the
+    reference's layer functions run under torch.autograd (tests/golden/tf_torch_shim.py)."""
+    from tf_gnn_samples_amd import gnns
+    case, h, adj, deg, weights, _ = CASES[i]
+    k, z = case["key"], AUTOGRAD_Z
+    hd = torch.tensor(h, device=gpu_device, requires_grad=True)
+    wd = {n: torch.tensor(v, device=gpu_device, requires_grad=True) for n, v in weights.items()}
+    kw = dict(case["kwargs"])
+    fn = getattr(gnns, case["function"])
+    adj_d = [torch.as_tensor(a, device=gpu_device) for a in adj]
+    deg_d = torch.as_tensor(deg, device=gpu_device)
+    if case["function"] == "sparse_rgdcn_layer":
+        out = fn(hd, adj_d, deg_d, weights=wd, **kw)
+    else:
+        state_dim = kw.pop("state_dim")
+        out = fn(hd, adj_d, deg_d, state_dim, weights=wd, **kw) if case["takes_degrees"] else fn(hd, adj_d, state_dim, weights=wd, **kw)
+    cot = torch.as_tensor(z[k + "/cotangent"].astype(np.float32), device=gpu_device)
+    (out * cot).sum().backward()
+    # a ReLU-like kink: one message whose float32 pre-activation has the other sign than the float64 one moves a whole gradient row;
+    # those cases are held to a norm-wise bar, the smooth ones element-wise
+    smooth = str(case["kwargs"].get("activation_function")).lower() not in NON_SMOOTH and case["function"] != "sparse_rgat_layer" \
+        and not (case["function"] == "sparse_gnn_edge_mlp_layer" and case["kwargs"].get("num_edge_hidden_layers", 1) > 0 and False)
+    for name in ["h"] + case["variables"]:
+        want = z["%s/grad/%s" % (k, "h" if name == "h" else "var/" + name)]
+        g = hd.grad if name == "h" else wd[name].grad
+        got = np.zeros_like(want) if g is None else g.cpu().numpy().astype(np.float64)
+        scale = max(1e-6, float(np.abs(want).max()))
+        err = float(np.abs(got - want).max())
+        fro = float(np.linalg.norm(got - want) / max(1e-12, np.linalg.norm(want)))
+        if smooth:
+            assert err <= 2e-4 * scale and fro <= 1e-4, (case["function"], name, err, scale, fro)
+        else:
+            assert fro <= 5e-3 and err <= 5e-2 * scale, (case["function"], name, err, scale, fro)
+
+
+@pytest.mark.parametrize("i", range(len(AUTOGRAD["train"])), ids=["%s-%s" % (t["model"], t["steps"][0]["optimizer"]) for t in AUTOGRAD["train"]])
+def test_two_training_steps_land_where_the_reference_s_train_step_lands(gpu_device, tmp_path, i):
+    """Sparse_Graph_Model.train_step twice on the reference-built minibatch, from the reference's initial variables, against the
+    variables the reference's own __make_train_step produced (float64 run): loss of both steps, every variable after each."""
+    from tf_gnn_samples_amd.tasks import DeviceBatch, MinibatchData
+    t, z = AUTOGRAD["train"][i], AUTOGRAD_Z
+    k, names = t["key"], t["variables"]
+    task = build_product_task(t, tmp_path)
+    model = build_product_model(t, task, str(gpu_device))
+    assert sorted(model.variables.names()) == sorted(names)
+    with torch.no_grad():
+        for n in names:
+            model.variables[n].copy_(torch.as_tensor(z["%s/initial/%s" % (k, n)], device=gpu_device))
+    from tf_gnn_samples_amd import dense
+    dense.weights_changed()
+    payload = t["payload"]
+    feed = {'initial_node_features': z[k + "/features"], 'type_to_num_incoming_edges': z[k + "/deg"],
+            'graph_nodes_list': z[k + "/graph_nodes_list"], payload: z[k + "/" + payload], 'out_layer_dropout_keep_prob': 1.0,
+            'adjacency_lists': [z["%s/adj%d" % (k, l)] for l in range(t["num_edge_types"])]}
+    mb = MinibatchData(feed_dict=feed, num_graphs=t["num_graphs"], num_nodes=t["num_nodes"], num_edges=t["num_edges"])
+    batch = DeviceBatch(mb, gpu_device)
+    lr = t["steps"][0]["learning_rate"]
+    adam = t["steps"][0]["optimizer"] == "_Adam"
+    for step in range(2):
+        metrics = model.train_step(batch)
+        loss = float(metrics['loss'].detach())
+        want_loss = t["steps"][step]["loss"]
+        assert abs(loss - want_loss) <= (1e-5 if step == 0 else 2e-3) * max(1.0, abs(want_loss)), (step, loss, want_loss)
+        for n in names:
+            want = z["%s/step%d/variable_after/%s" % (k, step, n)]
+            got = model.variables[n].detach().cpu().numpy().astype(np.float64)
+            diff = np.abs(got - want)
+            if adam:
+                # Adam moves every element by ~lr in the direction of its gradient's sign: an element whose gradient sits at the float32
+                # noise floor may go the other way; all but a handful agree closely, none is off by more than the two directions
+                assert float(diff.max()) <= 2.2 * lr * (step + 1), (step, n, float(diff.max()))
+                assert float((diff > 0.05 * lr).mean()) <= 0.02, (step, n, float((diff > 0.05 * lr).mean()))
+            else:
+                assert float(diff.max()) <= 2e-5 * max(1.0, float(np.abs(want).max())) * (step + 1), (step, n, float(diff.max()))

@@ -389,3 +389,81 @@ def test_unknown_names_raise_what_the_reference_raises():
     for alias, fn in manifest["aggregation_aliases"].items():
         assert ops.aggregation_mode_id(alias) == ops.aggregation_mode_id(fn.replace("unsorted_segment_", ""))
         assert utils.get_aggregation_function(alias).__name__ == fn
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference's sources under torch.autograd (tests/golden/tf_torch_shim.py): gradients and the train step
+# ------------------------------------------------------------------------------------------------------------------------------
+def autograd_fixture():
+    z, manifest = _load("reference_run_autograd.npz")
+    return z, manifest
+
+
+AUTOGRAD_Z, AUTOGRAD = autograd_fixture()
+NON_SMOOTH = ("relu", "leaky_relu", "selu")
+
+
+@pytest.mark.parametrize("i", range(len(CASES)), ids=["%s-%d" % (c[0]["function"], n) for n, c in enumerate(CASES)])
+def test_torch_mirrors_differentiate_like_the_reference_s_own_code(i):
+    """oracle/torch_ref.py supplies the float64 reference GRADIENTS of the GPU tests: its layer functions against d loss / d (node
+    states, every variable) of the reference's layer code run under autograd — same primitives on both sides, so a faithful mirror
+    agrees to rounding."""
+    import torch
+    from oracle import torch_ref as R
+    case, h, adj, deg, weights, _ = CASES[i]
+    k, z = case["key"], AUTOGRAD_Z
+    entry = AUTOGRAD["layers"][i]
+    assert entry["function"] == case["function"] and entry["variables"] == case["variables"]
+    ht = torch.tensor(h.astype(np.float64), requires_grad=True)
+    wt = {n: torch.tensor(v.astype(np.float64), requires_grad=True) for n, v in weights.items()}
+    kw = dict(case["kwargs"])
+    fn = getattr(R, case["function"])
+    adj_t, deg_t = [torch.as_tensor(a.astype(np.int64)) for a in adj], torch.as_tensor(deg.astype(np.float64))
+    if case["function"] == "sparse_rgdcn_layer":
+        out = fn(ht, adj_t, deg_t, weights=wt, **kw)
+    else:
+        state_dim = kw.pop("state_dim")
+        out = fn(ht, adj_t, deg_t, state_dim, weights=wt, **kw) if case["takes_degrees"] else fn(ht, adj_t, state_dim, weights=wt, **kw)
+    np.testing.assert_allclose(out.detach().numpy(), z[k + "/out64"], rtol=0, atol=1e-12 * max(1.0, float(np.abs(z[k + "/out64"]).max())))
+    loss = (out * torch.as_tensor(z[k + "/cotangent"])).sum()
+    names = case["variables"]
+    grads = torch.autograd.grad(loss, [ht] + [wt[n] for n in names], allow_unused=True)
+    for name, g in zip(["h"] + names, grads):
+        want = z["%s/grad/%s" % (k, "h" if name == "h" else "var/" + name)]
+        got = np.zeros_like(want) if g is None else g.numpy()
+        assert np.abs(got - want).max() <= 1e-10 * max(1.0, float(np.abs(want).max())), (case["function"], name)
+
+
+@pytest.mark.parametrize("i", range(len(AUTOGRAD["train"])), ids=["%s-%s" % (t["model"], t["steps"][0]["optimizer"]) for t in AUTOGRAD["train"]])
+def test_oracle_clip_and_optimizers_reproduce_the_reference_s_train_step(i):
+    """sparse_graph_model.py:227-260 executed by the reference (compute_gradients over the trainable variables, tf.clip_by_norm of
+    every gradient with clamp_gradient_norm, the optimizer the parameters name, the learning rate scaled by num_graphs /
+    lr_for_num_graphs_per_batch): oracle/optim.py's float32 classes, fed the recorded raw gradients, must land on the recorded
+    variables after each of the two steps."""
+    from oracle import optim
+    t, z = AUTOGRAD["train"][i], AUTOGRAD_Z
+    k, names, mp = t["key"], t["variables"], t["model_params"]
+    lr_scale = 1.0 if mp.get("lr_for_num_graphs_per_batch") is None else t["num_graphs"] / mp["lr_for_num_graphs_per_batch"]
+    assert abs(t["steps"][0]["learning_rate"] - mp["learning_rate"] * lr_scale) <= 1e-12
+    kind = mp["optimizer"].lower()
+    assert t["steps"][0]["optimizer"] == {"adam": "_Adam", "rmsprop": "_RMSProp", "sgd": "_SGD"}[kind]
+    init = [z["%s/initial/%s" % (k, n)] for n in names]
+    if kind == "adam":
+        opt = optim.Adam(init, mp["learning_rate"])
+    elif kind == "rmsprop":
+        opt = optim.RMSProp(init, mp["learning_rate"], decay=mp["learning_rate_decay"], momentum=mp["momentum"])
+    else:
+        opt = optim.GradientDescent(init, mp["learning_rate"])
+    for step in range(2):
+        raw = [z["%s/step%d/raw_gradient/%s" % (k, step, n)] for n in names]
+        unused = set(t["steps"][step]["without_gradient"])
+        clipped = [None if n in unused else optim.clip_by_norm(g, mp["clamp_gradient_norm"]) for n, g in zip(names, raw)]
+        for n, c in zip(names, clipped):
+            want = z["%s/step%d/applied_gradient/%s" % (k, step, n)]
+            if c is not None:
+                assert np.abs(c - want).max() <= 2e-6 * max(1e-30, float(np.abs(want).max())), n
+                assert float(np.sqrt((want ** 2).sum())) <= mp["clamp_gradient_norm"] * (1 + 1e-9)
+        opt.apply_gradients(clipped, lr_scale=lr_scale)
+        for n, v in zip(names, opt.vars):
+            want = z["%s/step%d/variable_after/%s" % (k, step, n)]
+            assert np.abs(v - want).max() <= 3e-6 * max(1.0, float(np.abs(want).max())), (step, n)
