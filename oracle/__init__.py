@@ -19,6 +19,9 @@ semantics it assumes (marked [TF-internal]).  What pins it:
     package's host code (bit for bit) and the HIP path (1e-5, tests/test_gpu_reference_run.py).  That removes the
     transcription risk: which ops run on which operands in which order, constants, variable names, concat / segment orders,
     batch packing.  The run also reproduces a known answer of the reference: "Model has 699257 parameters." (README.md:29).
+    A float64 torch backend of the same shim (tf_torch_shim.py, over oracle/torch_ref.py's primitives) runs the sources under
+    autograd: gradients of every layer case and the reference's own train step (clip_by_norm per variable, optimizer
+    selection, learning-rate normalisation) pin oracle/torch_ref.py and oracle/optim.py the same way.
   * The semantics of the individual TensorFlow ops are the shim's, i.e. oracle/tf_ops.py's: NOT pinned against TensorFlow.
     They are cross-checked against PyTorch's independent CPU kernels (tests/test_oracle_crosscheck_cpu.py), hand-derived
     vectors that fail under look-alike semantics, the RGIN G1/G2 docstring example (gnns/rgin.py:29-35), fp64-vs-fp32
