@@ -9,7 +9,8 @@
   layers_small.npz         seeded inputs + weights + the ORACLE's float32 outputs for all six layers on a small
                            3-edge-type graph.  The reference itself cannot run here (no TensorFlow), so these
                            are oracle outputs, not reference outputs: they pin the oracle against silent drift and
-                           give the GPU tests a fixed vector; parity with TF stays "unpinned" (oracle/__init__.py).
+                           give the GPU tests a fixed vector.  (Outputs of the reference's OWN code, run over a shim of
+                           the TF symbols it touches: make_reference_run.py -> reference_run_*.npz.)
 """
 import gzip
 import sys
