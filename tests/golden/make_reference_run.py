@@ -419,6 +419,13 @@ def run_models():
                 sys.stdout = stdout
             ops = model._Sparse_Graph_Model__ops
             key = "model%02d" % ci
+            checkpoint = None
+            if ci in (0, 2, 8):
+                # the reference's own save_model (sparse_graph_model.py:90-107) writes its best-model pickle from these variables
+                model.sess = S.session_stub()
+                (OUT / "reference_run_checkpoints").mkdir(exist_ok=True)
+                checkpoint = "reference_run_checkpoints/%s_%s.pickle" % (task_name, model_name)
+                model.save_model(str(OUT / checkpoint))
             names = [n for n in S.VARIABLES if n not in S.NON_TRAINABLE]
             for n in names:
                 arrays["%s/var/%s" % (key, n)] = S.VARIABLES[n]
@@ -435,7 +442,7 @@ def run_models():
             manifest.append(dict(key=key, model=model_name, task=task_name, task_params=tp, model_params=mp, num_edge_types=L,
                                  num_graphs=int(mb.num_graphs), num_nodes=int(mb.num_nodes), num_edges=int(mb.num_edges), payload=payload,
                                  variables=names, variable_shapes=[list(S.VARIABLES[n].shape) for n in names],
-                                 logged=log.strip().splitlines(), metrics=metrics,
+                                 logged=log.strip().splitlines(), metrics=metrics, checkpoint=checkpoint,
                                  total_num_graphs=int(np.asarray(ops["total_num_graphs"]))))
             print("%-20s %-4s V=%d  %3d variables  %s  metrics %s" % (model_name, task_name, mb.num_nodes, len(names), log.strip(),
                                                                      {k: round(v, 5) for k, v in metrics.items()}))

@@ -217,6 +217,20 @@ class _Var:
         return [_Dim(d) for d in self._shape]
 
 
+class _GlobalVar:
+    """An entry of the GLOBAL_VARIABLES collection as save_model uses it (sparse_graph_model.py:91-97): .name with TF's ':0'."""
+
+    def __init__(self, name, array):
+        self.name, self.value = name + ":0", array
+
+
+def session_stub():
+    """self.sess for save_model: graph.get_collection(GLOBAL_VARIABLES) -> the shim's variables (the model's and the non-trainable
+    total_num_graphs; optimizer slots do not exist here: their TF names are TF's own), run(dict) -> the values."""
+    graph = types.SimpleNamespace(get_collection=lambda which: [_GlobalVar(n, v) for n, v in VARIABLES.items()])
+    return types.SimpleNamespace(graph=graph, run=lambda fetches, **kw: {k: np.array(v.value) for k, v in fetches.items()})
+
+
 def _trainable_variables():
     return [_Var(n, v) for n, v in VARIABLES.items() if n not in NON_TRAINABLE]
 
@@ -364,7 +378,8 @@ def install() -> None:
         placeholder_with_default=_placeholder_with_default, zeros_initializer=_zeros_initializer,
         zeros_like=lambda x, **kw: _t(np.zeros_like(np.asarray(x))), reduce_sum=_reduce_sum, reduce_mean=_reduce_mean,
         abs=np.abs, square=np.square, squeeze=lambda x, **kw: np.squeeze(np.asarray(x)),
-        assign_add=lambda ref, value, **kw: ref + value, trainable_variables=_trainable_variables)
+        assign_add=lambda ref, value, **kw: ref + value, trainable_variables=_trainable_variables,
+        GraphKeys=types.SimpleNamespace(TRAINABLE_VARIABLES="trainable_variables", GLOBAL_VARIABLES="variables"))
     sys.modules["tensorflow"] = tf
     for m in (nn, layers, keras, keras_layers, contrib, initializers, summary):
         sys.modules[m.__name__] = m

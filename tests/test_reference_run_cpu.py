@@ -467,3 +467,25 @@ def test_oracle_clip_and_optimizers_reproduce_the_reference_s_train_step(i):
         for n, v in zip(names, opt.vars):
             want = z["%s/step%d/variable_after/%s" % (k, step, n)]
             assert np.abs(v - want).max() <= 3e-6 * max(1.0, float(np.abs(want).max())), (step, n)
+
+
+@pytest.mark.parametrize("entry", [m for m in MODEL_CASES if m.get("checkpoint")], ids=lambda m: "%s-%s" % (m["task"], m["model"]))
+def test_checkpoints_written_by_the_reference_s_save_model_restore_into_the_package(entry, capsys):
+    """tests/golden/reference_run_checkpoints/*.pickle come out of the reference's own save_model (sparse_graph_model.py:90-107); the
+    package's restore() (utils/model_utils.py:60-77) rebuilds task and model from them: class names through the name tables, metadata,
+    every model variable by its TF name with ':0' — nothing freshly initialised, nothing but the step counter left over."""
+    import pickle
+    from tf_gnn_samples_amd import models
+    path = GOLDEN / entry["checkpoint"]
+    data = pickle.load(open(path, "rb"))
+    assert set(data) == {"model_class", "task_class", "model_params", "task_params", "task_metadata", "weights"}
+    assert set(data["weights"]) == {n + ":0" for n in entry["variables"]} | {"total_num_graphs:0"}
+    model = models.restore(str(path), device="cpu")
+    out = capsys.readouterr().out
+    assert "Freshly initializing" not in out
+    assert [l for l in out.splitlines() if "not used by model" in l] in ([], ["Saved weights for total_num_graphs:0 not used by model."])
+    assert type(model).__name__ == entry["model"] and type(model.task).__name__ == entry["task"] + "_Task"
+    assert model.task.num_edge_types == entry["num_edge_types"]
+    k = entry["key"]
+    for n in entry["variables"]:
+        np.testing.assert_array_equal(model.variables[n].detach().numpy(), MODEL_Z["%s/var/%s" % (k, n)])

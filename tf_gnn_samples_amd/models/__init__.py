@@ -32,4 +32,27 @@ def name_to_model_class(name: str):
     return MODEL_CLASSES[entry[0]], dict(entry[1])
 
 
-__all__ = ["Sparse_Graph_Model", "MODEL_CLASSES", "name_to_model_class"] + sorted(ADAPTER_CLASSES)
+def restore(saved_model_path: str, result_dir: str = None, run_id: str = None, device=None):
+    """utils/model_utils.py:60-77: rebuild task and model from a best-model pickle (the reference's layout — its own save_model
+    writes these, sparse_graph_model.py:90-107) and load its weights.  `device` is this package's addition (default: the model's)."""
+    import os
+    import pickle
+    import time
+    from ..tasks import name_to_task_class
+    print("Loading model from file %s." % saved_model_path)
+    with open(saved_model_path, 'rb') as in_file:
+        data_to_load = pickle.load(in_file)
+    model_cls, _ = name_to_model_class(data_to_load['model_class'])
+    task_cls, _ = name_to_task_class(data_to_load['task_class'])
+    if run_id is None:
+        run_id = "_".join([task_cls.name(), model_cls.name(data_to_load['model_params']), time.strftime("%Y-%m-%d-%H-%M-%S"),
+                           str(os.getpid())])
+    task = task_cls(data_to_load['task_params'])
+    task.restore_from_metadata(data_to_load['task_metadata'])
+    model = model_cls(data_to_load['model_params'], task, run_id, result_dir if result_dir is not None else '.', device=device)
+    model.load_weights(data_to_load['weights'])
+    print("Loaded model from snapshot %s." % saved_model_path)
+    return model
+
+
+__all__ = ["Sparse_Graph_Model", "MODEL_CLASSES", "name_to_model_class", "restore"] + sorted(ADAPTER_CLASSES)
