@@ -680,6 +680,87 @@ def run_autograd():
     np.savez_compressed(OUT / "reference_run_autograd.npz", **arrays)
 
 
+def regenerate_variables(names, shapes, seed):
+    """The values tf_numpy_shim draws for variables created in this order under reset(seed) — what a test re-creates instead of
+    storing 700 k floats."""
+    S.reset(seed)
+    out = {}
+    for n, shape in zip(names, shapes):
+        kind = "gamma" if n.endswith("/gamma") else ("beta" if n.endswith("/beta") else ("bias" if n.endswith("/bias") else "kernel"))
+        out[n] = S._make(n, tuple(shape), kind)
+    return out
+
+
+def run_c2_full_size():
+    """BASELINE.json configs[1] at its full size: the reference's RGCN / PPI model code (README hyper-parameters: hidden 256, 3
+    layers) on the synthetic 16-graph PPI-shaped batch of bench.py and tests/test_gpu_baseline_size.py (32 203 nodes, 1 854 895
+    messages).  Stored: the loss / F1 the reference's code computes, checksums and 96 sampled rows of the final node representations;
+    the variables are re-drawn by the test (regenerate_variables)."""
+    _purge_reference_modules()
+    S.install()
+    import models as ref_models
+    from tasks.ppi_task import PPI_Task
+    from tasks.sparse_graph_task import DataFold
+    from tf_gnn_samples_amd.tasks import PPI_Task as Product_PPI_Task
+    product = Product_PPI_Task(Product_PPI_Task.default_params())
+    product.load_synthetic(16, 1, seed=0)                       # (synthetic data has no reference counterpart: the package's generator)
+    from tf_gnn_samples_amd.tasks import DataFold as PDF
+    data = list(product._loaded_data[PDF.TRAIN])
+    task = PPI_Task(PPI_Task.default_params())
+    task._PPI_Task__num_edge_types = product.num_edge_types
+    task._PPI_Task__initial_node_feature_size = product.initial_node_feature_size
+    task._PPI_Task__num_labels = product.num_labels
+    L = task.num_edge_types
+    ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", "target_labels",
+                                 "out_layer_dropout_keep_prob")}
+    ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(L)]
+    mb = next(iter(task.make_minibatch_iterator(data, DataFold.VALIDATION, ph, 10 ** 9)))      # the reference's iterator packs it
+    assert mb.num_nodes == 32203 and mb.num_edges == 1854895
+    fd = mb.feed_dict
+    seed = 4242
+    S.reset(seed)
+    S.FEEDS.update({"initial_node_features": fd[ph["initial_node_features"]], "type_to_num_incoming_edges": fd[ph["type_to_num_incoming_edges"]],
+                    "graph_nodes_list": fd[ph["graph_nodes_list"]], "target_labels": fd[ph["target_labels"]],
+                    "out_layer_dropout_keep_prob": 1.0, "num_graphs": mb.num_graphs})
+    for l in range(L):
+        S.FEEDS["adjacency_e%s" % l] = fd[ph["adjacency_lists"][l]]
+    readme = open(os.path.join(REFERENCE, "README.md")).read()
+    line = next(l for l in readme.splitlines() if "Using the following model params:" in l and '"hidden_size": 256' in l)
+    mp = ref_models.RGCN_Model.default_params()
+    mp.update(json.loads(line.split("model params:", 1)[1].strip()))
+    tmp = tempfile.mkdtemp()
+    try:
+        model = object.__new__(ref_models.RGCN_Model)
+        model.params, model.task, model.run_id, model.result_dir = mp, task, "shim", tmp
+        model._Sparse_Graph_Model__placeholders, model._Sparse_Graph_Model__ops = {}, {}
+        model._Sparse_Graph_Model__make_train_step = lambda: None
+        stdout, sys.stdout = sys.stdout, io.StringIO()
+        try:
+            model._Sparse_Graph_Model__make_model()
+            log = sys.stdout.getvalue().strip()
+        finally:
+            sys.stdout = stdout
+    finally:
+        shutil.rmtree(tmp)
+    ops = model._Sparse_Graph_Model__ops
+    final = np.asarray(ops["final_node_representations"])
+    names = [n for n in S.VARIABLES if n not in S.NON_TRAINABLE]
+    shapes = [list(S.VARIABLES[n].shape) for n in names]
+    again = regenerate_variables(names, shapes, seed)
+    originals = {n: np.array(S.VARIABLES[n]) for n in names} if False else None
+    rows = np.random.default_rng(1).choice(final.shape[0], 96, replace=False)
+    rows.sort()
+    arrays = dict(rows=rows.astype(np.int64), final_rows=final[rows], final_row_l2=np.sqrt((final.astype(np.float64) ** 2).sum(1)),
+                  final_column_sum=final.astype(np.float64).sum(0))
+    manifest = dict(model_params=mp, logged=log.splitlines(), variables=names, variable_shapes=shapes, variable_seed=seed,
+                    num_nodes=int(mb.num_nodes), num_edges=int(mb.num_edges), num_graphs=int(mb.num_graphs),
+                    metrics={k: float(np.asarray(v)) for k, v in ops["task_metrics"].items()},
+                    final_abs_max=float(np.abs(final).max()), variable_checksums={n: float(np.asarray(again[n], np.float64).sum()) for n in names})
+    arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "reference_run_c2_full_size.npz", **arrays)
+    print("C2 full size:", log, {k: round(v, 6) for k, v in manifest["metrics"].items()}, "max|final| %.4f" % manifest["final_abs_max"])
+
+
 def main():
     if not os.path.isdir(REFERENCE):
         raise SystemExit("make_reference_run.py needs %s (the build container)" % REFERENCE)
@@ -690,6 +771,7 @@ def main():
     run_tasks()
     run_models()
     run_autograd()
+    run_c2_full_size()
 
 
 if __name__ == "__main__":
