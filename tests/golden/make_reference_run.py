@@ -691,46 +691,19 @@ def regenerate_variables(names, shapes, seed):
     return out
 
 
-def run_c2_full_size():
-    """BASELINE.json configs[1] at its full size: the reference's RGCN / PPI model code (README hyper-parameters: hidden 256, 3
-    layers) on the synthetic 16-graph PPI-shaped batch of bench.py and tests/test_gpu_baseline_size.py (32 203 nodes, 1 854 895
-    messages).  Stored: the loss / F1 the reference's code computes, checksums and 96 sampled rows of the final node representations;
-    the variables are re-drawn by the test (regenerate_variables)."""
-    _purge_reference_modules()
-    S.install()
-    import models as ref_models
-    from tasks.ppi_task import PPI_Task
-    from tasks.sparse_graph_task import DataFold
-    from tf_gnn_samples_amd.tasks import PPI_Task as Product_PPI_Task
-    product = Product_PPI_Task(Product_PPI_Task.default_params())
-    product.load_synthetic(16, 1, seed=0)                       # (synthetic data has no reference counterpart: the package's generator)
-    from tf_gnn_samples_amd.tasks import DataFold as PDF
-    data = list(product._loaded_data[PDF.TRAIN])
-    task = PPI_Task(PPI_Task.default_params())
-    task._PPI_Task__num_edge_types = product.num_edge_types
-    task._PPI_Task__initial_node_feature_size = product.initial_node_feature_size
-    task._PPI_Task__num_labels = product.num_labels
-    L = task.num_edge_types
-    ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", "target_labels",
-                                 "out_layer_dropout_keep_prob")}
-    ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(L)]
-    mb = next(iter(task.make_minibatch_iterator(data, DataFold.VALIDATION, ph, 10 ** 9)))      # the reference's iterator packs it
-    assert mb.num_nodes == 32203 and mb.num_edges == 1854895
+def _full_size_run(ref_models, model_name, mp, task, mb, ph, payload, seed):
+    """The reference's __make_model (minus the optimizer) for one model on one reference-packed minibatch -> (arrays, manifest)."""
     fd = mb.feed_dict
-    seed = 4242
+    L = task.num_edge_types
     S.reset(seed)
     S.FEEDS.update({"initial_node_features": fd[ph["initial_node_features"]], "type_to_num_incoming_edges": fd[ph["type_to_num_incoming_edges"]],
-                    "graph_nodes_list": fd[ph["graph_nodes_list"]], "target_labels": fd[ph["target_labels"]],
+                    "graph_nodes_list": fd[ph["graph_nodes_list"]], payload: fd[ph[payload]],
                     "out_layer_dropout_keep_prob": 1.0, "num_graphs": mb.num_graphs})
     for l in range(L):
         S.FEEDS["adjacency_e%s" % l] = fd[ph["adjacency_lists"][l]]
-    readme = open(os.path.join(REFERENCE, "README.md")).read()
-    line = next(l for l in readme.splitlines() if "Using the following model params:" in l and '"hidden_size": 256' in l)
-    mp = ref_models.RGCN_Model.default_params()
-    mp.update(json.loads(line.split("model params:", 1)[1].strip()))
     tmp = tempfile.mkdtemp()
     try:
-        model = object.__new__(ref_models.RGCN_Model)
+        model = object.__new__(getattr(ref_models, model_name))
         model.params, model.task, model.run_id, model.result_dir = mp, task, "shim", tmp
         model._Sparse_Graph_Model__placeholders, model._Sparse_Graph_Model__ops = {}, {}
         model._Sparse_Graph_Model__make_train_step = lambda: None
@@ -746,19 +719,89 @@ def run_c2_full_size():
     final = np.asarray(ops["final_node_representations"])
     names = [n for n in S.VARIABLES if n not in S.NON_TRAINABLE]
     shapes = [list(S.VARIABLES[n].shape) for n in names]
+    metrics = {k: float(np.asarray(v)) for k, v in ops["task_metrics"].items()}
     again = regenerate_variables(names, shapes, seed)
-    originals = {n: np.array(S.VARIABLES[n]) for n in names} if False else None
-    rows = np.random.default_rng(1).choice(final.shape[0], 96, replace=False)
+    rows = np.random.default_rng(1).choice(final.shape[0], min(96, final.shape[0]), replace=False)
     rows.sort()
     arrays = dict(rows=rows.astype(np.int64), final_rows=final[rows], final_row_l2=np.sqrt((final.astype(np.float64) ** 2).sum(1)),
                   final_column_sum=final.astype(np.float64).sum(0))
-    manifest = dict(model_params=mp, logged=log.splitlines(), variables=names, variable_shapes=shapes, variable_seed=seed,
-                    num_nodes=int(mb.num_nodes), num_edges=int(mb.num_edges), num_graphs=int(mb.num_graphs),
-                    metrics={k: float(np.asarray(v)) for k, v in ops["task_metrics"].items()},
-                    final_abs_max=float(np.abs(final).max()), variable_checksums={n: float(np.asarray(again[n], np.float64).sum()) for n in names})
-    arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
-    np.savez_compressed(OUT / "reference_run_c2_full_size.npz", **arrays)
-    print("C2 full size:", log, {k: round(v, 6) for k, v in manifest["metrics"].items()}, "max|final| %.4f" % manifest["final_abs_max"])
+    manifest = dict(model=model_name, model_params=mp, logged=log.splitlines(), variables=names, variable_shapes=shapes, variable_seed=seed,
+                    num_nodes=int(mb.num_nodes), num_edges=int(mb.num_edges), num_graphs=int(mb.num_graphs), metrics=metrics,
+                    final_abs_max=float(np.abs(final).max()),
+                    variable_checksums={n: float(np.asarray(again[n], np.float64).sum()) for n in names})
+    print("%-12s V=%d M=%d  %s  %s  max|final| %.4f" % (model_name, mb.num_nodes, mb.num_edges, log, {k: round(v, 6) for k, v in metrics.items()},
+                                                       manifest["final_abs_max"]))
+    return arrays, manifest
+
+
+def run_c2_full_size():
+    """BASELINE.json's single-GPU configurations at their full size, through the reference's own model code:
+      c2  configs[1]: RGCN / PPI, README hyper-parameters (hidden 256, 3 layers, sum), on the synthetic 16-graph PPI-shaped batch of
+          bench.py and tests/test_gpu_baseline_size.py (32 203 nodes, 1 854 895 messages)
+      c4  configs[3]: RGAT on the same batch, hidden 256, 4 heads, 2 layers
+      c3  configs[2]: GGNN (GRU cell, mean aggregation, hidden 128, 6 layers, tasks/default_hypers/QM9_GGNN.json otherwise) on the
+          256 real QM9 molecules of tests/golden/qm9_valid_256.jsonl.gz
+    Stored per configuration: the metrics the reference's code computes, 96 sampled rows, every row norm and every column sum of the
+    final node representations; the variables are re-drawn by the tests (regenerate_variables)."""
+    _purge_reference_modules()
+    S.install()
+    import models as ref_models
+    from dpu_utils.utils import RichPath
+    from tasks.ppi_task import PPI_Task
+    from tasks.qm9_task import QM9_Task
+    from tasks.sparse_graph_task import DataFold
+    from tf_gnn_samples_amd.tasks import DataFold as PDF, PPI_Task as Product_PPI_Task
+    product = Product_PPI_Task(Product_PPI_Task.default_params())
+    product.load_synthetic(16, 1, seed=0)                       # (synthetic data has no reference counterpart: the package's generator)
+    data = list(product._loaded_data[PDF.TRAIN])
+    task = PPI_Task(PPI_Task.default_params())
+    task._PPI_Task__num_edge_types = product.num_edge_types
+    task._PPI_Task__initial_node_feature_size = product.initial_node_feature_size
+    task._PPI_Task__num_labels = product.num_labels
+    ph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", "target_labels",
+                                 "out_layer_dropout_keep_prob")}
+    ph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(task.num_edge_types)]
+    mb = next(iter(task.make_minibatch_iterator(data, DataFold.VALIDATION, ph, 10 ** 9)))      # the reference's iterator packs it
+    assert mb.num_nodes == 32203 and mb.num_edges == 1854895
+    readme = open(os.path.join(REFERENCE, "README.md")).read()
+    line = next(l for l in readme.splitlines() if "Using the following model params:" in l and '"hidden_size": 256' in l)
+    mp = ref_models.RGCN_Model.default_params()
+    mp.update(json.loads(line.split("model params:", 1)[1].strip()))
+    all_arrays, all_manifest = {}, {}
+    arrays, manifest = _full_size_run(ref_models, "RGCN_Model", mp, task, mb, ph, "target_labels", 4242)
+    all_manifest["c2"] = manifest
+    all_arrays.update({"c2/" + k: v for k, v in arrays.items()})
+    mp = ref_models.RGAT_Model.default_params()
+    mp.update(hidden_size=256, num_heads=4, graph_num_layers=2)
+    arrays, manifest = _full_size_run(ref_models, "RGAT_Model", mp, task, mb, ph, "target_labels", 4243)
+    all_manifest["c4"] = manifest
+    all_arrays.update({"c4/" + k: v for k, v in arrays.items()})
+    # ---- C3: GGNN on the real molecules ----
+    tmp = tempfile.mkdtemp()
+    try:
+        shutil.copy(OUT / "qm9_valid_256.jsonl.gz", os.path.join(tmp, "valid.jsonl.gz"))
+        shutil.copy(OUT / "qm9_valid_256.jsonl.gz", os.path.join(tmp, "train.jsonl.gz"))
+        qtask = QM9_Task(QM9_Task.default_params())
+        stdout, sys.stdout = sys.stdout, io.StringIO()
+        try:
+            qtask.load_data(RichPath(tmp))
+        finally:
+            sys.stdout = stdout
+    finally:
+        shutil.rmtree(tmp)
+    qph = {k: "ph:" + k for k in ("initial_node_features", "type_to_num_incoming_edges", "graph_nodes_list", "target_values",
+                                  "out_layer_dropout_keep_prob")}
+    qph["adjacency_lists"] = ["ph:adjacency_list_%d" % l for l in range(qtask.num_edge_types)]
+    qmb = next(iter(qtask.make_minibatch_iterator(list(qtask._loaded_data[DataFold.VALIDATION]), DataFold.VALIDATION, qph, 10 ** 9)))
+    mp = ref_models.GGNN_Model.default_params()
+    mp.update(json.load(open(os.path.join(REFERENCE, "tasks/default_hypers/QM9_GGNN.json")))["model_params"])
+    mp.update(graph_rnn_cell="GRU", message_aggregation_function="mean")
+    arrays, manifest = _full_size_run(ref_models, "GGNN_Model", mp, qtask, qmb, qph, "target_values", 4244)
+    manifest["task_params"] = qtask.params
+    all_manifest["c3"] = manifest
+    all_arrays.update({"c3/" + k: v for k, v in arrays.items()})
+    all_arrays["manifest"] = np.frombuffer(json.dumps(all_manifest).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "reference_run_baseline_size.npz", **all_arrays)
 
 
 def main():

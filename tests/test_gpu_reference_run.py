@@ -140,18 +140,20 @@ def test_two_training_steps_land_where_the_reference_s_train_step_lands(gpu_devi
                 assert float(diff.max()) <= 2e-5 * max(1.0, float(np.abs(want).max())) * (step + 1), (step, n, float(diff.max()))
 
 
-def test_hip_model_at_baseline_size_reproduces_the_reference_s_model_code(gpu_device):
-    """BASELINE.json configs[1] at its full size (RGCN, PPI-shaped batch of 32 203 nodes / 1 854 895 messages, hidden 256, 3 layers:
-    the README's hyper-parameters): the package's model against what the reference's OWN model code computed on that batch
-    (tests/golden/make_reference_run.py: run_c2_full_size) — loss, F1, sampled rows, every row norm, every column sum."""
-    from test_reference_run_cpu import c2_reference_run
-    from tf_gnn_samples_amd import dense
-    from tf_gnn_samples_amd.models import RGCN_Model
+@pytest.mark.parametrize("which", ["c2", "c4", "c3"])
+def test_hip_model_at_baseline_size_reproduces_the_reference_s_model_code(gpu_device, which):
+    """BASELINE.json's single-GPU configurations at full size — c2: RGCN on the PPI-shaped batch of 32 203 nodes / 1 854 895 messages
+    (hidden 256, 3 layers: the README's hyper-parameters); c4: RGAT on the same batch (hidden 256, 4 heads); c3: GGNN (GRU, mean) on 256
+    real QM9 molecules — against what the reference's OWN model code computed on those batches (tests/golden/make_reference_run.py:
+    run_c2_full_size): the task metrics, sampled rows, every row norm, every column sum of the final node representations."""
+    from test_reference_run_cpu import baseline_reference_run
+    from tf_gnn_samples_amd import dense, models
     from tf_gnn_samples_amd.tasks import DeviceBatch
-    z, m, W, task, mb = c2_reference_run()
-    p = RGCN_Model.default_params()
+    z, m, W, task, mb = baseline_reference_run(which)
+    cls = getattr(models, m["model"])
+    p = cls.default_params()
     p.update(m["model_params"])
-    model = RGCN_Model(p, task, device=str(gpu_device))
+    model = cls(p, task, device=str(gpu_device))
     assert sorted(model.variables.names()) == sorted(m["variables"])
     with torch.no_grad():
         for n in m["variables"]:
@@ -162,9 +164,10 @@ def test_hip_model_at_baseline_size_reproduces_the_reference_s_model_code(gpu_de
         final = model.compute_final_node_representations(batch.initial_node_features, batch.adjacency_lists,
                                                          batch.type_to_num_incoming_edges).cpu().numpy()
         metrics = model.forward_batch(batch, training=False)
-    scale = m["final_abs_max"]
+    scale = max(1.0, m["final_abs_max"])
     assert np.abs(final[z["rows"]] - z["final_rows"]).max() <= 1e-5 * scale
     assert np.abs(np.sqrt((final.astype(np.float64) ** 2).sum(1)) - z["final_row_l2"]).max() <= 2e-5 * scale
-    assert np.abs(final.astype(np.float64).sum(0) - z["final_column_sum"]).max() <= 2e-2 * scale      # (sums of 32 203 rows)
-    assert abs(float(metrics['loss']) - m["metrics"]["loss"]) <= 1e-5 * m["metrics"]["loss"]
-    assert abs(float(metrics['f1_score']) - m["metrics"]["f1_score"]) <= 1e-4
+    assert np.abs(final.astype(np.float64).sum(0) - z["final_column_sum"]).max() <= 2e-2 * scale      # (sums of up to 32 203 rows)
+    for name, want in m["metrics"].items():
+        got = float(metrics[name])
+        assert abs(got - want) <= (1e-4 if name == "f1_score" else 2e-5 * max(1.0, abs(want))), (name, got, want)
