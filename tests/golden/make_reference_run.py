@@ -800,6 +800,32 @@ def run_c2_full_size():
     manifest["task_params"] = qtask.params
     all_manifest["c3"] = manifest
     all_arrays.update({"c3/" + k: v for k, v in arrays.items()})
+    # ---- C5 (configs[4]): one rank's share of the VarMisuse-shaped batch (40 graphs, ~1.04 M messages, 23 edge types), one GNN-FiLM
+    #      layer at hidden 128 through the reference's sparse_gnn_film_layer (the layer the 10-layer model repeats) ----
+    import gnns as ref_gnns
+    from tf_gnn_samples_amd.tasks.synthetic import make_varmisuse_shaped_graphs
+    from oracle import bookkeeping
+    graphs = make_varmisuse_shaped_graphs(40, seed=0)
+    samples = [bookkeeping.GraphSample(g.adjacency_lists, g.type_to_node_to_num_incoming_edges, g.node_features, None) for g in graphs]
+    b = next(bookkeeping.pack_batches(samples, 23, 10 ** 9))
+    V, D = b["num_nodes"], 128
+    adj = [a.astype(np.int32) for a in b["adjacency_lists"]]
+    deg = b["type_to_num_incoming_edges"].astype(np.float32)
+    h = np.tanh(np.random.default_rng(2).standard_normal((V, D))).astype(np.float32)
+    S.reset(4245)
+    out = np.asarray(ref_gnns.sparse_gnn_film_layer(h, adj, deg, D, 1, "ReLU", "sum", False))
+    names = list(S.VARIABLES)
+    shapes = [list(S.VARIABLES[n].shape) for n in names]
+    again = regenerate_variables(names, shapes, 4245)
+    rows = np.random.default_rng(1).choice(V, 96, replace=False)
+    rows.sort()
+    all_arrays.update({"c5/rows": rows.astype(np.int64), "c5/final_rows": out[rows],
+                       "c5/final_row_l2": np.sqrt((out.astype(np.float64) ** 2).sum(1)), "c5/final_column_sum": out.astype(np.float64).sum(0)})
+    all_manifest["c5"] = dict(function="sparse_gnn_film_layer", variables=names, variable_shapes=shapes, variable_seed=4245,
+                              num_nodes=int(V), num_edges=int(sum(len(a) for a in adj)), num_graphs=40, input_seed=2,
+                              final_abs_max=float(np.abs(out).max()),
+                              variable_checksums={n: float(np.asarray(again[n], np.float64).sum()) for n in names})
+    print("C5 FiLM layer  V=%d M=%d  %d variables  max|out| %.4f" % (V, all_manifest["c5"]["num_edges"], len(names), np.abs(out).max()))
     all_arrays["manifest"] = np.frombuffer(json.dumps(all_manifest).encode(), dtype=np.uint8)
     np.savez_compressed(OUT / "reference_run_baseline_size.npz", **all_arrays)
 
