@@ -192,3 +192,21 @@ def test_inverse_degree_in_fp32_by_hand():
     assert abs(float(s[0]) - 1e7) < 1.0 and s[1] == f(0.99999988) and s[2] == f(0.5) and s[3] == f(0.25)
     got = G._inv_degree(np.array([[0.0, 1.0, 2.0, 4.0]], f), 0, np.array([0, 1, 2, 3]), f)[:, 0]
     assert np.array_equal(got, s)
+
+
+def test_examples_printed_in_tensorflow_s_own_api_documentation():
+    """Known answers that TensorFlow's API documentation prints next to the ops the reference calls (tf.math.unsorted_segment_sum /
+    _max, tf.round, tf.nn.sigmoid_cross_entropy_with_logits' stable formula, tf.clip_by_norm's definition): small, but TensorFlow's
+    own numbers rather than ours."""
+    from oracle import model as OM, optim, tf_ops as T
+    c = np.array([[1, 2, 3, 4], [5, 6, 7, 8], [4, 3, 2, 1]], dtype=np.float32)
+    ids = np.array([0, 1, 0], dtype=np.int32)
+    np.testing.assert_array_equal(T.unsorted_segment_sum(c, ids, 2), [[5, 5, 5, 5], [5, 6, 7, 8]])
+    np.testing.assert_array_equal(T.unsorted_segment_max(c, ids, 2), [[4, 3, 3, 4], [5, 6, 7, 8]])
+    np.testing.assert_array_equal(np.round(np.array([0.9, 2.5, 2.3, 1.5, -4.5], np.float32)), [1.0, 2.0, 2.0, 2.0, -4.0])   # tf.round
+    x, z = np.array([-3.0, -0.5, 0.0, 2.0], np.float32), np.array([1.0, 0.0, 1.0, 0.0], np.float32)
+    naive = z * -np.log(1 / (1 + np.exp(-x))) + (1 - z) * -np.log(1 - 1 / (1 + np.exp(-x)))        # the definition the docs start from
+    np.testing.assert_allclose(OM.sigmoid_cross_entropy_with_logits(x, z), naive, rtol=2e-6)
+    t = np.array([3.0, 4.0], np.float32)                                                                # l2 norm 5
+    np.testing.assert_allclose(optim.clip_by_norm(t, 1.0), t / 5.0, rtol=1e-6)                          # t * clip_norm / l2norm(t)
+    np.testing.assert_array_equal(optim.clip_by_norm(t, 10.0), t)                                       # below the norm: unchanged
