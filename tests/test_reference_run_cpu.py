@@ -470,7 +470,7 @@ def test_oracle_clip_and_optimizers_reproduce_the_reference_s_train_step(i):
 
 
 @pytest.mark.parametrize("entry", [m for m in MODEL_CASES if m.get("checkpoint")], ids=lambda m: "%s-%s" % (m["task"], m["model"]))
-def test_checkpoints_written_by_the_reference_s_save_model_restore_into_the_package(entry, capsys):
+def test_checkpoints_written_by_the_reference_s_save_model_restore_into_the_package(entry, capsys, tmp_path):
     """tests/golden/reference_run_checkpoints/*.pickle come out of the reference's own save_model (sparse_graph_model.py:90-107); the
     package's restore() (utils/model_utils.py:60-77) rebuilds task and model from them: class names through the name tables, metadata,
     every model variable by its TF name with ':0' — nothing freshly initialised, nothing but the step counter left over."""
@@ -480,7 +480,7 @@ def test_checkpoints_written_by_the_reference_s_save_model_restore_into_the_pack
     data = pickle.load(open(path, "rb"))
     assert set(data) == {"model_class", "task_class", "model_params", "task_params", "task_metadata", "weights"}
     assert set(data["weights"]) == {n + ":0" for n in entry["variables"]} | {"total_num_graphs:0"}
-    model = models.restore(str(path), device="cpu")
+    model = models.restore(str(path), str(tmp_path), device="cpu")
     out = capsys.readouterr().out
     assert "Freshly initializing" not in out
     assert [l for l in out.splitlines() if "not used by model" in l] in ([], ["Saved weights for total_num_graphs:0 not used by model."])

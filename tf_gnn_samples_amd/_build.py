@@ -41,11 +41,15 @@ def is_stale() -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     """Compile every csrc/*.hip into one shared object.  Returns its path."""
+    objdir = PKG_DIR / "build"
+    objdir.mkdir(exist_ok=True)
+    stems = {src.stem for src in _sources()}
+    for stale in objdir.glob("*.o"):                  # objects of kernels that no longer have a source (removed experiments)
+        if stale.stem not in stems:
+            stale.unlink()
     if not force and not is_stale():
         return LIB_PATH
     hipcc = _hipcc()
-    objdir = PKG_DIR / "build"
-    objdir.mkdir(exist_ok=True)
     objs = []
     procs = []
     for src in _sources():

@@ -32,7 +32,7 @@ def name_to_model_class(name: str):
     return MODEL_CLASSES[entry[0]], dict(entry[1])
 
 
-def restore(saved_model_path: str, result_dir: str = None, run_id: str = None, device=None):
+def restore(saved_model_path: str, result_dir: str, run_id: str = None, device=None):
     """utils/model_utils.py:60-77: rebuild task and model from a best-model pickle (the reference's layout — its own save_model
     writes these, sparse_graph_model.py:90-107) and load its weights.  `device` is this package's addition (default: the model's)."""
     import os
@@ -49,9 +49,9 @@ def restore(saved_model_path: str, result_dir: str = None, run_id: str = None, d
                            str(os.getpid())])
     task = task_cls(data_to_load['task_params'])
     task.restore_from_metadata(data_to_load['task_metadata'])
-    model = model_cls(data_to_load['model_params'], task, run_id, result_dir if result_dir is not None else '.', device=device)
+    model = model_cls(data_to_load['model_params'], task, run_id, result_dir, device=device)
     model.load_weights(data_to_load['weights'])
-    print("Loaded model from snapshot %s." % saved_model_path)
+    model.log_line("Loaded model from snapshot %s." % saved_model_path)
     return model
 
 
