@@ -59,7 +59,9 @@ def parse_args():
                     help="C2 (default): BASELINE configs[1], RGCN on PPI-shaped batches — the headline metric.  C5: BASELINE "
                          "configs[4], GNN-FiLM on VarMisuse-shaped batches (23 edge types, h=128, 10 layers), ~1.2 M edges per rank "
                          "and step, sharded by graph with ONE all-reduce of the ~46 MB FiLM gradient per step")
-    ap.add_argument("--cpu-sample-graphs", type=int, default=4)
+    ap.add_argument("--cpu-sample-graphs", type=int, default=GRAPHS_PER_BATCH,
+                    help="graphs of the bench batch the CPU baseline's TRAINING leg runs on (default: all %d = the whole C2 batch, "
+                         "~11 s per step on 16 host threads)" % GRAPHS_PER_BATCH)
     ap.add_argument("--model-param-overrides", default=None,
                     help="JSON dict of model hyper-parameters laid over the config's (the reference's train.py:38-59 layering: class "
                          "defaults -> the config's values -> this), e.g. '{\"graph_num_layers\": 4}'.  A run with overrides is NOT "
@@ -67,6 +69,10 @@ def parse_args():
     ap.add_argument("--task-param-overrides", default=None,
                     help="JSON dict laid over the synthetic fold's generator parameters (graphs_per_rank, mean_nodes, ...)")
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--no-allreduce-compare", action="store_true",
+                    help="N > 1: skip the second loop that times the other form of the gradient all-reduce")
+    ap.add_argument("--no-step-trace", action="store_true",
+                    help="skip the rocprofv3 kernel trace / PMC passes of the timed loop (roofline.c2 = null)")
     return ap.parse_args()
 
 
@@ -307,6 +313,89 @@ def roofline_section(device, iters, with_pmc):
     return roof
 
 
+def c2_in_step_section(edges_per_step, nodes_per_step, L, D, with_pmc=True, steps=12, warmup=4, timeout_s=240):
+    """The dominant kernel INSIDE the headline's timed loop (BASELINE.json configs[1]): `rocprofv3 --kernel-trace --stats` of this
+    file's own loop (child process, default switches, no extras) gives the average duration of seg_reduce_wave_kernel over all its
+    launches in training steps (3 forward gathers by target + 3 backward gathers by source per step: same messages, same row
+    width); algorithmic bytes per launch from the mean batch of the timed region (SURVEY.md 8d in the aggregate-first order:
+    M (4 D + 8) + V L 4 D + 4 (V L + 1)).  At this size the [V, D] table (33-37 MB) lives in L2 + Infinity Cache, so the bound is
+    the aggregate L2 rate (34.5 TB/s, MI355X_MICROARCH.md), not HBM: `frac_of_l2_peak`.  HBM side: 2 * FETCH_SIZE * 1024 +
+    WRITE_SIZE * 1024 per launch from two PMC passes of the same loop, over the compulsory bytes (every table row once + index /
+    weight streams + output rows + row pointers)."""
+    import bench_roofline as R
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.setdefault("LOCAL_RANK", "0")
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    child = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+             "--no-roofline", "--no-extras", "--no-cpu-baseline"]
+    tmp = tempfile.mkdtemp(prefix="relgnn_step_", dir="/tmp")
+    M, V = float(edges_per_step), float(nodes_per_step)
+    alg = M * (4 * D + 8) + V * L * 4 * D + 4 * (V * L + 1)
+    compulsory = V * 4 * D + M * 8 + V * L * 4 * D + 4 * (V * L + 1)
+    out = {"kernel": R.KERNEL_NAME, "what": c2_in_step_section.__doc__.split("\n")[0].strip(),
+           "launches_per_step": 6, "messages_per_launch": M, "algorithmic_bytes_per_launch": alg,
+           "compulsory_hbm_bytes_per_launch": compulsory, "l2_peak_GBps": R.L2_PEAK_GBS, "trace_steps": steps + warmup}
+    try:
+        d = os.path.join(tmp, "trace")
+        r = subprocess.run([exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "k", "--", *child],
+                           cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s, text=True)
+        files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return dict(out, error="rocprofv3 --kernel-trace of the timed loop failed (rc %d): %s" % (r.returncode, r.stdout[-300:]))
+        rows = list(csv.DictReader(open(files[0])))
+        keep = os.environ.get("RELGNN_BENCH_KEEP_TRACE")           # a directory: the stats table is copied there (profiles/)
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            shutil.copy(files[0], os.path.join(keep, "timed_loop_kernel_stats.csv"))
+        total_ns = sum(float(x["TotalDurationNs"]) for x in rows)
+        seg = [x for x in rows if R.KERNEL_NAME in x["Name"]]
+        calls = sum(int(x["Calls"]) for x in seg)
+        seg_ns = sum(float(x["TotalDurationNs"]) for x in seg)
+        if not calls:
+            return dict(out, error="no %s rows in the kernel trace" % R.KERNEL_NAME)
+        avg_ms = seg_ns / calls * 1e-6
+        out.update(avg_kernel_ms_in_step=avg_ms, launches_traced=calls, share_of_kernel_time=seg_ns / max(total_ns, 1.0),
+                   kernel_ms_per_step_all_kernels=total_ns * 1e-6 / (steps + warmup),
+                   algorithmic_GBps=alg / (avg_ms * 1e-3) / 1e9)
+        out["frac_of_l2_peak"] = out["algorithmic_GBps"] / R.L2_PEAK_GBS
+        out["frac_of_hbm_peak_algorithmic"] = out["algorithmic_GBps"] / R.HBM_PEAK_GBS      # (> 1: the table is cache resident)
+        top = sorted(rows, key=lambda x: -float(x["TotalDurationNs"]))[:8]
+        out["top_kernels"] = [{"name": x["Name"].split("(")[0][-70:], "calls": int(x["Calls"]),
+                               "avg_us": round(float(x["AverageNs"]) * 1e-3, 2),
+                               "share": round(float(x["TotalDurationNs"]) / max(total_ns, 1.0), 4)} for x in top]
+        if with_pmc:
+            sums = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "k", "--",
+                                    *child], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                   timeout=timeout_s, text=True)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    out["hbm_side_error"] = "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stdout[-200:])
+                    break
+                vals = [float(row["Counter_Value"]) for f in files for row in csv.DictReader(open(f))
+                        if R.KERNEL_NAME in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter]
+                if not vals:
+                    out["hbm_side_error"] = "no %s rows for %s" % (counter, R.KERNEL_NAME)
+                    break
+                sums[counter] = float(np.mean(vals))
+            if len(sums) == 2:
+                out["hbm_side_bytes_per_launch"] = 2.0 * sums["FETCH_SIZE"] * 1024.0 + sums["WRITE_SIZE"] * 1024.0
+                out["hbm_side_over_compulsory"] = out["hbm_side_bytes_per_launch"] / compulsory
+        return out
+    except subprocess.TimeoutExpired:
+        return dict(out, error="rocprofv3 pass of the timed loop timed out after %d s" % timeout_s)
+    except Exception as e:   # reporting only
+        return dict(out, error=repr(e))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def route_leg(route_env, what, steps, warmup, timeout_s=180):
     """The same timed loop in a child process on another arithmetic of the node-side Dense products (RELGNN_GEMM / RELGNN_LIMB are
     the initial values of tf_gnn_samples_amd.config.settings): reported next to `value` so that the gain of each limb arithmetic
@@ -398,9 +487,9 @@ def cpu_baseline(batch_graphs, sample_n, params):
     """Reference-order CPU restatement (oracle/torch_ref.py: gather -> per-edge [E,D]@[D,D] -> 1/deg scale
     -> concat -> index_add -> ReLU) on this box's host cores, SURVEY.md 8d's protocol:
       forward-only leg (the reference's validation pass): the WHOLE bench batch (all GRAPHS_PER_BATCH graphs = C2),
-      training leg (fwd + bwd through autograd): a bounded sample, the first `sample_n` graphs of that batch (the whole batch is
-      ~11 s per step here; the default bench run has to stay within minutes) — nothing is scaled, each leg's value = its own edges
-      / its own median step time.  The thread count is the fastest of {quota, quota / 2, quota / 4} on a short probe."""
+      training leg (fwd + bwd through autograd): the first `sample_n` graphs of that batch — by default ALL of them, the same batch
+      (~11 s per step on 16 threads: one warm-up + three timed steps) — nothing is scaled, each leg's value = its own edges / its
+      own median step time.  The thread count is the fastest of {quota, quota / 2, quota / 4} on a short probe (4 graphs)."""
     from oracle import torch_ref as R
     from tf_gnn_samples_amd.parallel import effective_cpu_count
     from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
@@ -421,7 +510,10 @@ def cpu_baseline(batch_graphs, sample_n, params):
                 "deg": torch.as_tensor(fd['type_to_num_incoming_edges'], dtype=torch.float32),
                 "labels": torch.as_tensor(fd['target_labels'])}
 
-    sample, full = load(batch_graphs[:sample_n]), load(batch_graphs)
+    sample_n = max(1, min(int(sample_n), len(batch_graphs)))
+    full = load(batch_graphs)
+    sample = full if sample_n == len(batch_graphs) else load(batch_graphs[:sample_n])
+    small = load(batch_graphs[:min(4, len(batch_graphs))])                 # (the thread probe's input)
     F, n_labels = sample["x"].shape[1], sample["labels"].shape[1]
     W = {"in": glorot(F, h), "dense0": glorot(h, h), "out": glorot(h, n_labels), "bias": torch.zeros(n_labels, requires_grad=True)}
     layers = [{"Edge_%i_Weight/kernel" % l: glorot(h, h) for l in range(3)} for _ in range(params['graph_num_layers'])]
@@ -460,18 +552,19 @@ def cpu_baseline(batch_graphs, sample_n, params):
     probe = {}
     for n in sorted({quota, max(1, quota // 2), max(1, quota // 4)}, reverse=True):
         torch.set_num_threads(n)
-        probe[n] = timed(lambda: fwd_step(sample), 1, 1, 0.0)[0]
+        probe[n] = timed(lambda: fwd_step(small), 1, 1, 0.0)[0]
     cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
     dt_fwd, n_fwd = timed(lambda: fwd_step(full), 1, 3, 40.0)          # the whole batch
-    dt, n = timed(train_step, 2, 5, 40.0)                              # the sample
+    train_warmups = 1 if sample_n > 8 else 2
+    dt, n = timed(train_step, train_warmups, 3 if sample_n > 8 else 5, 60.0)   # the whole batch by default
     torch.set_num_threads(max(1, quota // 2))
     smb, fmb = sample["mb"], full["mb"]
     return {"value": smb.num_edges / dt, "unit": "edges/sec", "cores": cores, "kind": "port",
             "host": "%d hardware threads visible, cgroup CPU quota %d" % (os.cpu_count() or 1, quota),
-            "thread_probe_forward_sample_s": {str(k): round(v, 3) for k, v in probe.items()},
+            "thread_probe_forward_4_graphs_s": {str(k): round(v, 3) for k, v in probe.items()},
             "sample": "training leg (`value`): the first %d of the bench batch's %d graphs (%d edges, %d nodes), full step fwd + bwd, "
-                      "median of %d after 2 warm-ups; forward-only leg (`forward_only_value`): the WHOLE batch (%d edges, %d nodes = "
+                      "median of %d after 1-2 warm-ups; forward-only leg (`forward_only_value`): the WHOLE batch (%d edges, %d nodes = "
                       "C2), median of %d after 1 warm-up.  Nothing is scaled: each value = that leg's edges / that leg's median step "
                       "time.  torch-CPU fp32 restatement of gnns/rgcn.py op order incl. the per-edge matmul, %d threads (the fastest "
                       "of the probed counts; the CPU quota is %d)"
@@ -542,111 +635,136 @@ def main():
     nodes = sorted(len(g.node_features) for g in fold)
     params['max_nodes_in_batch'] = int(sum(nodes) / max(1, len(fold) // cfg["graphs_per_batch"])) + nodes[-1]
     model = model_cls(params, task, device=str(device))
-    # RELGNN_ALLREDUCE=overlap: the gradient all-reduce in buckets that leave during the backward (parallel.py); default: one flat
-    # collective behind the backward (the form every N > 1 number so far was taken with)
-    overlap_reduce = route_config.settings.allreduce == "overlap"
-    if world > 1 and overlap_reduce:
-        from tf_gnn_samples_amd.parallel import OverlappedGradientAllReducer
-        reducer = OverlappedGradientAllReducer(model.optimizer.params)
-    else:
-        reducer = GradientAllReducer(model.optimizer.params) if world > 1 else None
+    # The gradient all-reduce (N > 1): one flat collective behind the backward (`flat`, the default) or buckets that leave during the
+    # backward (`overlap`, parallel.py).  The timed region runs the form config.settings.allreduce names; at N > 1 the OTHER form is
+    # timed right behind it over the same batch sequence (same shuffling seed), so that one run on an N-GPU node compares the two.
+    primary_kind = route_config.settings.allreduce
 
-    def batch_stream():
-        """Shuffled epochs over the HBM-resident fold, forever (models/sparse_graph_model.py:263-311)."""
-        while True:
-            for b in model._batches(fold, DataFold.TRAIN):
-                yield b
-
-    stream = batch_stream()
-    state = {"upcoming": next(stream), "pending": None, "edges": 0, "nodes": 0, "graphs": 0, "loss": 0.0, "fetched": 0,
-             "host_wait": 0.0}
-
-    def fetch(pending):
-        m, b = pending
-        t_wait = time.perf_counter()
-        m = m.get()                               # the host sync of sess.run's fetch (:293), one step late: waits for the
-        state["host_wait"] += time.perf_counter() - t_wait   # D2H copy enqueued right behind THAT step (MetricsReadback)
-        state["loss"] = m['loss']
-        m['f1_score']
-        state["fetched"] += 1
+    def make_reducer(kind):
+        if world == 1:
+            return None
+        if kind == "overlap":
+            from tf_gnn_samples_amd.parallel import OverlappedGradientAllReducer
+            return OverlappedGradientAllReducer(model.optimizer.params)
+        return GradientAllReducer(model.optimizer.params)
 
     cur_stream = torch.cuda.current_stream(device)
-    marks = {"step_end": [], "reduce": [], "step_edges": []}     # HIP events on the launch stream (GPU-side durations)
 
-    def reduce_hook(batch):
-        def hook(_params):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur_stream)
-            if overlap_reduce:
-                reducer.finish()                  # (what is left of the collective behind the backward)
-            else:
-                reducer(float(batch.num_nodes))
-            e1.record(cur_stream)
-            marks["reduce"].append((e0, e1))
-        return hook
+    def timed_loop(kind, steps, warmup):
+        """`warmup` untimed steps, barrier + synchronize, exactly `steps` timed steps, barrier + synchronize.  Returns the wall time
+        of this rank and its per-step records."""
+        reducer = make_reducer(kind)
+        overlap_reduce = kind == "overlap"
+        np.random.seed(20240924 + rank)           # the epoch shuffling (tasks/sparse_graph_task.py): same batch sequence per call
 
-    def one_step():
-        batch = state["upcoming"]
-        m = model.train_step(batch, grad_hook=reduce_hook(batch) if reducer is not None else None,
-                             pre_backward=(lambda: reducer.arm(float(batch.num_nodes))) if reducer is not None and overlap_reduce
-                             else None)
-        readback = MetricsReadback(m)             # async D2H of this step's metrics into pinned memory
-        end = torch.cuda.Event(enable_timing=True)
-        end.record(cur_stream)
-        marks["step_end"].append(end)
-        marks["step_edges"].append(batch.num_edges)
-        state["upcoming"] = next(stream)          # assembly + bucketing of the next batch, enqueued behind this step
-        if state["pending"] is not None:
-            fetch(state["pending"])
-        state["pending"] = (readback, batch)
-        state["edges"] += batch.num_edges
-        state["nodes"] += batch.num_nodes
-        state["graphs"] += batch.num_graphs
+        def batch_stream():
+            """Shuffled epochs over the HBM-resident fold, forever (models/sparse_graph_model.py:263-311)."""
+            while True:
+                for b in model._batches(fold, DataFold.TRAIN):
+                    yield b
 
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    state.update(edges=0, nodes=0, graphs=0, host_wait=0.0)
-    for k in marks:
-        marks[k].clear()
-    start_mark = torch.cuda.Event(enable_timing=True)
-    start_mark.record(cur_stream)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fetch(state["pending"])
-    check_pending_graph_errors()   # deferred device-side index validation of every step's bucketing
-    # per-step GPU-side durations of THIS rank (end-of-step event to end-of-step event), its all-reduce time, host wait
-    ends = [start_mark] + marks["step_end"]
-    step_ms = np.array([ends[i].elapsed_time(ends[i + 1]) for i in range(len(ends) - 1)]) if len(ends) > 1 else np.zeros(1)
-    reduce_ms = np.array([a.elapsed_time(b) for a, b in marks["reduce"]]) if marks["reduce"] else np.zeros(1)
-    local_counts = [float(state["edges"]), float(state["nodes"]), float(state["graphs"]), float(step_ms.min()),
-                    float(np.median(step_ms)), float(step_ms.max()), float(reduce_ms.mean()),
-                    state["host_wait"] / max(1, args.steps) * 1e3, elapsed * 1e3 / max(1, args.steps)]
-    step_edges = np.array(marks["step_edges"], dtype=np.float64)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        per_rank = torch.zeros((world, len(local_counts)), dtype=torch.float64, device=device)
-        per_rank[rank] = torch.tensor(local_counts, dtype=torch.float64, device=device)
-        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
-        edges_rs = torch.zeros((world, len(step_edges)), dtype=torch.float64, device=device)
-        edges_rs[rank] = torch.as_tensor(step_edges, device=device)
-        dist.all_reduce(edges_rs, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        per_rank = per_rank.cpu().numpy()
-        edges_rs = edges_rs.cpu().numpy()
-    else:
-        per_rank = np.array([local_counts])
-        edges_rs = step_edges[None, :]
+        stream = batch_stream()
+        state = {"upcoming": next(stream), "pending": None, "edges": 0, "nodes": 0, "graphs": 0, "loss": 0.0, "fetched": 0,
+                 "host_wait": 0.0}
+
+        def fetch(pending):
+            m, b = pending
+            t_wait = time.perf_counter()
+            m = m.get()                               # the host sync of sess.run's fetch (:293), one step late: waits for the
+            state["host_wait"] += time.perf_counter() - t_wait   # D2H copy enqueued right behind THAT step (MetricsReadback)
+            state["loss"] = m['loss']
+            m['f1_score']
+            state["fetched"] += 1
+
+        marks = {"step_end": [], "reduce": [], "step_edges": []}     # HIP events on the launch stream (GPU-side durations)
+
+        def reduce_hook(batch):
+            def hook(_params):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur_stream)
+                if overlap_reduce:
+                    reducer.finish()                  # (what is left of the collective behind the backward)
+                else:
+                    reducer(float(batch.num_nodes))
+                e1.record(cur_stream)
+                marks["reduce"].append((e0, e1))
+            return hook
+
+        def one_step():
+            batch = state["upcoming"]
+            m = model.train_step(batch, grad_hook=reduce_hook(batch) if reducer is not None else None,
+                                 pre_backward=(lambda: reducer.arm(float(batch.num_nodes))) if reducer is not None and overlap_reduce
+                                 else None)
+            readback = MetricsReadback(m)             # async D2H of this step's metrics into pinned memory
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(cur_stream)
+            marks["step_end"].append(end)
+            marks["step_edges"].append(batch.num_edges)
+            state["upcoming"] = next(stream)          # assembly + bucketing of the next batch, enqueued behind this step
+            if state["pending"] is not None:
+                fetch(state["pending"])
+            state["pending"] = (readback, batch)
+            state["edges"] += batch.num_edges
+            state["nodes"] += batch.num_nodes
+            state["graphs"] += batch.num_graphs
+
+        for _ in range(warmup):
+            one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        state.update(edges=0, nodes=0, graphs=0, host_wait=0.0)
+        for k in marks:
+            marks[k].clear()
+        start_mark = torch.cuda.Event(enable_timing=True)
+        start_mark.record(cur_stream)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        fetch(state["pending"])
+        check_pending_graph_errors()   # deferred device-side index validation of every step's bucketing
+        # per-step GPU-side durations of THIS rank (end-of-step event to end-of-step event), its all-reduce time, host wait
+        ends = [start_mark] + marks["step_end"]
+        step_ms = np.array([ends[i].elapsed_time(ends[i + 1]) for i in range(len(ends) - 1)]) if len(ends) > 1 else np.zeros(1)
+        reduce_ms = np.array([a.elapsed_time(b) for a, b in marks["reduce"]]) if marks["reduce"] else np.zeros(1)
+        local_counts = [float(state["edges"]), float(state["nodes"]), float(state["graphs"]), float(step_ms.min()),
+                        float(np.median(step_ms)), float(step_ms.max()), float(reduce_ms.mean()),
+                        state["host_wait"] / max(1, steps) * 1e3, elapsed * 1e3 / max(1, steps)]
+        step_edges = np.array(marks["step_edges"], dtype=np.float64)
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            per_rank = torch.zeros((world, len(local_counts)), dtype=torch.float64, device=device)
+            per_rank[rank] = torch.tensor(local_counts, dtype=torch.float64, device=device)
+            dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+            edges_rs = torch.zeros((world, len(step_edges)), dtype=torch.float64, device=device)
+            edges_rs[rank] = torch.as_tensor(step_edges, device=device)
+            dist.all_reduce(edges_rs, op=dist.ReduceOp.SUM)
+            elapsed = float(tmax[0])
+            per_rank = per_rank.cpu().numpy()
+            edges_rs = edges_rs.cpu().numpy()
+        else:
+            per_rank = np.array([local_counts])
+            edges_rs = step_edges[None, :]
+        info = {"nbytes": reducer.nbytes if reducer is not None else 0,
+                "buckets": len(reducer.buckets) if overlap_reduce and reducer is not None else (1 if reducer is not None else 0)}
+        if reducer is not None and hasattr(reducer, "close"):
+            reducer.close()                     # (the bucketed form's post-accumulate hooks must not outlive it)
+        return {"elapsed": elapsed, "per_rank": per_rank, "edges_rs": edges_rs, "state": state, "reducer": info}
+
+    run = timed_loop(primary_kind, args.steps, args.warmup)
+    elapsed, per_rank, edges_rs, state, reducer_info = run["elapsed"], run["per_rank"], run["edges_rs"], run["state"], run["reducer"]
+    overlap_reduce = primary_kind == "overlap"
+    other_run = None
+    if world > 1 and not args.no_allreduce_compare:
+        other_kind = "flat" if overlap_reduce else "overlap"
+        other_run = (other_kind, timed_loop(other_kind, args.steps, min(args.warmup, 3)))
     total_edges, total_nodes, total_graphs = (float(x) for x in per_rank[:, :3].sum(0))
     # the ranks meet once per step (the all-reduce): a step lasts as long as its largest shard
     imbalance = edges_rs.max(0) / np.maximum(edges_rs.mean(0), 1.0) if edges_rs.size else np.ones(1)
@@ -665,26 +783,26 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
-        # fp32 values everywhere in HBM and in every result; how the tall node-side Dense products are evaluated:
+        # fp32 values everywhere in HBM and in every result.  The tall node-side Dense products are evaluated on the 16-bit matrix
+        # pipe from the EXACT three-bf16-limb split of every fp32 operand (hi + mid + lo == x bit for bit; six limb products, fp32
+        # accumulation; the dropped terms are below 2^-23 of a product): fp32 semantics, the default route of the package.
+        "dtype": "f32" if (route_config.settings.gemm != "limb" or route_config.settings.limb == "triple")
+                 else "f32 storage; 2 x fp16-limb products (22-bit operands) in the K = 768 layer products",
         "dense_products": {
             "route": route_config.settings.gemm,
             "limbs": route_config.settings.limb,
             "switches": route_config.current(),
-            "pair": "the aggregate-first layer's products (forward, input gradient, weight gradient: K = 768) from TWO fp16 limbs per "
-                    "value (22 significant bits per operand instead of 24) behind exact power-of-two scales — per row of the "
-                    "streamed operand, from the magnitudes the gather writes with its rows; in the weight gradient per column of "
-                    "the gradient operand and per edge type of the bucket sums — three v_mfma_f32_32x32x16_f16 products per fp32 "
-                    "product.  Measured against float64 "
-                    "(tests/test_gpu_baseline_size.py over five model draws, profiles/r04_gradient_parity_by_seed.json; "
-                    "profiles/r04_trajectory_routes.json): within the same 1e-5 budget as the bf16 triple and the fp32 library, "
-                    "neither systematically closer; the triple and exact-fp32 legs of the same loop are timed below",
-            "limb": "each fp32 operand as three bf16 limbs (hi + mid + lo == x exactly), the six limb products of weight >= 2^-16 "
-                    "on v_mfma_f32_32x32x16_bf16 (each exact in fp32), fp32 accumulation; dropped terms < 2^-23 of a product. "
-                    "Measured against float64 at [36 k, 768] x [768, 256]: 4.0e-6 max abs (exact-fp32 library GEMM: 5.3e-6); "
-                    "C2 layer vs the fp32 oracle 3.8e-6 abs (library route 6.2e-6): profiles/r03_parity_margin.json",
-            "lib": "exact fp32 (v_mfma_f32_32x32x2_f32 through hipBLASLt): timed in `exact_fp32_gemm_route` below; the bf16-triple "
-                   "leg in `bf16_triple_limb_route`"},
+            "triple": "each fp32 operand as three bf16 limbs (hi + mid + lo == x exactly), the six limb products of weight >= 2^-16 "
+                      "on v_mfma_f32_32x32x16_bf16 (each exact in fp32), fp32 accumulation; dropped terms < 2^-23 of a product. "
+                      "Measured against float64 at [36 k, 768] x [768, 256]: 4.0e-6 max abs (exact-fp32 library GEMM: 5.3e-6); "
+                      "C2 layer vs the fp32 oracle 3.8e-6 abs (library route 6.2e-6): profiles/r03_parity_margin.json.  THE DEFAULT "
+                      "since round 5 (`value` / `ms_per_step` are measured on it)",
+            "pair": "opt-in (RELGNN_LIMB=pair): the aggregate-first layer's products (forward, input gradient, weight gradient: "
+                    "K = 768) from TWO fp16 limbs per value (22 significant bits per operand instead of 24) behind exact "
+                    "power-of-two scales, three v_mfma_f32_32x32x16_f16 products per fp32 product — narrower than fp32, so it is "
+                    "NOT the headline; timed in `fp16_pair_limb_route` (scalars: pair_route_ms_per_step / pair_route_value)",
+            "lib": "exact fp32 on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32 through hipBLASLt): timed in `exact_fp32_gemm_route` "
+                   "(scalars: exact_fp32_lib_ms_per_step / exact_fp32_lib_value)"},
         "data": "synthetic",
         "config": {
             "workload": ("C2: RGCN on synthetic PPI-shaped batches (~%d graphs, ~%.2f M edges, ~%d k nodes each), 3 edge types "
@@ -717,10 +835,17 @@ def main():
             "wall_ms_per_step": [round(float(x), 4) for x in per_rank[:, 8]],
         },
         "step_edge_imbalance_max_over_mean": {"mean": float(imbalance.mean()), "max": float(imbalance.max())},
-        "gradient_allreduce_bytes": reducer.nbytes if reducer is not None else 0,
-        "gradient_allreduce": ("none" if reducer is None else
-                               "%d buckets launched from the backward's post-accumulate hooks" % len(reducer.buckets) if overlap_reduce
+        "gradient_allreduce_bytes": reducer_info["nbytes"],
+        "gradient_allreduce": ("none" if world == 1 else
+                               "%d buckets launched from the backward's post-accumulate hooks" % reducer_info["buckets"] if overlap_reduce
                                else "one flat collective behind the backward"),
+        # scalars a reader of the driver's record needs to explain an N > 1 number (the lists are in `per_rank`)
+        "allreduce": primary_kind,
+        "allreduce_ms": round(float(per_rank[:, 6].max()), 4) if world > 1 else 0.0,
+        "gpu_step_ms": round(float(per_rank[:, 4].max()), 4),
+        "gpu_step_ms_slowest_over_fastest_rank": round(float(per_rank[:, 4].max() / max(per_rank[:, 4].min(), 1e-9)), 4),
+        "edge_imbalance": round(float(imbalance.mean()), 4),
+        "nranks": int(dist.get_world_size()) if world > 1 else 1,
         "gemm_autotuned": False,
         "final_loss": state["loss"],
         # time rank 0's host spent blocked on the (one step late) metrics copy: ~0 = the host is the bottleneck,
@@ -730,6 +855,19 @@ def main():
         "peak_device_bytes": int(torch.cuda.max_memory_allocated(device)),
     }
 
+    if other_run is not None:
+        kind, o = other_run
+        o_edges = float(o["per_rank"][:, 0].sum())
+        result["allreduce_compare"] = {
+            "what": "the same loop right behind the timed region with the OTHER form of the gradient all-reduce, same batch sequence "
+                    "(same shuffling seed per rank), %d steps after %d warm-up steps" % (args.steps, min(args.warmup, 3)),
+            "allreduce": kind, "ms_per_step": o["elapsed"] / args.steps * 1e3, "value": o_edges / o["elapsed"],
+            "allreduce_ms_mean_per_rank": [round(float(x), 4) for x in o["per_rank"][:, 6]],
+            "gpu_step_ms_median_per_rank": [round(float(x), 4) for x in o["per_rank"][:, 4]],
+            "buckets": o["reducer"]["buckets"]}
+        result["allreduce_%s_ms_per_step" % primary_kind] = result["ms_per_step"]
+        result["allreduce_%s_ms_per_step" % kind] = o["elapsed"] / args.steps * 1e3
+        result["allreduce_%s_ms" % kind] = round(float(o["per_rank"][:, 6].max()), 4)
     # ---- secondary figures (rank 0, single GPU): same-batch step, forward only, transfers ---------------------------
     if rank == 0 and world == 1 and not args.no_extras and args.config == "C2":
         try:
@@ -776,21 +914,46 @@ def main():
             del batch
         except Exception as e:
             result["same_batch"] = {"error": repr(e)}
-    del model, reducer
+    del model
     torch.cuda.empty_cache()
     if rank == 0 and not args.no_roofline:          # (at N > 1 the other ranks wait at the final barrier meanwhile)
         try:
             result["roofline"] = roofline_section(device, args.kernel_iters, not args.no_pmc)
         except Exception as e:
             result["roofline"] = {"error": repr(e)}
+    exact_split = route_config.settings.limb_gemm and route_config.settings.limb == "triple"
+    if exact_split:
+        result["fp32_exact_split_ms_per_step"], result["fp32_exact_split_value"] = result["ms_per_step"], result["value"]
     if (rank == 0 and world == 1 and not args.no_extras and args.config == "C2" and not model_overrides and not task_overrides
-            and route_config.settings.limb_pair):
+            and route_config.settings.limb_gemm):
+        # the same loop on the other arithmetics of the tall Dense products, each in a child process; their step times and rates
+        # are hoisted into scalar top-level keys so that a record that keeps only scalars still holds all three
         result["exact_fp32_gemm_route"] = route_leg(
-            {"RELGNN_GEMM": "lib"}, "the same loop with RELGNN_GEMM=lib (exact-fp32 library GEMMs for every Dense product)",
-            args.steps, args.warmup)
-        result["bf16_triple_limb_route"] = route_leg(
-            {"RELGNN_LIMB": "triple"}, "the same loop with RELGNN_LIMB=triple (every limb product from three bf16 limbs per value: "
-            "the exact split, six MFMA products per fp32 product)", args.steps, args.warmup)
+            {"RELGNN_GEMM": "lib"}, "the same loop with RELGNN_GEMM=lib (exact-fp32 library GEMMs on the fp32 matrix pipe for every "
+            "Dense product)", args.steps, args.warmup)
+        result["exact_fp32_lib_ms_per_step"] = result["exact_fp32_gemm_route"].get("ms_per_step")
+        result["exact_fp32_lib_value"] = result["exact_fp32_gemm_route"].get("value")
+        if exact_split:
+            result["fp16_pair_limb_route"] = route_leg(
+                {"RELGNN_LIMB": "pair"}, "the same loop with RELGNN_LIMB=pair (the K = 768 layer products from two fp16 limbs per "
+                "value: 22-bit operands, three MFMA products per fp32 product — reduced precision, opt-in, NOT the headline)",
+                args.steps, args.warmup)
+            result["pair_route_ms_per_step"] = result["fp16_pair_limb_route"].get("ms_per_step")
+            result["pair_route_value"] = result["fp16_pair_limb_route"].get("value")
+        else:
+            result["bf16_triple_limb_route"] = route_leg(
+                {"RELGNN_LIMB": "triple"}, "the same loop with RELGNN_LIMB=triple (every limb product from three bf16 limbs per "
+                "value: the exact split, six MFMA products per fp32 product)", args.steps, args.warmup)
+            result["fp32_exact_split_ms_per_step"] = result["bf16_triple_limb_route"].get("ms_per_step")
+            result["fp32_exact_split_value"] = result["bf16_triple_limb_route"].get("value")
+    if (rank == 0 and world == 1 and not args.no_roofline and not args.no_step_trace and args.config == "C2"
+            and isinstance(result.get("roofline"), dict) and "error" not in result["roofline"]):
+        # the BASELINE configuration's own roofline figure: the gather kernel inside the timed loop (kernel trace + PMC passes of
+        # this same file), not only the isolated launches above
+        edges_per_step = total_edges / max(1, args.steps)
+        nodes_per_step = total_nodes / max(1, args.steps)
+        result["roofline"]["c2"] = c2_in_step_section(edges_per_step, nodes_per_step, task.num_edge_types,
+                                                      params['hidden_size'], with_pmc=not args.no_pmc)
     if rank == 0 and world == 1 and not args.no_extras:
         result["other_configs"] = other_configs_section()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C2":

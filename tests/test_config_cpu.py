@@ -47,6 +47,31 @@ def test_the_environment_supplies_the_initial_values_only():
     assert bad.returncode != 0 and "RELGNN_TN must be one of" in bad.stderr
 
 
+def test_environment_values_of_earlier_rounds_are_still_accepted():
+    """RELGNN_PAIR_TABLES=true / false / '' (and the other 0 / 1 switches) were accepted before the switches moved into
+    config; a removed variable (RELGNN_PAIR_CHUNK) is reported once instead of silently ignored."""
+    code = ("import warnings; warnings.simplefilter('always'); from tf_gnn_samples_amd import config as c; "
+            "print(c.settings.pair_tables, c.settings.limb_cut, c.settings.weight_limb_cache, c.settings.bwd_overlap, c.settings.gemm)")
+    env = dict(os.environ, RELGNN_PAIR_TABLES="true", RELGNN_LIMB_CUT="False", RELGNN_WEIGHT_LIMB_CACHE="", RELGNN_BWD_OVERLAP="off",
+               RELGNN_GEMM="LIB", RELGNN_PAIR_CHUNK="256", PYTHONPATH=str(ROOT))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+    assert r.stdout.split() == ["1", "0", "1", "0", "lib"]
+    assert "RELGNN_PAIR_CHUNK is set and has no effect" in r.stderr
+    bad = subprocess.run([sys.executable, "-c", "import tf_gnn_samples_amd.config"], env=dict(env, RELGNN_EDGE_BWD="maybe"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert bad.returncode != 0 and "RELGNN_EDGE_BWD must be one of" in bad.stderr
+
+
+def test_the_default_limb_arithmetic_is_the_exact_split():
+    """Round 5: the headline runs on the default switches, and the default of the tall Dense products is the exact three-bf16-limb
+    split (fp32 semantics); the 22-bit two-fp16-limb form is opt-in."""
+    from tf_gnn_samples_amd import config
+    assert config.default_of("gemm") == "limb" and config.default_of("limb") == "triple"
+    with config.override(limb="pair"):
+        assert config.settings.limb_pair
+    assert not config.settings.limb_pair or config.settings.limb == "pair"
+
+
 def test_nothing_else_in_the_package_reads_relgnn_environment_variables():
     """One table, one reader: a RELGNN_* name anywhere else in the Python package is a comment / docstring, never os.environ."""
     offenders = []

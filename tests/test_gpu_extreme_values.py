@@ -232,6 +232,8 @@ def test_magnitude_reductions_skip_non_finite_elements(gpu_device):
     assert torch.equal(DN.col_absmax(torch.zeros((33, 8), device=gpu_device)), torch.zeros(8, device=gpu_device))
     v = x[:, :256]                                                   # strided rows
     assert torch.equal(DN.col_absmax(v), want[:, :256].amax(0))
+    for cols in (17, 18, 23, 254):                                   # wider than 16 and not a multiple of 4 (the bucket magnitudes
+        assert torch.equal(DN.col_absmax(x[:, :cols]), want[:, :cols].amax(0)), cols   # of an 18- or 23-type layer): zero-padded
 
 
 def _isolating_graph(rng, V, L, edges):

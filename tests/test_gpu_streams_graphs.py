@@ -234,7 +234,7 @@ def test_deferred_weight_gradients_only_go_aside_where_nothing_reads_them_early(
                     y.square().sum().backward()
                 pend = len(ops._DEFER["pending"])
                 ops.join_deferred()
-                assert not ops._DEFER["pending"] and not ops._DEFER["targets"]
+                assert not ops._DEFER["pending"] and not ops._DEFER["targets"] and not ops._DEFER["handed"]
             else:
                 y.square().sum().backward()
         torch.cuda.synchronize()
@@ -254,3 +254,75 @@ def test_deferred_weight_gradients_only_go_aside_where_nothing_reads_them_early(
             assert pend == expected_pending
             for a, b_ in zip(want, got):
                 assert torch.equal(a, b_)
+
+
+def test_deferred_weight_gradients_stay_on_the_main_stream_whenever_autograd_would_touch_them_early(gpu_device):
+    """The other ways autograd reads a gradient on the main stream before join_deferred(): a tensor hook on the
+    parameter (the accumulator copies), a post-accumulate hook, create_graph, anomaly mode, a second use by a Dense whose input
+    needs no gradient (its contribution is summed on the main stream: it must wait for the side stream first).  None of them may go
+    aside; all give the bits of the plain order.  And a use the package cannot see (a plain torch op on the same leaf whose
+    gradient arrives AFTER the deferred one) is reported by join_deferred() instead of racing silently."""
+    from tf_gnn_samples_amd import config, dense as DN, ops
+    torch.manual_seed(1)
+    x = torch.randn(6000, 128, device=gpu_device)
+    U0 = torch.randn(128, 256, device=gpu_device) * 0.05
+
+    def backward(fn, prepare=None, deferred=True, **backward_kw):
+        x_ = x.clone().requires_grad_(True)
+        U = U0.clone().requires_grad_(True)
+        if prepare is not None:
+            prepare(U)
+        y = fn(x_, U)
+        with config.override(bwd_overlap="1"):
+            if deferred:
+                with ops.deferred_weight_gradient_join():
+                    y.square().sum().backward(**backward_kw)
+                pend = len(ops._DEFER["pending"])
+                ops.join_deferred()
+            else:
+                pend = None
+                y.square().sum().backward(**backward_kw)
+        torch.cuda.synchronize()
+        return pend, [x_.grad.detach().clone(), U.grad.detach().clone()]
+
+    one = lambda x_, U: DN.dense(torch.tanh(x_), U, None)
+    _, want = backward(one, deferred=False)
+    pend, got = backward(one)
+    assert pend == 1 and all(torch.equal(a, b) for a, b in zip(want, got))
+    seen = []
+    cases = {
+        "tensor hook": dict(prepare=lambda U: U.register_hook(lambda g: g)),
+        "post-accumulate hook": dict(prepare=lambda U: U.register_post_accumulate_grad_hook(lambda p: seen.append(float(p.grad.sum())))),
+        "create_graph": dict(create_graph=True),
+    }
+    for name, kw in cases.items():
+        pend, got = backward(one, **kw)
+        assert pend == 0, name
+        assert all(torch.equal(a, b) for a, b in zip(want, got)), name
+    assert len(seen) == 1 and seen[0] == float(want[1].sum())
+    with torch.autograd.detect_anomaly(check_nan=False):
+        pend, got = backward(one)
+    assert pend == 0 and all(torch.equal(a, b) for a, b in zip(want, got))
+
+    # second use through a Dense whose input needs no gradient: the first sight (in backward order) goes aside, the second is
+    # produced on the main stream behind a wait and summed there
+    const = torch.randn(6000, 128, device=gpu_device)
+    two = lambda x_, U: DN.dense(torch.tanh(x_), U, None) + DN.dense(const, U, None)
+    _, want2 = backward(two, deferred=False)
+    for _ in range(3):
+        pend, got = backward(two)
+        assert pend == 1
+        assert all(torch.equal(a, b) for a, b in zip(want2, got))
+
+    # a use the package cannot see: a plain torch product on the same leaf, its gradient accumulated in place on the main stream
+    # behind the deferred one -> join_deferred() raises (the order of the two contributions is autograd's: accept either outcome
+    # of the ordering, but never a silent pass with pending work and an in-place write)
+    hidden = lambda x_, U: DN.dense(torch.tanh(x_), U, None) + torch.sin(const @ U)
+    try:
+        pend, got = backward(hidden)
+    except RuntimeError as e:
+        assert "deferred weight-gradient join" in str(e)
+    else:
+        assert pend == 0                    # (the plain op's gradient arrived first: nothing went aside)
+    assert not ops._DEFER["pending"] and not ops._DEFER["targets"] and not ops._DEFER["handed"]
+    torch.cuda.synchronize()

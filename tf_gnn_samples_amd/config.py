@@ -21,9 +21,10 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
     "gemm": ("RELGNN_GEMM", "limb", ("limb", "lib", "panel", "torch"),
              "route of the node-side Dense products: fp32 from bf16 / fp16 limbs on the 16-bit matrix pipe (csrc/limb_gemm.hip) | "
              "exact fp32 through hipBLASLt with cached solutions | the exact-fp32 row-panel MFMA kernel | torch.mm"),
-    "limb": ("RELGNN_LIMB", "pair", ("pair", "triple"),
-             "limb arithmetic of the aggregate-first layer's three products: two fp16 limbs behind power-of-two scales | three "
-             "bf16 limbs (exact split) everywhere"),
+    "limb": ("RELGNN_LIMB", "triple", ("triple", "pair"),
+             "limb arithmetic of the aggregate-first layer's three products: three bf16 limbs everywhere (the EXACT split "
+             "hi + mid + lo == x: fp32 semantics) | two fp16 limbs behind power-of-two scales (22-bit operands: a reduced-precision "
+             "fast path, opt-in)"),
     "limb_pair_parts": ("RELGNN_LIMB_PAIR_PARTS", "nn,nt,tn", None,
                         "which of the aggregate-first layer's products take the two-limb form (diagnostic): forward nn, input "
                         "gradient nt, weight gradient tn"),
@@ -67,8 +68,14 @@ class _Settings:
             value = os.environ.get(env, default)
             if name == "edge_bwd" and env not in os.environ and os.environ.get("RELGNN_EDGE_BWD_REGATHER") is not None:
                 value = "regather"                       # (the older spelling of RELGNN_EDGE_BWD=regather)
+            if allowed is not None and value not in allowed:
+                value = _legacy_spelling(value, allowed, default)
             _check(name, value)
             object.__setattr__(self, name, value)
+        for env, why in _REMOVED.items():
+            if env in os.environ:
+                import warnings
+                warnings.warn("%s is set and has no effect any more: %s" % (env, why), stacklevel=3)
 
     def __setattr__(self, name, value):
         _check(name, value)
@@ -89,6 +96,26 @@ class _Settings:
 
     def pair_part(self, kind: str) -> bool:
         return kind in self.limb_pair_parts.split(",")
+
+
+# switches that existed in earlier rounds and are gone (the environment variable is ignored: say so once, at import)
+_REMOVED = {
+    "RELGNN_PAIR_CHUNK": "compact pair tables always use 512-row tiles (graph.PAIR_CHUNK)",
+}
+
+
+def _legacy_spelling(value: str, allowed: Tuple[str, ...], default: str) -> str:
+    """Environment values that the switches accepted before they moved here: true / false / yes / no / on / off (any case) for
+    the 0 / 1 switches, and the empty string for 'leave the default'.  Anything else is returned unchanged (and rejected)."""
+    v = value.strip().lower()
+    if v == "":
+        return default
+    if "0" in allowed and "1" in allowed:
+        if v in ("true", "yes", "on"):
+            return "1"
+        if v in ("false", "no", "off"):
+            return "0"
+    return v if v in allowed else value
 
 
 def _check(name: str, value: str) -> None:

@@ -590,6 +590,11 @@ def col_absmax(x: torch.Tensor) -> torch.Tensor:
     """[cols] float32 on the device: the largest finite magnitude of every column of x [rows, cols] (relgnn_col_absmax_f32)."""
     from . import _lib
     lib = _lib.load_library()
+    cols = x.shape[1]
+    if cols > 16 and cols % 4:
+        # the kernel's wide form reads float4 columns: pad to the next multiple of 4 with zeros (a zero never is a column's largest
+        # magnitude unless the column is zero) — e.g. the [V, L] bucket magnitudes of an 18-type aggregate-first layer
+        return col_absmax(torch.nn.functional.pad(x, (0, (-cols) % 4)))[:cols]
     if x.shape[1] > 16 and not _rows_ok(x):
         x = x.contiguous()
     if x.shape[1] <= 16 and not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
@@ -762,7 +767,7 @@ def _leaf_params(kernel, bias):
     return ((kernel,) if bias is None else (kernel, bias)) if ok else None
 
 
-def _on_side_stream(run, operands, params):
+def _on_side_stream(run, operands, params, want=True):
     """A Dense layer's weight and bias gradient on the weight-gradient side stream (ops._side_stream) — only while train_step defers
     the joins behind the whole backward (ops.deferred_weight_gradient_join): the gradients then leave the main stream's critical
     path and run under the next layer's gather (C2 step 1.826 -> 1.807 ms).  With the join inside backward() the same move was measured and lost (both
@@ -770,7 +775,9 @@ def _on_side_stream(run, operands, params):
     `params`: the leaf parameters the gradients go to (ops.deferred_targets_ok: only a parameter that has no gradient yet takes its
     gradient tensor without launching anything on the main stream), or None.  Returns run()'s result, or None when not applicable."""
     from . import ops
-    if not (ops._DEFER["on"] and _cfg.bwd_overlap_on and all(t.is_cuda for t in operands)):
+    if not (want and ops._DEFER["on"] and _cfg.bwd_overlap_on and all(t.is_cuda for t in operands)):
+        if operands[0].is_cuda:
+            ops.wait_if_in_flight(params, operands[0].device)     # (no-op unless an earlier use of these parameters went aside)
         return None
     if not ops.deferred_targets_ok(params, operands[0].device):
         return None
@@ -785,7 +792,7 @@ def _on_side_stream(run, operands, params):
     for t in out:
         if t is not None:
             t.record_stream(cur)
-    ops._DEFER["pending"].append((device, side))
+    ops.hand_over_deferred(device, side, params, out)
     return out
 
 
@@ -810,7 +817,7 @@ class _DenseFn(torch.autograd.Function):
             gb = column_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return gk, gb
 
-        aside = _on_side_stream(weight_side, (x, g), ctx.leaf_params) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
+        aside = _on_side_stream(weight_side, (x, g), ctx.leaf_params, want=ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
             gx = lib_gemm(GEMM_NT, g, kernel, weight=True)
         gk, gb = aside if aside is not None else weight_side()
@@ -849,7 +856,7 @@ class _DenseReluFn(torch.autograd.Function):
             gb = column_sum(gm) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return gk, gb
 
-        aside = _on_side_stream(weight_side, (x, gm), ctx.leaf_params) if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else None
+        aside = _on_side_stream(weight_side, (x, gm), ctx.leaf_params, want=ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
         gx = lib_gemm(GEMM_NT, gm, kernel, weight=True) if ctx.needs_input_grad[0] else None
         gk, gb = aside if aside is not None else weight_side()
         return gx, gk, gb

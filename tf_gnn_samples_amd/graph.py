@@ -548,7 +548,10 @@ def _upload(arr, device, dtype=None) -> torch.Tensor:
     import numpy as np
     arr = np.ascontiguousarray(arr)
     device = torch.device(device)
-    if device.type != "cuda" or arr.nbytes > _UPLOAD_BYTES or arr.nbytes == 0:
+    if (device.type != "cuda" or arr.nbytes > _UPLOAD_BYTES or arr.nbytes == 0
+            or torch.cuda.is_current_stream_capturing()):
+        # (under stream capture: the ring's event.synchronize() is not capturable and a replay would re-read a staging slot that
+        #  has been overwritten since — a plain copy from the array's own memory instead)
         t = torch.as_tensor(arr, device=device)
         return t if dtype is None else t.to(dtype)
     k = _upload_ring["at"]
@@ -566,11 +569,29 @@ def _upload(arr, device, dtype=None) -> torch.Tensor:
     return out if dtype is None else out.to(dtype)
 
 
+_NONZERO_STATIC_OK = {}
+_VALIDATE_KNOWN_COUNTS = False     # debug (tests set it): compare host-side counts with the device's, one synchronisation each
+
+
 def _nonzero_known(mask: torch.Tensor, size: int) -> torch.Tensor:
     """torch.nonzero(mask).view(-1) for a 1-D mask whose number of set entries the HOST already knows: no device -> host round trip."""
-    if hasattr(torch, "nonzero_static"):
-        return torch.nonzero_static(mask, size=int(size)).view(-1)
-    return torch.nonzero(mask).view(-1)
+    key = mask.device.type
+    ok = _NONZERO_STATIC_OK.get(key)
+    if ok is None:                  # (older builds expose nonzero_static for CPU tensors only: probe once per device type)
+        try:
+            probe = torch.nonzero_static(torch.ones(2, dtype=torch.bool, device=mask.device), size=2)
+            ok = probe.numel() == 2
+        except (AttributeError, RuntimeError, NotImplementedError):
+            ok = False
+        _NONZERO_STATIC_OK[key] = ok
+    if not ok:
+        return torch.nonzero(mask).view(-1)
+    out = torch.nonzero_static(mask, size=int(size), fill_value=-1).view(-1)
+    if _VALIDATE_KNOWN_COUNTS:      # debug: the host-side count against the device's (one host synchronisation)
+        have = int(mask.sum())
+        if have != int(size):
+            raise ValueError("_nonzero_known: the producer of the graph said %d set entries, the mask has %d" % (int(size), have))
+    return out
 
 
 class SidePairs:

@@ -572,11 +572,12 @@ class _TypedLinearPanel(torch.autograd.Function):
             gH = _seg_reduce_raw(_lib.AGG_SUM, gX, side.node_rowptr, 1, side.node_col, None, H.shape[0])
         if side_stream is not None:
             if _DEFER["on"]:
-                _DEFER["pending"].append((gY.device, side_stream))
+                hand_over_deferred(gY.device, side_stream, ctx.leaf_params, gW.unbind(0))
             else:
                 torch.cuda.current_stream(gY.device).wait_stream(side_stream)
             gW.record_stream(torch.cuda.current_stream(gY.device))
         elif ctx.needs_input_grad[2]:
+            wait_if_in_flight(ctx.leaf_params, gY.device)     # (no-op unless an earlier use of these weights went aside)
             gW = weight_gradient()
         return gH, None, gW, None
 
@@ -836,7 +837,7 @@ _SIDE_STREAMS = {}
 # hold every wave slot and register), so its kernels really start at the gather's tail and finish AFTER the input-gradient product
 # — the main stream then idled at every layer's join.  deferred_weight_gradient_join() (models/sparse_graph_model.py: train_step)
 # moves the joins to join_deferred(), called once behind the backward.
-_DEFER = {"on": False, "pending": [], "targets": set()}
+_DEFER = {"on": False, "pending": [], "targets": set(), "handed": []}
 
 
 class deferred_weight_gradient_join:
@@ -850,33 +851,78 @@ class deferred_weight_gradient_join:
         return False
 
 
+def _accumulator_keeps_the_tensor(p) -> bool:
+    """Will autograd's AccumulateGrad take the gradient tensor of leaf `p` as it is, launching nothing on the main stream?  It
+    copies (reads the tensor at once) when a tensor hook sits on the parameter (the gradient passes through Python and gains a
+    reference), when the layouts differ, and under create_graph (grad mode on inside the backward); anomaly mode inspects every
+    gradient; a post-accumulate hook reads p.grad right behind the accumulation."""
+    return (p.is_leaf and p.requires_grad and p.grad is None and p.is_contiguous()
+            and not getattr(p, "_backward_hooks", None) and not getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 def deferred_targets_ok(params, device) -> bool:
     """May a weight gradient be left in flight on the side stream until join_deferred()?  Only if nothing on the main stream reads
     it before: every target must be a LEAF that has no gradient yet and has not been a target in this backward pass — autograd's
-    accumulator then keeps the tensor itself and launches nothing.  A parameter used twice in the graph (the timesteps of a GGNN
+    accumulator then keeps the tensor itself and launches nothing (_accumulator_keeps_the_tensor lists what else makes it copy;
+    join_deferred() verifies afterwards that it did keep it).  A parameter used twice in the graph (the timesteps of a GGNN
     layer share their weights) has its contributions SUMMED on the main stream (in the engine's input buffer, or `grad += new`),
     which would read tensors that are still being written: on the second sight of a parameter the main stream is made to wait for
     the side stream here and the caller computes on one stream."""
     seen = _DEFER["targets"]
-    if params is not None and all(p.is_leaf and p.grad is None and id(p) not in seen for p in params):
+    if (params is not None and not torch.is_grad_enabled() and not torch.is_anomaly_enabled()
+            and all(_accumulator_keeps_the_tensor(p) and id(p) not in seen for p in params)):
         seen.update(id(p) for p in params)
         return True
-    if params is not None and any(id(p) in seen for p in params):     # (a view's or a non-leaf's gradient never went aside: no wait)
-        side = _SIDE_STREAMS.get(device)
-        if side is not None:
-            torch.cuda.current_stream(device).wait_stream(side)
+    wait_if_in_flight(params, device)
     return False
 
 
+def wait_if_in_flight(params, device) -> None:
+    """A contribution to `params` is about to be produced on the main stream.  If an earlier one of this backward went aside,
+    autograd will sum the two on the main stream: it waits for the side stream first.  The parameters are marked as seen either
+    way — a LATER contribution must not go aside either (the engine would add it, still in flight, to the one buffered here).
+    Called on every sight of a parameter that does not go aside itself, whatever else the caller computes.  (A view's or a
+    non-leaf's gradient never goes aside and is consumed by the view's backward at once: params is None for those.)"""
+    if params is None:
+        return
+    seen = _DEFER["targets"]
+    if any(id(p) in seen for p in params):
+        side = _SIDE_STREAMS.get(device)
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
+    if _DEFER["on"]:
+        seen.update(id(p) for p in params)
+
+
+def hand_over_deferred(device, side, params, grads) -> None:
+    """Record that `grads` (in flight on `side`) are being returned to autograd as the gradients of the leaves `params`."""
+    _DEFER["pending"].append((device, side))
+    for p, g in zip(params, grads):
+        if g is not None:
+            _DEFER["handed"].append((p, g.data_ptr(), g._version))
+
+
 def join_deferred() -> None:
-    """Make the current stream wait for every side stream whose join was deferred (no host synchronisation)."""
+    """Make the current stream wait for every side stream whose join was deferred (no host synchronisation), then check that
+    autograd did what the deferral relies on: every parameter's .grad IS the tensor that was handed over (same storage, never
+    written in place since).  Anything else means the main stream read or wrote a gradient that was still being produced — raised
+    here rather than left as a silently wrong update."""
     pending, _DEFER["pending"] = _DEFER["pending"], []
+    handed, _DEFER["handed"] = _DEFER["handed"], []
     _DEFER["targets"].clear()
     done = set()
     for device, side in pending:
         if id(side) not in done:
             torch.cuda.current_stream(device).wait_stream(side)
             done.add(id(side))
+    for p, ptr, version in handed:
+        g = p.grad
+        if g is None or g.data_ptr() != ptr or g._version != version:
+            raise RuntimeError(
+                "deferred weight-gradient join: the gradient of a %s parameter was %s on the main stream while its producer was "
+                "still in flight on the side stream (a second use of the parameter outside this package's layers, a hook, or a "
+                "copying accumulator); run the backward without ops.deferred_weight_gradient_join() or set bwd_overlap=0"
+                % (tuple(p.shape), "dropped" if g is None else "copied" if g.data_ptr() != ptr else "accumulated into in place"))
 
 
 def _side_stream(device):
@@ -1002,17 +1048,18 @@ class _AggregateThenTransform(torch.autograd.Function):
                                  plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
             gH = grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=L)           # dH = sum_l dT_l @ W_l^T
         if side is not None:
-            if _DEFER["on"]:
-                _DEFER["pending"].append((gout.device, side))
-            else:
+            if not _DEFER["on"]:
                 torch.cuda.current_stream(gout.device).wait_stream(side)
             gW.record_stream(torch.cuda.current_stream(gout.device))
         elif want_w:
+            wait_if_in_flight(ctx.leaf_params, gout.device)     # (no-op unless an earlier use of these kernels went aside)
             f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
             gsc = gout if f is None else gout * f.unsqueeze(1)
             gW = _weight_gradient(agg, gsc, amax, L)
         gWs = tuple(gW[l * d_in:(l + 1) * d_in] if ctx.needs_input_grad[6 + l] else None for l in range(L)) \
             if gW is not None else (None,) * L           # dW_l = A_l^T @ dOut: row block l of [L*Din, Dout]
+        if side is not None and _DEFER["on"]:
+            hand_over_deferred(gout.device, side, kernels, gWs)
         return (gH, None, None, None, None, None) + gWs
 
 

@@ -155,6 +155,13 @@ class OverlappedGradientAllReducer(GradientAllReducer):
         self._armed = False
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
 
+    def close(self) -> None:
+        """Remove the post-accumulate hooks (a reducer that is dropped while its parameters live on; with the hooks in place
+        ops.deferred_targets_ok keeps every weight gradient on the main stream)."""
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
     def _make_hook(self, i):
         def hook(_param):
             if self._armed:
