@@ -364,7 +364,10 @@ def c2_in_step_section(edges_per_step, nodes_per_step, L, D, with_pmc=True, step
         out["frac_of_l2_peak"] = out["algorithmic_GBps"] / R.L2_PEAK_GBS
         out["frac_of_hbm_peak_algorithmic"] = out["algorithmic_GBps"] / R.HBM_PEAK_GBS      # (> 1: the table is cache resident)
         top = sorted(rows, key=lambda x: -float(x["TotalDurationNs"]))[:8]
-        out["top_kernels"] = [{"name": x["Name"].split("(")[0][-70:], "calls": int(x["Calls"]),
+        def short(name):
+            name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+            return name.split("(")[0][:70]
+        out["top_kernels"] = [{"name": short(x["Name"]), "calls": int(x["Calls"]),
                                "avg_us": round(float(x["AverageNs"]) * 1e-3, 2),
                                "share": round(float(x["TotalDurationNs"]) / max(total_ns, 1.0), 4)} for x in top]
         if with_pmc:

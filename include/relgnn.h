@@ -807,6 +807,20 @@ int64_t relgnn_col_absmax_workspace_bytes(int32_t rows, int32_t cols);
 int relgnn_col_absmax_f32(const float* X, int64_t ldx, int32_t rows, int32_t cols, float* out, void* workspace,
                           int64_t workspace_bytes, void* stream);
 int relgnn_absmax_f32(const float* x, int64_t n, float* out, void* stream);
+/* Input-gradient products with the activation gradient of the layer below in the epilogue:
+ *     C = act(bias + A @ B^T) * dact'(Y)
+ * dact'(Y) = the derivative of activation `dact` (RELGNN_ACT_TANH / RELU / LEAKY_RELU / ELU / SELU; GELU: RELGNN_EUNSUPPORTED, it
+ * needs the pre-activation) evaluated from its OUTPUT Y [M, N] (row stride ldy floats, 16-byte aligned rows) — TF's ReluGrad /
+ * TanhGrad behind the input-gradient MatMul: the backward of `activation_fn(...)` at gnns/rgcn.py:113-114 and of the Dense between
+ * layers, models/sparse_graph_model.py:194-200, meeting the MatMul gradient of the layer above.  Bit-identical to
+ * relgnn_limb_gemm_xf32 / relgnn_limb16_gemm_xf32 followed by relgnn_act_bwd_from_output; saves that pass (read 2, write 1 per
+ * element).  Y = NULL: plain product.  Other arguments as in relgnn_limb_gemm_xf32 / relgnn_limb16_gemm_xf32. */
+int relgnn_limb_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,
+                               int32_t dact, const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                               void* stream);
+int relgnn_limb16_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const float* xmax, int32_t xgroups, const uint16_t* B,
+                                 const float* wmax, const float* bias, const void* zeros, int32_t dact, const float* Y, int64_t ldy,
+                                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 /* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need
  * (gnns/gnn_film.py:92-106; the limb counterpart of relgnn_panel_gemm_f32's a_rows / b_select for the forward product and the input
  * gradient; K = 128 there):
@@ -833,6 +847,19 @@ int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64
 int64_t relgnn_limb_gemm_tn_chunks(int32_t V, int32_t J, int32_t C);
 int relgnn_limb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* P, int32_t V, int32_t J, int32_t C,
                             void* stream);
+/* Typed weight-gradient partials of many-type graphs — tf.gradients of the per-edge-type Dense kernels Edge_%i_Weight
+ * (gnns/gnn_film.py:94, gnns/rgcn.py:96-98) and Edge_%i_FiLM_Computations (gnns/gnn_film.py:102-106) where the transforms run over a
+ * compact table of the non-empty (node, type) buckets (relgnn_limb_dense_sel_f32's a_rows / b_select form).  The table's P rows come
+ * in tiles of rows_per_tile rows of ONE edge type each; tile z's partial gradient is
+ *     part[z] = A[a_rows[z * rows_per_tile .. ]]^T @ G[z * rows_per_tile .. ]        ([J, C] floats at part + z*J*C)
+ * with a_rows[r] the row of the [*, J] node table A that table row r was computed from (< 0: padding, contributes zeros), G [P, C]
+ * the gradient of the table.  Arithmetic: the exact three-bf16-limb split of both operands, gathered, transposed and split in
+ * flight (relgnn_limb_gemm_tn_f32's kernel).  The caller sums the tiles of a type in tile order (deterministic).
+ * Requirements (RELGNN_EUNSUPPORTED otherwise): rows_per_tile % 32 == 0, P % rows_per_tile == 0, J % 64 == 0, C % 128 == 0, 16-byte
+ * aligned rows and a_rows; zeros = the relgnn_panel_gemm_zeros_floats() block. */
+int relgnn_limb_gemm_tn_tiles_f32(const float* A, int64_t lda, const int32_t* a_rows, const float* G, int64_t ldg,
+                                  const void* zeros, float* part, int32_t P, int32_t rows_per_tile, int32_t J, int32_t C,
+                                  void* stream);
 /* The Dense product as the path calls it, fp32 in / fp32 out: splits the weights B (RELGNN_GEMM_NN: [K, N] as tf.layers.dense
  * stores its kernel; RELGNN_GEMM_NT: [N, K]) into limb_ws (>= relgnn_limb_elements(N, K) bf16 elements of device scratch, reusable
  * by the next call on the same stream), then runs relgnn_limb_gemm_xf32: C = act(bias + A @ B) resp. A @ B^T. */

@@ -254,8 +254,9 @@ def test_c5_film_rank_share(gpu_device):
     ref = G.sparse_gnn_film_layer(h, adj, deg, D, 1, "ReLU", "sum", False, weights=w)
     out = sparse_gnn_film_layer(_dev(h, gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), D, 1, "ReLU", "sum", False,
                                 weights=_dev(w, gpu_device))
-    # un-normalised sum followed by layer norm: the pre-norm states are O(sqrt(degree)); relative budget
-    assert_parity(out, ref, strict_abs=False, what="C5 film, one rank's share (%d messages)" % M)
+    # un-normalised sum followed by layer norm (outputs up to |7.5|): measured 6.0e-6 abs = 7.9e-7 relative — inside the north-star
+    # 1e-5 ABSOLUTE budget, so that is what is asserted (round 5; a relative budget before)
+    assert_parity(out, ref, strict_abs=True, what="C5 film, one rank's share (%d messages)" % M)
 
 
 @pytest.mark.parametrize("agg", ["mean", "max"])

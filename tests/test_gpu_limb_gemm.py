@@ -498,3 +498,121 @@ def test_limb16_gemm_tn_columns_over_ten_decades(gpu_device):
                                                  "decades inside an edge type, edge types three decades apart, G's columns ten decades",
                                          "errors": rep2}}, f, indent=1)
     assert rep2["fp16_pair_layer_form"] <= 4.0 * rep2["fp32_library_split_k"], rep2
+
+
+@pytest.mark.parametrize("J,C,tiles", [(128, 128, 37), (128, 256, 21), (64, 128, 9), (64, 256, 5), (256, 128, 4)])
+def test_typed_weight_gradient_tiles_from_three_limbs(gpu_device, J, C, tiles):
+    """relgnn_limb_gemm_tn_tiles_f32 (round 5): part[z] = A[a_rows[tile z]]^T @ G[tile z] over 512-row tiles of a compact pair table —
+    gathered rows (padding = -1 = zeros, repeated nodes, whole tiles of padding), both operands split into three bf16 limbs in
+    flight.  Against float64, next to the exact-fp32 panel kernel it replaces in ops.typed_linear's backward; magnitudes spread
+    over six decades per column (gradient-like)."""
+    from tf_gnn_samples_amd import dense as DN
+    torch.manual_seed(J * 7 + C + tiles)
+    chunk = 512
+    P, N = tiles * chunk, 3000
+    A = torch.randn(N, J, device=gpu_device)
+    G = torch.randn(P, C, device=gpu_device) * torch.exp(torch.empty(1, C, device=gpu_device).uniform_(-7, 7))
+    rows = torch.randint(0, N, (P,), device=gpu_device, dtype=torch.int32)
+    rows[torch.rand(P, device=gpu_device) < 0.2] = -1
+    if tiles > 4:
+        rows[3 * chunk:4 * chunk] = -1                                # a tile of padding only
+        rows[chunk:chunk + 100] = 17                                  # one node many times
+    assert DN.limb_tn_tiles_supported(A, G, rows, chunk)
+    got = DN.limb_gemm_tn_tiles(A, G, rows, chunk)
+    Ag = torch.where(rows.view(-1, 1) >= 0, A.double()[rows.clamp(min=0).long()], torch.zeros((), dtype=torch.float64, device=gpu_device))
+    want = torch.einsum("tkj,tkc->tjc", Ag.view(tiles, chunk, J), G.double().view(tiles, chunk, C))
+    panel = DN.panel_gemm(DN.GEMM_TN, A, G, a_rows=rows, batch=tiles, strides=(0, chunk * C, J * C), dims=(J, C, chunk))
+    assert got.shape == want.shape == panel.shape
+    scale = want.abs().amax(dim=(0, 1), keepdim=True).clamp(min=1e-30)            # per output column (its gradient column's magnitude)
+    e_limb = float(((got.double() - want).abs() / scale).max())
+    e_panel = float(((panel.double() - want).abs() / scale).max())
+    assert e_limb <= max(2.0 * e_panel, 2e-6), (e_limb, e_panel)
+    if tiles > 4:
+        assert float(got[3].abs().max()) == 0.0
+    # strided operands (a column block of a wider table) and a non-contiguous gradient fall back or are taken in place
+    wide = torch.randn(N, J + 64, device=gpu_device)
+    Aw = wide[:, :J]
+    if DN.limb_tn_tiles_supported(Aw, G, rows, chunk):
+        got_w = DN.limb_gemm_tn_tiles(Aw, G, rows, chunk)
+        Awg = torch.where(rows.view(-1, 1) >= 0, Aw.double()[rows.clamp(min=0).long()], torch.zeros((), dtype=torch.float64, device=gpu_device))
+        want_w = torch.einsum("tkj,tkc->tjc", Awg.view(tiles, chunk, J), G.double().view(tiles, chunk, C))
+        assert float(((got_w.double() - want_w).abs() / want_w.abs().amax(dim=(0, 1), keepdim=True).clamp(min=1e-30)).max()) <= 2e-6
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu", "leaky_relu", "elu", "selu"])
+def test_activation_gradient_in_the_input_gradient_epilogue(gpu_device, act):
+    """relgnn_limb_gemm_xf32_dact / relgnn_limb16_gemm_xf32_dact (round 5): (g @ W^T) * act'(y) in the product's epilogue is the
+    same bits as the product followed by relgnn_act_bwd_from_output — plain Dense shape (K = 256) and the aggregate-first layer's
+    grouped K = 768 product, bf16 triples and fp16 pairs, rows that do not fill the last panel."""
+    from tf_gnn_samples_amd import _lib, dense as DN, ops
+    torch.manual_seed(5)
+    a = ops.activation_id(act)
+    V = 4096 + 77
+    y = torch.tanh(torch.randn(V, 256, device=gpu_device)) if act == "tanh" else \
+        torch.nn.functional.elu(torch.randn(V, 256, device=gpu_device)) if act in ("elu", "selu") else \
+        torch.relu(torch.randn(V, 256, device=gpu_device)) if act == "relu" else \
+        torch.nn.functional.leaky_relu(torch.randn(V, 256, device=gpu_device), 0.2)
+    W = (torch.randn(256, 256, device=gpu_device) * 0.06).requires_grad_(True)          # a Dense kernel [in, out]
+    g = torch.randn(V, 256, device=gpu_device)
+    fused = DN.lib_gemm(DN.GEMM_NT, g, W, weight=True, premask=(a, y))
+    plain = DN.lib_gemm(DN.GEMM_NT, g, W, weight=True)
+    assert torch.equal(fused, DN.act_bwd_from_output(a, y, plain))
+    # grouped: three per-type kernels, g [V, 768]
+    Ws = [(torch.randn(256, 256, device=gpu_device) * 0.06).requires_grad_(True) for _ in range(3)]
+    gT = torch.randn(V, 768, device=gpu_device)
+    fused = DN.grouped_nt_gemm(gT, Ws, premask=(a, y))
+    assert torch.equal(fused, DN.act_bwd_from_output(a, y, DN.grouped_nt_gemm(gT, Ws)))
+    gmax = gT.abs().view(V, 3, 256).amax(2).contiguous().view(-1)
+    fused = DN.grouped_nt_gemm(gT, Ws, xmax=gmax, xgroups=3, premask=(a, y))
+    assert torch.equal(fused, DN.act_bwd_from_output(a, y, DN.grouped_nt_gemm(gT, Ws, xmax=gmax, xgroups=3)))
+    # a route without the epilogue applies the factor as a pass: same function
+    small = DN.lib_gemm(DN.GEMM_NT, g[:100], W, weight=True, premask=(a, y[:100]))
+    want = (g[:100].double() @ W.detach().double().t()) * {
+        "tanh": lambda t: 1 - t * t, "relu": lambda t: (t > 0).double(), "leaky_relu": lambda t: torch.where(t > 0, 1.0, 0.2),
+        "elu": lambda t: torch.where(t > 0, torch.ones_like(t), t + 1), "selu": lambda t: torch.where(
+            t > 0, torch.full_like(t, 1.0507009873554805), t + 1.7580993408473768)}[act](y[:100].double())
+    assert float((small.double() - want).abs().max()) <= 2e-5
+
+
+def test_folded_activation_gradients_leave_the_training_step_s_bits_alone(gpu_device, monkeypatch):
+    """The premask protocol end to end (dense.py): a 3-layer RGCN + PPI head on a batch tall enough for the limb kernels — ReLU
+    layers, tanh Dense between layers, tanh projection — with the activation gradients folded into the input-gradient products
+    (two ReLU' and two tanh' passes disappear) against the same step with the folding refused (every producer runs its own pass):
+    the SAME bits in the loss and in every gradient, and the fused step launches fewer relgnn_act_bwd_from_output passes."""
+    from tf_gnn_samples_amd import dense as DN
+    from tf_gnn_samples_amd.graph import clear_graph_cache
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(3, 1, seed=3)
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
+    assert mb.num_nodes >= 4096
+    calls = {"n": 0}
+    real = DN.act_bwd_from_output
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(DN, "act_bwd_from_output", counting)
+
+    def step(fold: bool):
+        clear_graph_cache()
+        if not fold:
+            monkeypatch.setattr(DN, "fusable_activation_of", lambda x: 0)
+        p = RGCN_Model.default_params()
+        p.update(hidden_size=256, graph_num_layers=3, graph_layer_input_dropout_keep_prob=1.0, random_seed=0)
+        model = RGCN_Model(p, task, device=str(gpu_device))
+        batch = DeviceBatch(mb, gpu_device)
+        model.optimizer.zero_grad()
+        calls["n"] = 0
+        m = model.forward_batch(batch, training=True)
+        m['loss'].backward()
+        torch.cuda.synchronize()
+        return float(m['loss']), {n: model.variables[n].grad.detach().clone() for n in model.variables.names()}, calls["n"]
+
+    loss_f, grads_f, passes_f = step(True)
+    loss_u, grads_u, passes_u = step(False)
+    assert loss_f == loss_u
+    for n in grads_u:
+        assert torch.equal(grads_f[n], grads_u[n]), n
+    assert passes_u == 5 and passes_f <= 2, (passes_u, passes_f)     # 3 ReLU' + 2 tanh' -> the head's ReLU' (+ nothing else)

@@ -22,7 +22,9 @@ def test_hip_layers_reproduce_the_reference_run(gpu_device, i):
     got = call_layer(gnns, case, h, adj, deg, weights, convert=to_device)
     assert got.dtype == torch.float32 and tuple(got.shape) == want.shape
     err = float(np.abs(got.cpu().numpy() - want).max())
-    assert err <= 1e-5 * max(1.0, float(np.abs(want).max())), (case["function"], case["kwargs"], err)
+    # north_star: within 1e-5 ABSOLUTE on fp32 node states.  Measured on all 26 cases (scripts/parity_margins.py,
+    # profiles/r05_parity_margins.json): 6e-8 .. 1.4e-6 with outputs up to |3.7| — strict, no scaling by max|ref|
+    assert err <= 1e-5, (case["function"], case["kwargs"], err, float(np.abs(want).max()))
 
 
 from test_reference_run_cpu import MODEL_CASES, MODEL_Z, build_product_model, build_product_task  # noqa: E402
@@ -52,7 +54,8 @@ def test_hip_models_reproduce_the_reference_s_forward_model(gpu_device, tmp_path
         metrics = model.forward_batch(batch, training=False)
     want = z[k + "/final_node_representations"]
     scale = max(1.0, float(np.abs(want).max()))
-    assert float(np.abs(final.cpu().numpy() - want).max()) <= 1e-5 * scale
+    # (strict 1e-5 absolute: measured 9e-8 .. 2.2e-6 over the 11 model x task cases, profiles/r05_parity_margins.json)
+    assert float(np.abs(final.cpu().numpy() - want).max()) <= 1e-5
     for name, value in entry["metrics"].items():
         got = float(metrics[name])
         tol = 1e-6 if name == "f1_score" else 2e-5 * max(1.0, abs(value), scale * (entry["num_nodes"] if "total" in name or "abs_err" in name else 1))
@@ -165,8 +168,8 @@ def test_hip_model_at_baseline_size_reproduces_the_reference_s_model_code(gpu_de
                                                          batch.type_to_num_incoming_edges).cpu().numpy()
         metrics = model.forward_batch(batch, training=False)
     scale = max(1.0, m["final_abs_max"])
-    assert np.abs(final[z["rows"]] - z["final_rows"]).max() <= 1e-5 * scale
-    assert np.abs(np.sqrt((final.astype(np.float64) ** 2).sum(1)) - z["final_row_l2"]).max() <= 2e-5 * scale
+    assert np.abs(final[z["rows"]] - z["final_rows"]).max() <= 1e-5                 # strict: 1e-5 absolute (measured <= 3e-6)
+    assert np.abs(np.sqrt((final.astype(np.float64) ** 2).sum(1)) - z["final_row_l2"]).max() <= 2e-5 * scale   # (a norm of 256 entries)
     assert np.abs(final.astype(np.float64).sum(0) - z["final_column_sum"]).max() <= 2e-2 * scale      # (sums of up to 32 203 rows)
     for name, want in m["metrics"].items():
         got = float(metrics[name])
@@ -197,6 +200,6 @@ def test_hip_film_layer_at_the_c5_rank_share_reproduces_the_reference_s_layer_co
     out = sparse_gnn_film_layer(h, adj, deg, D, 1, "ReLU", "sum", False,
                                 weights={n: torch.as_tensor(np.array(v), device=gpu_device) for n, v in W.items()}).cpu().numpy()
     scale = max(1.0, m["final_abs_max"])
-    assert np.abs(out[zz["c5/rows"]] - zz["c5/final_rows"]).max() <= 1e-5 * scale
+    assert np.abs(out[zz["c5/rows"]] - zz["c5/final_rows"]).max() <= 1e-5             # strict: 1e-5 absolute (measured 6.0e-6 at |7.5|)
     assert np.abs(np.sqrt((out.astype(np.float64) ** 2).sum(1)) - zz["c5/final_row_l2"]).max() <= 2e-5 * scale
     assert np.abs(out.astype(np.float64).sum(0) - zz["c5/final_column_sum"]).max() <= 5e-2 * scale       # (sums of 96 k rows)

@@ -304,15 +304,15 @@ def test_deferred_weight_gradients_stay_on_the_main_stream_whenever_autograd_wou
         pend, got = backward(one)
     assert pend == 0 and all(torch.equal(a, b) for a, b in zip(want, got))
 
-    # second use through a Dense whose input needs no gradient: the first sight (in backward order) goes aside, the second is
-    # produced on the main stream behind a wait and summed there
+    # second use through a Dense whose input needs no gradient: if the other use comes first in the backward it goes aside and this
+    # one is produced on the main stream behind a wait and summed there; if this one comes first, nothing goes aside at all
     const = torch.randn(6000, 128, device=gpu_device)
     two = lambda x_, U: DN.dense(torch.tanh(x_), U, None) + DN.dense(const, U, None)
     _, want2 = backward(two, deferred=False)
     for _ in range(3):
         pend, got = backward(two)
-        assert pend == 1
-        assert all(torch.equal(a, b) for a, b in zip(want2, got))
+        assert pend in (0, 1)               # (which of the two uses autograd runs first is its choice: the first one may go aside
+        assert all(torch.equal(a, b) for a, b in zip(want2, got))   #  only if it is the one whose input needs a gradient)
 
     # a use the package cannot see: a plain torch product on the same leaf, its gradient accumulated in place on the main stream
     # behind the deferred one -> join_deferred() raises (the order of the two contributions is autograd's: accept either outcome

@@ -19,6 +19,7 @@ ERRFLAG_INDEX_OUT_OF_RANGE = 1
 AGG_SUM, AGG_MEAN, AGG_SQRT_N, AGG_MAX = 0, 1, 2, 3
 MT_MAX = 48
 ACT_LINEAR, ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU, ACT_SELU, ACT_GELU = range(7)
+ACT_NAMES = ("linear", "tanh", "relu", "leaky_relu", "elu", "selu", "gelu")      # utils.get_activation's strings, by id
 
 _c_i32, _c_i64, _c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 _ptr = ctypes.c_void_p
@@ -89,8 +90,13 @@ _SIGNATURES = {
     "relgnn_limb_split_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr, _ptr]),
     "relgnn_limb_gemm_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_limb_gemm_xf32": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
+    "relgnn_limb_gemm_xf32_dact": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _c_i32,
+                                                  _c_i32, _ptr]),
+    "relgnn_limb16_gemm_xf32_dact": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr,
+                                                    _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_limb_gemm_tn_chunks": (_c_i64, [_c_i32, _c_i32, _c_i32]),
     "relgnn_limb_gemm_tn_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i32, _c_i32, _c_i32, _ptr]),
+    "relgnn_limb_gemm_tn_tiles_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i32, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_limb16_gemm_tn_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i32, _ptr, _c_i32, _ptr, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_col_absmax_workspace_bytes": (ctypes.c_int64, [_c_i32, _c_i32]),
     "relgnn_col_absmax_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _c_i64, _ptr]),

@@ -32,6 +32,9 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                  "N % 128 >= 96 products (the 121 logits of the PPI head) on the 128-column limb panels with the last chunk cut at N"),
     "weight_limb_cache": ("RELGNN_WEIGHT_LIMB_CACHE", "1", ("0", "1"),
                           "limb images of the weights kept across the products of a step (re-split once after the optimizer's update)"),
+    "act_fusion": ("RELGNN_ACT_FUSION", "1", ("0", "1"),
+                   "activations of the driver loop's Dense layers in the product's epilogue and activation GRADIENTS folded into the "
+                   "input-gradient product of the layer above (relgnn_limb_gemm_xf32_dact) | separate passes"),
     "tn": ("RELGNN_TN", "stream", ("stream", "lib"),
            "weight gradients with outputs up to 256 x 256: the streaming MFMA kernel (csrc/gemm_tn_stream.hip) | library split-K"),
     "rgcn_order": ("RELGNN_RGCN_ORDER", "aggregate_first", ("aggregate_first", "transform_first"),
@@ -49,6 +52,9 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                        "FiLM regather backward: pass A leaves one sign bit per message and feature for pass B"),
     "typed": ("RELGNN_TYPED", "panel", ("panel", "bmm"),
               "per-(node, type) transforms of many-type graphs: one gathered-row MFMA launch | index_select + torch.bmm"),
+    "typed_tn": ("RELGNN_TYPED_TN", "limb", ("limb", "panel"),
+                 "typed weight-gradient partials of many-type graphs: the gathered three-limb TN kernel on the 16-bit matrix pipe "
+                 "(needs gemm=limb) | the exact-fp32 row-panel MFMA kernel"),
     "pair_tables": ("RELGNN_PAIR_TABLES", "auto", ("auto", "0", "1"),
                     "compact tables over the non-empty (node, type) buckets (auto: L >= 8 and < 60 % of the buckets non-empty)"),
     "rgat_fused_sums": ("RELGNN_RGAT_FUSED_SUMS", "1", ("0", "1"),

@@ -62,10 +62,25 @@ struct LimbArgs {
   // two-fp16-limb arithmetic (NL = 2): per-row magnitudes of the left operand (xmax[m * xgroups + g], the row's scale comes from
   // their maximum) and the magnitude the right operand's limbs were scaled by (wmax[0]); both in device memory
   const float* xmax; int32_t xgroups; const float* wmax;
+  // epilogue of an input-gradient product: C *= act'(Y) with the derivative taken from the OUTPUT Y [M, N] of activation `dact`
+  // (what relgnn_act_bwd_from_output computes in a pass of its own); dy = nullptr: none
+  const float* dy; int64_t ldy; int32_t dact;
 #ifdef RELGNN_LIMB_TIMING
   unsigned long long* timing;          // [workgroup][wave][8] cycle totals per loop segment (diagnostic build only)
 #endif
 };
+
+// act'(x) as a function of y = act(x) — the same expressions, in the same order, as act_bwd_from_output_kernel (seg_reduce.hip)
+__device__ __forceinline__ float dact_from_output(int act, float yy) {
+  switch (act) {
+    case RELGNN_ACT_TANH: return 1.f - yy * yy;
+    case RELGNN_ACT_RELU: return yy > 0.f ? 1.f : 0.f;
+    case RELGNN_ACT_LEAKY_RELU: return yy > 0.f ? 1.f : 0.2f;
+    case RELGNN_ACT_ELU: return yy > 0.f ? 1.f : yy + 1.f;
+    case RELGNN_ACT_SELU: return yy > 0.f ? 1.0507009873554804934193349852946f : yy + 1.7580993408473768599402175208123f;
+    default: return 1.f;
+  }
+}
 
 // ---- fp32 -> two fp16 limbs behind an exact power-of-two scale ----------------------------------------------------------
 // x * s = hi + lo + r with hi = fp16(x s), lo = fp16(x s - hi), |r| <= 2^-22 |x s|; s = 2^j puts the largest magnitude of the
@@ -489,12 +504,19 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const LimbArgs a) {
         for (int g = 0; g < a.xgroups; ++g) mx = fmaxf(mx, a.xmax[(int64_t)(m0 + r) * a.xgroups + g]);
         unscale = limb16_unscale_exp(mx) + limb16_unscale_exp(a.wmax[0]);
       }
+      const float* yrow = a.dy ? a.dy + (int64_t)(m0 + r) * a.ldy : nullptr;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int col = colw + 8 * c + 4 * h32;
         f32x4 v = f32x4{acc[tm][4 * c], acc[tm][4 * c + 1], acc[tm][4 * c + 2], acc[tm][4 * c + 3]};
         if constexpr (NL == 2) v = f32x4{ldexpf(v[0], unscale), ldexpf(v[1], unscale), ldexpf(v[2], unscale), ldexpf(v[3], unscale)};
-        *reinterpret_cast<f32x4*>(crow + col) = finish(v, col);
+        v = finish(v, col);
+        if (yrow) {
+          const f32x4 y = *reinterpret_cast<const f32x4*>(yrow + col);
+          v = f32x4{v[0] * dact_from_output(a.dact, y[0]), v[1] * dact_from_output(a.dact, y[1]),
+                    v[2] * dact_from_output(a.dact, y[2]), v[3] * dact_from_output(a.dact, y[3])};
+        }
+        *reinterpret_cast<f32x4*>(crow + col) = v;
       }
     }
   }
@@ -975,6 +997,8 @@ struct LimbTnArgs {
   // the aggregate-first layer's [V, L*D] operand), column c of G gmax[c / g_cols].  A column's scale factors out of its row /
   // column of the product.
   const float* amax; const float* gmax; int32_t a_cols, g_cols;
+  // GATHER: reduction row r of A is row a_rows[r] of the [*, J] table A (< 0: a row of zeros, read from `zeros`); G is read in place
+  const int32_t* a_rows; const float* zeros;
 };
 
 // NL = 3: bf16 triples, six products; NL = 2: fp16 pairs behind one power-of-two scale per COLUMN of each operand (the reduction
@@ -982,13 +1006,20 @@ struct LimbTnArgs {
 // An element 2^-18 below its column's largest loses low bits of a term that is 2^-18 of the largest terms of ITS sum; with one
 // scale per operand (astride = gstride = 0, the first form) that was 2^-18 of the operand's largest, and a column of small
 // gradients lost relative precision (measured: tests/test_gpu_limb_gemm.py, column magnitudes 1 .. 1e-10).  Three products.
-template <int T32, int NL = 3>
+// NC = 256: a wave owns 32 of the 256 output columns and all T32 row tiles.  NC = 128 (the typed [128, 128] partials of many-type
+// graphs): four column blocks x two row groups — wave w owns column block w % 4 and row tiles (w / 4) * T32 / 2 .. + T32 / 2.
+// GATHER: the reduction rows of A are gathered through a_rows (the compact pair tables' row -> node map, ops.typed_linear): a chunk
+// is then one 512-row tile of ONE edge type and P[z] its partial weight gradient.
+template <int T32, int NL = 3, int NC = 256, bool GATHER = false>
 __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
-  constexpr int NC = 256, PR = 32 * T32;
+  constexpr int PR = 32 * T32;
+  constexpr int CW = NC / 32, RW = 8 / CW, TPW = T32 / RW;          // column waves, row groups, row tiles per wave
+  static_assert((NC == 256 || NC == 128) && T32 % RW == 0 && TPW >= 1, "wave roles");
   constexpr int PA = NL * T32, PB = NL * (NC / 32), P = PA + PB;
   constexpr int STAGE_BYTES = P * 1024;
   constexpr int XG = PR / 4;                          // 4-column groups of the panel's rows
-  constexpr int ITEMS = 256 + 4 * XG;                 // per 32-row super-tile: G: 64 groups x 4 row octets, A: XG x 4
+  constexpr int GG = NC / 4;                          // 4-column groups of G's column chunk
+  constexpr int ITEMS = NC + 4 * XG;                  // per 32-row super-tile: G: GG groups x 4 row octets, A: XG x 4
   static_assert(ITEMS <= 512 && STAGES * STAGE_BYTES <= 160 * 1024, "geometry");
   // (+ 3 KiB that nobody reads: where the limb stores of idle threads and of k-tiles past the end go — the split code has no
   //  branches, so that it sits in one basic block with the MFMAs of its k-tile and the scheduler can interleave the two)
@@ -1008,11 +1039,11 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   const int ntiles = (r_end - r_beg) / BK;                         // even and > 0: whole 32-row super-tiles only
 
   // ---- my patch: 4 columns x 8 reduction rows of every super-tile ---------------------------------------------------
-  const bool is_g = tid < 256;
+  const bool is_g = tid < NC;
   const bool active = tid < ITEMS;
-  const int idx = is_g ? tid : (active ? tid - 256 : 0);           // (idle threads shadow item 0 of A: loads in bounds, stores dumped)
-  const int grp = is_g ? (idx & 63) : (idx % XG);                  // column group
-  const int oct = is_g ? (idx >> 6) : (idx / XG);                  // row octet inside the super-tile: k-tile oct / 2, chunk oct % 2
+  const int idx = is_g ? tid : (active ? tid - NC : 0);            // (idle threads shadow item 0 of A: loads in bounds, stores dumped)
+  const int grp = is_g ? (idx % GG) : (idx % XG);                  // column group
+  const int oct = is_g ? (idx / GG) : (idx / XG);                  // row octet inside the super-tile: k-tile oct / 2, chunk oct % 2
   const int col = 4 * grp;                                         // first of my 4 columns inside the tile rows of the operand
   const float* base = is_g ? a.G + n0 + col : a.A + j0 + col;
   const int64_t ld = is_g ? a.ldg : a.lda;
@@ -1031,10 +1062,31 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   f32x4 pv[8];                                                      // the patch in flight: pv[m][c]
   float ph[16];                                                     // columns 2, 3 of the patch being stored
   const int nsuper = ntiles / 2;                                    // whole super-tiles only (the host hands over V - V % 32 rows)
+  // GATHER: the row ids of the NEXT super-tile are fetched one load step ahead (two dependent loads would otherwise sit inside the
+  // two k-tiles between a patch's load and its split)
+  int nix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto ix_load = [&](int S) {
+    if constexpr (GATHER) {
+      const int r0 = min(r_beg + 32 * S + 8 * oct, a.V - 8);       // (r0 % 8 == 0, V % 32 == 0: whole, aligned octets)
+      const int4 i0 = *reinterpret_cast<const int4*>(a.a_rows + r0), i1 = *reinterpret_cast<const int4*>(a.a_rows + r0 + 4);
+      nix[0] = i0.x; nix[1] = i0.y; nix[2] = i0.z; nix[3] = i0.w; nix[4] = i1.x; nix[5] = i1.y; nix[6] = i1.z; nix[7] = i1.w;
+    }
+  };
   auto p_load = [&](int S) {                                        // (past the end: some valid row; such a patch is never stored)
     const int r0 = r_beg + 32 * S + 8 * oct;
+    if constexpr (GATHER) {
+      const float* zsrc = a.zeros;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) pv[m] = *reinterpret_cast<const f32x4*>(base + (int64_t)min(r0 + m, a.V - 1) * ld);
+      for (int m = 0; m < 8; ++m) {
+        const int64_t row = is_g ? (int64_t)min(r0 + m, a.V - 1) : (int64_t)nix[m];
+        const float* p = row >= 0 ? base + row * ld : zsrc;
+        pv[m] = *reinterpret_cast<const f32x4*>(p);
+      }
+      ix_load(S + 1);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) pv[m] = *reinterpret_cast<const f32x4*>(base + (int64_t)min(r0 + m, a.V - 1) * ld);
+    }
   };
   auto p_store = [&](int S, int c, const float* v) {                // 8 reduction values of column c -> one chunk per plane
     const int off = (active && S < nsuper) ? ((2 * S + (oct >> 1)) % STAGES) * STAGE_BYTES + blk + (c ^ cswz) * 16 : dump;
@@ -1084,15 +1136,16 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
     }
     return f;
   };
+  const int cw = wave % CW, tm0 = (wave / CW) * TPW;               // my column block, my first row tile
   auto read_x = [&](int stage, int tm) {
-    return read_planes(lds + stage * STAGE_BYTES + (NL * tm) * 1024 + 16 * (lane ^ ((lane >> 3) & 3)));
+    return read_planes(lds + stage * STAGE_BYTES + (NL * (tm0 + tm)) * 1024 + 16 * (lane ^ ((lane >> 3) & 3)));
   };
   auto read_w = [&](int stage) {
-    return read_planes(lds + stage * STAGE_BYTES + (PA + NL * wave) * 1024 + 16 * (lane ^ ((lane >> 3) & 3)));
+    return read_planes(lds + stage * STAGE_BYTES + (PA + NL * cw) * 1024 + 16 * (lane ^ ((lane >> 3) & 3)));
   };
-  f32x16 acc[T32];
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int tm = 0; tm < T32; ++tm)
+  for (int tm = 0; tm < TPW; ++tm)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
   auto products = [&](f32x16 c, const Limbs& w, const Limbs& x) {
@@ -1127,6 +1180,7 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   Limbs w_cur, w_nxt, xs[2];
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  ix_load(0);
   p_load(0);
   p_step(0, I0{}); p_step(0, I1{}); p_step(0, I2{}); p_step(0, I3{});
   p_load(1);
@@ -1136,8 +1190,8 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
   xs[0] = read_x(0, 0);
   auto ktile = [&](int t, auto odd_c) {
     constexpr int ODD = decltype(odd_c)::value;
-    constexpr int PAR = (T32 & 1) ? ODD : 0;                   // row tile tm lives in register set (tm + PAR) & 1
-    constexpr int PRE = T32 - 1;                               // row tiles in front of the barrier
+    constexpr int PAR = (TPW & 1) ? ODD : 0;                   // row tile tm lives in register set (tm + PAR) & 1
+    constexpr int PRE = TPW - 1;                               // row tiles in front of the barrier
     const int stage = t % STAGES;
     const bool more = t + 1 < ntiles;
     const int S = (t >> 1) + 1;
@@ -1145,10 +1199,10 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
       if constexpr (ODD == 0) { p_step(S, I0{}); p_step(S, I1{}); p_load(S + 1); } else { p_step(S, I2{}); p_step(S, I3{}); }
     }
 #pragma unroll
-    for (int tm = 0; tm < T32; ++tm) {
+    for (int tm = 0; tm < TPW; ++tm) {
       Limbs& xc = xs[(tm + PAR) & 1];
       Limbs& xn = xs[(tm + PAR + 1) & 1];
-      if (tm == T32 - 1) {
+      if (tm == TPW - 1) {
         if (more) {
           wait_lgkm0();                                        // my reads of stage t % 4 and my limb stores are done
           __builtin_amdgcn_s_barrier();                        // -> k-tile t+1 complete for everybody, stage t % 4 free
@@ -1182,7 +1236,7 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
 
   // ---- partial product of this chunk ------------------------------------------------------------------------------------
   const int i32 = lane & 31, h32 = lane >> 5;
-  const int colw = n0 + wave * 32;
+  const int colw = n0 + cw * 32;
   float* slab = a.P + (int64_t)z * a.J * a.C;
   int ug[4][4];                                                     // NL = 2: log2(1 / scale) of my output columns
   if constexpr (NL == 2) {
@@ -1192,8 +1246,8 @@ __global__ __launch_bounds__(512) void limb_gemm_tn_kernel(const LimbTnArgs a) {
       for (int e = 0; e < 4; ++e) ug[c][e] = limb16_unscale_exp(a.gmax[(colw + 8 * c + 4 * h32 + e) / a.g_cols]);
   }
 #pragma unroll
-  for (int tm = 0; tm < T32; ++tm) {
-    const int j = j0 + tm * 32 + i32;
+  for (int tm = 0; tm < TPW; ++tm) {
+    const int j = j0 + (tm0 + tm) * 32 + i32;
     float* crow = slab + (int64_t)j * a.C;
     int ua = 0;
     if constexpr (NL == 2) ua = limb16_unscale_exp(a.amax[j / a.a_cols]);
@@ -1617,6 +1671,31 @@ int relgnn_limb_gemm_xf32(int32_t act, const float* A, int64_t lda, const uint16
   return dispatch_limb<true>(a, as_stream(stream));
 }
 
+static int dact_checks(int32_t dact, const float* Y, int64_t ldy, int32_t N) {
+  if (!Y) return -1;
+  if (dact < RELGNN_ACT_LINEAR || dact > RELGNN_ACT_SELU) return dact == RELGNN_ACT_GELU ? RELGNN_EUNSUPPORTED : RELGNN_EINVAL;
+  if (!aligned16(Y) || ldy % 4 || ldy < N) return RELGNN_EUNSUPPORTED;
+  return -1;
+}
+
+// relgnn_limb_gemm_xf32 with the activation gradient of the layer BELOW in its epilogue: C = act(bias + A @ B^T) * dact'(Y), the
+// derivative of activation `dact` evaluated from its output Y [M, N] (row stride ldy): what TF's ReluGrad / TanhGrad compute in an op
+// of their own behind the input-gradient MatMul (the backward of gnns/rgcn.py:114 / models/sparse_graph_model.py:198-200 meeting
+// the backward of the next layer's Dense).  Same bits as relgnn_limb_gemm_xf32 followed by relgnn_act_bwd_from_output.
+int relgnn_limb_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, const void* zeros,
+                               int32_t dact, const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                               void* stream) {
+  const int rc = limb_common_checks(act, A, B, bias, zeros, C, ldc, M, N, K);
+  if (rc >= 0) return rc;
+  if (lda % 4 || lda < K) return RELGNN_EUNSUPPORTED;
+  const int rd = dact_checks(dact, Y, ldy, N);
+  if (rd >= 0) return rd;
+  LimbArgs a{};
+  a.Ax = A; a.lda = lda; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M;
+  a.N = N; a.K = K; a.act = act; a.dy = Y; a.ldy = ldy; a.dact = dact;
+  return dispatch_limb<true>(a, as_stream(stream));
+}
+
 // ---- two fp16 limbs -------------------------------------------------------------------------------------------------------------
 int64_t relgnn_limb16_elements(int64_t rows, int64_t cols) { return ((rows + 31) / 32) * (cols / 16) * 1024; }
 
@@ -1669,6 +1748,20 @@ int relgnn_limb16_gemm_xf32(int32_t act, const float* A, int64_t lda, const floa
   LimbArgs a{};
   a.Ax = A; a.lda = lda; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M;
   a.N = N; a.K = K; a.act = act; a.xmax = xmax; a.xgroups = xgroups; a.wmax = wmax;
+  return dispatch_limb<true, 2>(a, as_stream(stream));
+}
+
+int relgnn_limb16_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const float* xmax, int32_t xgroups, const uint16_t* B,
+                                 const float* wmax, const float* bias, const void* zeros, int32_t dact, const float* Y, int64_t ldy,
+                                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  const int rc = limb_common_checks(act, A, B, bias, zeros, C, ldc, M, N, K);
+  if (rc >= 0) return rc;
+  if (lda % 4 || lda < K || !xmax || !wmax || xgroups < 1) return RELGNN_EUNSUPPORTED;
+  const int rd = dact_checks(dact, Y, ldy, N);
+  if (rd >= 0) return rd;
+  LimbArgs a{};
+  a.Ax = A; a.lda = lda; a.B = B; a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M;
+  a.N = N; a.K = K; a.act = act; a.xmax = xmax; a.xgroups = xgroups; a.wmax = wmax; a.dy = Y; a.ldy = ldy; a.dact = dact;
   return dispatch_limb<true, 2>(a, as_stream(stream));
 }
 
@@ -1797,6 +1890,40 @@ static int limb_tn_any(const float* A, int64_t lda, const float* G, int64_t ldg,
     case 4: limb_gemm_tn_kernel<4><<<grid, 512, 0, st>>>(a); break;
     case 2: limb_gemm_tn_kernel<2><<<grid, 512, 0, st>>>(a); break;
     default: limb_gemm_tn_kernel<1><<<grid, 512, 0, st>>>(a); break;
+  }
+  return launch_status();
+}
+
+// Typed weight-gradient partials of many-type graphs (ops.typed_linear's backward; gnns/gnn_film.py:92-106, gnns/rgcn.py:96-98 per edge
+// type): the P rows of a compact pair table come in tiles of `rows_per_tile` rows that belong to ONE edge type each; tile z's partial is
+//   part[z] = A[a_rows[z * rows_per_tile ..]]^T @ G[z * rows_per_tile ..]          ([J, C] each; a_rows < 0: a row of zeros)
+// from the exact three-bf16-limb split of both operands (six MFMA products, fp32 accumulation), the gather and both splits in flight.
+// The caller sums the tiles of a type in tile order (a segment reduction over [tiles, J * C]).  J % 64 == 0, J <= 128 per panel
+// geometry (J = 64: T32 = 2, J % 128 == 0: T32 = 4), C % 128 == 0, P % rows_per_tile == 0, rows_per_tile % 32 == 0.
+int relgnn_limb_gemm_tn_tiles_f32(const float* A, int64_t lda, const int32_t* a_rows, const float* G, int64_t ldg,
+                                  const void* zeros, float* part, int32_t P, int32_t rows_per_tile, int32_t J, int32_t C,
+                                  void* stream) {
+  if (P < 0 || J < 0 || C < 0 || rows_per_tile <= 0) return RELGNN_EINVAL;
+  if (P == 0 || J == 0 || C == 0) return RELGNN_OK;
+  if (!A || !a_rows || !G || !zeros || !part) return RELGNN_EINVAL;
+  if (rows_per_tile % 32 != 0 || P % rows_per_tile != 0 || J % 64 != 0 || C % 128 != 0 || lda % 4 || ldg % 4 || lda < J || ldg < C ||
+      !aligned16(A) || !aligned16(G) || !aligned16(part) || !aligned16(a_rows) || !aligned16(zeros))
+    return RELGNN_EUNSUPPORTED;
+  LimbTnArgs a{};
+  a.A = A; a.lda = lda; a.G = G; a.ldg = ldg; a.P = part; a.V = P; a.J = J; a.C = C; a.a_cols = 1; a.g_cols = 1;
+  a.a_rows = a_rows; a.zeros = static_cast<const float*>(zeros);
+  const bool wide = C % 256 == 0;
+  const int t32 = J % 128 == 0 ? 4 : 2;
+  a.panels = (J / 32) / t32; a.chunks = C / (wide ? 256 : 128); a.rows_per_chunk = rows_per_tile; a.Z = P / rows_per_tile;
+  const int64_t logical = (int64_t)a.panels * a.chunks * a.Z;
+  const unsigned grid = (unsigned)(8 * ((logical + 7) / 8));
+  hipStream_t st = as_stream(stream);
+  if (wide) {
+    if (t32 == 4) limb_gemm_tn_kernel<4, 3, 256, true><<<grid, 512, 0, st>>>(a);
+    else limb_gemm_tn_kernel<2, 3, 256, true><<<grid, 512, 0, st>>>(a);
+  } else {
+    if (t32 == 4) limb_gemm_tn_kernel<4, 3, 128, true><<<grid, 512, 0, st>>>(a);
+    else limb_gemm_tn_kernel<2, 3, 128, true><<<grid, 512, 0, st>>>(a);
   }
   return launch_status();
 }

@@ -39,6 +39,72 @@ GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 _WARNED_UNSUPPORTED = False
 
 
+# ---- activation gradients folded into the product that feeds them ------------------------------------------------------------------
+# y = act(z) is differentiated from its OUTPUT (relgnn_act_bwd_from_output: tanh, relu, leaky_relu, elu, selu) by the function that
+# produced it: g_z = g_y * act'(y) — one pass over [V, D] per activation and step (three ReLU' and two tanh' passes per C2 step,
+# 16-34 us each).  The function that CONSUMES y computes g_y as an input-gradient product and can apply act'(y) in that product's
+# epilogue (relgnn_limb_gemm_xf32_dact: same bits, no pass).  Protocol, all on Python attributes of the tensors involved:
+#   * a producer tags its output:            mark_activation_output(y, act, sole_consumer=...)
+#   * a consumer that sees a tagged input x and whose input-gradient route can fuse returns g_x already multiplied by act'(x) and
+#     tags it:                               mark_premasked(g_x, x, act)
+#   * the producer's backward skips its own pass iff the gradient it receives IS that tagged tensor:  is_premasked(g, y, act)
+# A gradient that autograd had to sum with other contributions, copy or pass through a hook arrives as another tensor object
+# without the tag, and the producer multiplies as always.  That is exact for ReLU whatever happened in between (its factor is 0 or
+# 1: applying it twice, or to a sum whose first term already carries it, changes nothing).  The other activations' factors are not
+# idempotent, so they are only fused when the producer's caller vouches that y has exactly ONE consumer (sole_consumer=True: the
+# driver loop of models/sparse_graph_model.py knows its own dataflow).
+_FROM_OUTPUT_ACTS = (1, 2, 3, 4, 5)          # _lib.ACT_TANH .. ACT_SELU (GELU needs the pre-activation)
+_IDEMPOTENT_ACTS = (2,)                      # _lib.ACT_RELU
+
+
+def mark_activation_output(y: torch.Tensor, act: int, sole_consumer: bool = False) -> torch.Tensor:
+    if act in _FROM_OUTPUT_ACTS and y.is_cuda and y.dtype == torch.float32 and y.dim() == 2:
+        y._relgnn_act = (int(act), y._version, bool(sole_consumer))
+    return y
+
+
+def vouch_sole_consumer(y: torch.Tensor, sole: bool) -> torch.Tensor:
+    """The caller knows how many functions will read y (a tagged activation output): set / clear the tag's sole-consumer word."""
+    tag = getattr(y, "_relgnn_act", None)
+    if tag is not None:
+        y._relgnn_act = (tag[0], tag[1], bool(sole))
+    return y
+
+
+def fusable_activation_of(x: torch.Tensor) -> int:
+    """The activation whose gradient a consumer of x may apply in its input-gradient product (0 = none)."""
+    tag = getattr(x, "_relgnn_act", None)
+    if tag is None or tag[1] != x._version or getattr(x, "_backward_hooks", None) or _cfg.act_fusion != "1":
+        return 0
+    act, _, sole = tag
+    return act if (act in _IDEMPOTENT_ACTS or sole) else 0
+
+
+def mark_premasked(g: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
+    g._relgnn_premasked = (y.data_ptr(), y._version, int(act), tuple(y.shape))
+    return g
+
+
+def is_premasked(g: torch.Tensor, y: torch.Tensor, act: int) -> bool:
+    return getattr(g, "_relgnn_premasked", None) == (y.data_ptr(), y._version, int(act), tuple(y.shape))
+
+
+def act_bwd_from_output(act: int, y: torch.Tensor, g: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """g * act'(y) with the derivative taken from the activation's output (relgnn_act_bwd_from_output); out may be g itself."""
+    from . import _lib
+    g = g if g.is_contiguous() else g.contiguous()
+    if out is None:
+        out = torch.empty_like(g)
+    _lib.check(_lib.load_library().relgnn_act_bwd_from_output(act, _lib.ptr(y), _lib.ptr(g), g.numel(), _lib.ptr(out),
+                                                              _lib.current_stream()), "relgnn_act_bwd_from_output")
+    return out
+
+
+def _premask_operand_ok(y: torch.Tensor, rows: int, cols: int) -> bool:
+    return (y is not None and y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and tuple(y.shape) == (rows, cols)
+            and y.stride(1) == 1 and y.stride(0) % 4 == 0 and y.stride(0) >= cols and y.data_ptr() % 16 == 0)
+
+
 class _PerStream(dict):
     """Scratch keyed by (device, raw stream handle): products issued on different streams may run concurrently and must not
     share it.  Bounded: at most `limit` streams per cache are remembered, the least recently used entry goes first (a process
@@ -97,10 +163,18 @@ def _workspace(device):
 
 
 def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, out: torch.Tensor = None,
-             accumulate: bool = False, relu: bool = False, weight: bool = False) -> torch.Tensor:
+             accumulate: bool = False, relu: bool = False, weight: bool = False, act: int = None, premask=None) -> torch.Tensor:
     """Plain library GEMM with a cached solution (relgnn_blaslt_gemm_f32): NN a @ b (+ bias) | NT a @ b^T | TN a^T @ b.
     Falls back to torch for operands the C entry point does not take (not fp32 / not row-dense / CPU).
-    weight=True: b is a parameter (or a view of one) — the limb route keeps its limb image across the step (weight_limbs)."""
+    weight=True: b is a parameter (or a view of one) — the limb route keeps its limb image across the step (weight_limbs).
+    act: an activation id for the epilogue (overrides relu; routes without that epilogue apply it in a pass of their own).
+    premask = (act id, y): the result times act'(y), y [M, N] the OUTPUT of that activation (an input-gradient product meeting the
+    activation gradient of the layer below): in the limb kernel's epilogue, or as relgnn_act_bwd_from_output behind any other route."""
+    if act is None:
+        act = 2 if relu else 0                                     # _lib.ACT_RELU / ACT_LINEAR
+    relu = act == 2
+    if premask is not None or act not in (0, 2):
+        return _gemm_with_epilogues(layout, a, b, bias, act, weight, premask)
     if _cfg.limb_gemm and layout != GEMM_TN and out is None and not accumulate:
         from . import _lib
         if _limb_route_ok(layout, a, b, bias):
@@ -158,6 +232,33 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
         return out.add_(res) if accumulate else out.copy_(res)
     _lib.check(code, "relgnn_blaslt_gemm_f32")
     return out
+
+
+_TORCH_ACT_ = {1: torch.tanh_, 2: torch.relu_, 3: lambda t: torch.nn.functional.leaky_relu_(t, 0.2), 4: torch.nn.functional.elu_,
+               5: torch.selu_}
+
+
+def _gemm_with_epilogues(layout: int, a, b, bias, act: int, weight: bool, premask) -> torch.Tensor:
+    """lib_gemm's products that carry an activation other than ReLU and / or an activation-gradient factor: both ride in the limb
+    kernel's epilogue where that route applies (the tall products of the path); elsewhere they follow the plain product as passes."""
+    from . import _lib
+    M = a.shape[0]
+    N = b.shape[1] if layout == GEMM_NN else b.shape[0]
+    if premask is not None and not _premask_operand_ok(premask[1], M, N):
+        raise ValueError("lib_gemm: premask operand must be a float32 device [%d, %d] matrix with 16-byte aligned rows" % (M, N))
+    if (_cfg.limb_gemm and layout != GEMM_TN and weight and _limb_route_ok(layout, a, b, bias)
+            and weight_image_ok(_weight_matrices(b), WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT)):
+        return limb_gemm_weight(a, b, WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT, bias, act,
+                                dact=premask[0] if premask is not None else 0, dy=premask[1] if premask is not None else None)
+    res = lib_gemm(layout, a, b, bias, relu=(act == _lib.ACT_RELU), weight=weight)
+    if act not in (_lib.ACT_LINEAR, _lib.ACT_RELU):
+        fn = _TORCH_ACT_.get(act)
+        if fn is None:
+            raise ValueError("lib_gemm: no epilogue for activation id %d" % act)
+        res = fn(res)
+    if premask is not None:
+        res = act_bwd_from_output(premask[0], premask[1], res, out=res)
+    return res
 
 
 def _rows_ok(t: torch.Tensor) -> bool:
@@ -460,7 +561,8 @@ def weight_image(w, kind: str, pair: bool = False) -> "_WeightImage":
 
 
 def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, act: int = 0,
-                     out: torch.Tensor = None, xmax: torch.Tensor = None, xgroups: int = 0) -> torch.Tensor:
+                     out: torch.Tensor = None, xmax: torch.Tensor = None, xgroups: int = 0, dact: int = 0,
+                     dy: torch.Tensor = None) -> torch.Tensor:
     """act(bias + a @ B^T) with B = weight_limbs(w, kind), a fp32 [M, K] split inside the kernel (relgnn_limb_gemm_xf32).
     xmax [M * xgroups] (per-row magnitudes of `a` from its producer, ops._seg_reduce_raw(rowmax=)): the two-fp16-limb form
     (relgnn_limb16_gemm_xf32)."""
@@ -475,11 +577,22 @@ def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, a
         if xmax.numel() != a.shape[0] * xgroups or xmax.dtype != torch.float32 or not xmax.is_contiguous():
             raise ValueError("limb_gemm_weight: xmax must be a contiguous float32 [%d * %d]" % (a.shape[0], xgroups))
         im = weight_image(w, kind, pair=True)
+        if dy is not None:           # (dy [M, n]: the activation output whose gradient factor rides in the epilogue)
+            _lib.check(lib.relgnn_limb16_gemm_xf32_dact(act, a.data_ptr(), a.stride(0), xmax.data_ptr(), int(xgroups), im.buf.data_ptr(),
+                                                        im.wmax.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)), int(dact),
+                                                        dy.data_ptr(), dy.stride(0), out.data_ptr(), out.stride(0), a.shape[0], n, k,
+                                                        _lib.current_stream()), "relgnn_limb16_gemm_xf32_dact")
+            return out
         _lib.check(lib.relgnn_limb16_gemm_xf32(act, a.data_ptr(), a.stride(0), xmax.data_ptr(), int(xgroups), im.buf.data_ptr(),
                                                im.wmax.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)), out.data_ptr(),
                                                out.stride(0), a.shape[0], n, k, _lib.current_stream()), "relgnn_limb16_gemm_xf32")
         return out
     buf = weight_limbs(w, kind)
+    if dy is not None:
+        _lib.check(lib.relgnn_limb_gemm_xf32_dact(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
+                                                  int(dact), dy.data_ptr(), dy.stride(0), out.data_ptr(), out.stride(0), a.shape[0], n, k,
+                                                  _lib.current_stream()), "relgnn_limb_gemm_xf32_dact")
+        return out
     _lib.check(lib.relgnn_limb_gemm_xf32(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
                                          out.data_ptr(), out.stride(0), a.shape[0], n, k, _lib.current_stream()),
                "relgnn_limb_gemm_xf32")
@@ -503,14 +616,17 @@ def grouped_nn_gemm(a: torch.Tensor, kernels, relu: bool = False, xmax: torch.Te
     return lib_gemm(GEMM_NN, a, torch.cat(kernels, dim=0) if len(kernels) > 1 else kernels[0], relu=relu)
 
 
-def grouped_nt_gemm(g: torch.Tensor, kernels, xmax: torch.Tensor = None, xgroups: int = 0) -> torch.Tensor:
+def grouped_nt_gemm(g: torch.Tensor, kernels, xmax: torch.Tensor = None, xgroups: int = 0, premask=None) -> torch.Tensor:
     """sum_l g[:, block l] @ kernels[l]^T for g [V, sum_l K_l], kernels[l] [N, K_l]: the input gradient of grouped_nn_gemm's layer
-    (dH = sum_l dT_l @ W_l^T)."""
+    (dH = sum_l dT_l @ W_l^T).  premask = (act id, y): times act'(y), y [V, N] the layer's INPUT as the output of that activation
+    (lib_gemm's premask)."""
     kernels = list(kernels)
-    if _limb_group_ok(g, kernels, WEIGHT_NT):
-        return limb_gemm_weight(g, kernels, WEIGHT_NT, xmax=xmax, xgroups=xgroups)
+    if _limb_group_ok(g, kernels, WEIGHT_NT) and (premask is None or _premask_operand_ok(premask[1], g.shape[0], kernels[0].shape[0])):
+        return limb_gemm_weight(g, kernels, WEIGHT_NT, xmax=xmax, xgroups=xgroups,
+                                dact=premask[0] if premask is not None else 0, dy=premask[1] if premask is not None else None)
     # (the stacked [sum K_l, N] right operand is W_l^T row blocks, 0.8 MB re-laid per call at C2)
-    return lib_gemm(GEMM_NN, g, torch.cat([k.t() for k in kernels], dim=0))
+    res = lib_gemm(GEMM_NN, g, torch.cat([k.t() for k in kernels], dim=0))
+    return res if premask is None else act_bwd_from_output(premask[0], premask[1], res, out=res)
 
 
 def _limb_cut_route_ok(a: torch.Tensor, b: torch.Tensor, bias) -> bool:
@@ -584,6 +700,29 @@ def limb_dense_sel(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Te
 def limb_tn_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
     return (_rows_ok(a) and _rows_ok(b) and a.shape[0] == b.shape[0] and a.shape[0] >= _LIMB_MIN_ROWS and a.shape[1] % 32 == 0
             and b.shape[1] % 256 == 0)
+
+
+def limb_tn_tiles_supported(a: torch.Tensor, g: torch.Tensor, a_rows: torch.Tensor, rows_per_tile: int) -> bool:
+    """Shapes relgnn_limb_gemm_tn_tiles_f32 takes (the typed weight-gradient partials of ops.typed_linear)."""
+    return (_cfg.limb_gemm and _rows_ok(a) and _rows_ok(g) and a_rows.is_cuda and a_rows.dtype == torch.int32 and a_rows.is_contiguous()
+            and a_rows.data_ptr() % 16 == 0 and a_rows.numel() == g.shape[0] and rows_per_tile % 32 == 0
+            and g.shape[0] % rows_per_tile == 0 and a.shape[1] % 64 == 0 and g.shape[1] % 128 == 0)
+
+
+def limb_gemm_tn_tiles(a: torch.Tensor, g: torch.Tensor, a_rows: torch.Tensor, rows_per_tile: int) -> torch.Tensor:
+    """part[z] = a[a_rows[tile z]]^T @ g[tile z] for the P / rows_per_tile tiles of a compact pair table (a [*, J] node table, g [P, C]
+    the table's gradient, a_rows [P] int32, < 0 = padding): [tiles, J, C], three bf16 limbs per value, gathered / transposed /
+    split in flight (relgnn_limb_gemm_tn_tiles_f32)."""
+    from . import _lib
+    lib = _lib.load_library()
+    P, C = g.shape
+    J = a.shape[1]
+    tiles = P // rows_per_tile
+    part = torch.empty((tiles, J, C), dtype=torch.float32, device=g.device)
+    _lib.check(lib.relgnn_limb_gemm_tn_tiles_f32(a.data_ptr(), a.stride(0), a_rows.data_ptr(), g.data_ptr(), g.stride(0),
+                                                 _lib.ptr(_zeros(g.device)), part.data_ptr(), P, int(rows_per_tile), J, C,
+                                                 _lib.current_stream()), "relgnn_limb_gemm_tn_tiles_f32")
+    return part
 
 
 def col_absmax(x: torch.Tensor) -> torch.Tensor:
@@ -797,16 +936,26 @@ def _on_side_stream(run, operands, params, want=True):
 
 
 class _DenseFn(torch.autograd.Function):
+    """act(x @ kernel (+ bias)) for act in {linear, tanh, relu, leaky_relu, elu, selu} — the activation in the product's epilogue where
+    the route has one, differentiated from the saved OUTPUT — with a split-K weight gradient.
+    x_act: the activation x itself is the output of, when the caller may fold its gradient into this function's input-gradient
+    product (fusable_activation_of(x)): g_x then leaves already multiplied by x_act'(x) and tagged (mark_premasked)."""
+
     @staticmethod
-    def forward(ctx, x, kernel, bias):
-        ctx.save_for_backward(x, kernel)
-        ctx.has_bias = bias is not None
+    def forward(ctx, x, kernel, bias, act: int, x_act: int):
+        y = lib_gemm(GEMM_NN, x, kernel, bias, weight=True, act=act)
+        ctx.save_for_backward(x, kernel, y if act else None)
+        ctx.has_bias, ctx.act, ctx.x_act = bias is not None, act, x_act
         ctx.leaf_params = _leaf_params(kernel, bias)
-        return lib_gemm(GEMM_NN, x, kernel, bias, weight=True)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, kernel = ctx.saved_tensors
+        x, kernel, y = ctx.saved_tensors
+        if ctx.act:
+            # g * act'(y): nothing to do when the consumer of y already folded it into the product that made g
+            if not is_premasked(g, y, ctx.act):
+                g = act_bwd_from_output(ctx.act, y, g)
         if g.dim() != 2 or g.stride(1) != 1 or not g.is_cuda or (g.stride(0) < g.shape[1] and g.shape[0] != 1):
             g = g.contiguous()             # (a row-strided gradient, e.g. a column block of the GRU's gate gradients, is
         gx = None                          # read in place: every consumer below takes a leading dimension; an expanded one,
@@ -819,52 +968,38 @@ class _DenseFn(torch.autograd.Function):
 
         aside = _on_side_stream(weight_side, (x, g), ctx.leaf_params, want=ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
-            gx = lib_gemm(GEMM_NT, g, kernel, weight=True)
+            if ctx.x_act and _premask_operand_ok(x, g.shape[0], kernel.shape[0]):
+                gx = mark_premasked(lib_gemm(GEMM_NT, g, kernel, weight=True, premask=(ctx.x_act, x)), x, ctx.x_act)
+            else:
+                gx = lib_gemm(GEMM_NT, g, kernel, weight=True)
         gk, gb = aside if aside is not None else weight_side()
-        return gx, gk, gb
+        return gx, gk, gb, None, None
 
 
 def dense(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
     """x @ kernel (+ bias) with a split-K weight gradient."""
-    return _DenseFn.apply(x, kernel, bias)
+    return _DenseFn.apply(x, kernel, bias, 0, fusable_activation_of(x) if x.requires_grad else 0)
 
 
-class _DenseReluFn(torch.autograd.Function):
-    """relu(x @ kernel (+ bias)): the ReLU rides in the library GEMM's epilogue (one kernel instead of GEMM + clamp), the
-    backward masks the incoming gradient by the saved OUTPUT (relgnn_act_bwd_from_output) and continues as _DenseFn."""
-
-    @staticmethod
-    def forward(ctx, x, kernel, bias):
-        y = lib_gemm(GEMM_NN, x, kernel, bias, relu=True, weight=True)
-        ctx.save_for_backward(x, kernel, y)
-        ctx.has_bias = bias is not None
-        ctx.leaf_params = _leaf_params(kernel, bias)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        from . import _lib
-        x, kernel, y = ctx.saved_tensors
-        g = g.contiguous()
-        gm = torch.empty_like(g)
-        _lib.check(_lib.load_library().relgnn_act_bwd_from_output(_lib.ACT_RELU, _lib.ptr(y), _lib.ptr(g), g.numel(),
-                                                                  _lib.ptr(gm), _lib.current_stream()),
-                   "relgnn_act_bwd_from_output")
-        def weight_side():
-            gk = matmul_tn_splitk(x if (x.dim() == 2 and x.stride(1) == 1 and x.is_cuda) else x.contiguous(), gm) \
-                if ctx.needs_input_grad[1] else None
-            gb = column_sum(gm) if ctx.has_bias and ctx.needs_input_grad[2] else None
-            return gk, gb
-
-        aside = _on_side_stream(weight_side, (x, gm), ctx.leaf_params, want=ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
-        gx = lib_gemm(GEMM_NT, gm, kernel, weight=True) if ctx.needs_input_grad[0] else None
-        gk, gb = aside if aside is not None else weight_side()
-        return gx, gk, gb
+def dense_act(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None, act: int = 0,
+              sole_consumer: bool = False) -> torch.Tensor:
+    """act(dense(x, kernel, bias)) as ONE product with the activation in its epilogue (activation ids of _lib; gelu and anything the
+    epilogue does not take: the two-step route).  The result is tagged as an activation output (mark_activation_output) so that the
+    function that consumes it may fold act' into its input-gradient product; sole_consumer: the caller vouches that nothing else
+    will read the result (needed for every activation but ReLU, see the protocol at the top of this file)."""
+    from . import _lib
+    if act == _lib.ACT_LINEAR:
+        return dense(x, kernel, bias)
+    if not (act in _FROM_OUTPUT_ACTS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _cfg.gemm != "torch"
+            and (_cfg.act_fusion == "1" or act == _lib.ACT_RELU)):
+        from .utils import apply_activation, get_activation
+        return apply_activation(get_activation(_lib.ACT_NAMES[act]), dense(x, kernel, bias))
+    y = _DenseFn.apply(x, kernel, bias, act, fusable_activation_of(x) if x.requires_grad else 0)
+    return mark_activation_output(y, act, sole_consumer)
 
 
 def dense_relu(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
     """relu(dense(x, kernel, bias)) as one GEMM with a ReLU epilogue (CUDA fp32 operands; anything else takes the two-step
     route)."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and (_cfg.gemm != "torch")):
-        return torch.relu(dense(x, kernel, bias))
-    return _DenseReluFn.apply(x, kernel, bias)
+    from . import _lib
+    return dense_act(x, kernel, bias, _lib.ACT_RELU)

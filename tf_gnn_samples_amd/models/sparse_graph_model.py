@@ -435,8 +435,25 @@ class Sparse_Graph_Model(ABC):
         num_nodes = initial_node_features.shape[0]
         # bucketed once, shared by every layer; the index range check is read back at the next fetch
         graph = as_rel_graph(adjacency_lists, num_nodes, validate="deferred")
+        from ..dense import dense_act, vouch_sole_consumer
+        from ..ops import activation_id
+        act_id = activation_id(p['graph_model_activation_function'])
+        num_layers, res_every = p['graph_num_layers'], p['graph_residual_connection_every_num_layers']
+
+        def only_the_next_layer_reads(next_layer_idx: int) -> bool:
+            """Does the tensor handed to iteration `next_layer_idx` have exactly one reader, that layer's function?  (It is what lets a
+            layer fold a non-idempotent activation gradient — tanh' of the Dense below it — into its input-gradient product:
+            dense.py, "activation gradients folded into the product that feeds them".)  At a residual step the tensor is read by
+            the average instead (and kept for the next residual step); at layer 0 it is kept for the first residual step too."""
+            if next_layer_idx >= num_layers or dropout_keep_prob < 1.0:
+                return False
+            if next_layer_idx % res_every == 0:
+                return next_layer_idx == 0 and res_every >= num_layers
+            return True
+
         if self.task.initial_node_feature_size != p['hidden_size']:
-            cur_node_representations = apply_activation(activation_fn, dense(initial_node_features, w["dense/kernel"]))
+            cur_node_representations = dense_act(initial_node_features, w["dense/kernel"], None, act_id,
+                                                 sole_consumer=only_the_next_layer_reads(0))
         else:
             cur_node_representations = initial_node_features
         last_residual_representations = None          # (the reference's zeros_like is overwritten at layer 0 before any use)
@@ -457,9 +474,11 @@ class Sparse_Graph_Model(ABC):
                 cur_node_representations = layer_norm(cur_node_representations,
                                                       self._layer_weights[ln + "/gamma"], self._layer_weights[ln + "/beta"])
             if layer_idx % p['graph_dense_between_every_num_gnn_layers'] == 0:
-                cur_node_representations = apply_activation(
-                    activation_fn, dense(cur_node_representations, self._layer_weights["Dense/kernel"]))
-        return cur_node_representations
+                cur_node_representations = dense_act(cur_node_representations, self._layer_weights["Dense/kernel"], None, act_id,
+                                                     sole_consumer=only_the_next_layer_reads(layer_idx + 1))
+            else:
+                vouch_sole_consumer(cur_node_representations, only_the_next_layer_reads(layer_idx + 1))
+        return vouch_sole_consumer(cur_node_representations, False)     # (a task head may read it more than once)
 
     @abstractmethod
     def _apply_gnn_layer(self,

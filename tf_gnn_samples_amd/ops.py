@@ -542,8 +542,14 @@ class _TypedLinearPanel(torch.autograd.Function):
 
         def weight_gradient():
             tiles = side.P // side.chunk
-            part = panel_gemm(GEMM_TN, H, gY, a_rows=node32, batch=tiles, strides=(0, side.chunk * Dout, Din * Dout),
-                              dims=(Din, Dout, side.chunk))                          # [tiles, Din, Dout]
+            from .dense import limb_gemm_tn_tiles, limb_tn_tiles_supported
+            if _cfg.typed_tn == "limb" and limb_tn_tiles_supported(H, gY, node32, side.chunk):
+                # (round 5: the exact-fp32 panel TN was 26.7 % of the C5 step — 0.6 / 0.96 ms per launch; the three-limb TN on the
+                #  16-bit matrix pipe gathers, transposes and splits in flight)
+                part = limb_gemm_tn_tiles(H, gY, node32, side.chunk)                 # [tiles, Din, Dout]
+            else:
+                part = panel_gemm(GEMM_TN, H, gY, a_rows=node32, batch=tiles, strides=(0, side.chunk * Dout, Din * Dout),
+                                  dims=(Din, Dout, side.chunk))                      # [tiles, Din, Dout]
             n = Din * Dout
             sub = 1024 if n % 1024 == 0 else n
             K = n // sub
@@ -890,6 +896,10 @@ def wait_if_in_flight(params, device) -> None:
         side = _SIDE_STREAMS.get(device)
         if side is not None:
             torch.cuda.current_stream(device).wait_stream(side)
+        # their first contributions are complete as far as the main stream is concerned from here on: summing into them is safe and
+        # join_deferred() has nothing left to verify for these parameters
+        mine = {id(p) for p in params}
+        _DEFER["handed"] = [h for h in _DEFER["handed"] if id(h[0]) not in mine]
     if _DEFER["on"]:
         seen.update(id(p) for p in params)
 
@@ -975,7 +985,7 @@ class _AggregateThenTransform(torch.autograd.Function):
     dW_l = A_l^T @ dOut from the saved aggregated rows."""
 
     @staticmethod
-    def forward(ctx, H, graph, w, mode: int, act: int, act_name, *kernels):
+    def forward(ctx, H, graph, w, mode: int, act: int, act_name, h_act: int, *kernels):
         from .dense import grouped_nn_gemm
         H = H.contiguous()
         L = len(kernels)                                # kernels[l]: [Din, Dout], the per-edge-type variables themselves
@@ -987,7 +997,7 @@ class _AggregateThenTransform(torch.autograd.Function):
             amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
         agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
                               acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
-        want_w = any(ctx.needs_input_grad[6:])
+        want_w = any(ctx.needs_input_grad[7:])
         f = _mode_factor(graph, mode)
         fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the product's epilogue
         out = grouped_nn_gemm(agg, kernels, relu=fused_relu, xmax=amax, xgroups=L)
@@ -1002,27 +1012,29 @@ class _AggregateThenTransform(torch.autograd.Function):
             from .utils import apply_activation, get_activation
             out = apply_activation(get_activation(act_name), out)
         ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L = graph, w, mode, act, L
+        # h_act: H is itself the output of that activation and its gradient factor may ride in the input-gradient product's
+        # epilogue (dense.fusable_activation_of; needs d_in == the product's N, i.e. H's own rows as the epilogue operand)
+        ctx.h_act = h_act if ctx.needs_input_grad[0] else 0
         ctx.save_for_backward(agg if want_w else None, out if act != _lib.ACT_LINEAR else None,
-                              amax if want_w else None, *kernels)
+                              amax if want_w else None, H if ctx.h_act else None, *kernels)
         ctx.leaf_params = tuple(kernels) if all(k.is_leaf for k in kernels) else None
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        from .dense import grouped_nt_gemm, matmul_tn_splitk
-        lib = _lib.load_library()
+        from .dense import act_bwd_from_output, grouped_nt_gemm, is_premasked, mark_premasked, matmul_tn_splitk
         graph, w, mode, act, L = ctx.graph, ctx.w, ctx.mode, ctx.act, ctx.L
-        agg, out, amax, *kernels = ctx.saved_tensors
+        agg, out, amax, H_in, *kernels = ctx.saved_tensors
         d_in, d_out = kernels[0].shape
         V = graph.V
+        # g * act'(out) — unless the consumer of `out` folded that factor into the product that made this gradient (the tag is on
+        # the tensor object: look before anything copies it)
+        premasked = act != _lib.ACT_LINEAR and is_premasked(gout, out, act)
         gout = gout.contiguous()
-        if act != _lib.ACT_LINEAR:
-            g = torch.empty_like(gout)
-            _lib.check(lib.relgnn_act_bwd_from_output(act, _lib.ptr(out), _lib.ptr(gout), gout.numel(), _lib.ptr(g),
-                                                      _lib.current_stream()), "relgnn_act_bwd_from_output")
-            gout = g
+        if act != _lib.ACT_LINEAR and not premasked:
+            gout = act_bwd_from_output(act, out, gout)
         gH = gW = None
-        want_w = any(ctx.needs_input_grad[6:])
+        want_w = any(ctx.needs_input_grad[7:])
         # The weight gradient (matrix-pipe bound, one workgroup per CU, 147 KB of LDS, no L2 pressure) does not depend on the input
         # gradient's gather (L2-latency bound, no LDS, few registers): it runs on a side stream next to it (fork / join by events,
         # capturable in a hipGraph; the result is the same bits, the kernels are the same).
@@ -1046,7 +1058,10 @@ class _AggregateThenTransform(torch.autograd.Function):
                 gmax = torch.empty(V * L, dtype=torch.float32, device=gout.device)
             gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
                                  plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
-            gH = grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=L)           # dH = sum_l dT_l @ W_l^T
+            if ctx.h_act and H_in is not None:                               # dH = sum_l dT_l @ W_l^T (* act'(H): H's producer skips its pass)
+                gH = mark_premasked(grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=L, premask=(ctx.h_act, H_in)), H_in, ctx.h_act)
+            else:
+                gH = grouped_nt_gemm(gT, kernels, xmax=gmax, xgroups=L)
         if side is not None:
             if not _DEFER["on"]:
                 torch.cuda.current_stream(gout.device).wait_stream(side)
@@ -1056,11 +1071,11 @@ class _AggregateThenTransform(torch.autograd.Function):
             f = _mode_factor(graph, mode)               # agg holds the raw sums: the factor multiplies dOut
             gsc = gout if f is None else gout * f.unsqueeze(1)
             gW = _weight_gradient(agg, gsc, amax, L)
-        gWs = tuple(gW[l * d_in:(l + 1) * d_in] if ctx.needs_input_grad[6 + l] else None for l in range(L)) \
+        gWs = tuple(gW[l * d_in:(l + 1) * d_in] if ctx.needs_input_grad[7 + l] else None for l in range(L)) \
             if gW is not None else (None,) * L           # dW_l = A_l^T @ dOut: row block l of [L*Din, Dout]
         if side is not None and _DEFER["on"]:
             hand_over_deferred(gout.device, side, kernels, gWs)
-        return (gH, None, None, None, None, None) + gWs
+        return (gH, None, None, None, None, None, None) + gWs
 
 
 def aggregate_then_transform(H, W, graph, w, aggregation: str, activation: Optional[str]):
@@ -1069,7 +1084,10 @@ def aggregate_then_transform(H, W, graph, w, aggregation: str, activation: Optio
         raise ValueError("aggregate_then_transform: max aggregation / %r do not apply" % activation)
     # W: the per-edge-type kernels [Din, Dout] (a sequence: the variables themselves — nothing is stacked) or one [L, Din, Dout] tensor
     kernels = W.unbind(0) if torch.is_tensor(W) else tuple(W)
-    return _AggregateThenTransform.apply(H, graph, w, mode, act, activation, *kernels)
+    from .dense import fusable_activation_of, mark_activation_output
+    h_act = fusable_activation_of(H) if (H.requires_grad and H.is_contiguous() and H.shape[1] == kernels[0].shape[0]) else 0
+    out = _AggregateThenTransform.apply(H, graph, w, mode, act, activation, h_act, *kernels)
+    return mark_activation_output(out, act)     # (ReLU: any consumer may fold its gradient; the others need a caller's word that it is the only one)
 
 
 # ---- RGDCN dynamic kernels applied node-side (csrc/rgdcn.hip) --------------------------------------------------------
