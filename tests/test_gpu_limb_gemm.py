@@ -616,3 +616,39 @@ def test_folded_activation_gradients_leave_the_training_step_s_bits_alone(gpu_de
     for n in grads_u:
         assert torch.equal(grads_f[n], grads_u[n]), n
     assert passes_u == 5 and passes_f <= 2, (passes_u, passes_f)     # 3 ReLU' + 2 tanh' -> the head's ReLU' (+ nothing else)
+
+
+def test_a_tanh_output_with_two_readers_is_never_folded(gpu_device):
+    """The failure the two-word protocol exists for (found by the reference-run RMSProp case of a GGNN model in round 5): y = tanh(.)
+    handed to a layer with the hander's word "only you read it", and the layer reads it TWICE (messages and cell).  Folding tanh'
+    into one of the two input-gradient products would leave the producer multiplying the sum again.  Neither reader passes
+    sole_reader, so nothing is folded and the gradients equal the plain composition; with ONE reader that says so, it is folded —
+    same bits."""
+    from tf_gnn_samples_amd import _lib, dense as DN
+    torch.manual_seed(11)
+    x0 = torch.randn(5000, 256, device=gpu_device)
+    W0 = torch.randn(256, 256, device=gpu_device) * 0.06
+    U0 = torch.randn(256, 256, device=gpu_device) * 0.06
+    R0 = torch.randn(256, 256, device=gpu_device) * 0.06
+
+    def run(two_readers: bool, words: bool):
+        x = x0.clone().requires_grad_(True)
+        W, U, R = (t.clone().requires_grad_(True) for t in (W0, U0, R0))
+        y = DN.dense_act(x, W, None, _lib.ACT_TANH, sole_consumer=True)
+        if two_readers:
+            out = DN.dense(y, U, sole_reader=words) + DN.dense(y, R, sole_reader=words)
+        else:
+            out = DN.dense(y, U, sole_reader=words)
+        out.square().sum().backward()
+        return [t.grad.clone() for t in (x, W, U)] + ([R.grad.clone()] if two_readers else [])
+
+    one_folded, one_plain = run(False, True), run(False, False)
+    for a, b in zip(one_folded, one_plain):
+        assert torch.equal(a, b)
+    two = run(True, False)
+    xd = x0.double().requires_grad_(True)
+    Wd, Ud, Rd = (t.double().requires_grad_(True) for t in (W0, U0, R0))
+    yd = torch.tanh(xd @ Wd)
+    (yd @ Ud + yd @ Rd).square().sum().backward()
+    for got, want in zip(two, (xd.grad, Wd.grad, Ud.grad, Rd.grad)):
+        assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))

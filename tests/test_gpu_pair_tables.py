@@ -273,3 +273,43 @@ def test_ggnn_layer_compact_vs_oracle(gpu_device, monkeypatch, agg):
         clear_graph_cache()
         out = sparse_ggnn_layer(dev(h), [dev(a) for a in adj], D, 2, "gru", "tanh", agg, weights={k: dev(v) for k, v in w.items()})
         assert np.abs(out.cpu().numpy() - ref).max() < 1e-5, flag
+
+
+@pytest.mark.parametrize("Dout", [128, 256])
+def test_typed_weight_gradient_routes_agree(gpu_device, Dout):
+    """config typed_tn: the per-edge-type weight gradients of ops.typed_linear from the gathered three-limb TN kernel (limb) and from
+    the exact-fp32 panel TN (panel) — the FiLM layer's two products at hidden 128: [128, 128] message kernels, [128, 256] FiLM
+    kernels — against float64; `auto` picks limb for the 256-column one."""
+    from tf_gnn_samples_amd import config, ops
+    from tf_gnn_samples_amd.graph import RelGraph
+    rng, adj, _ = _sparse_many_type_graph(5)
+    V, L, Din = 300, 12, 128
+    g = RelGraph([torch.as_tensor(a, device=gpu_device) for a in adj], V)
+    side = g.pair_tables().src
+    H = rng.standard_normal((V, Din)).astype(np.float32)
+    Ws = [glorot(rng, (Din, Dout)) for _ in range(L)]
+    gY = None
+    grads = {}
+    for route in ("limb", "panel", "auto"):
+        with config.override(typed_tn=route):
+            Hd = torch.as_tensor(H, device=gpu_device).requires_grad_(True)
+            Wd = [torch.as_tensor(w, device=gpu_device).requires_grad_(True) for w in Ws]
+            assert ops._typed_panel_ok(Hd, side, Wd)
+            Y = ops.typed_linear(Hd, side, Wd)
+            if gY is None:
+                gY = torch.as_tensor(rng.standard_normal(tuple(Y.shape)).astype(np.float32), device=gpu_device)
+            Y.backward(gY)
+            torch.cuda.synchronize()
+            grads[route] = [w.grad.detach().cpu().numpy().astype(np.float64) for w in Wd]
+    node = side.node.cpu().numpy()
+    types = np.repeat(np.arange(L), np.diff(side.offsets))
+    Hz = np.concatenate([H, np.zeros((1, Din), np.float32)]).astype(np.float64)
+    gYn = gY.cpu().numpy().astype(np.float64)
+    for t in range(L):
+        rows = np.nonzero((types == t) & (node != V))[0]
+        want = Hz[node[rows]].T @ gYn[rows]
+        scale = max(1.0, np.abs(want).max())
+        for route in ("limb", "panel", "auto"):
+            assert np.abs(grads[route][t] - want).max() <= 5e-6 * scale, (route, t)
+        same = "limb" if Dout % 256 == 0 else "panel"
+        assert np.array_equal(grads["auto"][t], grads[same][t])

@@ -96,10 +96,13 @@ def test_hip_backward_reproduces_the_gradients_of_the_reference_s_own_code(gpu_d
         scale = max(1e-6, float(np.abs(want).max()))
         err = float(np.abs(got - want).max())
         fro = float(np.linalg.norm(got - want) / max(1e-12, np.linalg.norm(want)))
+        # measured on all 26 cases x every variable (scripts/parity_margins.py, profiles/r05_parity_margins.json): element-wise
+        # <= 9.4e-7 of the gradient's largest entry, Frobenius <= 9.4e-7 — kink cases included on these fixtures (no unit flips);
+        # the bars keep a factor 20 (smooth) / 100 (kinks) over that, where rounds 1-4 asserted 2e-4 / 5e-2
         if smooth:
-            assert err <= 2e-4 * scale and fro <= 1e-4, (case["function"], name, err, scale, fro)
+            assert err <= 2e-5 * scale and fro <= 2e-5, (case["function"], name, err, scale, fro)
         else:
-            assert fro <= 5e-3 and err <= 5e-2 * scale, (case["function"], name, err, scale, fro)
+            assert fro <= 1e-4 and err <= 1e-4 * scale, (case["function"], name, err, scale, fro)
 
 
 @pytest.mark.parametrize("i", range(len(AUTOGRAD["train"])), ids=["%s-%s" % (t["model"], t["steps"][0]["optimizer"]) for t in AUTOGRAD["train"]])

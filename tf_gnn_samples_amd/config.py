@@ -40,6 +40,9 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
     "rgcn_order": ("RELGNN_RGCN_ORDER", "aggregate_first", ("aggregate_first", "transform_first"),
                    "sum / mean / sqrt_n RGCN layers: gather raw states into the (target, type) buckets, then one K = L*D product | "
                    "the reference's order (per-type transform, then gather)"),
+    "gather_warm": ("RELGNN_GATHER_WARM", "0", ("0", "1"),
+                    "aggregate-first layers: stream the [V, D] table through each XCD's L2 right before the gather that reads it "
+                    "(relgnn_seg_reduce_warm_table; results unchanged) | nothing"),
     "agg_acc": ("RELGNN_AGG_ACC", "f32", ("f32", "f64"),
                 "accumulator width of the bucket sums in front of the aggregate-first product"),
     "bwd_overlap": ("RELGNN_BWD_OVERLAP", "auto", ("auto", "0", "1"),
@@ -52,9 +55,10 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                        "FiLM regather backward: pass A leaves one sign bit per message and feature for pass B"),
     "typed": ("RELGNN_TYPED", "panel", ("panel", "bmm"),
               "per-(node, type) transforms of many-type graphs: one gathered-row MFMA launch | index_select + torch.bmm"),
-    "typed_tn": ("RELGNN_TYPED_TN", "limb", ("limb", "panel"),
+    "typed_tn": ("RELGNN_TYPED_TN", "auto", ("auto", "limb", "panel"),
                  "typed weight-gradient partials of many-type graphs: the gathered three-limb TN kernel on the 16-bit matrix pipe "
-                 "(needs gemm=limb) | the exact-fp32 row-panel MFMA kernel"),
+                 "(needs gemm=limb) | the exact-fp32 row-panel MFMA kernel (auto: limb for 256-column outputs, where it measured "
+                 "405 vs 484 us; panel for 128-column ones, 262 vs 325 us: profiles/r05_typed_tn.jsonl)"),
     "pair_tables": ("RELGNN_PAIR_TABLES", "auto", ("auto", "0", "1"),
                     "compact tables over the non-empty (node, type) buckets (auto: L >= 8 and < 60 % of the buckets non-empty)"),
     "rgat_fused_sums": ("RELGNN_RGAT_FUSED_SUMS", "1", ("0", "1"),

@@ -51,8 +51,11 @@ _WARNED_UNSUPPORTED = False
 # A gradient that autograd had to sum with other contributions, copy or pass through a hook arrives as another tensor object
 # without the tag, and the producer multiplies as always.  That is exact for ReLU whatever happened in between (its factor is 0 or
 # 1: applying it twice, or to a sum whose first term already carries it, changes nothing).  The other activations' factors are not
-# idempotent, so they are only fused when the producer's caller vouches that y has exactly ONE consumer (sole_consumer=True: the
-# driver loop of models/sparse_graph_model.py knows its own dataflow).
+# idempotent: folding one into ONE of several contributions would leave the producer multiplying the sum again.  They are only
+# folded when y provably has exactly one reader in the autograd graph, which takes two words: whoever hands y over vouches that
+# only the function it is handed to will read it (the tag's flag: the driver loop of models/sparse_graph_model.py knows its own
+# dataflow), and that function says that it reads it exactly once (sole_reader=True: the aggregate-first RGCN layer's first
+# timestep, the driver's Dense between layers; a GGNN layer, which feeds its input to the messages AND to the cell, does not).
 _FROM_OUTPUT_ACTS = (1, 2, 3, 4, 5)          # _lib.ACT_TANH .. ACT_SELU (GELU needs the pre-activation)
 _IDEMPOTENT_ACTS = (2,)                      # _lib.ACT_RELU
 
@@ -71,13 +74,14 @@ def vouch_sole_consumer(y: torch.Tensor, sole: bool) -> torch.Tensor:
     return y
 
 
-def fusable_activation_of(x: torch.Tensor) -> int:
-    """The activation whose gradient a consumer of x may apply in its input-gradient product (0 = none)."""
+def fusable_activation_of(x: torch.Tensor, sole_reader: bool = False) -> int:
+    """The activation whose gradient a consumer of x may apply in its input-gradient product (0 = none).  sole_reader: the caller
+    reads x exactly once (needed, together with the hander's word in the tag, for every activation but ReLU)."""
     tag = getattr(x, "_relgnn_act", None)
     if tag is None or tag[1] != x._version or getattr(x, "_backward_hooks", None) or _cfg.act_fusion != "1":
         return 0
-    act, _, sole = tag
-    return act if (act in _IDEMPOTENT_ACTS or sole) else 0
+    act, _, only_this_callee = tag
+    return act if (act in _IDEMPOTENT_ACTS or (only_this_callee and sole_reader)) else 0
 
 
 def mark_premasked(g: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
@@ -976,25 +980,26 @@ class _DenseFn(torch.autograd.Function):
         return gx, gk, gb, None, None
 
 
-def dense(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
-    """x @ kernel (+ bias) with a split-K weight gradient."""
-    return _DenseFn.apply(x, kernel, bias, 0, fusable_activation_of(x) if x.requires_grad else 0)
+def dense(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None, sole_reader: bool = False) -> torch.Tensor:
+    """x @ kernel (+ bias) with a split-K weight gradient.  sole_reader: this call is the only reader of x (see the protocol at the
+    top of this file; it only matters when x is a tagged activation output)."""
+    return _DenseFn.apply(x, kernel, bias, 0, fusable_activation_of(x, sole_reader) if x.requires_grad else 0)
 
 
 def dense_act(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None, act: int = 0,
-              sole_consumer: bool = False) -> torch.Tensor:
+              sole_consumer: bool = False, sole_reader: bool = False) -> torch.Tensor:
     """act(dense(x, kernel, bias)) as ONE product with the activation in its epilogue (activation ids of _lib; gelu and anything the
     epilogue does not take: the two-step route).  The result is tagged as an activation output (mark_activation_output) so that the
-    function that consumes it may fold act' into its input-gradient product; sole_consumer: the caller vouches that nothing else
-    will read the result (needed for every activation but ReLU, see the protocol at the top of this file)."""
+    function that consumes it may fold act' into its input-gradient product; sole_consumer: the caller vouches that only the function
+    it hands the result to will read it; sole_reader: this call is the only reader of x (both: the protocol at the top of this file)."""
     from . import _lib
     if act == _lib.ACT_LINEAR:
-        return dense(x, kernel, bias)
+        return dense(x, kernel, bias, sole_reader=sole_reader)
     if not (act in _FROM_OUTPUT_ACTS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _cfg.gemm != "torch"
             and (_cfg.act_fusion == "1" or act == _lib.ACT_RELU)):
         from .utils import apply_activation, get_activation
-        return apply_activation(get_activation(_lib.ACT_NAMES[act]), dense(x, kernel, bias))
-    y = _DenseFn.apply(x, kernel, bias, act, fusable_activation_of(x) if x.requires_grad else 0)
+        return apply_activation(get_activation(_lib.ACT_NAMES[act]), dense(x, kernel, bias, sole_reader=sole_reader))
+    y = _DenseFn.apply(x, kernel, bias, act, fusable_activation_of(x, sole_reader) if x.requires_grad else 0)
     return mark_activation_output(y, act, sole_consumer)
 
 

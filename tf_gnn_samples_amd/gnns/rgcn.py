@@ -77,9 +77,11 @@ def sparse_rgcn_layer(node_embeddings: torch.Tensor,
     if (not use_both_source_and_target and aggregate_first_enabled() and mode != _lib.AGG_MAX and act in ops._FUSABLE_ACTS
             and in_dim % 4 == 0 and state_dim % 4 == 0):
         kernels = [weights["Edge_%i_Weight/kernel" % l] for l in range(L)]                       # L x [D, state_dim]
-        for _ in range(num_timesteps):
+        for t in range(num_timesteps):
+            # (the first timestep is this function's only read of node_embeddings: with the caller's word that nobody else reads
+            #  them, the gradient of the activation that produced them rides in this layer's input-gradient product)
             cur_node_states = ops.aggregate_then_transform(cur_node_states, kernels, graph, w,
-                                                           message_aggregation_function, activation_function)
+                                                           message_aggregation_function, activation_function, sole_reader=(t == 0))
         return cur_node_states
     if not use_both_source_and_target:
         plan = graph.plan_transformed(w)

@@ -441,10 +441,11 @@ class Sparse_Graph_Model(ABC):
         num_layers, res_every = p['graph_num_layers'], p['graph_residual_connection_every_num_layers']
 
         def only_the_next_layer_reads(next_layer_idx: int) -> bool:
-            """Does the tensor handed to iteration `next_layer_idx` have exactly one reader, that layer's function?  (It is what lets a
-            layer fold a non-idempotent activation gradient — tanh' of the Dense below it — into its input-gradient product:
-            dense.py, "activation gradients folded into the product that feeds them".)  At a residual step the tensor is read by
-            the average instead (and kept for the next residual step); at layer 0 it is kept for the first residual step too."""
+            """Is the layer function of iteration `next_layer_idx` the only reader of the tensor handed to it?  (One of the two words
+            that let a layer fold a non-idempotent activation gradient — tanh' of the Dense below it — into its input-gradient
+            product: dense.py, "activation gradients folded into the product that feeds them"; the other one is the layer's own:
+            that it reads its input once.)  At a residual step the tensor is read by the average instead (and kept for the next
+            residual step); at layer 0 it is kept for the first residual step too."""
             if next_layer_idx >= num_layers or dropout_keep_prob < 1.0:
                 return False
             if next_layer_idx % res_every == 0:
@@ -474,8 +475,10 @@ class Sparse_Graph_Model(ABC):
                 cur_node_representations = layer_norm(cur_node_representations,
                                                       self._layer_weights[ln + "/gamma"], self._layer_weights[ln + "/beta"])
             if layer_idx % p['graph_dense_between_every_num_gnn_layers'] == 0:
-                cur_node_representations = dense_act(cur_node_representations, self._layer_weights["Dense/kernel"], None, act_id,
-                                                     sole_consumer=only_the_next_layer_reads(layer_idx + 1))
+                # (the layer's / the norm's output is referenced nowhere else: this Dense is its only reader)
+                cur_node_representations = dense_act(vouch_sole_consumer(cur_node_representations, True),
+                                                     self._layer_weights["Dense/kernel"], None, act_id,
+                                                     sole_consumer=only_the_next_layer_reads(layer_idx + 1), sole_reader=True)
             else:
                 vouch_sole_consumer(cur_node_representations, only_the_next_layer_reads(layer_idx + 1))
         return vouch_sole_consumer(cur_node_representations, False)     # (a task head may read it more than once)

@@ -108,6 +108,15 @@ def rowmax_supported(X, rowptr, stride, acc64: bool = False) -> bool:
             and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0)
 
 
+def _warm_table(X) -> None:
+    """config gather_warm=1: stream the table a gather is about to read through every XCD's L2 (relgnn_seg_reduce_warm_table) —
+    tables between 8 MB and 128 MB: smaller ones are warm after the first buckets, larger ones do not stay."""
+    if (_cfg.gather_warm == "1" and X.is_cuda and X.dim() == 2 and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
+            and (8 << 20) <= X.shape[0] * X.stride(0) * 4 <= (128 << 20)):
+        _lib.check(_lib.load_library().relgnn_seg_reduce_warm_table(_lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0),
+                                                                   _lib.current_stream()), "relgnn_seg_reduce_warm_table")
+
+
 def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEAR, acc64: bool = False, rowmax=None):
     """acc64: float64 bucket accumulators (relgnn_seg_reduce_acc64_fwd) — for sums that feed a GEMM, never for values that
     stand for the reference's own segment sums.  Split (hub) plans keep the float32 two-pass route.
@@ -543,9 +552,11 @@ class _TypedLinearPanel(torch.autograd.Function):
         def weight_gradient():
             tiles = side.P // side.chunk
             from .dense import limb_gemm_tn_tiles, limb_tn_tiles_supported
-            if _cfg.typed_tn == "limb" and limb_tn_tiles_supported(H, gY, node32, side.chunk):
-                # (round 5: the exact-fp32 panel TN was 26.7 % of the C5 step — 0.6 / 0.96 ms per launch; the three-limb TN on the
-                #  16-bit matrix pipe gathers, transposes and splits in flight)
+            if ((_cfg.typed_tn == "limb" or (_cfg.typed_tn == "auto" and Dout % 256 == 0))
+                    and limb_tn_tiles_supported(H, gY, node32, side.chunk)):
+                # (round 5, isolated at a C5-sized table of 1400 tiles: three-limb TN 405 us vs exact-fp32 panel TN 484 us for
+                #  [128, 256] partials, 325 vs 262 us for [128, 128] ones — the panel kernel runs near the fp32 matrix pipe's rate;
+                #  the 0.6 / 0.96 ms per launch of the round-4 traces were contention on the side stream, not the kernel)
                 part = limb_gemm_tn_tiles(H, gY, node32, side.chunk)                 # [tiles, Din, Dout]
             else:
                 part = panel_gemm(GEMM_TN, H, gY, a_rows=node32, batch=tiles, strides=(0, side.chunk * Dout, Din * Dout),
@@ -995,6 +1006,7 @@ class _AggregateThenTransform(torch.autograd.Function):
         amax = None
         if _pair_products(H, graph.rowptr_t, 1, V, L * d_in, d_out, kernels, "nn"):
             amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
+        _warm_table(H)
         agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
                               acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
         want_w = any(ctx.needs_input_grad[7:])
@@ -1056,6 +1068,7 @@ class _AggregateThenTransform(torch.autograd.Function):
             if (plan.num_rows_x == V * L and
                     _pair_products(gout, plan.rowptr_b, plan.stride_b, V, L * d_out, d_in, kernels, "nt")):
                 gmax = torch.empty(V * L, dtype=torch.float32, device=gout.device)
+            _warm_table(gout)
             gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
                                  plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
             if ctx.h_act and H_in is not None:                               # dH = sum_l dT_l @ W_l^T (* act'(H): H's producer skips its pass)
@@ -1078,14 +1091,15 @@ class _AggregateThenTransform(torch.autograd.Function):
         return (gH, None, None, None, None, None, None) + gWs
 
 
-def aggregate_then_transform(H, W, graph, w, aggregation: str, activation: Optional[str]):
+def aggregate_then_transform(H, W, graph, w, aggregation: str, activation: Optional[str], sole_reader: bool = False):
+    """sole_reader: this call is the only reader of H (dense.py, "activation gradients folded into the product that feeds them")."""
     mode, act = aggregation_mode_id(aggregation), activation_id(activation)
     if mode == _lib.AGG_MAX or act not in _FUSABLE_ACTS:
         raise ValueError("aggregate_then_transform: max aggregation / %r do not apply" % activation)
     # W: the per-edge-type kernels [Din, Dout] (a sequence: the variables themselves — nothing is stacked) or one [L, Din, Dout] tensor
     kernels = W.unbind(0) if torch.is_tensor(W) else tuple(W)
     from .dense import fusable_activation_of, mark_activation_output
-    h_act = fusable_activation_of(H) if (H.requires_grad and H.is_contiguous() and H.shape[1] == kernels[0].shape[0]) else 0
+    h_act = fusable_activation_of(H, sole_reader) if (H.requires_grad and H.is_contiguous() and H.shape[1] == kernels[0].shape[0]) else 0
     out = _AggregateThenTransform.apply(H, graph, w, mode, act, activation, h_act, *kernels)
     return mark_activation_output(out, act)     # (ReLU: any consumer may fold its gradient; the others need a caller's word that it is the only one)
 
