@@ -281,12 +281,6 @@ int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* ro
                        const float* w_b, const float* out, const float* gsel, int64_t ldo,
                        float* gX, int64_t ldgx, void* stream);
 
-/* L2 warm-up of the table a relgnn_seg_reduce_fwd* call is about to gather from (tf.nn.embedding_lookup's params, gnns/rgcn.py:87-89,
- * when a producer kernel has just written it): every XCD streams the eighth of X [num_rows_x, ldx] whose rows its share of the
- * gather's workgroups will read first (both kernels hand each XCD one contiguous range of a disjoint-union batch).  Loads only —
- * results are unchanged; it pays when the table is a few times the 4 MiB L2 per XCD and was not read since it was written
- * (config switch gather_warm).  Requirements: 16-byte aligned rows. */
-int relgnn_seg_reduce_warm_table(const float* X, int64_t num_rows_x, int64_t ldx, void* stream);
 /* elementwise epilogue gradient: gin = gout * act'(.) evaluated from the activation OUTPUT y
  * (valid for LINEAR/TANH/RELU/LEAKY_RELU/ELU/SELU).  n = number of floats. */
 int relgnn_act_bwd_from_output(int32_t act, const float* y, const float* gout, int64_t n,

@@ -598,7 +598,7 @@ def test_folded_activation_gradients_leave_the_training_step_s_bits_alone(gpu_de
     def step(fold: bool):
         clear_graph_cache()
         if not fold:
-            monkeypatch.setattr(DN, "fusable_activation_of", lambda x: 0)
+            monkeypatch.setattr(DN, "fusable_activation_of", lambda x, sole_reader=False: 0)
         p = RGCN_Model.default_params()
         p.update(hidden_size=256, graph_num_layers=3, graph_layer_input_dropout_keep_prob=1.0, random_seed=0)
         model = RGCN_Model(p, task, device=str(gpu_device))

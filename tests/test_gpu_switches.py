@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 VARIANTS = [dict(gemm="lib"), dict(gemm="panel"), dict(gemm="torch"), dict(limb="pair"), dict(limb="pair", limb_pair_parts="nn"),
             dict(limb="pair", limb_pair_parts="nt,tn"), dict(limb_cut="0"), dict(weight_limb_cache="0"), dict(tn="lib"),
             dict(rgcn_order="transform_first"), dict(agg_acc="f64"), dict(bwd_overlap="0"), dict(gemm="lib", bwd_overlap="1"),
-            dict(act_fusion="0"), dict(act_fusion="0", limb="pair"), dict(gemm="lib", act_fusion="1"), dict(gather_warm="1")]
+            dict(act_fusion="0"), dict(act_fusion="0", limb="pair"), dict(gemm="lib", act_fusion="1")]
 
 
 @pytest.fixture(scope="module")

@@ -40,9 +40,6 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
     "rgcn_order": ("RELGNN_RGCN_ORDER", "aggregate_first", ("aggregate_first", "transform_first"),
                    "sum / mean / sqrt_n RGCN layers: gather raw states into the (target, type) buckets, then one K = L*D product | "
                    "the reference's order (per-type transform, then gather)"),
-    "gather_warm": ("RELGNN_GATHER_WARM", "0", ("0", "1"),
-                    "aggregate-first layers: stream the [V, D] table through each XCD's L2 right before the gather that reads it "
-                    "(relgnn_seg_reduce_warm_table; results unchanged) | nothing"),
     "agg_acc": ("RELGNN_AGG_ACC", "f32", ("f32", "f64"),
                 "accumulator width of the bucket sums in front of the aggregate-first product"),
     "bwd_overlap": ("RELGNN_BWD_OVERLAP", "auto", ("auto", "0", "1"),

@@ -452,28 +452,6 @@ __global__ __launch_bounds__(256) void seg_max_bwd_vec_kernel(
   }
 }
 
-// L2 warm-up of a gather's table: XCD x streams the x-th eighth of the table (the rows of the graphs whose targets its share of the
-// gather's workgroups will fold: both kernels give every XCD one contiguous range, xcd_logical_block), so that the gather's first
-// touch of a row hits its XCD's 4 MiB L2 instead of the Infinity Cache / HBM.  The fold is a chain of dependent row fetches per
-// bucket: behind a producer kernel the table is cold and 1 / 28 of the fetches (every row's first) carry the full miss latency —
-// measured 118-123 us in a training step against 93 us on a warm table (profiles/r04, r05).  Streaming the 33-37 MB through takes
-// ~10 us at the fabric's rate.  Loads only; nothing is written.
-__global__ __launch_bounds__(256) void l2_warm_kernel(const float4* __restrict__ X, int64_t n4, int64_t per_block4) {
-  const int64_t lb = xcd_logical_block(gridDim.x);
-  if (lb < 0) return;
-  const int64_t beg = lb * per_block4, end = min(n4, beg + per_block4);
-  for (int64_t i = beg + threadIdx.x; i < end; i += 4 * 256) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t j = i + (int64_t)u * 256;
-      v[u] = j < end ? X[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" : : "v"(v[u].x), "v"(v[u].y), "v"(v[u].z), "v"(v[u].w));
-  }
-}
-
 template <int ACT>
 __global__ __launch_bounds__(256) void act_bwd_from_output_kernel(const float* __restrict__ y,
                                                                   const float* __restrict__ gout,
@@ -790,19 +768,6 @@ int relgnn_seg_max_bwd(const float* X, int64_t ldx, int32_t D, const int32_t* ro
   }
   seg_max_bwd_kernel<<<(unsigned)((num_rows_x + 3) / 4), 256, 0, as_stream(stream)>>>(
       X, ldx, D, rowptr_b, num_rows_x, seg_stride_b, seg_b, w_b, out, gsel, ldo, gX, ldgx);
-  return launch_status();
-}
-
-int relgnn_seg_reduce_warm_table(const float* X, int64_t num_rows_x, int64_t ldx, void* stream) {
-  if (num_rows_x < 0 || ldx < 0) return RELGNN_EINVAL;
-  const int64_t n = num_rows_x * ldx;
-  if (n == 0) return RELGNN_OK;
-  if (!X) return RELGNN_EINVAL;
-  if (!aligned16(X) || ldx % 4 != 0) return RELGNN_EUNSUPPORTED;
-  const int64_t n4 = n / 4;
-  const int blocks = 512;                                    // 64 per XCD, two per CU
-  const int64_t per_block4 = (n4 + blocks - 1) / blocks;
-  l2_warm_kernel<<<blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(X), n4, per_block4);
   return launch_status();
 }
 

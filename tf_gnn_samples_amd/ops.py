@@ -108,15 +108,6 @@ def rowmax_supported(X, rowptr, stride, acc64: bool = False) -> bool:
             and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0)
 
 
-def _warm_table(X) -> None:
-    """config gather_warm=1: stream the table a gather is about to read through every XCD's L2 (relgnn_seg_reduce_warm_table) —
-    tables between 8 MB and 128 MB: smaller ones are warm after the first buckets, larger ones do not stay."""
-    if (_cfg.gather_warm == "1" and X.is_cuda and X.dim() == 2 and X.stride(1) == 1 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0
-            and (8 << 20) <= X.shape[0] * X.stride(0) * 4 <= (128 << 20)):
-        _lib.check(_lib.load_library().relgnn_seg_reduce_warm_table(_lib.ptr(X, rows_strided=True), X.shape[0], X.stride(0),
-                                                                   _lib.current_stream()), "relgnn_seg_reduce_warm_table")
-
-
 def _seg_reduce_raw(mode, X, rowptr, stride, col, w, num_out, act=_lib.ACT_LINEAR, acc64: bool = False, rowmax=None):
     """acc64: float64 bucket accumulators (relgnn_seg_reduce_acc64_fwd) — for sums that feed a GEMM, never for values that
     stand for the reference's own segment sums.  Split (hub) plans keep the float32 two-pass route.
@@ -1006,7 +997,6 @@ class _AggregateThenTransform(torch.autograd.Function):
         amax = None
         if _pair_products(H, graph.rowptr_t, 1, V, L * d_in, d_out, kernels, "nn"):
             amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
-        _warm_table(H)
         agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
                               acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
         want_w = any(ctx.needs_input_grad[7:])
@@ -1068,7 +1058,6 @@ class _AggregateThenTransform(torch.autograd.Function):
             if (plan.num_rows_x == V * L and
                     _pair_products(gout, plan.rowptr_b, plan.stride_b, V, L * d_out, d_in, kernels, "nt")):
                 gmax = torch.empty(V * L, dtype=torch.float32, device=gout.device)
-            _warm_table(gout)
             gT = _seg_reduce_raw(_lib.AGG_SUM, gout, plan.rowptr_b, plan.stride_b, plan.col_b, plan.w_bwd(mode),
                                  plan.num_rows_x, acc64=aggregate_acc64(), rowmax=gmax).view(V, L * d_out)   # row u: [dT_0 | .. | dT_{L-1}]
             if ctx.h_act and H_in is not None:                               # dH = sum_l dT_l @ W_l^T (* act'(H): H's producer skips its pass)
