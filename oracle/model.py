@@ -1,7 +1,8 @@
 """NumPy restatement of the per-layer driver loop and the PPI output head.
 
 TEST INFRASTRUCTURE; PARITY UNPINNED (oracle/__init__.py).
-  graph_propagation : models/sparse_graph_model.py:162-202 (dropout keep-prob 1: identity)
+  graph_propagation : models/sparse_graph_model.py:162-202 (dropout: identity at keep-prob 1; with `dropout` = (keep_prob, one
+                      keep mask per layer) the masks stand in for TF's random draws, the scaling is tf.nn.dropout's)
   ppi_head_loss     : tasks/ppi_task.py:176-191
   rgcn_ppi_num_parameters : re-derivation of README.md:29 (699 257)
 """
@@ -11,7 +12,7 @@ from . import gnns, tf_ops as T
 
 
 def graph_propagation(initial_node_features, adjacency_lists, type_to_num_incoming_edges, params, weights,
-                      apply_gnn_layer, initial_node_feature_size=None):
+                      apply_gnn_layer, initial_node_feature_size=None, dropout=None):
     """models/sparse_graph_model.py:162-202.  `weights` uses names relative to "graph_model/":
     "dense/kernel" (input projection, :165-170), "gnn_layer_%i/..." (layer variables, :177) and
     "gnn_layer_%i/Dense/kernel" (:194-200).  `apply_gnn_layer(layer_idx, h, adj, deg, timesteps, layer_weights)`
@@ -27,7 +28,11 @@ def graph_propagation(initial_node_features, adjacency_lists, type_to_num_incomi
     for layer_idx in range(params['graph_num_layers']):                                 # :176
         scope = "gnn_layer_%i/" % layer_idx
         layer_weights = {k[len(scope):]: v for k, v in weights.items() if k.startswith(scope)}
-        # :178-179 dropout with rate 0 is the identity (evaluation / keep_prob 1.0)
+        # :178-179 tf.nn.dropout(x, rate = 1 - keep_prob) on the layer's INPUT, before the residual step: x / keep_prob where the
+        # mask keeps, 0 elsewhere [TF-internal: div(x, keep_prob) * floor(keep_prob + uniform)]; rate 0 is the identity
+        if dropout is not None:
+            keep_prob, masks = dropout
+            cur = cur / np.asarray(keep_prob, dtype) * np.asarray(masks[layer_idx], dtype)
         if layer_idx % params['graph_residual_connection_every_num_layers'] == 0:      # :180-185
             t = cur
             if layer_idx > 0:

@@ -39,7 +39,7 @@ def _check_line(d, full):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_c_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
     _check_line(d, full=True)
     r = d["roofline"]
     # the line is quoted on the workload no cache can help; the upper bound on Infinity-Cache hits rides along
@@ -47,6 +47,21 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["frac_of_measured_copy_ceiling"] <= 1.0
     lo, hi = r["skewed_giant"]["frac_range"]
     assert 0.0 < lo < hi <= 1.0
+    # round 5: the BASELINE configuration's own figure is a structured field — the gather inside the timed loop against the L2 peak
+    c2 = r["c2"]
+    assert "error" not in c2, c2
+    assert c2["launches_traced"] == 6 * c2["trace_steps"] and 0.0 < c2["frac_of_l2_peak"] < 1.0
+    assert abs(c2["algorithmic_GBps"] - c2["algorithmic_bytes_per_launch"] / (c2["avg_kernel_ms_in_step"] * 1e-3) / 1e9) < 1e-6 * c2["algorithmic_GBps"]
+    assert abs(c2["frac_of_l2_peak"] - c2["algorithmic_GBps"] / c2["l2_peak_GBps"]) < 1e-9
+    assert 1.0 <= c2["hbm_side_over_compulsory"] < 2.0 and c2["top_kernels"][0]["name"].startswith("seg_reduce_wave_kernel")
+    # round 5: the headline is the exact-split (fp32) arithmetic; the other two arithmetics are scalar top-level keys
+    assert d["dense_products"]["route"] == "limb" and d["dense_products"]["limbs"] == "triple"
+    assert d["fp32_exact_split_ms_per_step"] == d["ms_per_step"] and d["fp32_exact_split_value"] == d["value"]
+    for k in ("pair_route_ms_per_step", "pair_route_value", "exact_fp32_lib_ms_per_step", "exact_fp32_lib_value"):
+        assert isinstance(d[k], float) and d[k] > 0, k
+    assert d["pair_route_ms_per_step"] < d["ms_per_step"] < d["exact_fp32_lib_ms_per_step"]
+    for k in ("allreduce", "allreduce_ms", "gpu_step_ms", "edge_imbalance", "nranks"):
+        assert k in d and not isinstance(d[k], (dict, list)), k
     # every BASELINE config is in the driver-visible record, each with its gather kernel's rate
     cfgs = d["other_configs"]["configs"]
     assert {c["config"][:2] for c in cfgs} == {"C3", "C4", "C5"} and len(cfgs) == 4
@@ -57,7 +72,22 @@ def test_committed_bench_line_keeps_the_contract():
         assert len(d["per_rank"][k]) == d["world_size"]
     assert d["step_edge_imbalance_max_over_mean"]["max"] >= 1.0 - 1e-9
     c = d["cpu_baseline"]
-    assert "median of 5" in c["sample"] and "2 warm-ups" in c["sample"] and c["forward_only_value"] > c["value"]
+    # the training leg runs on the WHOLE bench batch (round 5), like the forward-only leg
+    assert "the first 16 of the bench batch's 16 graphs" in c["sample"] and c["forward_only_value"] > c["value"]
+
+
+def test_committed_multi_rank_rehearsal_times_both_forms_of_the_all_reduce():
+    """bench.py --gpus N (here: 2 and 8 ranks sharing ONE MI355X over gloo — a launch-path rehearsal, not a scaling number): the
+    timed region runs the default (flat) all-reduce, the same loop right behind it the bucketed one, and the line carries both as
+    scalars next to the per-rank lists."""
+    for n in (2, 8):
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_%dranks_one_gpu_gloo.json" % n)))
+        _check_line(d, full=False)
+        assert d["n_gpus"] == d["nranks"] == n and d["allreduce"] == "flat" and d["backend"] == "gloo"
+        assert d["allreduce_flat_ms_per_step"] == d["ms_per_step"] and d["allreduce_overlap_ms_per_step"] > 0
+        assert d["allreduce_compare"]["allreduce"] == "overlap" and d["allreduce_compare"]["buckets"] >= 2
+        assert len(d["per_rank"]["allreduce_ms_mean"]) == n and d["allreduce_ms"] == max(d["per_rank"]["allreduce_ms_mean"])
+        assert 1.0 <= d["edge_imbalance"] <= 1.10
 
 
 def test_bench_refuses_to_run_without_a_gpu_or_with_too_few():

@@ -155,3 +155,50 @@ def test_c5_film_varmisuse_shaped(gpu_device):
     out = sparse_gnn_film_layer(_dev(h, gpu_device), _dev(adj, gpu_device), _dev(deg, gpu_device), D, 1, "ReLU", "sum", False,
                                 weights=_dev(w, gpu_device))
     assert_parity(out, ref, strict_abs=False, what="C5 film small")
+
+
+@pytest.mark.parametrize("residual_every", [2, 10000])
+def test_driver_loop_dropout_sits_where_the_reference_puts_it(gpu_device, monkeypatch, residual_every):
+    """models/sparse_graph_model.py:178-179: tf.nn.dropout on every layer's INPUT, before the residual average, x / keep_prob where the
+    mask keeps (the shipped PPI hyper-parameters train with keep 0.8-0.9; VERDICT r04 missing 5: outside every fixture).  TF's random
+    draws cannot be reproduced, so the draws are replaced on both sides by the same recorded masks: the driver loop's
+    torch.nn.functional.dropout is patched to apply them, the oracle takes them as an argument.  Node states within 1e-5 abs; the
+    folded activation gradients must stand aside (a dropped-out tensor is another tensor: no tag)."""
+    import torch.nn.functional as F
+    from oracle import model as OM
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(2, 1, seed=4, mean_nodes=300, std_nodes=40, min_nodes=100, max_nodes=400, fwd_edges_per_node=5.0)
+    p = RGCN_Model.default_params()
+    p.update(hidden_size=64, graph_num_layers=4, graph_residual_connection_every_num_layers=residual_every,
+             graph_dense_between_every_num_gnn_layers=2, graph_layer_input_dropout_keep_prob=0.8)
+    model = RGCN_Model(p, task, device=str(gpu_device))
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 6))
+    batch = DeviceBatch(mb, gpu_device)
+    rng = np.random.default_rng(0)
+    masks = [rng.random((mb.num_nodes, 64)) < 0.8 for _ in range(4)]
+    calls = []
+
+    def recorded_dropout(x, p=0.5, training=True, inplace=False):
+        assert training and abs(p - 0.2) < 1e-12
+        m = torch.as_tensor(masks[len(calls)], device=x.device)
+        calls.append(tuple(x.shape))
+        return x / 0.8 * m
+
+    monkeypatch.setattr(F, "dropout", recorded_dropout)
+    x = batch.initial_node_features.clone().requires_grad_(True)
+    final = model.compute_final_node_representations(x, batch.adjacency_lists, batch.type_to_num_incoming_edges, dropout_keep_prob=0.8)
+    assert len(calls) == 4
+    W = {n[len("graph_model/"):]: model.variables[n].detach().cpu().numpy() for n in model.variables.names() if n.startswith("graph_model/")}
+    fd = mb.feed_dict
+    want = OM.graph_propagation(fd['initial_node_features'].astype(np.float32), fd['adjacency_lists'],
+                                fd['type_to_num_incoming_edges'].astype(np.float32), p, W, OM.rgcn_apply(p), dropout=(0.8, masks))
+    assert float(np.abs(final.detach().cpu().numpy() - want).max()) <= 1e-5
+    final.square().sum().backward()                       # and the backward runs (dropout outputs carry no activation tag)
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    # evaluation: keep-prob 1 is the exact identity (no dropout call at all)
+    calls.clear()
+    with torch.no_grad():
+        model.compute_final_node_representations(batch.initial_node_features, batch.adjacency_lists, batch.type_to_num_incoming_edges)
+    assert calls == []
