@@ -821,6 +821,35 @@ int relgnn_limb_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const u
 int relgnn_limb16_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const float* xmax, int32_t xgroups, const uint16_t* B,
                                  const float* wmax, const float* bias, const void* zeros, int32_t dact, const float* Y, int64_t ldy,
                                  float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/*
+ * relgnn_rgcn_fused_fwd — the aggregate-first RGCN layer in ONE kernel (north_star "per-edge-type linear transform
+ * fused as an MFMA GEMM"):
+ *
+ *     S[v, l, :] = sum_{p in bucket (v, l)} (w ? w[p] : 1) * H[col[p], :]      bucket (v, l) = rowptr[v*L + l] .. rowptr[v*L + l + 1]
+ *     out[v, :]  = act(bias + sum_l S[v, l, :] @ W_l)
+ *
+ * = gnns/rgcn.py:84-114 for the sum-like aggregations in the aggregate-first order (embedding_lookup :87-89, 1/in-degree scale
+ * :100-104, the per-type Dense :96-98 summed over the types, unsorted_segment_sum :109-112, activation :114) — what
+ * relgnn_seg_reduce_fwd (mode SUM, seg_stride 1) followed by relgnn_limb_gemm_xf32 compute, bit for bit (same sequential fp32
+ * fold per bucket, same three-bf16-limb split, same k-tile and limb-product order), without the [V, L*256] fp32 round trip and
+ * with the gather and the matrix-pipe work of a row panel overlapped on one CU (csrc/rgcn_fused.hip: gather waves hand the
+ * bucket sums, already split into limbs, to the MFMA waves through LDS).
+ *
+ * H [num_rows_h, ldh] fp32 (256 columns read); w_limbs: the limb tiles of the stacked W^T [256, L*256]
+ * (relgnn_limb_split_multi_f32 with transpose: the operand relgnn_limb_gemm_xf32 takes as B); bias nullable;
+ * bucket_sums (nullable, [V, lds >= L*256]): S as fp32, for the weight gradient of a training step (dW_l = S_l^T dOut);
+ * out [V, ldo].  d_in = d_out = 256 only (RELGNN_EUNSUPPORTED otherwise); 16-byte aligned pointers, strides % 4 == 0.
+ * Buckets of any length are walked by ONE wave: callers with hub buckets (ops.SplitPlan) keep the two-kernel route.
+ *
+ * relgnn_rgcn_fused_status: the kernel's hand-over between gather and matrix waves polls counters in LDS; a poll that exceeds
+ * 2^22 rounds gives up (results are then wrong) and sets bit 0 (a matrix wave) / bit 1 (a gather wave) of a status word that
+ * this call synchronises the device for and returns (reset != 0 clears it).  0 = every launch so far completed its hand-overs.
+ */
+int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const int32_t* rowptr, int32_t num_nodes,
+                          int32_t num_edge_types, const int32_t* col, const float* w, const uint16_t* w_limbs, const float* bias,
+                          int32_t act, float* bucket_sums, int64_t lds, float* out, int64_t ldo, int32_t d_in, int32_t d_out,
+                          void* stream);
+int relgnn_rgcn_fused_status(int32_t* status, int32_t reset);
 /* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need
  * (gnns/gnn_film.py:92-106; the limb counterpart of relgnn_panel_gemm_f32's a_rows / b_select for the forward product and the input
  * gradient; K = 128 there):

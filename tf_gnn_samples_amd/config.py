@@ -40,6 +40,9 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
     "rgcn_order": ("RELGNN_RGCN_ORDER", "aggregate_first", ("aggregate_first", "transform_first"),
                    "sum / mean / sqrt_n RGCN layers: gather raw states into the (target, type) buckets, then one K = L*D product | "
                    "the reference's order (per-type transform, then gather)"),
+    "rgcn_fused": ("RELGNN_RGCN_FUSED", "0", ("0", "1"),
+                   "aggregate-first RGCN layer, 256 -> 256 states, exact-split arithmetic: gather and product in ONE kernel "
+                   "(csrc/rgcn_fused.hip: gather waves feed the MFMA waves through LDS, bit-identical) | gather kernel, then product"),
     "agg_acc": ("RELGNN_AGG_ACC", "f32", ("f32", "f64"),
                 "accumulator width of the bucket sums in front of the aggregate-first product"),
     "bwd_overlap": ("RELGNN_BWD_OVERLAP", "auto", ("auto", "0", "1"),

@@ -976,6 +976,33 @@ def _pair_products(X, rowptr, stride, V, k, n, kernels, kind) -> bool:
             and DN.weight_image_ok(list(kernels), DN.WEIGHT_NN if kind == "nn" else DN.WEIGHT_NT))
 
 
+def _fused_layer_ok(H, graph, w, kernels) -> bool:
+    """relgnn_rgcn_fused_fwd applies: switch on, exact-split limb route, 256 -> 256, no hub plan on the by-target buckets."""
+    from .dense import WEIGHT_NN, _rows_ok, weight_image_ok
+    if _cfg.rgcn_fused != "1" or not _cfg.limb_gemm or aggregate_acc64():
+        return False
+    if not (H.is_cuda and _rows_ok(H) and kernels[0].shape == (256, 256) and H.shape[1] == 256 and weight_image_ok(kernels, WEIGHT_NN)):
+        return False
+    split = getattr(graph.rowptr_t, "_relgnn_split", None)
+    if (split is not None and 1 in split) or graph.V <= 0 or len(kernels) > 64:
+        return False
+    return w is None or (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous())
+
+
+def _rgcn_fused(H, graph, w, kernels, relu: bool, want_sums: bool):
+    from .dense import WEIGHT_NN, weight_limbs
+    lib = _lib.load_library()
+    V, L = graph.V, len(kernels)
+    out = torch.empty((V, 256), dtype=torch.float32, device=H.device)
+    agg = torch.empty((V, L * 256), dtype=torch.float32, device=H.device) if want_sums else None
+    buf = weight_limbs(list(kernels), WEIGHT_NN)
+    _lib.check(lib.relgnn_rgcn_fused_fwd(_lib.ptr(H, rows_strided=True), H.shape[0], H.stride(0), _lib.ptr(graph.rowptr_t), V, L,
+                                         _lib.ptr(graph.src_t), _lib.ptr(w), buf.data_ptr(), None,
+                                         _lib.ACT_RELU if relu else _lib.ACT_LINEAR, _lib.ptr(agg), L * 256, _lib.ptr(out), 256,
+                                         256, 256, _lib.current_stream()), "relgnn_rgcn_fused_fwd")
+    return agg, out
+
+
 class _AggregateThenTransform(torch.autograd.Function):
     """out = act(f_mode(sum_l A_l @ W_l)),  A_l[v] = sum_{p in (v,l)} w_p H[src_p]   (W: [L, Din, Dout]).
 
@@ -997,12 +1024,17 @@ class _AggregateThenTransform(torch.autograd.Function):
         amax = None
         if _pair_products(H, graph.rowptr_t, 1, V, L * d_in, d_out, kernels, "nn"):
             amax = torch.empty(V * L, dtype=torch.float32, device=H.device)
-        agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
-                              acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
         want_w = any(ctx.needs_input_grad[7:])
         f = _mode_factor(graph, mode)
         fused_relu = act == _lib.ACT_RELU and f is None       # sum aggregation: ReLU rides in the product's epilogue
-        out = grouped_nn_gemm(agg, kernels, relu=fused_relu, xmax=amax, xgroups=L)
+        if amax is None and _fused_layer_ok(H, graph, w, kernels):
+            # one kernel: the gather waves hand the bucket sums to the matrix waves through LDS (csrc/rgcn_fused.hip); the sums are
+            # also stored as fp32 when the weight gradient will read them.  Same bits as the two launches below.
+            agg, out = _rgcn_fused(H, graph, w, kernels, fused_relu, want_w)
+        else:
+            agg = _seg_reduce_raw(_lib.AGG_SUM, H, graph.rowptr_t, 1, graph.src_t, w, V * L,
+                                  acc64=aggregate_acc64(), rowmax=amax).view(V, L * d_in)
+            out = grouped_nn_gemm(agg, kernels, relu=fused_relu, xmax=amax, xgroups=L)
         if f is not None:
             out.mul_(f.unsqueeze(1))
         if act == _lib.ACT_RELU:
