@@ -12,40 +12,51 @@
 // Geometry (D_in = D_out = 256; K = L * 256): one persistent workgroup of 16 waves per CU owns a contiguous range of 32-row units,
 // taken as panels of 64 rows.  Waves 0-7 (two per SIMD) are the CONSUMERS: wave c owns output columns 32 c .. 32 c + 31 of the
 // panel (two 32 x 32 accumulators), reads its W limb fragments straight from L2 into registers (the weight image is in MFMA
-// operand layout: one 16-byte load per lane and limb, four k-tiles ahead) and the X limb fragments from LDS.  Waves 8-15 are the
-// PRODUCERS.  The unit of hand-over is a SUB-SLAB: 64 rows x 128 columns (half an edge type's block = 8 k-tiles) as limbs, 49.5 KiB;
-// three of them rotate through LDS, so the producers run up to two sub-slabs ahead of the matrix pipe.  Hand-over is by counters
-// in LDS (filled / freed per buffer, monotonic), polled with s_sleep: no workgroup barrier after the first one.
+// operand layout: one 16-byte load per lane and limb, three k-tiles ahead) and the X limb fragments from LDS.  Waves 8-15 are the
+// PRODUCERS.  The unit of hand-over is a SUB-SLAB: one 32-row tile x one edge type's 256 columns (16 k-tiles) as limbs, 49.5 KiB;
+// three of them rotate through LDS: the matrix waves work on the two row tiles of edge type l while the gather waves fill the
+// first tile of type l + 1 (the gather is the longer side, so the matrix waves are done before that tile is full and the second
+// one finds its buffer free).  Hand-over is by counters in LDS (filled / freed per buffer, monotonic), polled with s_sleep: no
+// workgroup barrier after the first one.
 //
-// Producers.  A wave gathers half rows: lane = two columns (8 bytes; 512 bytes per message and wave).  Work is drawn from a queue
+// Producers.  A wave gathers whole rows: lane = four columns (16 bytes; 1 KiB per message and wave).  Work is drawn from a queue
 // (an LDS counter) in BATCHES of 8 rows of one sub-slab.  The messages of a batch's 8 buckets are laid out as one flat stream (an
-// empty bucket takes one placeholder position) and walked in groups of 16 row loads, one group in flight while the previous one is
-// folded; bucket boundaries are wave-uniform flags inside the stream, so a wave always has 16-32 loads in flight whatever the
-// bucket lengths are (a PPI-shaped batch has one message per self-loop bucket and up to ~550 per forward-edge bucket).  The next
-// batch's bucket bounds and the next 64 stream positions' (col, w) are fetched one step ahead.  At a bucket's end the two sums of a
-// lane are split (limb_split.h) and written as three ds_write_b32 into the sub-slab — pieces of 32 rows x 16 B padded to 528 B, so
-// that the 16 pieces a wave writes for one row fall into 16 different bank quads — and, when asked for, stored to S as fp32 (the
-// weight gradient of a training step reads them: gnns/rgcn.py:96-98 backward).
+// empty bucket takes one placeholder position) and walked in groups of 16 positions = two half groups of 8 row loads, one half
+// group in flight while the other is folded; bucket boundaries are wave-uniform flags inside the stream, so a wave has 8-16 KiB
+// in flight whatever the bucket lengths are (a PPI-shaped batch has one message per self-loop bucket and up to ~550 per
+// forward-edge bucket).  The next batch's bucket bounds and the (col, w) of the group four steps ahead are on their way
+// meanwhile.  At a bucket's end the four sums of a lane are split (limb_split.h) and written as three ds_write_b64 into the
+// sub-slab — pieces of 32 rows x 16 B padded to 528 B, so that the 32 pieces a wave writes for one row spread over all bank
+// quads — and, when asked for, stored to S as fp32 (the weight gradient of a training step reads them: gnns/rgcn.py:96-98
+// backward).
+//
+// First form (commit 6b8c427: half rows, 64-row x half-type sub-slabs, a switch re-entered behind every bucket end): bit-identical,
+// 513 us against 164 us for the two kernels on the C2 batch; s_memtime stamps showed the gather waves 97 % busy issuing
+// instructions (row-load wait 0.3 % of their time) and the matrix waves 91 % of the time in polls.
 #include "common.h"
 #include "lds_dma.h"
 #include "limb_split.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace relgnn;
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PIECE = 528;              // 32 rows x 16 B (8 k of one limb) + 16 B: consecutive pieces start in consecutive bank quads
-constexpr int PLANE = 16 * PIECE;       // the 16 (k-tile, k half) pieces of one (row tile, limb)
-constexpr int SLAB = 6 * PLANE;         // 2 row tiles x 3 limbs: 50 688 B
+constexpr int PLANE = 32 * PIECE;       // the 32 (k-tile, k half) pieces of one limb of a sub-slab (32 rows x 256 columns)
+constexpr int SLAB = 3 * PLANE;         // 3 limbs: 50 688 B
 constexpr int NBUF = 3;
-constexpr int UNR = 16;                 // row loads per group
-constexpr int BROWS = 8;                // rows per batch
+constexpr int GROUP = 16;               // stream positions per group
+constexpr int HALF = 8;                 // row loads per half group
+constexpr int BROWS = 4;                // rows per batch (8: the slowest of a tile pair's 8 batches held the other gather waves in polls 40 % of the time)
+constexpr int BPS = 32 / BROWS;         // batches per sub-slab
 constexpr int CTL = 16;                 // control words behind the slabs
 constexpr uint32_t M_LAST = 1u << 31, M_EMPTY = 1u << 30, M_INVALID = 1u << 29;
 constexpr int SPIN_LIMIT = 1 << 22;     // a poll that takes this long is a bug: give up, flag it, finish with wrong numbers
@@ -88,16 +99,21 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = (int)xcd_logical_block(a.groups);
   if (q < 0) return;
+  const int L = a.L;
+  // My range of 32-row units: equal rows.  (Equal COST — messages + 8 L per row, boundaries by a 64-way search over rowptr at
+  // kernel start — was measured: 231 us against 217 us.  At a granularity of 32 rows the message counts still differ by +-25 %,
+  // and the slowest workgroups are not the ones with the most messages but the ones whose panel holds a 300-550 message bucket:
+  // one gather wave folds it while the other seven run into the three-buffer limit.)
   const int u0 = q * a.units_base + min(q, a.units_rem);
   const int nu = a.units_base + (q < a.units_rem ? 1 : 0);
-  const int npan = (nu + 1) >> 1;
-  const int L = a.L;
-  const int nsub = 2 * L;                                    // sub-slabs per panel
-  const int nseq = npan * nsub;
-  const int rend = min((u0 + nu) * 32, a.V);                 // first row that is not mine
-  const int ntiles = L * 16;
   if (tid < CTL) ctl[tid] = 0;
   __syncthreads();
+  const int nfull = nu >> 1;                                 // panels of two units; an odd unit left over is a panel of one row tile
+  const int npan = (nu + 1) >> 1;
+  const int nsub = 2 * L;                                    // sub-slabs per full panel: (edge type, row tile); the half panel has L
+  const int nseq = nfull * nsub + (nu & 1) * L;
+  const int rend = min((u0 + nu) * 32, a.V);                 // first row that is not mine
+  const int ntiles = L * 16;
   bool dead = false;                                          // a poll gave up: stop waiting for anything
 #ifdef RELGNN_FUSED_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -155,37 +171,52 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
       return f;
     };
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
-    int b = 0, gen = 0;
+    int b0 = 0, gen0 = 0;                                     // buffer / generation of the next sub-slab in sequence
+    const int xlane = h32 * PIECE + i32 * 16;
     for (int pi = 0; pi < npan; ++pi) {
       const int m0 = (u0 + 2 * pi) * 32;
       const int rows_here = min(64, rend - m0);
-      const bool two = rows_here > 32;
+      const bool two = pi < nfull;
       f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      for (int sub = 0; sub < nsub; ++sub) {
-        poll(ctl + 1 + b, 64 * (gen + 1));
-        const unsigned char* xb = lds + b * SLAB + h32 * PIECE + i32 * 16;
+      for (int l = 0; l < L; ++l) {
+        int b1 = b0, gen1 = gen0;                              // (a half panel: one sub-slab per edge type)
+        if (two) {
+          if (++b1 == NBUF) { b1 = 0; ++gen1; }
+        }
+        poll(ctl + 1 + b0, 32 * (gen0 + 1));
+        if (two) poll(ctl + 1 + b1, 32 * (gen1 + 1));
+        const unsigned char* x0b = lds + b0 * SLAB + xlane;
+        const unsigned char* x1b = lds + b1 * SLAB + xlane;
         TSTAMP(tk0);
+        // (four k-tiles per trip = the period of the W ring; unrolling all sixteen, in a copy per panel height, made the kernel
+        //  76 KB of code: more than the 64 KB instruction cache two CUs share)
+#pragma nounroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const unsigned char* x0k = x0b + k4 * 8 * PIECE;
+          const unsigned char* x1k = x1b + k4 * 8 * PIECE;
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-          wload(wr[(kt + 3) & 3]);
-          const unsigned char* p = xb + kt * 2 * PIECE;
-          const Frag x0 = xread(p);
-          if (two) {
-            const Frag x1 = xread(p + 3 * PLANE);
-            acc0 = products(acc0, wr[kt & 3], x0);
-            acc1 = products(acc1, wr[kt & 3], x1);
-          } else {
-            acc0 = products(acc0, wr[kt & 3], x0);
+          for (int kt = 0; kt < 4; ++kt) {
+            wload(wr[(kt + 3) & 3]);
+            const Frag x0 = xread(x0k + kt * 2 * PIECE);
+            acc0 = products(acc0, wr[kt], x0);
+            if (two) {
+              const Frag x1 = xread(x1k + kt * 2 * PIECE);
+              acc1 = products(acc1, wr[kt], x1);
+            }
           }
         }
-        wait_lgkm0();                                          // my reads of this buffer have returned
+        wait_lgkm0();                                          // my reads of both buffers have returned
         compiler_fence();
         TSTAMP(tk1);
         TACC(6, tk1, tk0);
-        if (lane == 0) __hip_atomic_fetch_add(ctl + 4 + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (++b == NBUF) { b = 0; ++gen; }
+        if (lane == 0) {
+          __hip_atomic_fetch_add(ctl + 4 + b0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (two) __hip_atomic_fetch_add(ctl + 4 + b1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        b0 = b1 + 1; gen0 = gen1;
+        if (b0 == NBUF) { b0 = 0; ++gen0; }
       }
       // epilogue: lane holds output row (lane & 31) x columns 8 c + 4 h + {0..3}, c = 0..3 (register 4 c + {0..3}) of its 32 x 32 tile
       const int colw = wave * 32;
@@ -197,8 +228,11 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
           const int cc = colw + 8 * c + 4 * h32;
           f32x4 v = f32x4{acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
           if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + cc);
-          if (a.act != RELGNN_ACT_LINEAR) {
-            v[0] = act_rt(a.act, v[0]); v[1] = act_rt(a.act, v[1]); v[2] = act_rt(a.act, v[2]); v[3] = act_rt(a.act, v[3]);
+          // (ReLU or nothing: act_rt's switch inlines tanhf / expf / erff thirty-two times — 30 KB of code that would share the
+          //  instruction cache with the gather loop; the other activations take the two-kernel route)
+          if (a.act == RELGNN_ACT_RELU) {
+            v[0] = act_fwd<RELGNN_ACT_RELU>(v[0]); v[1] = act_fwd<RELGNN_ACT_RELU>(v[1]);
+            v[2] = act_fwd<RELGNN_ACT_RELU>(v[2]); v[3] = act_fwd<RELGNN_ACT_RELU>(v[3]);
           }
           *reinterpret_cast<f32x4*>(crow + cc) = v;
         }
@@ -217,8 +251,8 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
   // under a condition lands in a temporary that hipcc copies into the loop-carried register at the end of the region — behind an
   // s_waitcnt vmcnt(0) that drains the whole gather pipeline (the same lesson as limb_gemm.hip's x_load).  Hence: bucket bounds
   // of the next batch are re-requested every step, (col, w) go by clamped addresses instead of predicates, register sets rotate
-  // by name (the loop is unrolled by four steps) and never by copy.
-  const int nbatches = nseq * (64 / BROWS);
+  // by name (the loop is unrolled by three steps) and never by copy.
+  const int nbatches = nseq * BPS;
   // ---- the batch that has been drawn from the queue; its bucket bounds are on their way (lanes 0 .. BROWS-1)
   int nb_id = nbatches, nb_g = 0, nb_bi = 0, nb_m0 = 0, nb_sub = 0;
   int rp_b = 0, rp_e = 0;
@@ -228,14 +262,15 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
     id = __builtin_amdgcn_readfirstlane(id);
     nb_id = id;
     if (id < nbatches) {
-      nb_g = id >> 3; nb_bi = id & 7;
-      const int pi = nb_g / nsub;
-      nb_sub = nb_g - pi * nsub;
+      nb_g = id / BPS; nb_bi = id % BPS;
+      int pi = nb_g / nsub;
+      nb_sub = nb_g - pi * nsub;                              // edge type = sub >> 1, row tile = sub & 1
+      if (pi >= nfull) { pi = nfull; nb_sub = (nb_g - nfull * nsub) << 1; }      // the half panel: row tile 0 of every edge type
       nb_m0 = (u0 + 2 * pi) * 32;
     }
   };
   auto reload_bounds = [&]() {
-    const int row = nb_m0 + nb_bi * BROWS + lane;
+    const int row = nb_m0 + (nb_sub & 1) * 32 + nb_bi * BROWS + lane;
     const bool ok = nb_id < nbatches && lane < BROWS && row < rend;
     const int32_t* p = ok ? a.rowptr + ((int64_t)row * L + (nb_sub >> 1)) : a.rowptr;      // (rowptr has at least two entries)
     const int b = p[0], e = p[1];
@@ -287,9 +322,9 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
       msg += ge ? bb_base[k] - bb_base[k - 1] : 0;
       lastpos += ge ? bb_P[k + 1] - bb_P[k] : 0;
     }
-    const int r = bb_r0 + j;
+    const int r = bb_r0 + j;                          // row inside the 32-row tile
     const int emp = (bb_empty >> j) & 1;
-    const bool valid = bb_valid && lane < UNR && f < bb_total;
+    const bool valid = bb_valid && lane < GROUP && f < bb_total;
     c.meta = valid ? ((uint32_t)r | (f == lastpos ? M_LAST : 0u) | (emp ? M_EMPTY : 0u)) : M_INVALID;
     const bool real = valid && !emp;
     const int32_t* cp = real ? a.col + msg : a.rowptr;                    // (rowptr[0] == 0: a placeholder gathers row 0)
@@ -300,97 +335,118 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
     } else {
       c.w = 1.f;
     }
-    if (bb_valid) bb_pos += UNR;
+    if (bb_valid) bb_pos += GROUP;
     TSTAMP(tq1);
     TACC(5, tq1, tq0);
   };
 
-  const f32x2* H2 = reinterpret_cast<const f32x2*>(a.H);
-  const int64_t ldh2 = a.ldh >> 1;
-  auto issue = [&](const Group& c, f32x2 (&v)[UNR]) {
+  const f32x4* H4 = reinterpret_cast<const f32x4*>(a.H);
+  const int64_t ldh4 = a.ldh >> 2;
+  auto issue = [&](const Group& c, auto half_c, f32x4 (&v)[HALF]) {
+    constexpr int HF = decltype(half_c)::value;
     TSTAMP(ti0);
-    const int hoff = (c.sub & 1) * 64;                                     // float2 units
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(c.col, u);
-      const f32x2* row = H2 + (int64_t)r * ldh2 + hoff;                    // wave-uniform base
+    for (int u = 0; u < HALF; ++u) {
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(c.col, HF * HALF + u);
+      const f32x4* row = H4 + (int64_t)r * ldh4;                           // wave-uniform base
       v[u] = row[lane];
     }
     TSTAMP(ti1);
     TACC(6, ti1, ti0);
   };
-  f32x2 acc = f32x2{0.f, 0.f};
-  // lane = columns 2 lane, 2 lane + 1 of the half = k-tile lane >> 3, k half (lane >> 2) & 1, k 2 (lane & 3) of that half
-  const int wr_lane = (lane >> 2) * PIECE + (lane & 3) * 4;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  // lane = columns 4 lane .. 4 lane + 3 = k-tile lane >> 2, k half (lane >> 1) & 1, k 4 (lane & 1) .. + 3 of that half
+  const int wr_lane = (lane >> 1) * PIECE + (lane & 1) * 8;
   auto finalize = [&](const Group& c, int r) {
-    const int grow = c.m0 + r;
+    const int grow = c.m0 + (c.sub & 1) * 32 + r;
     if (a.S && grow < rend)
-      *reinterpret_cast<f32x2*>(a.S + (int64_t)grow * a.lds_ + (c.sub >> 1) * 256 + (c.sub & 1) * 128 + 2 * lane) = acc;
-    uint32_t h, m, l;
-    split_pair(acc[0], acc[1], h, m, l);
-    if (__builtin_expect(fmaxf(fabsf(acc[0]), fabsf(acc[1])) >= __uint_as_float(0x7F7F8000u), 0))
-      split_pair_sat(acc[0], acc[1], h, m, l);
+      *reinterpret_cast<f32x4*>(a.S + (int64_t)grow * a.lds_ + (c.sub >> 1) * 256 + 4 * lane) = acc;
+    uint32_t h0, m0_, l0, h1, m1, l1;
+    split_pair(acc[0], acc[1], h0, m0_, l0);
+    split_pair(acc[2], acc[3], h1, m1, l1);
+    if (__builtin_expect(max3_abs(max3_abs(acc[0], acc[1], acc[2]), acc[3], acc[3]) >= __uint_as_float(0x7F7F8000u), 0)) {
+      split_pair_sat(acc[0], acc[1], h0, m0_, l0);
+      split_pair_sat(acc[2], acc[3], h1, m1, l1);
+    }
     const int fill = c.g % NBUF;
-    unsigned char* p = lds + fill * SLAB + (r >> 5) * 3 * PLANE + (r & 31) * 16 + wr_lane;
-    *reinterpret_cast<uint32_t*>(p) = h;
-    *reinterpret_cast<uint32_t*>(p + PLANE) = m;
-    *reinterpret_cast<uint32_t*>(p + 2 * PLANE) = l;
+    unsigned char* p = lds + fill * SLAB + r * 16 + wr_lane;
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0_, m1);
+    *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
     wait_lgkm0();
     compiler_fence();
     if (lane == 0) __hip_atomic_fetch_add(ctl + 1 + fill, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    acc = f32x2{0.f, 0.f};
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  // One copy of finalize per fold: the sixteen positions are the cases of a switch that is re-entered behind a bucket's end.
-#define RELGNN_FOLD_STEP(u)                                                                                                  \
-  case u: {                                                                                                                  \
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)c.meta, u);                                                  \
-    const float wk = HAS_W ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.w), u)) : 1.f;                        \
-    if (!(m & (M_INVALID | M_EMPTY))) acc = acc + f32x2{wk * v[u][0], wk * v[u][1]};   /* two roundings (-ffp-contract=off) */ \
-    if (m & M_LAST) { r = (int)(m & 63u); next = u + 1; break; }                                                             \
-  }                                                                                                                          \
-    [[fallthrough]];
-  auto fold = [&](const Group& c, const f32x2 (&v)[UNR]) {
-    // everything but the UNR row loads issued last (the next group's) has landed: this group's rows, and (col, w, meta) before them.
-    // Stated through the builtin, which hipcc's wait insertion understands — left to itself it puts vmcnt(0) in front of the
-    // switch loop, which drains the next group's loads as well.  (gfx9 encoding: vmcnt 16 = bit 14, expcnt 7, lgkmcnt 15: no wait)
-    static_assert(UNR == 16, "the immediate below says vmcnt(16)");
+  // ONE copy of the bucket-end code per fold: the half group is walked segment by segment — a loop whose body offers every position
+  // (statically indexed registers) a scalar bit test, adds the ones of the current segment and closes the bucket behind them.
+  // (One copy per POSITION was ~60 KB of code over the eight fold sites, the size of the instruction cache two CUs share; a switch
+  // re-entered behind every bucket end — the first form — came out of hipcc's structurizer as chains of mask arithmetic, 275
+  // cycles per message; registers indexed by a scalar become a seven-deep select chain per column.)
+  auto fold = [&](const Group& c, auto half_c, const f32x4 (&v)[HALF]) {
+    constexpr int HF = decltype(half_c)::value;
+    // everything but the HALF row loads issued last has landed: this half group's rows, and (col, w, meta) before them.  Stated
+    // through the builtin, which hipcc's wait insertion understands (an inline-asm wait it does not see, and adds its own).
+    // (gfx9 encoding: vmcnt 8 in bits 3:0, expcnt 7, lgkmcnt 15: no wait)
+    static_assert(HALF == 8, "the immediate below says vmcnt(8)");
     TSTAMP(tw0);
-    __builtin_amdgcn_s_waitcnt(0x4F70);
+    __builtin_amdgcn_s_waitcnt(0x0F78);
     TSTAMP(tw1);
     TACC(3, tw1, tw0);
-    if (c.flags & 1) poll(ctl + 4 + c.g % NBUF, 8 * (c.g / NBUF));       // the buffer's previous user has been consumed
-    int next = 0;
-    do {
-      int r = -1;
-      switch (next) {
-        RELGNN_FOLD_STEP(0) RELGNN_FOLD_STEP(1) RELGNN_FOLD_STEP(2) RELGNN_FOLD_STEP(3)
-        RELGNN_FOLD_STEP(4) RELGNN_FOLD_STEP(5) RELGNN_FOLD_STEP(6) RELGNN_FOLD_STEP(7)
-        RELGNN_FOLD_STEP(8) RELGNN_FOLD_STEP(9) RELGNN_FOLD_STEP(10) RELGNN_FOLD_STEP(11)
-        RELGNN_FOLD_STEP(12) RELGNN_FOLD_STEP(13) RELGNN_FOLD_STEP(14) RELGNN_FOLD_STEP(15)
-        default: next = UNR;
+    if (HF == 0 && (c.flags & 1)) poll(ctl + 4 + c.g % NBUF, 8 * (c.g / NBUF));   // the buffer's previous user has been consumed
+    const uint64_t bl = __builtin_amdgcn_ballot_w64((c.meta & M_LAST) != 0u);
+    const uint64_t bk = __builtin_amdgcn_ballot_w64((c.meta & (M_INVALID | M_EMPTY)) != 0u);
+    uint32_t ends = (uint32_t)(bl >> (HF * HALF)) & 0xFFu;               // positions that close a bucket
+    const uint32_t skip = (uint32_t)(bk >> (HF * HALF)) & 0xFFu;         // placeholders and positions past the batch
+    uint32_t done = 0u;
+#pragma clang loop unroll(disable)
+    for (;;) {
+      const int e = ends ? __builtin_ctz(ends) : HALF - 1;               // last position of the segment
+      const uint32_t upto = (2u << e) - 1u;
+      const uint32_t now = upto & ~done & ~skip;
+      if (now == 0xFFu) {                                                  // the common case: eight messages of one bucket, no tests
+#pragma unroll
+        for (int u = 0; u < HALF; ++u) {
+          const float wk = HAS_W ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.w), HF * HALF + u)) : 1.f;
+          const f32x4 t = f32x4{wk * v[u][0], wk * v[u][1], wk * v[u][2], wk * v[u][3]};
+          acc = acc + t;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < HALF; ++u)
+          if ((now >> u) & 1u) {
+            const float wk = HAS_W ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.w), HF * HALF + u)) : 1.f;
+            const f32x4 t = f32x4{wk * v[u][0], wk * v[u][1], wk * v[u][2], wk * v[u][3]};  // two roundings (-ffp-contract=off)
+            acc = acc + t;
+          }
       }
-      if (r >= 0) finalize(c, r);
-    } while (next < UNR);
+      if (!ends) break;
+      finalize(c, (int)((uint32_t)__builtin_amdgcn_readlane((int)c.meta, HF * HALF + e) & 31u));
+      done = upto;
+      ends &= ends - 1u;
+      if (e == HALF - 1) break;
+    }
     TSTAMP(tw2);
     TACC(4, tw2, tw1);
   };
-#undef RELGNN_FOLD_STEP
 
-  Group G0, G1, G2, G3;
+  Group G0, G1, G2;
   grab();
   reload_bounds();
-  prepare(G0); prepare(G1); prepare(G2); prepare(G3);
-  f32x2 v0[UNR], v1[UNR];
-  issue(G0, v0);
-  for (;;) {                      // step k: rows of group k + 1 requested, group k folded, (col, w) of group k + 4 requested
+  prepare(G0); prepare(G1); prepare(G2);
+  f32x4 va[HALF], vb[HALF];
+  const std::integral_constant<int, 0> H0{};
+  const std::integral_constant<int, 1> H1{};
+  issue(G0, H0, va);
+  // step k: second half of group k requested, first half folded, first half of group k + 1 requested, second half folded,
+  // (col, w) of group k + 3 requested (read a step and a half later).  Three steps per trip: the group sets rotate by name.
+  for (;;) {
     if (G0.flags & 2) break;
-    issue(G1, v1); fold(G0, v0); prepare(G0);
+    issue(G0, H1, vb); fold(G0, H0, va); issue(G1, H0, va); fold(G0, H1, vb); prepare(G0);
     if (G1.flags & 2) break;
-    issue(G2, v0); fold(G1, v1); prepare(G1);
+    issue(G1, H1, vb); fold(G1, H0, va); issue(G2, H0, va); fold(G1, H1, vb); prepare(G1);
     if (G2.flags & 2) break;
-    issue(G3, v1); fold(G2, v0); prepare(G2);
-    if (G3.flags & 2) break;
-    issue(G0, v0); fold(G3, v1); prepare(G3);
+    issue(G2, H1, vb); fold(G2, H0, va); issue(G0, H0, va); fold(G2, H1, vb); prepare(G2);
   }
 #ifdef RELGNN_FUSED_TIMING
   tflush();
@@ -411,7 +467,8 @@ int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const
     return RELGNN_EINVAL;
   if (num_nodes == 0 || d_out == 0) return RELGNN_OK;
   if (!H || !rowptr || !w_limbs || !out) return RELGNN_EINVAL;
-  if (d_in != 256 || d_out != 256 || num_edge_types > 64) return RELGNN_EUNSUPPORTED;
+  if (d_in != 256 || d_out != 256 || num_edge_types > 64 || (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU))
+    return RELGNN_EUNSUPPORTED;
   if (ldh < d_in || ldo < d_out || (bucket_sums && lds < (int64_t)num_edge_types * d_in)) return RELGNN_EINVAL;
   if (!aligned16(H) || !aligned16(out) || !aligned16(w_limbs) || (bias && !aligned16(bias)) || (bucket_sums && !aligned16(bucket_sums)) ||
       ldh % 4 || ldo % 4 || lds % 4)
