@@ -516,6 +516,12 @@ int relgnn_sigmoid_ce_stats(const float* logits, const float* labels, int64_t n,
                             void* workspace, size_t workspace_bytes, void* stream);
 int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, const float* g_mean, float mean_scale,
                           const float* g_total, float* glogits, void* stream);
+/* The same gradient written into rows of ldg >= cols floats (logits / labels [rows, cols] contiguous), the ldg - cols columns behind
+ * every row set to zero: the gradient of tasks/ppi_task.py:183-189 laid out as the left operand of the head's input-gradient
+ * MatMul with its reduction length (121 labels) filled up to a multiple of 16 — relgnn_limb_gemm_xf32 over ldg columns against
+ * the weight limbs of relgnn_limb_split_multi_f32, which fills the last k-tile of a matrix with zeros. */
+int relgnn_sigmoid_ce_bwd_padded(const float* logits, const float* labels, int64_t rows, int32_t cols, const float* g_mean,
+                                 float mean_scale, const float* g_total, float* glogits, int32_t ldg, void* stream);
 
 /* ========================================================================== *
  * 8. GRU cell elementwise halves (node-side; gnns/ggnn.py:92 via utils/utils.py:15-16)
@@ -760,7 +766,9 @@ int relgnn_limb_split_batch_f32(const float* X, int64_t ldx, int64_t x_batch_str
  * kt_offset[d] .. kt_offset[d] + C/16 - 1 of a limb matrix with kt_total[d] k-tiles per 32-row block at out[d] (kt_offset 0 and
  * kt_total = C/16: a whole matrix, as relgnn_limb_split_f32; several items with one `out` lay matrices side by side along k, e.g. the
  * stacked right operand [W_0 | W_1 | ..] of the input gradient of gnns/rgcn.py:96-98 without forming it in fp32).  The weight operands
- * of a training step change once per step (the optimizer's update): the host side splits them all behind it with this entry. */
+ * of a training step change once per step (the optimizer's update): the host side splits them all behind it with this entry.
+ * C (the k extent of an item) need not be a multiple of 16: the item then takes ceil(C / 16) k-tiles and the last one is filled up
+ * with zeros (the 121-label head: K = 128 against a left operand whose rows are zero-padded alike). */
 int relgnn_limb_split_multi_f32(int32_t n, const float* const* X, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
                                 const int32_t* transpose, uint16_t* const* out, const int32_t* kt_offset, const int32_t* kt_total,
                                 void* stream);

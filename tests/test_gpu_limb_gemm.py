@@ -652,3 +652,68 @@ def test_a_tanh_output_with_two_readers_is_never_folded(gpu_device):
     (yd @ Ud + yd @ Rd).square().sum().backward()
     for got, want in zip(two, (xd.grad, Wd.grad, Ud.grad, Rd.grad)):
         assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_zero_padded_gradient_route(gpu_device):
+    """The PPI head's backward (tasks/ppi_task.py:183-191 behind models/sparse_graph_model.py's last layer): the loss gradient
+    written into rows zero-padded from 121 to 128 columns (relgnn_sigmoid_ce_bwd_padded) meets the head's kernel [256, 121] as a
+    limb product with K = 128 — the weight image's last k-tile filled with zeros by the split — and the ReLU' of the layer below in
+    the epilogue.  Against float64, and against the route it replaces (library product + relgnn_act_bwd_from_output)."""
+    from tf_gnn_samples_amd import _lib, config, dense as DN
+    from tf_gnn_samples_amd.tasks.ppi_task import _SigmoidCEStats
+    dev = gpu_device
+    V, D, C = 6000, 256, 121
+    x = _rand((V, D), dev, 1).relu_()                       # the last GNN layer's output
+    kernel = _rand((D, C), dev, 2, 0.1)
+    bias = _rand((C,), dev, 3, 0.1)
+    labels = (_rand((V, C), dev, 4) > 0.4).float()
+    res = {}
+    for pad in ("0", "1"):
+        with config.override(head_pad=pad):
+            xx = DN.mark_activation_output(x.clone().requires_grad_(True), _lib.ACT_RELU)
+            kk, bb = kernel.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+            logits = DN.dense(xx, kk, bb)
+            mean, total, f1, counts = _SigmoidCEStats.apply(logits, labels, 1.0 / V)
+            total.backward()
+            res[pad] = (xx.grad.clone(), kk.grad.clone(), bb.grad.clone())
+    # float64 truth: g = sigmoid(logits) - labels; gx = (g @ kernel^T) * relu'(x)
+    lg = x.double() @ kernel.double() + bias.double()
+    g = torch.sigmoid(lg) - labels.double()
+    gx = (g @ kernel.double().t()) * (x > 0).double()
+    gk = x.double().t() @ g
+    for pad in ("0", "1"):
+        gxx, gkk, gbb = res[pad]
+        scale = float(gx.abs().max())
+        assert float((gxx.double() - gx).abs().max()) <= 2e-6 * max(scale, 1.0), pad
+        assert float((gkk.double() - gk).abs().max()) <= 4e-6 * float(gk.abs().max()), pad
+        assert float((gbb.double() - g.sum(0)).abs().max()) <= 4e-6 * float(g.sum(0).abs().max()), pad
+    assert torch.equal(res["0"][1], res["1"][1]) and torch.equal(res["0"][2], res["1"][2])     # weight / bias gradients: the same kernels
+    # the padded loss gradient itself: the unpadded kernel's values, zeros behind them
+    lib = _lib.load_library()
+    logits = (x @ kernel + bias).contiguous()
+    one = torch.ones(1, device=dev)
+    plain = torch.empty_like(logits)
+    _lib.check(lib.relgnn_sigmoid_ce_bwd(logits.data_ptr(), labels.data_ptr(), logits.numel(), None, 0.0, one.data_ptr(),
+                                         plain.data_ptr(), None), "relgnn_sigmoid_ce_bwd")
+    padded = torch.full((V, 128), 7.0, device=dev)
+    _lib.check(lib.relgnn_sigmoid_ce_bwd_padded(logits.data_ptr(), labels.data_ptr(), V, C, None, 0.0, one.data_ptr(),
+                                                padded.data_ptr(), 128, None), "relgnn_sigmoid_ce_bwd_padded")
+    assert torch.equal(padded[:, :C], plain) and float(padded[:, C:].abs().max()) == 0.0
+
+
+def test_weight_image_with_a_ragged_last_k_tile(gpu_device):
+    """relgnn_limb_split_multi_f32 on a [256, 121] matrix with unaligned rows (ld = 121) and on its transpose-read twin [121, 256]:
+    k-tiles 0 .. 7, the last one zero behind column 121; the limbs add up to the fp32 values exactly."""
+    from tf_gnn_samples_amd import dense as DN
+    dev = gpu_device
+    w = _rand((256, 121), dev, 5) * torch.logspace(-10, 10, 121, device=dev)
+    x = _rand((5000, 128), dev, 6)
+    x[:, 121:] = 0.0
+    out = DN.limb_gemm_weight(x, w, DN.WEIGHT_NT)                       # x @ w_padded^T
+    truth = x[:, :121].double() @ w.double().t()
+    assert float((out.double() - truth).abs().max()) <= 4e-7 * float(truth.abs().max())
+    wn = w.t().contiguous()                                             # [121, 256]: the forward operand, read transposed
+    out2 = DN.limb_gemm_weight(x, wn, DN.WEIGHT_NN)
+    assert torch.equal(out2, out)
+    x[:, 121:] = 3.0                                                    # the zero k-tile really is zero: junk there changes nothing
+    assert torch.equal(DN.limb_gemm_weight(x, w, DN.WEIGHT_NT), out)

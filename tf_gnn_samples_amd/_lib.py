@@ -72,6 +72,7 @@ _SIGNATURES = {
     "relgnn_sigmoid_ce_stats_workspace_bytes": (ctypes.c_size_t, []),
     "relgnn_sigmoid_ce_stats": (ctypes.c_int, [_ptr, _ptr, _c_i64, _c_f32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     "relgnn_sigmoid_ce_bwd": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _c_f32, _ptr, _ptr, _ptr]),
+    "relgnn_sigmoid_ce_bwd_padded": (ctypes.c_int, [_ptr, _ptr, _c_i64, _c_i32, _ptr, _c_f32, _ptr, _ptr, _c_i32, _ptr]),
     "relgnn_gru_gates_fwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_gru_out_fwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_gru_out_bwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr]),

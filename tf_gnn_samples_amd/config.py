@@ -30,6 +30,10 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                         "gradient nt, weight gradient tn"),
     "limb_cut": ("RELGNN_LIMB_CUT", "1", ("0", "1"),
                  "N % 128 >= 96 products (the 121 logits of the PPI head) on the 128-column limb panels with the last chunk cut at N"),
+    "head_pad": ("RELGNN_HEAD_PAD", "1", ("0", "1"),
+                 "PPI head backward: the loss gradient written into rows zero-padded to a multiple of 16 columns, so that the head's "
+                 "input-gradient product (K = 121) runs on the limb route with the last layer's ReLU' in its epilogue | the library "
+                 "product + a ReLU' pass"),
     "weight_limb_cache": ("RELGNN_WEIGHT_LIMB_CACHE", "1", ("0", "1"),
                           "limb images of the weights kept across the products of a step (re-split once after the optimizer's update)"),
     "act_fusion": ("RELGNN_ACT_FUSION", "1", ("0", "1"),

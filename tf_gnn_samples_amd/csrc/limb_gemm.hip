@@ -1344,22 +1344,28 @@ __device__ __forceinline__ void limb_split_tile(const float* __restrict__ X, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = 8 * wave + (lane & 7);                // row inside the 32-row tile
   const int g8 = bx * 8 + (lane >> 3);                // group of 8 k
-  if (g8 * 8 >= C) return;
+  // C need not be a multiple of 16: the last k-tile is filled up with zeros (a reduction length of 121 — the PPI head's input
+  // gradient — or 50 becomes 128 / 64 against a left operand whose rows are zero-padded the same way)
+  if (g8 * 8 >= ((C + 15) & ~15)) return;
   const int r = rb * 32 + i;
   float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
   if (r < R) {
     if constexpr (TRANSPOSE) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = X[(int64_t)(8 * g8 + j) * ldx + r];
-    } else {
+      for (int j = 0; j < 8; ++j)
+        if (8 * g8 + j < C) v[j] = X[(int64_t)(8 * g8 + j) * ldx + r];
+    } else if (8 * g8 + 8 <= C && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + 8 * g8);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ldx + 8 * g8 + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
-    }
-  } else {
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      for (int j = 0; j < 8; ++j)
+        if (8 * g8 + j < C) v[j] = X[(int64_t)r * ldx + 8 * g8 + j];
+    }
   }
   uint4 h, m, l;
   split8(v, h, m, l);
@@ -1375,7 +1381,7 @@ __global__ __launch_bounds__(256) void limb_split_kernel(const float* __restrict
                                                          uint16_t* __restrict__ out, int64_t x_stride, int64_t out_stride) {
   X += (int64_t)blockIdx.z * x_stride;                // batch: one matrix per blockIdx.z
   out += (int64_t)blockIdx.z * out_stride;
-  limb_split_tile<TRANSPOSE>(X, ldx, rows, cols, out, (TRANSPOSE ? rows : cols) / 16, 0, blockIdx.x, blockIdx.y);
+  limb_split_tile<TRANSPOSE>(X, ldx, rows, cols, out, ((TRANSPOSE ? rows : cols) + 15) / 16, 0, blockIdx.x, blockIdx.y);
 }
 
 // Several matrices in one launch (the weight operands of a training step, split once after the optimizer's update): item d owns
@@ -1562,10 +1568,10 @@ int relgnn_limb_split_multi_f32(int32_t n, const float* const* X, const int64_t*
     a.n = 0;
     for (int32_t d = first; d < n && a.n < SPLIT_MULTI_MAX; ++d) {
       const int R = transpose[d] ? cols[d] : rows[d], C = transpose[d] ? rows[d] : cols[d];
-      if (rows[d] < 0 || cols[d] < 0 || C % 16 != 0 || kt_offset[d] < 0 || kt_offset[d] + C / 16 > kt_total[d]) return RELGNN_EINVAL;
+      if (rows[d] < 0 || cols[d] < 0 || kt_offset[d] < 0 || kt_offset[d] + (C + 15) / 16 > kt_total[d]) return RELGNN_EINVAL;
       if (R == 0 || C == 0) continue;
       if (!X[d] || !out[d]) return RELGNN_EINVAL;
-      if (!aligned16(X[d]) || !aligned16(out[d]) || ldx[d] % 4 || ldx[d] < cols[d]) return RELGNN_EUNSUPPORTED;
+      if (!aligned16(out[d]) || ldx[d] < cols[d]) return RELGNN_EUNSUPPORTED;     // (rows of any alignment: read element-wise then)
       SplitItem& it = a.it[a.n++];
       it.X = X[d]; it.ldx = ldx[d]; it.out = out[d]; it.rows = rows[d]; it.cols = cols[d]; it.transpose = transpose[d];
       it.kt_off = kt_offset[d]; it.kt_total = kt_total[d]; it.gx = (C + 63) / 64;

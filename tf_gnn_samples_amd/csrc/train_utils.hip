@@ -199,6 +199,28 @@ __global__ __launch_bounds__(256) void sigmoid_ce_bwd_kernel(const float* __rest
   }
 }
 
+// the same gradient into rows of ldg >= cols floats, the columns behind `cols` written as zeros: the operand of an input-gradient
+// product whose reduction length (cols = 121 labels) is then a multiple of 16 (relgnn_limb_gemm_xf32 over ldg columns)
+__global__ __launch_bounds__(256) void sigmoid_ce_bwd_padded_kernel(const float* __restrict__ logits,
+                                                                    const float* __restrict__ labels, long long rows, int cols,
+                                                                    int ldg, const float* __restrict__ g_mean, float mean_scale,
+                                                                    const float* __restrict__ g_total, float* __restrict__ gl) {
+  float gs = 0.f;
+  if (g_mean) gs = g_mean[0] * mean_scale;
+  if (g_total) gs = g_mean ? gs + g_total[0] : g_total[0];
+  const long long n = rows * ldg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / ldg;
+    const int c = (int)(i - r * ldg);
+    float v = 0.f;
+    if (c < cols) {
+      const float x = logits[r * cols + c];
+      v = gs * (1.f / (1.f + expf(-x)) - labels[r * cols + c]);
+    }
+    gl[i] = v;
+  }
+}
+
 constexpr int kStatsBlocks = 256;
 
 }  // namespace
@@ -290,6 +312,16 @@ int relgnn_sigmoid_ce_bwd(const float* logits, const float* labels, int64_t n, c
   if (!logits || !labels || (!g_mean && !g_total) || !glogits) return RELGNN_EINVAL;
   sigmoid_ce_bwd_kernel<<<flat_grid(n, 256), 256, 0, as_stream(stream)>>>(logits, labels, n, g_mean, mean_scale, g_total,
                                                                           glogits);
+  return launch_status();
+}
+
+int relgnn_sigmoid_ce_bwd_padded(const float* logits, const float* labels, int64_t rows, int32_t cols, const float* g_mean,
+                                 float mean_scale, const float* g_total, float* glogits, int32_t ldg, void* stream) {
+  if (rows < 0 || cols < 0 || ldg < cols) return RELGNN_EINVAL;
+  if (rows == 0 || ldg == 0) return RELGNN_OK;
+  if (!logits || !labels || (!g_mean && !g_total) || !glogits) return RELGNN_EINVAL;
+  sigmoid_ce_bwd_padded_kernel<<<flat_grid(rows * ldg, 256), 256, 0, as_stream(stream)>>>(logits, labels, rows, cols, ldg, g_mean,
+                                                                                          mean_scale, g_total, glogits);
   return launch_status();
 }
 

@@ -93,6 +93,24 @@ def is_premasked(g: torch.Tensor, y: torch.Tensor, act: int) -> bool:
     return getattr(g, "_relgnn_premasked", None) == (y.data_ptr(), y._version, int(act), tuple(y.shape))
 
 
+def mark_zero_padded(g: torch.Tensor, ld: int) -> torch.Tensor:
+    """g [M, K] is a view of rows of ld >= K floats whose columns K .. ld-1 hold ZEROS (written by g's producer: the loss gradient
+    of tasks/ppi_task.py through relgnn_sigmoid_ce_bwd_padded).  A consumer whose product reduces over K may then read [M, ld]
+    and meet a reduction length that is a multiple of 16 — the limb route — without a padding copy.  The tag is on the tensor
+    object: anything autograd copies, sums or passes through a hook arrives untagged and takes the plain route."""
+    g._relgnn_zero_pad = (g.data_ptr(), tuple(g.shape), g.stride(0), int(ld))
+    return g
+
+
+def zero_padded_operand(g: torch.Tensor):
+    """The [M, ld] view behind a tensor tagged by mark_zero_padded (None: not tagged, or no longer the tensor that was tagged)."""
+    tag = getattr(g, "_relgnn_zero_pad", None)
+    if (tag is None or g.dim() != 2 or tag != (g.data_ptr(), tuple(g.shape), g.stride(0), tag[3]) or g.stride(1) != 1
+            or g.stride(0) != tag[3] or tag[3] < g.shape[1] or tag[3] % 16):
+        return None
+    return torch.as_strided(g, (g.shape[0], tag[3]), (tag[3], 1))
+
+
 def act_bwd_from_output(act: int, y: torch.Tensor, g: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """g * act'(y) with the derivative taken from the activation's output (relgnn_act_bwd_from_output); out may be g itself."""
     from . import _lib
@@ -177,6 +195,14 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
     if act is None:
         act = 2 if relu else 0                                     # _lib.ACT_RELU / ACT_LINEAR
     relu = act == 2
+    if layout == GEMM_NT and weight and out is None and not accumulate and a.is_cuda and _cfg.limb_gemm:
+        # a gradient whose rows are zero-padded to a multiple of 16 columns by its producer (mark_zero_padded): the limb route over
+        # the padded reduction length, with the activation gradient of the layer below in its epilogue — for the 121-label PPI
+        # head that is one launch instead of a library product (K = 121) and a ReLU' pass over [V, 256]
+        ap = zero_padded_operand(a)
+        if ap is not None and _limb_padded_nt_ok(ap, a.shape[1], b, bias) and (premask is None or _premask_operand_ok(premask[1], a.shape[0], b.shape[0])):
+            return limb_gemm_weight(ap, b, WEIGHT_NT, bias, act, dact=premask[0] if premask is not None else 0,
+                                    dy=premask[1] if premask is not None else None)
     if premask is not None or act not in (0, 2):
         return _gemm_with_epilogues(layout, a, b, bias, act, weight, premask)
     if _cfg.limb_gemm and layout != GEMM_TN and out is None and not accumulate:
@@ -397,6 +423,13 @@ def limb_gemm_xf32(a: torch.Tensor, b: "Limbs", bias: torch.Tensor = None, act: 
     return out
 
 
+def _limb_padded_nt_ok(ap: torch.Tensor, k: int, b: torch.Tensor, bias) -> bool:
+    """ap [M, ld] (zero_padded_operand) @ b^T with b [N, k] a weight matrix, k <= ld = the next multiple of 16."""
+    return (_rows_ok(ap) and ap.shape[0] >= _LIMB_MIN_ROWS and b.dim() == 2 and b.shape[1] == k and ap.shape[1] == (k + 15) // 16 * 16
+            and b.shape[0] % 256 == 0 and 16 <= ap.shape[1] <= _LIMB_MAX_K and weight_image_ok([b], WEIGHT_NT)
+            and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0)))
+
+
 def _limb_route_ok(layout: int, a: torch.Tensor, b: torch.Tensor, bias, columns: int = 256) -> bool:
     if not (_rows_ok(a) and _rows_ok(b)) or a.shape[0] < _LIMB_MIN_ROWS:
         return False
@@ -446,19 +479,22 @@ def _weight_matrices(w):
 
 def _weight_image_shape(ws, kind: str):
     """(N, K) of B [N, K] = [w_0^T | w_1^T | ..] (WEIGHT_NN: w_l [K_l, N]) or [w_0 | w_1 | ..] (WEIGHT_NT: w_l [N, K_l])."""
-    if kind == WEIGHT_NN:
-        return ws[0].shape[1], sum(m.shape[0] for m in ws)
-    return ws[0].shape[0], sum(m.shape[1] for m in ws)
+    # (a single matrix whose k extent is not a multiple of 16 — the 121-label head — fills its last k-tile with zeros)
+    k = sum(m.shape[0] if kind == WEIGHT_NN else m.shape[1] for m in ws)
+    if len(ws) == 1:
+        k = (k + 15) // 16 * 16
+    return (ws[0].shape[1] if kind == WEIGHT_NN else ws[0].shape[0]), k
 
 
 def weight_image_ok(ws, kind: str) -> bool:
     ws = _weight_matrices(ws)
     n = ws[0].shape[1] if kind == WEIGHT_NN else ws[0].shape[0]
     for m in ws:
-        if not (m.is_cuda and m.dtype == torch.float32 and m.dim() == 2 and m.stride(1) == 1 and m.stride(0) % 4 == 0
-                and m.stride(0) >= m.shape[1] and m.data_ptr() % 16 == 0):
-            return False
-        if (m.shape[1] if kind == WEIGHT_NN else m.shape[0]) != n or (m.shape[0] if kind == WEIGHT_NN else m.shape[1]) % 16 != 0:
+        if not (m.is_cuda and m.dtype == torch.float32 and m.dim() == 2 and m.stride(1) == 1 and m.stride(0) >= m.shape[1]
+                and (len(ws) == 1 or (m.stride(0) % 4 == 0 and m.data_ptr() % 16 == 0))):
+            return False                   # (a single matrix may have rows of any alignment — [256, 121]: the split reads element-wise)
+        if (m.shape[1] if kind == WEIGHT_NN else m.shape[0]) != n or ((m.shape[0] if kind == WEIGHT_NN else m.shape[1]) % 16 != 0
+                                                                     and len(ws) > 1):
             return False
     return True
 
@@ -469,7 +505,7 @@ def _weight_image_items(ws, kind: str, buf: torch.Tensor):
     items, kt = [], 0
     for m in ws:
         items.append((m.data_ptr(), m.stride(0), m.shape[0], m.shape[1], 1 if kind == WEIGHT_NN else 0, buf.data_ptr(), kt, total))
-        kt += (m.shape[0] if kind == WEIGHT_NN else m.shape[1]) // 16
+        kt += ((m.shape[0] if kind == WEIGHT_NN else m.shape[1]) + 15) // 16
     return items
 
 

@@ -12,6 +12,7 @@ from typing import Any, Dict, Iterator, List, Optional
 import numpy as np
 import torch
 
+from .. import config as _cfg
 from ..dense import dense
 from ..utils import micro_f1
 from .sparse_graph_task import DataFold, MinibatchData, Sparse_Graph_Task
@@ -53,6 +54,18 @@ class _SigmoidCEStats(torch.autograd.Function):
         def scalar(g):                            # the incoming gradients stay on the device: the kernel reads them
             return None if g is None else g.reshape(1).to(torch.float32).contiguous()
         g_mean, g_total = scalar(g_mean), scalar(g_total)
+        rows, cols = logits.shape if logits.dim() == 2 else (1, logits.numel())
+        if logits.dim() == 2 and cols % 16 and _cfg.settings.limb_gemm and _cfg.settings.head_pad == "1":
+            # rows of the next multiple of 16 floats, zeros behind the labels: the head's input-gradient product then runs on the limb
+            # route with the ReLU' of the last GNN layer in its epilogue (dense.mark_zero_padded) instead of a K = 121 library
+            # product + a pass over [V, 256]
+            from ..dense import mark_zero_padded
+            ld = (cols + 15) // 16 * 16
+            buf = torch.empty((rows, ld), dtype=torch.float32, device=logits.device)
+            _lib.check(lib.relgnn_sigmoid_ce_bwd_padded(_lib.ptr(logits), _lib.ptr(labels), rows, cols, _lib.ptr(g_mean), ctx.inv_n,
+                                                        _lib.ptr(g_total), _lib.ptr(buf), ld, _lib.current_stream()),
+                       "relgnn_sigmoid_ce_bwd_padded")
+            return mark_zero_padded(buf[:, :cols], ld), None, None
         gl = torch.empty_like(logits)
         _lib.check(lib.relgnn_sigmoid_ce_bwd(_lib.ptr(logits), _lib.ptr(labels), logits.numel(), _lib.ptr(g_mean), ctx.inv_n,
                                              _lib.ptr(g_total), _lib.ptr(gl), _lib.current_stream()), "relgnn_sigmoid_ce_bwd")
