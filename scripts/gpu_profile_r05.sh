@@ -8,6 +8,7 @@
 #  (5) kernel trace + stats of the C5 step (bench_other.py C5)
 #  (6) PMC rows (FETCH_SIZE / WRITE_SIZE) of the FiLM edge kernels (C5) and the RGAT kernels (C4) on the final code
 #  (7) limb kernels per shape (time + error vs float64), typed TN isolated
+#  (8) the fused layer kernel (opt-in): bit identity + time against gather + product, matrix-pipe / VALU / LDS counters
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -36,6 +37,8 @@ find $O -name "*kernel_trace.csv" -delete; rm -rf $O/trace_giant_uniform $O/trac
 GRAFT_REPO_ROOT=$R timeout 900 bash scripts/profile_edge_pmc.sh > $O/edge_pmc.log 2>&1; cp gpurun_out/prof_edge_pmc/edge_kernels_pmc.csv $O/ 2>/dev/null
 timeout 600 python scripts/bench_limb_gemm.py > $O/limb_gemm.jsonl 2> $O/limb_gemm.err
 timeout 300 python scripts/bench_typed_tn.py > $O/typed_tn.jsonl 2> $O/typed_tn.err
+timeout 300 python scripts/bench_rgcn_fused.py > $O/rgcn_fused.txt 2>&1
+GRAFT_REPO_ROOT=$R timeout 900 bash scripts/gpu_pmc_rgcn_fused.sh > $O/rgcn_fused_pmc.log 2>&1; cp gpurun_out/pmc_rgcn_fused/summary.txt $O/rgcn_fused_pmc.txt 2>/dev/null
 python - <<'PY'
 import json, os
 O = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r05_profile"
