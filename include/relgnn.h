@@ -829,6 +829,15 @@ int relgnn_limb_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const u
 int relgnn_limb16_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const float* xmax, int32_t xgroups, const uint16_t* B,
                                  const float* wmax, const float* bias, const void* zeros, int32_t dact, const float* Y, int64_t ldy,
                                  float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* relgnn_limb_gemm_xf32 (_dact) with the work divided between wave ROLES (csrc/limb_gemm_pc.hip): eight producer waves stream the fp32
+ * rows of A, split them and lay them out as limb sub-slabs in LDS; eight matrix waves multiply them with W fragments read straight
+ * from L2, without a workgroup barrier (hand-over by counters in LDS, as in relgnn_rgcn_fused_fwd).  The same MatMuls (gnns/rgcn.py:
+ * 96-98 forward and input gradient; the Dense layers of models/sparse_graph_model.py:194-200), the same bits as
+ * relgnn_limb_gemm_xf32_dact.  K % 256 == 0, N % 256 == 0 and K == 256 or N == 256; act: linear or ReLU; Y (nullable) / dact as in
+ * relgnn_limb_gemm_xf32_dact.  RELGNN_EUNSUPPORTED otherwise: callers keep relgnn_limb_gemm_xf32 for those.
+ * relgnn_rgcn_fused_status reports the give-up bits of this kernel's polls too (bits 2 / 3). */
+int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, int32_t dact,
+                             const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 /*
  * relgnn_rgcn_fused_fwd — the aggregate-first RGCN layer in ONE kernel (north_star "per-edge-type linear transform
  * fused as an MFMA GEMM"):

@@ -506,7 +506,9 @@ def test_typed_weight_gradient_tiles_from_three_limbs(gpu_device, J, C, tiles):
     gathered rows (padding = -1 = zeros, repeated nodes, whole tiles of padding), both operands split into three bf16 limbs in
     flight.  Against float64, next to the exact-fp32 panel kernel it replaces in ops.typed_linear's backward; magnitudes spread
     over six decades per column (gradient-like)."""
-    from tf_gnn_samples_amd import dense as DN
+    from tf_gnn_samples_amd import config, dense as DN
+    if not config.settings.limb_gemm:
+        pytest.skip("the gathered three-limb TN belongs to RELGNN_GEMM=limb (limb_tn_tiles_supported says no under any other route)")
     torch.manual_seed(J * 7 + C + tiles)
     chunk = 512
     P, N = tiles * chunk, 3000
@@ -615,7 +617,9 @@ def test_folded_activation_gradients_leave_the_training_step_s_bits_alone(gpu_de
     assert loss_f == loss_u
     for n in grads_u:
         assert torch.equal(grads_f[n], grads_u[n]), n
-    assert passes_u == 5 and passes_f <= 2, (passes_u, passes_f)     # 3 ReLU' + 2 tanh' -> the head's ReLU' (+ nothing else)
+    from tf_gnn_samples_amd import config
+    if config.settings.limb_gemm:            # (the passes fold into the LIMB products' epilogues; other routes keep them, same bits)
+        assert passes_u == 5 and passes_f <= 2, (passes_u, passes_f)     # 3 ReLU' + 2 tanh' -> the head's ReLU' (+ nothing else)
 
 
 def test_a_tanh_output_with_two_readers_is_never_folded(gpu_device):
@@ -717,3 +721,31 @@ def test_weight_image_with_a_ragged_last_k_tile(gpu_device):
     assert torch.equal(out2, out)
     x[:, 121:] = 3.0                                                    # the zero k-tile really is zero: junk there changes nothing
     assert torch.equal(DN.limb_gemm_weight(x, w, DN.WEIGHT_NT), out)
+
+
+@pytest.mark.parametrize("M", [4096, 4097, 4160, 5000, 36096])
+@pytest.mark.parametrize("K,N", [(768, 256), (256, 768), (256, 256), (512, 256), (256, 1024)])
+def test_producer_consumer_product_is_bit_identical(gpu_device, M, K, N):
+    """relgnn_limb_gemm_xf32_pc (wave roles, LDS hand-over) against relgnn_limb_gemm_xf32(_dact): forward with bias + ReLU, input
+    gradient with the activation-gradient epilogue; odd unit counts, rows % 32 != 0, a strided left operand."""
+    import ctypes
+    from tf_gnn_samples_amd import _lib, config, dense as DN
+    dev = gpu_device
+    wide = _rand((M, K + 32), dev, M + K)
+    a = wide[:, 16:16 + K]                                  # row stride K + 32, 16-byte aligned
+    a[7, 3] = -torch.finfo(torch.float32).max               # the saturating split
+    w = [_rand((N, 256), dev, 100 + i, 0.1) for i in range(K // 256)]       # NT operands side by side along k
+    bias = _rand((N,), dev, 5, 0.1)
+    y = _rand((M, N), dev, 6).relu_()
+    outs = {}
+    for pc in ("0", "1"):
+        with config.override(limb_pc=pc):
+            outs[pc] = (DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, bias, _lib.ACT_RELU),
+                        DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, dact=_lib.ACT_RELU, dy=y),
+                        DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, dact=_lib.ACT_TANH, dy=y))
+    torch.cuda.synchronize()
+    s = ctypes.c_int32(-1)
+    _lib.check(_lib.load_library().relgnn_rgcn_fused_status(ctypes.byref(s), 1), "relgnn_rgcn_fused_status")
+    assert s.value == 0
+    for p, q in zip(outs["0"], outs["1"]):
+        assert torch.equal(p, q)

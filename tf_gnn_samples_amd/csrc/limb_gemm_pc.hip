@@ -1,0 +1,310 @@
+// relgnn_limb_gemm_xf32 with the work split between wave ROLES instead of between k-loop phases: C = act(bias + A @ B^T) (* dact'(Y)),
+// A fp32 [M, K] split into three bf16 limbs on its way into LDS, B the limb image of a weight operand — the tall Dense products of
+// gnns/rgcn.py:96-98 in the aggregate-first order (forward [V, L*256] @ [L*256, 256]; input gradient [V, 256] @ [256, L*256]).
+//
+// limb_gemm_kernel (limb_gemm.hip) runs eight waves that ALL feed the matrix pipe and of which five also split the streamed
+// operand at the top of every k-tile, behind a workgroup barrier per k-tile, with both operands staged in a 156 KB LDS ring: 75-86 us
+// for [36 096, 768] x [768, 256] against 59.5 us for its own MFMA-only loop (LABNOTES 7.4).  The matrix waves of rgcn_fused.hip —
+// X limbs from LDS sub-slabs that other waves fill, W fragments straight from L2 into registers three k-tiles ahead, no barrier,
+// hand-over by counters — ran at the MFMA-only time there.  This kernel keeps those matrix waves and replaces the gather waves by
+// eight STREAMING producer waves: each owns four rows of every 32-row x 256-k sub-slab (one coalesced 1 KiB load per row), splits
+// them (limb_split.h: the same limbs) and writes them in the sub-slab layout; the next sub-slab's rows are in flight meanwhile.
+// Same k-tile order and limb-product order per accumulator as limb_gemm_kernel: bit-identical results.
+//
+// A persistent 16-wave workgroup per CU owns a contiguous range of 32-row units, taken as 64-row panels.  Three 49.5 KB sub-slabs
+// rotate through LDS.  K = 256 S: the panel's sub-slabs come slab by slab, (s, tile 0), (s, tile 1).  Either N = 256 (one column
+// chunk; any S: the matrix waves consume a slab's tile pair while the next tile is filled) or S = 1 (any number of 256-column
+// chunks: the tile pair stays while the matrix waves pass over it once per chunk).  Everything else: limb_gemm_kernel.
+#include "common.h"
+#include "handover.h"
+#include "lds_dma.h"
+#include "limb_split.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+using namespace relgnn;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PIECE = 528;              // 32 rows x 16 B (8 k of one limb) + 16 B: consecutive pieces start in consecutive bank quads
+constexpr int PLANE = 32 * PIECE;       // the 32 (k-tile, k half) pieces of one limb of a sub-slab (32 rows x 256 k)
+constexpr int SLAB = 3 * PLANE;         // 3 limbs: 50 688 B
+constexpr int NBUF = 3;
+constexpr int CTL = 16;
+
+struct PcArgs {
+  const float* A; int64_t lda;
+  const uint16_t* B;                     // limb tiles of the [N, K] right operand
+  const float* bias;
+  const float* dy; int64_t ldy; int32_t dact;    // epilogue of an input-gradient product: C *= dact'(Y) (limb_gemm.hip)
+  float* C; int64_t ldc;
+  int32_t M, N, K, act;
+  int32_t units_base, units_rem, groups;
+  int32_t* status;
+};
+
+struct Frag { bf16x8 hi, mid, lo; };
+
+// act'(x) as a function of y = act(x) — the expressions of act_bwd_from_output_kernel (seg_reduce.hip) and limb_gemm.hip
+__device__ __forceinline__ float dact_from_output(int act, float yy) {
+  switch (act) {
+    case RELGNN_ACT_TANH: return 1.f - yy * yy;
+    case RELGNN_ACT_RELU: return yy > 0.f ? 1.f : 0.f;
+    case RELGNN_ACT_LEAKY_RELU: return yy > 0.f ? 1.f : 0.2f;
+    case RELGNN_ACT_ELU: return yy > 0.f ? 1.f : yy + 1.f;
+    case RELGNN_ACT_SELU: return yy > 0.f ? 1.0507009873554804934193349852946f : yy + 1.7580993408473768599402175208123f;
+    default: return 1.f;
+  }
+}
+
+__global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * SLAB + CTL * 4];
+  int* ctl = reinterpret_cast<int*>(lds + NBUF * SLAB);      // [1..3] rows filled, [4..6] matrix waves done
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = (int)xcd_logical_block(a.groups);
+  if (q < 0) return;
+  const int u0 = q * a.units_base + min(q, a.units_rem);
+  const int nu = a.units_base + (q < a.units_rem ? 1 : 0);
+  if (tid < CTL) ctl[tid] = 0;
+  __syncthreads();
+  const int S = a.K >> 8;                                    // 256-k slabs
+  const int chunks = a.N >> 8;
+  const int ntiles = a.K >> 4;
+  const int nfull = nu >> 1;                                 // panels of two units; an odd unit left over is a panel of one row tile
+  const int npan = (nu + 1) >> 1;
+  const int nseq = nfull * 2 * S + (nu & 1) * S;
+  const int rend = min((u0 + nu) * 32, a.M);
+  bool dead = false;
+  auto poll = [&](int* p, int target) {
+    if (dead) return;
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(handover_counter(p)) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > HANDOVER_SPIN_LIMIT) { dead = true; if (lane == 0 && a.status) atomicOr(a.status, 4 + (wave < 8 ? 0 : 4)); break; }
+    }
+    handover_fence();
+  };
+
+  if (wave < 8) {
+    // =================================================== matrix waves ===================================================
+    const int i32 = lane & 31, h32 = lane >> 5;
+    Frag wr[4];
+    int wc = 0, wt = 0;                                       // (column chunk, k-tile) whose W fragments are requested next
+    auto wload = [&](Frag& f) {
+      const uint16_t* p = a.B + ((int64_t)(wc * 8 + wave) * ntiles + wt) * 1536 + 8 * lane;
+      f.hi = *reinterpret_cast<const bf16x8*>(p);
+      f.mid = *reinterpret_cast<const bf16x8*>(p + 512);
+      f.lo = *reinterpret_cast<const bf16x8*>(p + 1024);
+      if (++wt == ntiles) { wt = 0; if (++wc == chunks) wc = 0; }
+    };
+    auto products = [&](f32x16 c, const Frag& w, const Frag& x) {        // limb_gemm.hip's order: small terms first
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, c, 0, 0, 0);
+      return c;
+    };
+    auto xread = [&](const unsigned char* p) {
+      Frag f;
+      f.hi = *reinterpret_cast<const bf16x8*>(p);
+      f.mid = *reinterpret_cast<const bf16x8*>(p + PLANE);
+      f.lo = *reinterpret_cast<const bf16x8*>(p + 2 * PLANE);
+      return f;
+    };
+    wload(wr[0]); wload(wr[1]); wload(wr[2]);
+    int b0 = 0, gen0 = 0;                                     // buffer / generation of the next sub-slab in sequence
+    const int xlane = h32 * PIECE + i32 * 16;
+    for (int pi = 0; pi < npan; ++pi) {
+      const int m0 = (u0 + 2 * pi) * 32;
+      const int rows_here = min(64, rend - m0);
+      const bool two = pi < nfull;
+      f32x16 acc0, acc1;
+      auto clear = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      };
+      // 32 x 32 tile: lane holds output row (lane & 31) x columns 8 c + 4 h + {0..3}, c = 0..3 (register 4 c + {0..3})
+      auto store_tile = [&](const f32x16& acc, int r, int colw) {
+        if (r >= rows_here) return;
+        float* crow = a.C + (int64_t)(m0 + r) * a.ldc;
+        const float* yrow = a.dy ? a.dy + (int64_t)(m0 + r) * a.ldy : nullptr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int cc = colw + 8 * c + 4 * h32;
+          f32x4 v = f32x4{acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + cc);
+          if (a.act == RELGNN_ACT_RELU) {
+            v[0] = act_fwd<RELGNN_ACT_RELU>(v[0]); v[1] = act_fwd<RELGNN_ACT_RELU>(v[1]);
+            v[2] = act_fwd<RELGNN_ACT_RELU>(v[2]); v[3] = act_fwd<RELGNN_ACT_RELU>(v[3]);
+          }
+          if (yrow) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(yrow + cc);
+            v = f32x4{v[0] * dact_from_output(a.dact, y[0]), v[1] * dact_from_output(a.dact, y[1]),
+                      v[2] * dact_from_output(a.dact, y[2]), v[3] * dact_from_output(a.dact, y[3])};
+          }
+          *reinterpret_cast<f32x4*>(crow + cc) = v;
+        }
+      };
+      auto slab_pass = [&](int ba, int bb) {                   // sixteen k-tiles over the tile pair in buffers ba (, bb)
+        const unsigned char* x0b = lds + ba * SLAB + xlane;
+        const unsigned char* x1b = lds + bb * SLAB + xlane;
+#pragma nounroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const unsigned char* x0k = x0b + k4 * 8 * PIECE;
+          const unsigned char* x1k = x1b + k4 * 8 * PIECE;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            wload(wr[(kt + 3) & 3]);
+            const Frag x0 = xread(x0k + kt * 2 * PIECE);
+            acc0 = products(acc0, wr[kt], x0);
+            if (two) {
+              const Frag x1 = xread(x1k + kt * 2 * PIECE);
+              acc1 = products(acc1, wr[kt], x1);
+            }
+          }
+        }
+      };
+      auto next_pair = [&](int& b1, int& gen1) {               // the tile pair that starts at (b0, gen0): its second buffer
+        b1 = b0; gen1 = gen0;
+        if (two && ++b1 == NBUF) { b1 = 0; ++gen1; }
+      };
+      auto release = [&](int b1, int gen1) {
+        wait_lgkm0();                                          // my reads of both buffers have returned
+        handover_fence();
+        if (lane == 0) {
+          __hip_atomic_fetch_add(ctl + 4 + b0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (two) __hip_atomic_fetch_add(ctl + 4 + b1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        b0 = b1 + 1; gen0 = gen1;
+        if (b0 == NBUF) { b0 = 0; ++gen0; }
+      };
+      // one call site for the sixteen k-tiles (two copies of it, and of the stores, spilled registers): a panel is S x chunks passes,
+      // of which one factor is 1 — slabs: acquire and release a tile pair per pass, clear before the first, store behind the last;
+      // chunks: acquire before the first pass, clear and store around every pass, release behind the last
+      const int passes = chunks == 1 ? S : chunks;
+      int b1 = 0, gen1 = 0;
+      for (int ps = 0; ps < passes; ++ps) {
+        if (chunks == 1 || ps == 0) {
+          next_pair(b1, gen1);
+          poll(ctl + 1 + b0, 32 * (gen0 + 1));
+          if (two) poll(ctl + 1 + b1, 32 * (gen1 + 1));
+        }
+        if (chunks > 1 || ps == 0) clear();
+        slab_pass(b0, b1);
+        if (chunks > 1 || ps == passes - 1) {
+          const int colw = (chunks > 1 ? ps * 256 : 0) + wave * 32;
+          store_tile(acc0, i32, colw);
+          if (two) store_tile(acc1, 32 + i32, colw);
+        }
+        if (chunks == 1 || ps == passes - 1) release(b1, gen1);
+      }
+    }
+    return;
+  }
+
+  // ===================================================== producer waves =====================================================
+  // wave p streams rows 4 p .. 4 p + 3 of every sub-slab: one 1 KiB load per row (lane = 4 k), the split, three 8-byte LDS writes
+  // per row.  The loads of sub-slab g + 1 are issued before sub-slab g is split; the two register sets alternate by name and the
+  // loads are unconditional (a row past the end reads a valid address and is zeroed), so that the wait in front of the split is
+  // exactly "all but the four loads issued last".
+  const int pw = wave - 8;
+  const int wr_lane = (lane >> 1) * PIECE + (lane & 1) * 8;   // k-tile lane >> 2, k half (lane >> 1) & 1, k 4 (lane & 1) .. + 3
+  const f32x4* A4 = reinterpret_cast<const f32x4*>(a.A);
+  const int64_t lda4 = a.lda >> 2;
+  // sequence position -> (panel, slab, row tile), advanced incrementally
+  struct Pos { int g, pi, s, tm; };
+  auto advance = [&](Pos& p) {
+    ++p.g;
+    const bool two = p.pi < nfull;
+    if (two && p.tm == 0) { p.tm = 1; return; }
+    p.tm = 0;
+    if (++p.s == S) { p.s = 0; ++p.pi; }
+  };
+  auto row0 = [&](const Pos& p) { return (u0 + 2 * p.pi) * 32 + p.tm * 32 + 4 * pw; };
+  auto issue = [&](const Pos& p, f32x4 (&v)[4]) {
+    const int r0 = row0(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (p.g < nseq && r0 + j < rend) ? r0 + j : 0;           // (row 0 exists: M > 0)
+      v[j] = A4[(int64_t)r * lda4 + (p.g < nseq ? p.s : 0) * 64 + lane];
+    }
+  };
+  auto process = [&](const Pos& p, f32x4 (&v)[4]) {
+    __builtin_amdgcn_s_waitcnt(0x0F74);                        // vmcnt(4): everything but the four loads issued last has landed
+    const int fill = p.g % NBUF, gen = p.g / NBUF;
+    poll(ctl + 4 + fill, 8 * gen);                            // the buffer's previous user has been consumed by the eight matrix waves
+    const int r0 = row0(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 x = v[j];
+      if (r0 + j >= rend) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint32_t h0, m0_, l0, h1, m1, l1;
+      split_pair(x[0], x[1], h0, m0_, l0);
+      split_pair(x[2], x[3], h1, m1, l1);
+      if (__builtin_expect(max3_abs(max3_abs(x[0], x[1], x[2]), x[3], x[3]) >= __uint_as_float(0x7F7F8000u), 0)) {
+        split_pair_sat(x[0], x[1], h0, m0_, l0);
+        split_pair_sat(x[2], x[3], h1, m1, l1);
+      }
+      unsigned char* o = lds + fill * SLAB + (4 * pw + j) * 16 + wr_lane;
+      *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(o + PLANE) = make_uint2(m0_, m1);
+      *reinterpret_cast<uint2*>(o + 2 * PLANE) = make_uint2(l0, l1);
+    }
+    wait_lgkm0();
+    handover_fence();
+    if (lane == 0) __hip_atomic_fetch_add(ctl + 1 + fill, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  Pos pa{0, 0, 0, 0}, pb{0, 0, 0, 0};
+  f32x4 va[4], vb[4];
+  issue(pa, va);
+  for (;;) {
+    if (pa.g >= nseq) break;
+    pb = pa; advance(pb);
+    issue(pb, vb);
+    process(pa, va);
+    if (pb.g >= nseq) break;
+    pa = pb; advance(pa);
+    issue(pa, va);
+    process(pb, vb);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, int32_t dact,
+                             const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!A || !B || !C) return RELGNN_EINVAL;
+  if (K == 0 || K % 256 != 0 || N % 256 != 0 || (N != 256 && K != 256) || (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU))
+    return RELGNN_EUNSUPPORTED;
+  if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias)) || ldc % 4 || ldc < N || lda % 4 || lda < K)
+    return RELGNN_EUNSUPPORTED;
+  if (Y) {
+    if (dact < RELGNN_ACT_LINEAR || dact > RELGNN_ACT_SELU) return dact == RELGNN_ACT_GELU ? RELGNN_EUNSUPPORTED : RELGNN_EINVAL;
+    if (!aligned16(Y) || ldy % 4 || ldy < N) return RELGNN_EUNSUPPORTED;
+  }
+  PcArgs a{};
+  a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.dy = Y; a.ldy = ldy; a.dact = dact; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.act = act;
+  a.status = handover_status_word();
+  if (!a.status) return RELGNN_EHIP;
+  const int units = (M + 31) / 32;
+  int groups = (units + 1) / 2;                               // at least one full panel per workgroup
+  if (groups > 256) groups = 256;
+  a.groups = groups; a.units_base = units / groups; a.units_rem = units % groups;
+  limb_gemm_pc_kernel<<<(unsigned)(8 * ((groups + 7) / 8)), 1024, 0, as_stream(stream)>>>(a);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -34,6 +34,7 @@
 // 513 us against 164 us for the two kernels on the C2 batch; s_memtime stamps showed the gather waves 97 % busy issuing
 // instructions (row-load wait 0.3 % of their time) and the matrix waves 91 % of the time in polls.
 #include "common.h"
+#include "handover.h"
 #include "lds_dma.h"
 #include "limb_split.h"
 
@@ -59,7 +60,6 @@ constexpr int BROWS = 4;                // rows per batch (8: the slowest of a t
 constexpr int BPS = 32 / BROWS;         // batches per sub-slab
 constexpr int CTL = 16;                 // control words behind the slabs
 constexpr uint32_t M_LAST = 1u << 31, M_EMPTY = 1u << 30, M_INVALID = 1u << 29;
-constexpr int SPIN_LIMIT = 1 << 22;     // a poll that takes this long is a bug: give up, flag it, finish with wrong numbers
 
 struct FusedArgs {
   const float* H; int64_t ldh;           // [*, ldh] states, 256 columns read
@@ -88,8 +88,8 @@ unsigned long long* g_fused_timing = nullptr;   // diagnostic build: [workgroup]
 #define TACC(slot, t1, t0)
 #endif
 
-__device__ __forceinline__ int lds_counter(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ int lds_counter(int* p) { return handover_counter(p); }
+__device__ __forceinline__ void compiler_fence() { handover_fence(); }
 
 template <bool HAS_W>
 __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(lds_counter(p)) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > SPIN_LIMIT) { dead = true; if (lane == 0 && a.status) atomicOr(a.status, 1 + (wave < 8 ? 0 : 1)); break; }
+      if (++spins > HANDOVER_SPIN_LIMIT) { dead = true; if (lane == 0 && a.status) atomicOr(a.status, 1 + (wave < 8 ? 0 : 1)); break; }
     }
     compiler_fence();
 #ifdef RELGNN_FUSED_TIMING
@@ -457,6 +457,16 @@ int32_t* g_status = nullptr;
 
 }  // namespace
 
+namespace relgnn {
+int32_t* handover_status_word() {
+  if (!g_status) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_status), sizeof(int32_t)) != hipSuccess) { g_status = nullptr; return nullptr; }
+    if (hipMemset(g_status, 0, sizeof(int32_t)) != hipSuccess) return nullptr;
+  }
+  return g_status;
+}
+}  // namespace relgnn
+
 extern "C" {
 
 int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const int32_t* rowptr, int32_t num_nodes,
@@ -473,10 +483,7 @@ int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const
   if (!aligned16(H) || !aligned16(out) || !aligned16(w_limbs) || (bias && !aligned16(bias)) || (bucket_sums && !aligned16(bucket_sums)) ||
       ldh % 4 || ldo % 4 || lds % 4)
     return RELGNN_EUNSUPPORTED;
-  if (!g_status) {
-    if (hipMalloc(reinterpret_cast<void**>(&g_status), sizeof(int32_t)) != hipSuccess) return RELGNN_EHIP;
-    if (hipMemset(g_status, 0, sizeof(int32_t)) != hipSuccess) return RELGNN_EHIP;
-  }
+  if (!handover_status_word()) return RELGNN_EHIP;
   FusedArgs a{};
   a.H = H; a.ldh = ldh; a.rowptr = rowptr; a.col = col; a.w = w; a.B = w_limbs; a.bias = bias; a.S = bucket_sums; a.lds_ = lds;
   a.C = out; a.ldc = ldo; a.V = num_nodes; a.L = num_edge_types; a.act = act; a.status = g_status;

@@ -628,6 +628,13 @@ def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, a
                                                out.stride(0), a.shape[0], n, k, _lib.current_stream()), "relgnn_limb16_gemm_xf32")
         return out
     buf = weight_limbs(w, kind)
+    if _limb_pc_ok(a, n, k, bias, act, dy, out):
+        # wave roles instead of k-loop phases (csrc/limb_gemm_pc.hip): the same bits, the matrix waves at their MFMA-only time
+        _lib.check(lib.relgnn_limb_gemm_xf32_pc(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), int(dact),
+                                                dy.data_ptr() if dy is not None else None, dy.stride(0) if dy is not None else 0,
+                                                out.data_ptr(), out.stride(0), a.shape[0], n, k, _lib.current_stream()),
+                   "relgnn_limb_gemm_xf32_pc")
+        return out
     if dy is not None:
         _lib.check(lib.relgnn_limb_gemm_xf32_dact(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
                                                   int(dact), dy.data_ptr(), dy.stride(0), out.data_ptr(), out.stride(0), a.shape[0], n, k,
@@ -637,6 +644,14 @@ def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, a
                                          out.data_ptr(), out.stride(0), a.shape[0], n, k, _lib.current_stream()),
                "relgnn_limb_gemm_xf32")
     return out
+
+
+def _limb_pc_ok(a, n: int, k: int, bias, act: int, dy, out) -> bool:
+    """Shapes relgnn_limb_gemm_xf32_pc takes (config limb_pc): K % 256 == 0, N % 256 == 0, one of them 256; ReLU / no activation."""
+    if _cfg.limb_pc != "1" or act not in (0, 2) or k % 256 or n % 256 or (n != 256 and k != 256) or a.shape[0] < _LIMB_MIN_ROWS:
+        return False
+    return (a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+            and (bias is None or bias.data_ptr() % 16 == 0) and (dy is None or (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0)))
 
 
 def _limb_group_ok(a: torch.Tensor, ws, kind: str) -> bool:
