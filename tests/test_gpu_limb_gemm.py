@@ -724,7 +724,7 @@ def test_weight_image_with_a_ragged_last_k_tile(gpu_device):
 
 
 @pytest.mark.parametrize("M", [4096, 4097, 4160, 5000, 36096])
-@pytest.mark.parametrize("K,N", [(768, 256), (256, 768), (256, 256), (512, 256), (256, 1024)])
+@pytest.mark.parametrize("K,N", [(768, 256), (256, 768), (256, 256), (512, 256), (256, 1024), (128, 256), (384, 256), (128, 512)])
 def test_producer_consumer_product_is_bit_identical(gpu_device, M, K, N):
     """relgnn_limb_gemm_xf32_pc (wave roles, LDS hand-over) against relgnn_limb_gemm_xf32(_dact): forward with bias + ReLU, input
     gradient with the activation-gradient epilogue; odd unit counts, rows % 32 != 0, a strided left operand."""
@@ -734,7 +734,7 @@ def test_producer_consumer_product_is_bit_identical(gpu_device, M, K, N):
     wide = _rand((M, K + 32), dev, M + K)
     a = wide[:, 16:16 + K]                                  # row stride K + 32, 16-byte aligned
     a[7, 3] = -torch.finfo(torch.float32).max               # the saturating split
-    w = [_rand((N, 256), dev, 100 + i, 0.1) for i in range(K // 256)]       # NT operands side by side along k
+    w = [_rand((N, 128), dev, 100 + i, 0.1) for i in range(K // 128)]       # NT operands side by side along k
     bias = _rand((N,), dev, 5, 0.1)
     y = _rand((M, N), dev, 6).relu_()
     outs = {}

@@ -28,10 +28,10 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
     "limb_pair_parts": ("RELGNN_LIMB_PAIR_PARTS", "nn,nt,tn", None,
                         "which of the aggregate-first layer's products take the two-limb form (diagnostic): forward nn, input "
                         "gradient nt, weight gradient tn"),
-    "limb_pc": ("RELGNN_LIMB_PC", "1", ("0", "1"),
-                "exact-split products with K or N = 256 (the aggregate-first layer's forward and input gradient, the Dense layers "
-                "between GNN layers): producer / matrix wave roles with LDS hand-over (csrc/limb_gemm_pc.hip) | every wave splits and "
-                "multiplies behind a barrier per k-tile (limb_gemm_kernel); the same bits"),
+    "limb_pc": ("RELGNN_LIMB_PC", "fwd", ("fwd", "0", "1"),
+                "exact-split products with N = 256 or K <= 256: producer / matrix wave roles with LDS hand-over "
+                "(csrc/limb_gemm_pc.hip) for the forward products only (input-gradient products run next to the side stream's weight "
+                "gradient, which a kernel that holds every CU starves) | never | for every product that fits; the same bits"),
     "limb_cut": ("RELGNN_LIMB_CUT", "1", ("0", "1"),
                  "N % 128 >= 96 products (the 121 logits of the PPI head) on the 128-column limb panels with the last chunk cut at N"),
     "head_pad": ("RELGNN_HEAD_PAD", "1", ("0", "1"),

@@ -11,10 +11,13 @@
 // them (limb_split.h: the same limbs) and writes them in the sub-slab layout; the next sub-slab's rows are in flight meanwhile.
 // Same k-tile order and limb-product order per accumulator as limb_gemm_kernel: bit-identical results.
 //
-// A persistent 16-wave workgroup per CU owns a contiguous range of 32-row units, taken as 64-row panels.  Three 49.5 KB sub-slabs
-// rotate through LDS.  K = 256 S: the panel's sub-slabs come slab by slab, (s, tile 0), (s, tile 1).  Either N = 256 (one column
-// chunk; any S: the matrix waves consume a slab's tile pair while the next tile is filled) or S = 1 (any number of 256-column
-// chunks: the tile pair stays while the matrix waves pass over it once per chunk).  Everything else: limb_gemm_kernel.
+// A persistent 16-wave workgroup per CU owns a contiguous range of 32-row units, taken as 64-row panels.  A sub-slab is one 32-row
+// tile x 128 k (eight k-tiles) as limbs, 24.75 KB; SIX of them rotate through LDS: the matrix waves hold a tile pair while the
+// producers are up to four sub-slabs ahead (with three sub-slabs of 256 k — the geometry rgcn_fused.hip needs for its whole-row
+// gathers — the matrix waves waited for the second tile of every pair: measured 74 us per product on average against 94 us for
+// limb_gemm_kernel; this geometry: see profiles/).  The panel's sub-slabs come in k order, (hs, tile 0), (hs, tile 1).  Either
+// N = 256 (one column chunk; any K % 128 == 0) or K <= 256 (any number of 256-column chunks: the panel's <= 4 sub-slabs stay
+// while the matrix waves pass over them once per chunk).  Everything else: limb_gemm_kernel.
 #include "common.h"
 #include "handover.h"
 #include "lds_dma.h"
@@ -32,10 +35,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PIECE = 528;              // 32 rows x 16 B (8 k of one limb) + 16 B: consecutive pieces start in consecutive bank quads
-constexpr int PLANE = 32 * PIECE;       // the 32 (k-tile, k half) pieces of one limb of a sub-slab (32 rows x 256 k)
-constexpr int SLAB = 3 * PLANE;         // 3 limbs: 50 688 B
-constexpr int NBUF = 3;
-constexpr int CTL = 16;
+constexpr int PLANE = 16 * PIECE;       // the 16 (k-tile, k half) pieces of one limb of a sub-slab (32 rows x 128 k)
+constexpr int SLAB = 3 * PLANE;         // 3 limbs: 25 344 B
+constexpr int NBUF = 6;
+constexpr int CTL = 16;                 // control words: [1..6] rows filled per buffer, [8..13] matrix waves done with it
 
 struct PcArgs {
   const float* A; int64_t lda;
@@ -62,9 +65,13 @@ __device__ __forceinline__ float dact_from_output(int act, float yy) {
   }
 }
 
+// S2 = K / 128 is a template parameter: the k-tiles of a pass are straight-line code.  (With a run-time loop over the half slabs
+// hipcc's wait insertion loses track of the W fragments that are in flight across the loop's back edge and drains them at every
+// loop header — vmcnt(0) in front of the first MFMA of every four k-tiles: a full L2 round trip per 1.7 us of matrix work.)
+template <int S2>
 __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * SLAB + CTL * 4];
-  int* ctl = reinterpret_cast<int*>(lds + NBUF * SLAB);      // [1..3] rows filled, [4..6] matrix waves done
+  int* ctl = reinterpret_cast<int*>(lds + NBUF * SLAB);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = (int)xcd_logical_block(a.groups);
@@ -73,12 +80,11 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
   const int nu = a.units_base + (q < a.units_rem ? 1 : 0);
   if (tid < CTL) ctl[tid] = 0;
   __syncthreads();
-  const int S = a.K >> 8;                                    // 256-k slabs
   const int chunks = a.N >> 8;
   const int ntiles = a.K >> 4;
   const int nfull = nu >> 1;                                 // panels of two units; an odd unit left over is a panel of one row tile
   const int npan = (nu + 1) >> 1;
-  const int nseq = nfull * 2 * S + (nu & 1) * S;
+  const int nseq = nfull * 2 * S2 + (nu & 1) * S2;
   const int rend = min((u0 + nu) * 32, a.M);
   bool dead = false;
   auto poll = [&](int* p, int target) {
@@ -122,15 +128,25 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
     int b0 = 0, gen0 = 0;                                     // buffer / generation of the next sub-slab in sequence
     const int xlane = h32 * PIECE + i32 * 16;
+    auto buf_of = [&](int i) { const int b = b0 + i; return b >= NBUF ? b - NBUF : b; };      // i <= 4 < NBUF
+    auto poll_buf = [&](int i) {
+      const int b = b0 + i;
+      if (b >= NBUF) poll(ctl + 1 + b - NBUF, 32 * (gen0 + 2)); else poll(ctl + 1 + b, 32 * (gen0 + 1));
+    };
+    auto release = [&](int n) {
+      wait_lgkm0();                                            // my reads of these buffers have returned
+      handover_fence();
+      if (lane == 0)
+        for (int i = 0; i < n; ++i) __hip_atomic_fetch_add(ctl + 8 + buf_of(i), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      b0 += n;
+      if (b0 >= NBUF) { b0 -= NBUF; ++gen0; }
+    };
     for (int pi = 0; pi < npan; ++pi) {
       const int m0 = (u0 + 2 * pi) * 32;
       const int rows_here = min(64, rend - m0);
       const bool two = pi < nfull;
+      const int per = two ? 2 : 1;
       f32x16 acc0, acc1;
-      auto clear = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      };
       // 32 x 32 tile: lane holds output row (lane & 31) x columns 8 c + 4 h + {0..3}, c = 0..3 (register 4 c + {0..3})
       auto store_tile = [&](const f32x16& acc, int r, int colw) {
         if (r >= rows_here) return;
@@ -153,99 +169,82 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
           *reinterpret_cast<f32x4*>(crow + cc) = v;
         }
       };
-      auto slab_pass = [&](int ba, int bb) {                   // sixteen k-tiles over the tile pair in buffers ba (, bb)
-        const unsigned char* x0b = lds + ba * SLAB + xlane;
-        const unsigned char* x1b = lds + bb * SLAB + xlane;
-#pragma nounroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const unsigned char* x0k = x0b + k4 * 8 * PIECE;
-          const unsigned char* x1k = x1b + k4 * 8 * PIECE;
+      // One call site for the k-tiles (two copies of it, and of the stores, spilled registers).  A panel is `chunks` passes over
+      // its S2 half slabs.  One chunk: a tile pair is acquired and released per half slab.  Several chunks (K <= 256): all the
+      // panel's sub-slabs are acquired before the first pass and released behind the last.
+      if (chunks > 1)
+        for (int i = 0; i < S2 * per; ++i) poll_buf(i);
+      for (int ps = 0; ps < chunks; ++ps) {
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            wload(wr[(kt + 3) & 3]);
-            const Frag x0 = xread(x0k + kt * 2 * PIECE);
-            acc0 = products(acc0, wr[kt], x0);
-            if (two) {
-              const Frag x1 = xread(x1k + kt * 2 * PIECE);
-              acc1 = products(acc1, wr[kt], x1);
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int hs = 0; hs < S2; ++hs) {
+          const int i0 = chunks > 1 ? hs * per : 0;
+          if (chunks == 1) { poll_buf(0); if (two) poll_buf(1); }
+          const unsigned char* x0b = lds + buf_of(i0) * SLAB + xlane;
+          const unsigned char* x1b = lds + buf_of(i0 + per - 1) * SLAB + xlane;
+#pragma unroll
+          for (int k4 = 0; k4 < 2; ++k4) {
+            const unsigned char* x0k = x0b + k4 * 8 * PIECE;
+            const unsigned char* x1k = x1b + k4 * 8 * PIECE;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+              wload(wr[(kt + 3) & 3]);
+              __builtin_amdgcn_s_waitcnt(0x0F79);               // vmcnt(9): the W fragments of this k-tile have landed, three k-tiles stay in flight
+              const Frag x0 = xread(x0k + kt * 2 * PIECE);
+              acc0 = products(acc0, wr[kt], x0);
+              if (two) {
+                const Frag x1 = xread(x1k + kt * 2 * PIECE);
+                acc1 = products(acc1, wr[kt], x1);
+              }
             }
           }
+          if (chunks == 1) release(per);
         }
-      };
-      auto next_pair = [&](int& b1, int& gen1) {               // the tile pair that starts at (b0, gen0): its second buffer
-        b1 = b0; gen1 = gen0;
-        if (two && ++b1 == NBUF) { b1 = 0; ++gen1; }
-      };
-      auto release = [&](int b1, int gen1) {
-        wait_lgkm0();                                          // my reads of both buffers have returned
-        handover_fence();
-        if (lane == 0) {
-          __hip_atomic_fetch_add(ctl + 4 + b0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (two) __hip_atomic_fetch_add(ctl + 4 + b1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        b0 = b1 + 1; gen0 = gen1;
-        if (b0 == NBUF) { b0 = 0; ++gen0; }
-      };
-      // one call site for the sixteen k-tiles (two copies of it, and of the stores, spilled registers): a panel is S x chunks passes,
-      // of which one factor is 1 — slabs: acquire and release a tile pair per pass, clear before the first, store behind the last;
-      // chunks: acquire before the first pass, clear and store around every pass, release behind the last
-      const int passes = chunks == 1 ? S : chunks;
-      int b1 = 0, gen1 = 0;
-      for (int ps = 0; ps < passes; ++ps) {
-        if (chunks == 1 || ps == 0) {
-          next_pair(b1, gen1);
-          poll(ctl + 1 + b0, 32 * (gen0 + 1));
-          if (two) poll(ctl + 1 + b1, 32 * (gen1 + 1));
-        }
-        if (chunks > 1 || ps == 0) clear();
-        slab_pass(b0, b1);
-        if (chunks > 1 || ps == passes - 1) {
-          const int colw = (chunks > 1 ? ps * 256 : 0) + wave * 32;
-          store_tile(acc0, i32, colw);
-          if (two) store_tile(acc1, 32 + i32, colw);
-        }
-        if (chunks == 1 || ps == passes - 1) release(b1, gen1);
+        const int colw = ps * 256 + wave * 32;
+        store_tile(acc0, i32, colw);
+        if (two) store_tile(acc1, 32 + i32, colw);
       }
+      if (chunks > 1) release(S2 * per);
     }
     return;
   }
 
   // ===================================================== producer waves =====================================================
-  // wave p streams rows 4 p .. 4 p + 3 of every sub-slab: one 1 KiB load per row (lane = 4 k), the split, three 8-byte LDS writes
-  // per row.  The loads of sub-slab g + 1 are issued before sub-slab g is split; the two register sets alternate by name and the
-  // loads are unconditional (a row past the end reads a valid address and is zeroed), so that the wait in front of the split is
-  // exactly "all but the four loads issued last".
+  // wave p streams rows 4 p .. 4 p + 3 of every sub-slab: two 1 KiB loads (two rows x 128 k each: lane = row (lane >> 5), 4 k), the
+  // split, three 8-byte LDS writes per load.  The loads of the three sub-slabs behind the current one are in flight; the four
+  // register sets alternate by name and the loads are unconditional (a row past the end reads a valid address and is zeroed), so
+  // that the wait in front of the split is exactly "all but the six loads issued last".
   const int pw = wave - 8;
-  const int wr_lane = (lane >> 1) * PIECE + (lane & 1) * 8;   // k-tile lane >> 2, k half (lane >> 1) & 1, k 4 (lane & 1) .. + 3
+  const int col4 = lane & 31, rsub = lane >> 5;
+  const int wr_lane = (col4 >> 1) * PIECE + (col4 & 1) * 8;   // k-tile col4 >> 2, k half (col4 >> 1) & 1, k 4 (col4 & 1) .. + 3
   const f32x4* A4 = reinterpret_cast<const f32x4*>(a.A);
   const int64_t lda4 = a.lda >> 2;
-  // sequence position -> (panel, slab, row tile), advanced incrementally
-  struct Pos { int g, pi, s, tm; };
+  struct Pos { int g, pi, hs, tm; };                          // sequence position -> (panel, half slab, row tile)
   auto advance = [&](Pos& p) {
     ++p.g;
-    const bool two = p.pi < nfull;
-    if (two && p.tm == 0) { p.tm = 1; return; }
+    if (p.pi < nfull && p.tm == 0) { p.tm = 1; return; }
     p.tm = 0;
-    if (++p.s == S) { p.s = 0; ++p.pi; }
+    if (++p.hs == S2) { p.hs = 0; ++p.pi; }
   };
-  auto row0 = [&](const Pos& p) { return (u0 + 2 * p.pi) * 32 + p.tm * 32 + 4 * pw; };
-  auto issue = [&](const Pos& p, f32x4 (&v)[4]) {
+  auto row0 = [&](const Pos& p) { return (u0 + 2 * p.pi) * 32 + p.tm * 32 + 4 * pw + rsub; };
+  auto issue = [&](const Pos& p, f32x4 (&v)[2]) {
     const int r0 = row0(p);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = (p.g < nseq && r0 + j < rend) ? r0 + j : 0;           // (row 0 exists: M > 0)
-      v[j] = A4[(int64_t)r * lda4 + (p.g < nseq ? p.s : 0) * 64 + lane];
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = p.g < nseq && r0 + 2 * j < rend;
+      v[j] = A4[(ok ? (int64_t)(r0 + 2 * j) * lda4 + p.hs * 32 : 0) + col4];          // (row 0 exists: M > 0, K >= 128)
     }
   };
-  auto process = [&](const Pos& p, f32x4 (&v)[4]) {
-    __builtin_amdgcn_s_waitcnt(0x0F74);                        // vmcnt(4): everything but the four loads issued last has landed
+  auto process = [&](const Pos& p, f32x4 (&v)[2]) {
+    __builtin_amdgcn_s_waitcnt(0x0F76);                        // vmcnt(6): everything but the six loads issued last has landed
     const int fill = p.g % NBUF, gen = p.g / NBUF;
-    poll(ctl + 4 + fill, 8 * gen);                            // the buffer's previous user has been consumed by the eight matrix waves
+    poll(ctl + 8 + fill, 8 * gen);                            // the buffer's previous user has been consumed by the eight matrix waves
     const int r0 = row0(p);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       f32x4 x = v[j];
-      if (r0 + j >= rend) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r0 + 2 * j >= rend) x = f32x4{0.f, 0.f, 0.f, 0.f};
       uint32_t h0, m0_, l0, h1, m1, l1;
       split_pair(x[0], x[1], h0, m0_, l0);
       split_pair(x[2], x[3], h1, m1, l1);
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
         split_pair_sat(x[0], x[1], h0, m0_, l0);
         split_pair_sat(x[2], x[3], h1, m1, l1);
       }
-      unsigned char* o = lds + fill * SLAB + (4 * pw + j) * 16 + wr_lane;
+      unsigned char* o = lds + fill * SLAB + (4 * pw + 2 * j + rsub) * 16 + wr_lane;
       *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(o + PLANE) = make_uint2(m0_, m1);
       *reinterpret_cast<uint2*>(o + 2 * PLANE) = make_uint2(l0, l1);
@@ -262,18 +261,19 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
     handover_fence();
     if (lane == 0) __hip_atomic_fetch_add(ctl + 1 + fill, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  Pos pa{0, 0, 0, 0}, pb{0, 0, 0, 0};
-  f32x4 va[4], vb[4];
-  issue(pa, va);
-  for (;;) {
-    if (pa.g >= nseq) break;
-    pb = pa; advance(pb);
-    issue(pb, vb);
-    process(pa, va);
-    if (pb.g >= nseq) break;
-    pa = pb; advance(pa);
-    issue(pa, va);
-    process(pb, vb);
+  Pos p0{0, 0, 0, 0}, p1, p2, p3;
+  f32x4 v0[2], v1[2], v2[2], v3[2];
+  p1 = p0; advance(p1); p2 = p1; advance(p2); p3 = p2; advance(p3);
+  issue(p0, v0); issue(p1, v1); issue(p2, v2);
+  for (;;) {                                                   // step: the loads of sub-slab g + 3, then the split of sub-slab g
+    if (p0.g >= nseq) break;
+    issue(p3, v3); process(p0, v0); p0 = p3; advance(p0);
+    if (p1.g >= nseq) break;
+    issue(p0, v0); process(p1, v1); p1 = p0; advance(p1);
+    if (p2.g >= nseq) break;
+    issue(p1, v1); process(p2, v2); p2 = p1; advance(p2);
+    if (p3.g >= nseq) break;
+    issue(p2, v2); process(p3, v3); p3 = p2; advance(p3);
   }
 }
 
@@ -286,7 +286,7 @@ int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uin
   if (M < 0 || N < 0 || K < 0 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
   if (M == 0 || N == 0) return RELGNN_OK;
   if (!A || !B || !C) return RELGNN_EINVAL;
-  if (K == 0 || K % 256 != 0 || N % 256 != 0 || (N != 256 && K != 256) || (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU))
+  if (K == 0 || K % 128 != 0 || K > 1024 || K == 640 || K == 896 || N % 256 != 0 || (N != 256 && K > 256) || (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU))
     return RELGNN_EUNSUPPORTED;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias)) || ldc % 4 || ldc < N || lda % 4 || lda < K)
     return RELGNN_EUNSUPPORTED;
@@ -303,7 +303,17 @@ int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uin
   int groups = (units + 1) / 2;                               // at least one full panel per workgroup
   if (groups > 256) groups = 256;
   a.groups = groups; a.units_base = units / groups; a.units_rem = units % groups;
-  limb_gemm_pc_kernel<<<(unsigned)(8 * ((groups + 7) / 8)), 1024, 0, as_stream(stream)>>>(a);
+  const unsigned grid = (unsigned)(8 * ((groups + 7) / 8));
+  hipStream_t st = as_stream(stream);
+  switch (K >> 7) {
+    case 1: limb_gemm_pc_kernel<1><<<grid, 1024, 0, st>>>(a); break;
+    case 2: limb_gemm_pc_kernel<2><<<grid, 1024, 0, st>>>(a); break;
+    case 3: limb_gemm_pc_kernel<3><<<grid, 1024, 0, st>>>(a); break;
+    case 4: limb_gemm_pc_kernel<4><<<grid, 1024, 0, st>>>(a); break;
+    case 6: limb_gemm_pc_kernel<6><<<grid, 1024, 0, st>>>(a); break;
+    case 8: limb_gemm_pc_kernel<8><<<grid, 1024, 0, st>>>(a); break;
+    default: return RELGNN_EUNSUPPORTED;
+  }
   return launch_status();
 }
 

@@ -628,7 +628,7 @@ def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, a
                                                out.stride(0), a.shape[0], n, k, _lib.current_stream()), "relgnn_limb16_gemm_xf32")
         return out
     buf = weight_limbs(w, kind)
-    if _limb_pc_ok(a, n, k, bias, act, dy, out):
+    if _limb_pc_ok(a, n, k, bias, act, dy, out, kind):
         # wave roles instead of k-loop phases (csrc/limb_gemm_pc.hip): the same bits, the matrix waves at their MFMA-only time
         _lib.check(lib.relgnn_limb_gemm_xf32_pc(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), int(dact),
                                                 dy.data_ptr() if dy is not None else None, dy.stride(0) if dy is not None else 0,
@@ -646,9 +646,16 @@ def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, a
     return out
 
 
-def _limb_pc_ok(a, n: int, k: int, bias, act: int, dy, out) -> bool:
-    """Shapes relgnn_limb_gemm_xf32_pc takes (config limb_pc): K % 256 == 0, N % 256 == 0, one of them 256; ReLU / no activation."""
-    if _cfg.limb_pc != "1" or act not in (0, 2) or k % 256 or n % 256 or (n != 256 and k != 256) or a.shape[0] < _LIMB_MIN_ROWS:
+def _limb_pc_ok(a, n: int, k: int, bias, act: int, dy, out, kind: str) -> bool:
+    """Shapes relgnn_limb_gemm_xf32_pc takes (config limb_pc): K % 128 == 0 (<= 1024), N % 256 == 0, N == 256 or K <= 256; ReLU / no
+    activation.  limb_pc = fwd (the default): forward products only (WEIGHT_NN).  The kernel holds every CU for its whole run
+    (one persistent 16-wave workgroup each); an input-gradient product runs next to the weight gradient on the side stream, whose
+    workgroups then wait for CUs: measured in the C2 step, forward products 106 -> 87 us, input-gradient products 116 -> 128 us
+    and the side stream's kernels twice as long (profiles/r05_g_limb_pc_step_timelines.txt)."""
+    mode = _cfg.limb_pc
+    if mode == "0" or (mode == "fwd" and kind != WEIGHT_NN):
+        return False
+    if act not in (0, 2) or k % 128 or k > 1024 or k in (640, 896) or n % 256 or (n != 256 and k > 256) or a.shape[0] < _LIMB_MIN_ROWS:
         return False
     return (a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
             and (bias is None or bias.data_ptr() % 16 == 0) and (dy is None or (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0)))
