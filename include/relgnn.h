@@ -833,7 +833,7 @@ int relgnn_limb16_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const
  * rows of A, split them and lay them out as limb sub-slabs in LDS; eight matrix waves multiply them with W fragments read straight
  * from L2, without a workgroup barrier (hand-over by counters in LDS, as in relgnn_rgcn_fused_fwd).  The same MatMuls (gnns/rgcn.py:
  * 96-98 forward and input gradient; the Dense layers of models/sparse_graph_model.py:194-200), the same bits as
- * relgnn_limb_gemm_xf32_dact.  K % 128 == 0, N % 256 == 0 and N == 256 or K <= 256; act: linear or ReLU; Y (nullable) / dact as in
+ * relgnn_limb_gemm_xf32_dact.  K % 128 == 0, N % 256 == 0 and N == 256 or K <= 256; act: linear, ReLU, or tanh with K in {128, 256, 512}; Y (nullable) / dact as in
  * relgnn_limb_gemm_xf32_dact.  RELGNN_EUNSUPPORTED otherwise: callers keep relgnn_limb_gemm_xf32 for those.
  * relgnn_rgcn_fused_status reports the give-up bits of this kernel's polls too (bits 2 / 3). */
 int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, int32_t dact,

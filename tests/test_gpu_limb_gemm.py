@@ -741,6 +741,7 @@ def test_producer_consumer_product_is_bit_identical(gpu_device, M, K, N):
     for pc in ("0", "1"):
         with config.override(limb_pc=pc):
             outs[pc] = (DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, bias, _lib.ACT_RELU),
+                        DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, bias, _lib.ACT_TANH),
                         DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, dact=_lib.ACT_RELU, dy=y),
                         DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, dact=_lib.ACT_TANH, dy=y))
     torch.cuda.synchronize()

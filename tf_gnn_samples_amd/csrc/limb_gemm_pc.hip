@@ -68,7 +68,9 @@ __device__ __forceinline__ float dact_from_output(int act, float yy) {
 // S2 = K / 128 is a template parameter: the k-tiles of a pass are straight-line code.  (With a run-time loop over the half slabs
 // hipcc's wait insertion loses track of the W fragments that are in flight across the loop's back edge and drains them at every
 // loop header — vmcnt(0) in front of the first MFMA of every four k-tiles: a full L2 round trip per 1.7 us of matrix work.)
-template <int S2>
+// TANH: the epilogue's activation is tanh (the Dense layers between GNN layers, models/sparse_graph_model.py:194-200) instead of
+// ReLU / none — a variant of its own: tanhf inlines thirty-two times into the stores.
+template <int S2, bool TANH = false>
 __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * SLAB + CTL * 4];
   int* ctl = reinterpret_cast<int*>(lds + NBUF * SLAB);
@@ -157,7 +159,10 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
           const int cc = colw + 8 * c + 4 * h32;
           f32x4 v = f32x4{acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
           if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + cc);
-          if (a.act == RELGNN_ACT_RELU) {
+          if constexpr (TANH) {
+            v[0] = act_fwd<RELGNN_ACT_TANH>(v[0]); v[1] = act_fwd<RELGNN_ACT_TANH>(v[1]);
+            v[2] = act_fwd<RELGNN_ACT_TANH>(v[2]); v[3] = act_fwd<RELGNN_ACT_TANH>(v[3]);
+          } else if (a.act == RELGNN_ACT_RELU) {
             v[0] = act_fwd<RELGNN_ACT_RELU>(v[0]); v[1] = act_fwd<RELGNN_ACT_RELU>(v[1]);
             v[2] = act_fwd<RELGNN_ACT_RELU>(v[2]); v[3] = act_fwd<RELGNN_ACT_RELU>(v[3]);
           }
@@ -286,7 +291,7 @@ int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uin
   if (M < 0 || N < 0 || K < 0 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
   if (M == 0 || N == 0) return RELGNN_OK;
   if (!A || !B || !C) return RELGNN_EINVAL;
-  if (K == 0 || K % 128 != 0 || K > 1024 || K == 640 || K == 896 || N % 256 != 0 || (N != 256 && K > 256) || (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU))
+  if (K == 0 || K % 128 != 0 || K > 1024 || K == 640 || K == 896 || N % 256 != 0 || (N != 256 && K > 256) || (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU && act != RELGNN_ACT_TANH))
     return RELGNN_EUNSUPPORTED;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias)) || ldc % 4 || ldc < N || lda % 4 || lda < K)
     return RELGNN_EUNSUPPORTED;
@@ -299,12 +304,25 @@ int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uin
   a.act = act;
   a.status = handover_status_word();
   if (!a.status) return RELGNN_EHIP;
+  // the fewest workgroups that keep the longest range: 1128 units over 256 CUs are ranges of 4 and 5 units — 226 ranges of 5 finish
+  // at the same time and leave 30 CUs to whatever runs next to this kernel (the weight gradient on the side stream)
   const int units = (M + 31) / 32;
   int groups = (units + 1) / 2;                               // at least one full panel per workgroup
   if (groups > 256) groups = 256;
+  const int longest = (units + groups - 1) / groups;
+  groups = (units + longest - 1) / longest;
   a.groups = groups; a.units_base = units / groups; a.units_rem = units % groups;
   const unsigned grid = (unsigned)(8 * ((groups + 7) / 8));
   hipStream_t st = as_stream(stream);
+  if (act == RELGNN_ACT_TANH) {
+    switch (K >> 7) {
+      case 1: limb_gemm_pc_kernel<1, true><<<grid, 1024, 0, st>>>(a); break;
+      case 2: limb_gemm_pc_kernel<2, true><<<grid, 1024, 0, st>>>(a); break;
+      case 4: limb_gemm_pc_kernel<4, true><<<grid, 1024, 0, st>>>(a); break;
+      default: return RELGNN_EUNSUPPORTED;
+    }
+    return launch_status();
+  }
   switch (K >> 7) {
     case 1: limb_gemm_pc_kernel<1><<<grid, 1024, 0, st>>>(a); break;
     case 2: limb_gemm_pc_kernel<2><<<grid, 1024, 0, st>>>(a); break;

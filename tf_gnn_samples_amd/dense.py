@@ -655,7 +655,8 @@ def _limb_pc_ok(a, n: int, k: int, bias, act: int, dy, out, kind: str) -> bool:
     mode = _cfg.limb_pc
     if mode == "0" or (mode == "fwd" and kind != WEIGHT_NN):
         return False
-    if act not in (0, 2) or k % 128 or k > 1024 or k in (640, 896) or n % 256 or (n != 256 and k > 256) or a.shape[0] < _LIMB_MIN_ROWS:
+    if (act not in (0, 1, 2) or (act == 1 and k not in (128, 256, 512)) or k % 128 or k > 1024 or k in (640, 896) or n % 256
+            or (n != 256 and k > 256) or a.shape[0] < _LIMB_MIN_ROWS):
         return False
     return (a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
             and (bias is None or bias.data_ptr() % 16 == 0) and (dy is None or (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0)))
