@@ -851,6 +851,7 @@ def main():
         "nranks": int(dist.get_world_size()) if world > 1 else 1,
         "gemm_autotuned": False,
         "final_loss": state["loss"],
+        "handover_status": __import__("tf_gnn_samples_amd.ops", fromlist=["handover_status"]).handover_status(),        # 0: every LDS hand-over of the wave-role kernels completed (ops.handover_status)
         # time rank 0's host spent blocked on the (one step late) metrics copy: ~0 = the host is the bottleneck,
         # large = the GPU is
         "host_blocked_on_gpu_ms_per_step": state["host_wait"] / args.steps * 1e3,

@@ -302,8 +302,7 @@ int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uin
   PcArgs a{};
   a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.dy = Y; a.ldy = ldy; a.dact = dact; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.act = act;
-  a.status = handover_status_word();
-  if (!a.status) return RELGNN_EHIP;
+  a.status = handover_status_word(as_stream(stream));
   // the fewest workgroups that keep the longest range: 1128 units over 256 CUs are ranges of 4 and 5 units — 226 ranges of 5 finish
   // at the same time and leave 30 CUs to whatever runs next to this kernel (the weight gradient on the side stream)
   const int units = (M + 31) / 32;

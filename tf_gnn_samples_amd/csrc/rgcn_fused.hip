@@ -458,8 +458,10 @@ int32_t* g_status = nullptr;
 }  // namespace
 
 namespace relgnn {
-int32_t* handover_status_word() {
+int32_t* handover_status_word(hipStream_t stream) {
   if (!g_status) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
     if (hipMalloc(reinterpret_cast<void**>(&g_status), sizeof(int32_t)) != hipSuccess) { g_status = nullptr; return nullptr; }
     if (hipMemset(g_status, 0, sizeof(int32_t)) != hipSuccess) return nullptr;
   }
@@ -483,10 +485,9 @@ int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const
   if (!aligned16(H) || !aligned16(out) || !aligned16(w_limbs) || (bias && !aligned16(bias)) || (bucket_sums && !aligned16(bucket_sums)) ||
       ldh % 4 || ldo % 4 || lds % 4)
     return RELGNN_EUNSUPPORTED;
-  if (!handover_status_word()) return RELGNN_EHIP;
   FusedArgs a{};
   a.H = H; a.ldh = ldh; a.rowptr = rowptr; a.col = col; a.w = w; a.B = w_limbs; a.bias = bias; a.S = bucket_sums; a.lds_ = lds;
-  a.C = out; a.ldc = ldo; a.V = num_nodes; a.L = num_edge_types; a.act = act; a.status = g_status;
+  a.C = out; a.ldc = ldo; a.V = num_nodes; a.L = num_edge_types; a.act = act; a.status = handover_status_word(as_stream(stream));
 #ifdef RELGNN_FUSED_TIMING
   a.timing = g_fused_timing;
 #endif

@@ -976,6 +976,17 @@ def _pair_products(X, rowptr, stride, V, k, n, kernels, kind) -> bool:
             and DN.weight_image_ok(list(kernels), DN.WEIGHT_NN if kind == "nn" else DN.WEIGHT_NT))
 
 
+def handover_status(reset: bool = True) -> int:
+    """The give-up word of the kernels whose wave roles hand data over through LDS counters (relgnn_limb_gemm_xf32_pc: the default
+    forward products; relgnn_rgcn_fused_fwd): 0 = every poll of every launch so far completed.  A poll is bounded (2^22 rounds)
+    so that a protocol bug cannot hang the device; a kernel that gave up has written wrong results and says so here.  Synchronises
+    the device: call it where the host waits anyway (bench.py and smoke() do, behind their timed regions)."""
+    import ctypes
+    s = ctypes.c_int32(-1)
+    _lib.check(_lib.load_library().relgnn_rgcn_fused_status(ctypes.byref(s), 1 if reset else 0), "relgnn_rgcn_fused_status")
+    return int(s.value)
+
+
 def _fused_layer_ok(H, graph, w, kernels) -> bool:
     """relgnn_rgcn_fused_fwd applies: switch on, exact-split limb route, 256 -> 256, no hub plan on the by-target buckets."""
     from .dense import WEIGHT_NN, _rows_ok, weight_image_ok
