@@ -29,7 +29,8 @@ for cfg in ("C5", "C4"):
                 name = next((w for w in want if w in k), None)
                 if name and r["Counter_Name"] == c:
                     # keep template arguments short
-                    short = k.split("(")[0].split("::")[-1][:60]
+                    # ("void (anonymous namespace)::edge_fwd_kernel<32, 1, 0, false>(...)": the text before the first "(" is "void ")
+                    short = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
                     by.setdefault(short, []).append(float(r["Counter_Value"]))
             for k, v in sorted(by.items()):
                 lines.append("%s,%s,%s,%d,%.1f" % (cfg, k, c, len(v), sum(v) / len(v)))
