@@ -653,8 +653,8 @@ def _limb_pc_ok(a, n: int, k: int, bias, act: int, dy, out, kind: str) -> bool:
     workgroups then wait for CUs: measured in the C2 step, forward products 106 -> 87 us, input-gradient products 116 -> 128 us
     and the side stream's kernels twice as long (profiles/r05_g_limb_pc_step_timelines.txt)."""
     mode = _cfg.limb_pc
-    if mode == "0" or (mode == "fwd" and kind != WEIGHT_NN):
-        return False
+    if mode == "0" or (mode == "fwd" and kind != WEIGHT_NN):     # (the small input-gradient products, K <= 256 and N = 256, on it too: no
+        return False                                              #  difference, 1.8115 vs 1.8101 ms over three alternations)
     if (act not in (0, 1, 2) or (act == 1 and k not in (128, 256, 512)) or k % 128 or k > 1024 or k in (640, 896) or n % 256
             or (n != 256 and k > 256) or a.shape[0] < _LIMB_MIN_ROWS):
         return False
