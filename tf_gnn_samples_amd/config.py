@@ -38,6 +38,12 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                  "PPI head backward: the loss gradient written into rows zero-padded to a multiple of 16 columns, so that the head's "
                  "input-gradient product (K = 121) runs on the limb route with the last layer's ReLU' in its epilogue | the library "
                  "product + a ReLU' pass"),
+    "feature_pad": ("RELGNN_FEATURE_PAD", "0", ("0", "1"),
+                    "unpadded feature rows: the input projection is a K = 50 library product + an activation pass | resident folds keep "
+                    "the node features in rows zero-padded to a multiple of 16 columns (PPI: 50 -> 64) and the input projection runs on "
+                    "the limb route with its activation in the epilogue (measured: 1.996 vs 1.937 ms per C2 step, three alternations — "
+                    "a four-k-tile product is all prologue and epilogue on the limb kernel, and tanhf in the epilogue costs what the "
+                    "pass did: opt-in)"),
     "weight_limb_cache": ("RELGNN_WEIGHT_LIMB_CACHE", "1", ("0", "1"),
                           "limb images of the weights kept across the products of a step (re-split once after the optimizer's update)"),
     "act_fusion": ("RELGNN_ACT_FUSION", "1", ("0", "1"),

@@ -195,12 +195,19 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
     if act is None:
         act = 2 if relu else 0                                     # _lib.ACT_RELU / ACT_LINEAR
     relu = act == 2
+    if layout == GEMM_NN and weight and out is None and not accumulate and a.is_cuda and _cfg.limb_gemm and premask is None:
+        # node features whose rows their producer zero-padded to a multiple of 16 columns (a resident fold's [V, 50] features live
+        # in rows of 64: tasks/resident.py): the input projection on the limb route over the padded reduction length, its
+        # activation in the epilogue, instead of a K = 50 library product + an activation pass
+        ap = zero_padded_operand(a)
+        if ap is not None and _limb_padded_ok(ap, a.shape[1], b, bias, WEIGHT_NN):
+            return limb_gemm_weight(ap, b, WEIGHT_NN, bias, act)
     if layout == GEMM_NT and weight and out is None and not accumulate and a.is_cuda and _cfg.limb_gemm:
         # a gradient whose rows are zero-padded to a multiple of 16 columns by its producer (mark_zero_padded): the limb route over
         # the padded reduction length, with the activation gradient of the layer below in its epilogue — for the 121-label PPI
         # head that is one launch instead of a library product (K = 121) and a ReLU' pass over [V, 256]
         ap = zero_padded_operand(a)
-        if ap is not None and _limb_padded_nt_ok(ap, a.shape[1], b, bias) and (premask is None or _premask_operand_ok(premask[1], a.shape[0], b.shape[0])):
+        if ap is not None and _limb_padded_ok(ap, a.shape[1], b, bias, WEIGHT_NT) and (premask is None or _premask_operand_ok(premask[1], a.shape[0], b.shape[0])):
             return limb_gemm_weight(ap, b, WEIGHT_NT, bias, act, dact=premask[0] if premask is not None else 0,
                                     dy=premask[1] if premask is not None else None)
     if premask is not None or act not in (0, 2):
@@ -423,10 +430,12 @@ def limb_gemm_xf32(a: torch.Tensor, b: "Limbs", bias: torch.Tensor = None, act: 
     return out
 
 
-def _limb_padded_nt_ok(ap: torch.Tensor, k: int, b: torch.Tensor, bias) -> bool:
-    """ap [M, ld] (zero_padded_operand) @ b^T with b [N, k] a weight matrix, k <= ld = the next multiple of 16."""
-    return (_rows_ok(ap) and ap.shape[0] >= _LIMB_MIN_ROWS and b.dim() == 2 and b.shape[1] == k and ap.shape[1] == (k + 15) // 16 * 16
-            and b.shape[0] % 256 == 0 and 16 <= ap.shape[1] <= _LIMB_MAX_K and weight_image_ok([b], WEIGHT_NT)
+def _limb_padded_ok(ap: torch.Tensor, k: int, b: torch.Tensor, bias, kind: str) -> bool:
+    """ap [M, ld] (zero_padded_operand) times a weight matrix b — [N, k] (WEIGHT_NT: ap @ b^T) or [k, N] (WEIGHT_NN: ap @ b) — with
+    k <= ld = the next multiple of 16."""
+    n, kb = (b.shape[0], b.shape[1]) if kind == WEIGHT_NT else (b.shape[1], b.shape[0])
+    return (_rows_ok(ap) and ap.shape[0] >= _LIMB_MIN_ROWS and b.dim() == 2 and kb == k and ap.shape[1] == (k + 15) // 16 * 16
+            and n % 256 == 0 and 16 <= ap.shape[1] <= _LIMB_MAX_K and weight_image_ok([b], kind)
             and (bias is None or (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0)))
 
 

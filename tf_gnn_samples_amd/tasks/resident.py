@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import config as _cfg
 from ..graph import RelGraph
 from .batcher import GraphStore
 from .sparse_graph_task import DeviceBatch
@@ -50,6 +51,15 @@ class ResidentDataset:
             raise ValueError("data fold too large for one int32-indexed union; use the host batcher")
         # flat arrays -> HBM
         self.payload_d = [torch.as_tensor(a, device=dev) for a in store.payload]
+        # the node features in rows padded with zeros to a multiple of 16 columns (PPI: 50 -> 64): a batch's feature rows are then
+        # copied padded, and the input projection runs on the limb route over the padded reduction length (dense.mark_zero_padded)
+        self._feature_cols = None
+        if _cfg.settings.limb_gemm and _cfg.settings.feature_pad == "1" and features in store.payload_names:
+            i = store.payload_names.index(features)
+            t = self.payload_d[i]
+            if t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] % 16 and t.shape[0] > 0:
+                self._feature_cols = int(t.shape[1])
+                self.payload_d[i] = torch.nn.functional.pad(t, (0, (-t.shape[1]) % 16)).contiguous()
         self.graph_payload_d = {k: torch.as_tensor(v, device=dev) for k, v in store.graph_payload.items()}
         self.deg_d = torch.stack([torch.as_tensor(a, device=dev) for a in store.deg]) if L else torch.zeros((0, N), device=dev)
         self.adj_d = [torch.as_tensor(a, device=dev) for a in store.adj]         # [E_l, 2] int32, graph-local ids
@@ -151,6 +161,9 @@ class ResidentDataset:
             src = self.payload_d[i]
             out_fast.append(torch.empty((V,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev))
             payload[names[i]] = out_fast[-1]
+            if names[i] == self.features and self._feature_cols is not None:
+                from ..dense import mark_zero_padded
+                payload[names[i]] = mark_zero_padded(out_fast[-1][:, :self._feature_cols], int(src.shape[1]))
         deg = torch.empty((L, V), dtype=torch.float32, device=dev)
         n2g = torch.empty(V, dtype=torch.int32, device=dev)
         nf = len(self._fast)
