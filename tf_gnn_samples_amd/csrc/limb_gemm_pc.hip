@@ -188,20 +188,23 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
           if (chunks == 1) { poll_buf(0); if (two) poll_buf(1); }
           const unsigned char* x0b = lds + buf_of(i0) * SLAB + xlane;
           const unsigned char* x1b = lds + buf_of(i0 + per - 1) * SLAB + xlane;
+          // the X fragments of k-tile t + 1 are requested right behind the MFMAs that read those of k-tile t (the matrix pipe has read
+          // its operands by then): an LDS round trip hides under six MFMAs instead of standing in front of them
+          Frag x0 = xread(x0b), x1 = x0;
+          if (two) x1 = xread(x1b);
 #pragma unroll
-          for (int k4 = 0; k4 < 2; ++k4) {
-            const unsigned char* x0k = x0b + k4 * 8 * PIECE;
-            const unsigned char* x1k = x1b + k4 * 8 * PIECE;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-              wload(wr[(kt + 3) & 3]);
-              __builtin_amdgcn_s_waitcnt(0x0F79);               // vmcnt(9): the W fragments of this k-tile have landed, three k-tiles stay in flight
-              const Frag x0 = xread(x0k + kt * 2 * PIECE);
-              acc0 = products(acc0, wr[kt], x0);
-              if (two) {
-                const Frag x1 = xread(x1k + kt * 2 * PIECE);
-                acc1 = products(acc1, wr[kt], x1);
-              }
+          for (int kt = 0; kt < 8; ++kt) {
+            wload(wr[(kt + 3) & 3]);
+            __builtin_amdgcn_s_waitcnt(0x0F79);                 // vmcnt(9): the W fragments of this k-tile have landed, three k-tiles stay in flight
+            acc0 = products(acc0, wr[kt & 3], x0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < 8) x0 = xread(x0b + (kt + 1) * 2 * PIECE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) {
+              acc1 = products(acc1, wr[kt & 3], x1);
+              __builtin_amdgcn_sched_barrier(0);
+              if (kt + 1 < 8) x1 = xread(x1b + (kt + 1) * 2 * PIECE);
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
           if (chunks == 1) release(per);
