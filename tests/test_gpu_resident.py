@@ -194,6 +194,8 @@ def test_padded_feature_rows_feed_the_input_projection(gpu_device):
     from tf_gnn_samples_amd import _lib, config, dense as DN
     from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
     from tf_gnn_samples_amd.tasks.resident import ResidentDataset
+    if not config.settings.limb_gemm:
+        pytest.skip("padded feature rows exist for the limb route (RELGNN_GEMM=limb)")
     task = PPI_Task(PPI_Task.default_params())
     task.load_synthetic(3, 1, seed=5)
     store = task.make_graph_store(task._loaded_data[DataFold.TRAIN])

@@ -454,16 +454,21 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
 }
 
 int32_t* g_status = nullptr;
+int g_status_device = -1;
 
 }  // namespace
 
 namespace relgnn {
 int32_t* handover_status_word(hipStream_t stream) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (g_status && dev != g_status_device) return nullptr;      // (one process per GPU: a second device in the process reports nothing)
   if (!g_status) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
     if (hipMalloc(reinterpret_cast<void**>(&g_status), sizeof(int32_t)) != hipSuccess) { g_status = nullptr; return nullptr; }
     if (hipMemset(g_status, 0, sizeof(int32_t)) != hipSuccess) return nullptr;
+    g_status_device = dev;
   }
   return g_status;
 }
