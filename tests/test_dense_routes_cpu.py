@@ -1,0 +1,64 @@
+"""Host logic of the round-5 product routes in dense.py — no kernel runs: the zero-padded tag of a gradient / feature tensor
+(mark_zero_padded / zero_padded_operand), the k extent of a weight image whose matrix has a ragged last k-tile, and which products
+take the wave-role kernel (relgnn_limb_gemm_xf32_pc) under each value of config.limb_pc."""
+import pytest
+import torch
+
+
+def test_zero_padded_tag_lives_and_dies_with_the_tensor_object():
+    from tf_gnn_samples_amd import dense as DN
+    buf = torch.zeros((10, 128))
+    buf[:, :121] = torch.randn(10, 121)
+    g = DN.mark_zero_padded(buf[:, :121], 128)
+    ap = DN.zero_padded_operand(g)
+    assert ap is not None and ap.shape == (10, 128) and ap.data_ptr() == buf.data_ptr() and torch.equal(ap, buf)
+    # whatever autograd (or anybody) derives from it is a new object without the tag: the plain route
+    assert DN.zero_padded_operand(g.contiguous()) is None
+    assert DN.zero_padded_operand(g * 2.0) is None
+    assert DN.zero_padded_operand(g[1:]) is None
+    assert DN.zero_padded_operand(torch.randn(10, 121)) is None
+    # a tag that no longer describes its tensor is ignored: another view carrying a copied tag, a row stride that is not the padded one
+    other = buf[:, :100]
+    other._relgnn_zero_pad = g._relgnn_zero_pad
+    assert DN.zero_padded_operand(other) is None
+    wide = torch.zeros((10, 130))[:, :121]
+    wide._relgnn_zero_pad = (wide.data_ptr(), tuple(wide.shape), wide.stride(0), 128)
+    assert DN.zero_padded_operand(wide) is None
+    # a padded width that is not a multiple of 16 is not a padded operand
+    odd = DN.mark_zero_padded(torch.zeros((4, 120))[:, :100], 120)
+    assert DN.zero_padded_operand(odd) is None
+
+
+def test_weight_image_extent_of_a_single_matrix_rounds_its_k_up_to_a_k_tile():
+    from tf_gnn_samples_amd import dense as DN
+    head = torch.zeros((256, 121))                                  # the PPI head's kernel^T view: NT, K = 121
+    assert DN._weight_image_shape([head], DN.WEIGHT_NT) == (256, 128)
+    proj = torch.zeros((50, 256))                                   # the input projection: NN, K = 50
+    assert DN._weight_image_shape([proj], DN.WEIGHT_NN) == (256, 64)
+    layer = [torch.zeros((256, 256)) for _ in range(3)]
+    assert DN._weight_image_shape(layer, DN.WEIGHT_NN) == (256, 768)
+    # matrices side by side along k must each fill whole k-tiles: only a single matrix may be ragged
+    items = DN._weight_image_items([head], DN.WEIGHT_NT, torch.zeros(1))
+    assert items[0][6:] == (0, 8)                                   # k-tiles 0 .. 7 of 8
+
+
+@pytest.mark.parametrize("mode,kind,n,k,act,expect", [
+    ("fwd", "nn", 256, 768, 2, True),        # the layer's forward product, ReLU
+    ("fwd", "nt", 256, 768, 0, False),       # its input gradient: next to the side stream's weight gradient
+    ("1", "nt", 256, 768, 0, True),
+    ("0", "nn", 256, 768, 2, False),
+    ("fwd", "nn", 256, 256, 1, True),        # a tanh Dense layer
+    ("fwd", "nn", 256, 768, 1, False),       # tanh: K in {128, 256, 512} only
+    ("fwd", "nn", 768, 256, 0, True),        # several column chunks: K <= 256
+    ("fwd", "nn", 768, 512, 0, False),
+    ("fwd", "nn", 256, 640, 0, False),       # no variant for five half slabs
+    ("fwd", "nn", 128, 256, 0, False),       # N % 256
+    ("fwd", "nn", 256, 768, 5, False),       # selu: the old kernel's epilogue
+])
+def test_which_products_take_the_wave_role_kernel(mode, kind, n, k, act, expect):
+    from tf_gnn_samples_amd import config, dense as DN
+    a = torch.zeros((8192, k))
+    out = torch.zeros((8192, n))
+    with config.override(limb_pc=mode):
+        assert DN._limb_pc_ok(a, n, k, None, act, None, out, kind) is expect
+        assert DN._limb_pc_ok(a[:100], n, k, None, act, None, out[:100], kind) is False      # below the limb routes' minimum height
