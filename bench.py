@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-allreduce-compare", action="store_true",
                     help="N > 1: skip the second loop that times the other form of the gradient all-reduce")
+    ap.add_argument("--no-detail", action="store_true",
+                    help="do not write the sidecar bench_detail.json (child runs of this file must not overwrite the parent's)")
     ap.add_argument("--no-step-trace", action="store_true",
                     help="skip the rocprofv3 kernel trace / PMC passes of the timed loop (roofline.c2 = null)")
     return ap.parse_args()
@@ -331,7 +333,7 @@ def c2_in_step_section(edges_per_step, nodes_per_step, L, D, with_pmc=True, step
     for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
         env.pop(k, None)
     child = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
-             "--no-roofline", "--no-extras", "--no-cpu-baseline"]
+             "--no-roofline", "--no-extras", "--no-cpu-baseline", "--no-detail"]
     tmp = tempfile.mkdtemp(prefix="relgnn_step_", dir="/tmp")
     M, V = float(edges_per_step), float(nodes_per_step)
     alg = M * (4 * D + 8) + V * L * 4 * D + 4 * (V * L + 1)
@@ -364,10 +366,7 @@ def c2_in_step_section(edges_per_step, nodes_per_step, L, D, with_pmc=True, step
         out["frac_of_l2_peak"] = out["algorithmic_GBps"] / R.L2_PEAK_GBS
         out["frac_of_hbm_peak_algorithmic"] = out["algorithmic_GBps"] / R.HBM_PEAK_GBS      # (> 1: the table is cache resident)
         top = sorted(rows, key=lambda x: -float(x["TotalDurationNs"]))[:8]
-        def short(name):
-            name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-            return name.split("(")[0][:70]
-        out["top_kernels"] = [{"name": short(x["Name"]), "calls": int(x["Calls"]),
+        out["top_kernels"] = [{"name": _short_kernel(x["Name"]), "calls": int(x["Calls"]),
                                "avg_us": round(float(x["AverageNs"]) * 1e-3, 2),
                                "share": round(float(x["TotalDurationNs"]) / max(total_ns, 1.0), 4)} for x in top]
         if with_pmc:
@@ -390,6 +389,7 @@ def c2_in_step_section(edges_per_step, nodes_per_step, L, D, with_pmc=True, step
             if len(sums) == 2:
                 out["hbm_side_bytes_per_launch"] = 2.0 * sums["FETCH_SIZE"] * 1024.0 + sums["WRITE_SIZE"] * 1024.0
                 out["hbm_side_over_compulsory"] = out["hbm_side_bytes_per_launch"] / compulsory
+            out["mfma"] = mfma_pass(exe, child, env, tmp, rows, timeout_s)
         return out
     except subprocess.TimeoutExpired:
         return dict(out, error="rocprofv3 pass of the timed loop timed out after %d s" % timeout_s)
@@ -397,6 +397,61 @@ def c2_in_step_section(edges_per_step, nodes_per_step, L, D, with_pmc=True, step
         return dict(out, error=repr(e))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+BF16_DENSE_PEAK_PFLOPS = 2.5      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+MFMA_FLOPS_32x32x16 = 2 * 32 * 32 * 16
+
+
+def _short_kernel(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+def mfma_pass(exe, child, env, tmp, stat_rows, timeout_s):
+    """Matrix-pipe counters of the Dense-product kernels that actually run in the timed loop (one more --pmc pass of the same child):
+    busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) — the guide's MfmaUtil —, and the bf16 rate
+    SQ_INSTS_MFMA x 32768 flop (every MFMA of these kernels is v_mfma_f32_32x32x16_{bf16,f16}) / the kernel's average duration in the
+    kernel trace of the same loop.  Returns {kernels: [...], + the kernel with the largest share of MFMA time hoisted}."""
+    group = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"]
+    d = os.path.join(tmp, "mfma")
+    try:
+        r = subprocess.run([exe, "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "k", "--", *child],
+                           cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s, text=True)
+    except subprocess.TimeoutExpired:
+        return {"error": "rocprofv3 --pmc (MFMA counters) timed out after %d s" % timeout_s}
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(group), r.returncode, r.stdout[-200:])}
+    acc = {}
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            acc.setdefault(_short_kernel(row.get("Kernel_Name", "")), {}).setdefault(row.get("Counter_Name"), []).append(
+                float(row["Counter_Value"]))
+    avg_ns = {_short_kernel(x["Name"]): (float(x["AverageNs"]), float(x["TotalDurationNs"]), int(x["Calls"])) for x in stat_rows}
+    kernels = []
+    for name, c in acc.items():
+        if not all(k in c for k in group):
+            continue
+        insts, busy, gui = (float(np.mean(c[k])) for k in ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
+        if insts <= 0 or name not in avg_ns or gui <= 0:
+            continue
+        ns, total_ns, calls = avg_ns[name]
+        pf = insts * MFMA_FLOPS_32x32x16 / (ns * 1e-9) / 1e15
+        kernels.append({"kernel": name, "calls": calls, "avg_kernel_us": round(ns * 1e-3, 2), "mfma_insts_per_launch": insts,
+                        "busy_frac": round(busy / (gui / 8.0 * 1024.0), 4), "bf16_PFLOPs": round(pf, 4),
+                        "frac_of_bf16_peak": round(pf / BF16_DENSE_PEAK_PFLOPS, 4), "_total_ns": total_ns})
+    if not kernels:
+        return {"error": "no kernel with MFMA instructions in the counter rows"}
+    kernels.sort(key=lambda k: -k["_total_ns"])
+    for k in kernels:
+        k["share_of_mfma_kernel_time"] = round(k.pop("_total_ns") / sum(avg_ns[x["kernel"]][1] for x in kernels), 4)
+    top = dict(kernels[0])
+    top["kernels"] = kernels
+    top["what"] = mfma_pass.__doc__.split("\n")[0].strip()
+    top["caveat"] = ("rates assume 32x32x16 16-bit MFMAs (true of limb_gemm*; the exact-fp32 panel / streaming kernels issue "
+                     "v_mfma_f32_32x32x2_f32: read their busy_frac, not their PFLOPs)")
+    return top
 
 
 def route_leg(route_env, what, steps, warmup, timeout_s=180):
@@ -412,7 +467,7 @@ def route_leg(route_env, what, steps, warmup, timeout_s=180):
         env.pop(k, None)
     try:
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
-                            "--no-roofline", "--no-extras", "--no-cpu-baseline"], cwd=str(ROOT), env=env,
+                            "--no-roofline", "--no-extras", "--no-cpu-baseline", "--no-detail"], cwd=str(ROOT), env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
@@ -573,9 +628,130 @@ def cpu_baseline(batch_graphs, sample_n, params):
                       "of the probed counts; the CPU quota is %d)"
                       % (sample_n, len(batch_graphs), smb.num_edges, smb.num_nodes, n, fmb.num_edges, fmb.num_nodes, n_fwd, cores,
                          quota),
+            "sample_short": "train leg: %d of %d graphs of the C2 batch (%d edges), fwd+bwd, median of %d; fwd leg: whole batch; "
+                            "torch-CPU port, %d threads" % (sample_n, len(batch_graphs), smb.num_edges, n, cores),
             "ms_per_step": dt * 1e3,
             "forward_only_value": fmb.num_edges / dt_fwd, "forward_only_ms": dt_fwd * 1e3,
             "forward_only_sample": "whole batch"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the printed line: scalars + short structured fields; everything else goes to the sidecar
+# ------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT_BYTES = 6144          # the driver parses the line out of a bounded tail of stdout (round 5's 20 KB line did not parse)
+DETAIL_NAME = "bench_detail.json"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _cut(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1].rstrip() + "…"
+
+
+def compact_line(full):
+    """The ONE line bench.py prints, derived from the full record (which goes to bench_detail.json): every scalar of the driver's
+    contract, `config` (workload + sizes, no prose), `roofline` and `cpu_baseline` with the fields the contract names, the three
+    arithmetic legs and the other BASELINE configs as scalars.  Pure function of the record (tests/test_bench_contract.py runs it
+    over committed records); always below LINE_LIMIT_BYTES."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"))
+    line["metric"] = _cut(line.get("metric", ""), 120)
+    cfg = full.get("config", {})
+    c = _pick(cfg, ("graphs_per_rank", "max_nodes_in_batch", "input_pipeline", "parallelism", "edges_all_ranks_timed_region",
+                    "nodes_all_ranks_timed_region"))
+    c = dict({"workload": _cut(cfg.get("workload", ""), 160)}, **c)
+    for k in ("model_param_overrides", "task_param_overrides"):
+        if cfg.get(k):
+            c[k] = cfg[k]
+    line["config"] = c
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        if "error" in r and "achieved" not in r:
+            line["roofline"] = {"error": _cut(r["error"], 200)}
+        else:
+            rr = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "algorithmic_bytes_per_launch",
+                           "messages_per_launch", "frac_of_measured_copy_ceiling"))
+            rr["kernel"] = _cut(r.get("kernel", ""), 100)
+            rr["workload"] = _cut(r.get("workload", ""), 80)
+            c2 = r.get("c2")
+            if isinstance(c2, dict):
+                rr["c2"] = _pick(c2, ("avg_kernel_ms_in_step", "launches_traced", "algorithmic_bytes_per_launch", "frac_of_l2_peak",
+                                      "hbm_side_over_compulsory", "share_of_kernel_time"))
+                if "error" in c2:
+                    rr["c2"]["error"] = _cut(c2["error"], 160)
+            m = r.get("mfma")
+            if isinstance(m, dict):
+                rr["mfma"] = (_pick(m, ("kernel", "busy_frac", "bf16_PFLOPs", "frac_of_bf16_peak", "avg_kernel_us"))
+                              if "error" not in m else {"error": _cut(m["error"], 160)})
+            line["roofline"] = rr
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_step", "forward_only_value", "forward_only_ms"))
+        if "sample" in cb:
+            line["cpu_baseline"]["sample"] = _cut(cb.get("sample_short") or cb["sample"], 140)
+        if "error" in cb:
+            line["cpu_baseline"]["error"] = _cut(cb["error"], 160)
+    for k in ("fp32_exact_split_ms_per_step", "fp32_exact_split_value", "exact_fp32_lib_ms_per_step", "exact_fp32_lib_value",
+              "pair_route_ms_per_step", "pair_route_value"):
+        if k in full:
+            line[k] = full[k]
+    oc = full.get("other_configs")
+    if isinstance(oc, dict):
+        o = {}
+        for row in oc.get("configs", []):
+            name = str(row.get("config", "?"))
+            key = name[:2] + ("_max" if name.startswith("C3") and "max aggregation" in name else "")
+            if "error" in row:
+                o[key + "_error"] = _cut(row["error"], 100)
+                continue
+            o[key + "_train_ms"] = row.get("train_ms")
+            if isinstance(row.get("train_ms_hipgraph"), (int, float)):
+                o[key + "_train_ms_hipgraph"] = row["train_ms_hipgraph"]
+        if "error" in oc:
+            o["error"] = _cut(oc["error"], 160)
+        line["other_configs"] = o
+    for k in ("world_size", "nranks", "backend", "per_rank_edges", "allreduce", "allreduce_ms", "gpu_step_ms",
+              "gpu_step_ms_slowest_over_fastest_rank", "edge_imbalance", "gradient_allreduce_bytes", "final_loss",
+              "handover_status", "host_blocked_on_gpu_ms_per_step", "peak_device_bytes"):
+        if k in full:
+            line[k] = full[k]
+    for k in sorted(full):                       # N > 1: both all-reduce forms as scalars
+        if k.startswith("allreduce_") and k not in line and not isinstance(full[k], (dict, list)):
+            line[k] = full[k]
+    pr = full.get("per_rank")
+    if isinstance(pr, dict):
+        line["per_rank"] = _pick(pr, ("gpu_step_ms_median", "allreduce_ms_mean"))
+    sb = full.get("same_batch")
+    if isinstance(sb, dict) and "ms_per_step" in sb:
+        line["same_batch_ms_per_step"], line["forward_only_ms"] = sb["ms_per_step"], sb.get("forward_only_ms")
+    line["detail"] = full.get("detail", DETAIL_NAME)
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT_BYTES:             # cannot happen with the bounded fields above; never lose the number over it
+        for k in ("per_rank", "other_configs", "per_rank_edges"):
+            line.pop(k, None)
+        text = json.dumps(line)
+    assert len(text) < LINE_LIMIT_BYTES, len(text)
+    return line
+
+
+def write_detail(full):
+    """The full record (per-size roofline rows, PMC blocks, top kernels, prose) next to bench.py and, on a gpurun box, under
+    gpurun_out/ so that it travels back.  Returns the path the line names."""
+    text = json.dumps(full, indent=1)
+    paths = [ROOT / DETAIL_NAME]
+    if (ROOT / "gpurun_out").is_dir():
+        paths.append(ROOT / "gpurun_out" / DETAIL_NAME)
+    written = None
+    for p in paths:
+        try:
+            p.write_text(text)
+            written = written or p
+        except OSError:
+            pass
+    return str(written.relative_to(ROOT)) if written else None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -966,8 +1142,14 @@ def main():
         except Exception as e:  # the baseline is reporting only; never lose the GPU number over it
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
+        # the mfma block of the in-step trace belongs to the roofline (north_star: "MFMA utilisation" of the Dense products)
+        c2 = result.get("roofline", {}).get("c2") if isinstance(result.get("roofline"), dict) else None
+        if isinstance(c2, dict) and "mfma" in c2:
+            result["roofline"]["mfma"] = c2.pop("mfma")
+        if not args.no_detail:
+            result["detail"] = write_detail(dict(result, detail=DETAIL_NAME))
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(result) + "\n").encode())
+        os.write(json_fd, (json.dumps(compact_line(result)) + "\n").encode())
     os.close(json_fd)
     if world > 1:
         dist.barrier()

@@ -39,6 +39,68 @@ def _check_line(d, full):
     assert c["kind"] in ("port", "reference") and c["unit"] == "edges/sec" and c["cores"] >= 1 and c["value"] > 0
 
 
+LINE_LIMIT = 6144      # the driver parses the line out of a bounded tail of stdout: round 5's 20 KB line came back `parsed: null`
+
+
+def _compact(d):
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.LINE_LIMIT_BYTES == LINE_LIMIT
+    line = bench.compact_line(d)
+    text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, len(text)
+    assert max(len(v) for v in _strings(line)) <= 160            # no prose in the line
+    return line
+
+
+def _strings(x):
+    if isinstance(x, str):
+        yield x
+    elif isinstance(x, dict):
+        for v in x.values():
+            yield from _strings(v)
+    elif isinstance(x, list):
+        for v in x:
+            yield from _strings(v)
+
+
+def test_the_printed_line_is_small_and_keeps_the_contract_on_every_committed_record():
+    """bench.py prints compact_line(record) and writes the record itself to bench_detail.json: over the full records of round 5
+    (N = 1 with every section: 20 KB; C5; 2 and 8 ranks) the line stays below 6 KB, keeps every key of the driver's contract with
+    `roofline` + `cpu_baseline` and the internal arithmetic, and names its sidecar."""
+    for name, full in (("r05_bench.json", True), ("r05_bench_c5.json", False), ("r05_bench_2ranks_one_gpu_gloo.json", False),
+                       ("r05_bench_8ranks_one_gpu_gloo.json", False)):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        line = _compact(d)
+        _check_line(line, full=full)
+        assert line["detail"] == "bench_detail.json"
+        for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup"):
+            assert line[k] == d[k]
+        if d["n_gpus"] > 1:
+            assert line["allreduce_flat_ms_per_step"] == d["ms_per_step"] and line["allreduce_overlap_ms_per_step"] > 0
+            assert len(line["per_rank"]["gpu_step_ms_median"]) == d["n_gpus"] == len(line["per_rank_edges"])
+    line = _compact(json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json"))))
+    assert set(line["roofline"]["c2"]) >= {"avg_kernel_ms_in_step", "frac_of_l2_peak", "hbm_side_over_compulsory"}
+    assert set(line["other_configs"]) >= {"C3_train_ms", "C3_max_train_ms", "C4_train_ms", "C5_train_ms"}
+    for k in ("fp32_exact_split_ms_per_step", "pair_route_ms_per_step", "exact_fp32_lib_ms_per_step"):
+        assert line[k] > 0
+
+
+def test_round6_line_and_sidecar_when_committed():
+    """The round-6 evidence run: profiles/r06_bench.json is the LINE as printed, profiles/r06_bench_detail.json the sidecar."""
+    lp, dp = (os.path.join(ROOT, "profiles", n) for n in ("r06_bench.json", "r06_bench_detail.json"))
+    if not (os.path.exists(lp) and os.path.exists(dp)):
+        pytest.skip("no round-6 evidence run committed yet")
+    raw = open(lp).read().strip()
+    assert len(raw) < LINE_LIMIT and "\n" not in raw
+    line, detail = json.loads(raw), json.load(open(dp))
+    _check_line(line, full=True)
+    assert _compact(detail) == line                       # the line IS the compaction of the sidecar
+    assert len(detail["roofline"]["sizes"]) >= 4 and "top_kernels" in detail["roofline"]["c2"]
+    m = line["roofline"]["mfma"]
+    assert "error" not in m and 0.0 < m["busy_frac"] <= 1.0 and 0.0 < m["frac_of_bf16_peak"] <= 1.0
+
+
 def test_committed_bench_line_keeps_the_contract():
     d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
     _check_line(d, full=True)
@@ -107,10 +169,29 @@ def test_live_short_run_prints_one_json_line():
                        timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(lines[0]) < LINE_LIMIT
     d = json.loads(lines[0])
     _check_line(d, full=False)
     assert d["steps"] == 4 and d["warmup"] == 2 and d["n_gpus"] == 1
+    # the sidecar holds the full record and the line is its compaction
+    detail = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert _compact(detail) == d and "dense_products" in detail and "generator" in detail["config"]
+
+
+@pytest.mark.gpu
+def test_live_multi_rank_line_is_small_too():
+    """8 ranks sharing this box's GPU over gloo (launch-path rehearsal): the line obeys the same size bound."""
+    env = dict(os.environ, RELGNN_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--no-roofline", "--no-cpu-baseline", "--no-extras", "--no-detail",
+                        "--task-param-overrides", '{"graphs_per_rank": 16}'], capture_output=True, text=True, cwd=ROOT,
+                       timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < LINE_LIMIT
+    d = json.loads(lines[0])
+    _check_line(d, full=False)
+    assert d["n_gpus"] == d["nranks"] == 8 and len(d["per_rank"]["gpu_step_ms_median"]) == 8
 
 
 @pytest.mark.gpu
