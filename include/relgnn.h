@@ -835,9 +835,24 @@ int relgnn_limb16_gemm_xf32_dact(int32_t act, const float* A, int64_t lda, const
  * 96-98 forward and input gradient; the Dense layers of models/sparse_graph_model.py:194-200), the same bits as
  * relgnn_limb_gemm_xf32_dact.  K % 128 == 0, N % 256 == 0 and N == 256 or K <= 256; act: linear, ReLU, or tanh with K in {128, 256, 512}; Y (nullable) / dact as in
  * relgnn_limb_gemm_xf32_dact.  RELGNN_EUNSUPPORTED otherwise: callers keep relgnn_limb_gemm_xf32 for those.
- * relgnn_rgcn_fused_status reports the give-up bits of this kernel's polls too (bits 2 / 3). */
+ *
+ * status (nullable): the caller's hand-over status block, device int32[2].  The wave roles hand sub-slabs over through counters in
+ * LDS; every poll of a counter is bounded so that a protocol bug cannot hang the device.  A wave whose poll runs out stops waiting,
+ * finishes WITH WRONG NUMBERS and ORs RELGNN_HANDOVER_PC_MATRIX / RELGNN_HANDOVER_PC_PRODUCER into status[0] (the err_flag
+ * convention: reporting through the return value would need a device sync).  status[1] is the poll bound, 0 = the default 2^22
+ * rounds (tests write 1 to provoke a give-up).  The caller zeroes the block once and reads status[0] where it synchronises anyway
+ * (the package: with every step's metrics copy, models/sparse_graph_model.py MetricsReadback -> RuntimeError).  NULL: nothing is
+ * reported.
+ * relgnn_limb_gemm_xf32_pc_supported: 1 iff (act, has_dact, M, N, K) is a shape this entry takes (alignment of the pointers aside) —
+ * the one place the list lives, so that callers choose between this entry and relgnn_limb_gemm_xf32 without repeating it. */
+#define RELGNN_HANDOVER_FUSED_MATRIX 1
+#define RELGNN_HANDOVER_FUSED_GATHER 2
+#define RELGNN_HANDOVER_PC_MATRIX 4
+#define RELGNN_HANDOVER_PC_PRODUCER 8
 int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, int32_t dact,
-                             const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+                             const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t* status,
+                             void* stream);
+int relgnn_limb_gemm_xf32_pc_supported(int32_t act, int32_t M, int32_t N, int32_t K);
 /*
  * relgnn_rgcn_fused_fwd — the aggregate-first RGCN layer in ONE kernel (north_star "per-edge-type linear transform
  * fused as an MFMA GEMM"):
@@ -858,15 +873,13 @@ int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uin
  * out [V, ldo].  d_in = d_out = 256 only (RELGNN_EUNSUPPORTED otherwise); 16-byte aligned pointers, strides % 4 == 0.
  * Buckets of any length are walked by ONE wave: callers with hub buckets (ops.SplitPlan) keep the two-kernel route.
  *
- * relgnn_rgcn_fused_status: the kernel's hand-over between gather and matrix waves polls counters in LDS; a poll that exceeds
- * 2^22 rounds gives up (results are then wrong) and sets bit 0 (a matrix wave) / bit 1 (a gather wave) of a status word that
- * this call synchronises the device for and returns (reset != 0 clears it).  0 = every launch so far completed its hand-overs.
+ * status (nullable): the hand-over status block of relgnn_limb_gemm_xf32_pc (device int32[2]); a gather / matrix wave whose poll
+ * runs out ORs RELGNN_HANDOVER_FUSED_GATHER / RELGNN_HANDOVER_FUSED_MATRIX into status[0] and the results are wrong.
  */
 int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const int32_t* rowptr, int32_t num_nodes,
                           int32_t num_edge_types, const int32_t* col, const float* w, const uint16_t* w_limbs, const float* bias,
                           int32_t act, float* bucket_sums, int64_t lds, float* out, int64_t ldo, int32_t d_in, int32_t d_out,
-                          void* stream);
-int relgnn_rgcn_fused_status(int32_t* status, int32_t reset);
+                          int32_t* status, void* stream);
 /* The same product in 128 x 128 panels, two workgroups per CU, with what the per-(node, type) transforms of many-type graphs need
  * (gnns/gnn_film.py:92-106; the limb counterpart of relgnn_panel_gemm_f32's a_rows / b_select for the forward product and the input
  * gradient; K = 128 there):

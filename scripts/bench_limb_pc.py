@@ -42,7 +42,6 @@ for name, M, K, N in (("forward  [V, 768] @ [768, 256]", 36096, 768, 256), ("inp
             row["plain_dact_us" if pc == "0" else "roles_dact_us"] = timed(
                 lambda: DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, out=out, dact=_lib.ACT_RELU, dy=y))
     row["bit_identical"] = bool(torch.equal(res["0"], res["1"]))
-    s = ctypes.c_int32(-1)
-    _lib.load_library().relgnn_rgcn_fused_status(ctypes.byref(s), 1)
-    row["status_word"] = s.value
+    from tf_gnn_samples_amd import ops
+    row["status_word"] = ops.handover_status()
     print(json.dumps(row), flush=True)

@@ -31,9 +31,8 @@ def timed(fn, reps=7, inner=10):
 
 
 def status():
-    s = ctypes.c_int32(-1)
-    _lib.check(_lib.load_library().relgnn_rgcn_fused_status(ctypes.byref(s), 1), "relgnn_rgcn_fused_status")
-    return s.value
+    from tf_gnn_samples_amd import ops
+    return ops.handover_status()
 
 
 def c2_batch():

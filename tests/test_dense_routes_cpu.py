@@ -62,3 +62,24 @@ def test_which_products_take_the_wave_role_kernel(mode, kind, n, k, act, expect)
     with config.override(limb_pc=mode):
         assert DN._limb_pc_ok(a, n, k, None, act, None, out, kind) is expect
         assert DN._limb_pc_ok(a[:100], n, k, None, act, None, out[:100], kind) is False      # below the limb routes' minimum height
+
+
+def test_a_backward_that_raises_leaves_no_deferred_join_state_behind():
+    """ops.deferred_weight_gradient_join: when the backward inside it raises, nobody calls join_deferred() for that pass — the
+    context forgets the pass itself, so that the next step's join does not verify (or keep alive) this step's parameters."""
+    from tf_gnn_samples_amd import ops
+    p = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(RuntimeError, match="boom"):
+        with ops.deferred_weight_gradient_join():
+            assert ops._DEFER["on"]
+            ops._DEFER["handed"].append((p, 1234, 0))
+            ops._DEFER["targets"].add(id(p))
+            raise RuntimeError("boom")
+    assert not ops._DEFER["on"] and ops._DEFER["handed"] == [] and not ops._DEFER["targets"] and ops._DEFER["pending"] == []
+    ops.join_deferred()                                   # nothing to verify: does not raise
+    # a clean exit keeps the pass for join_deferred()
+    with ops.deferred_weight_gradient_join():
+        ops._DEFER["targets"].add(id(p))
+    assert ops._DEFER["targets"]
+    ops.join_deferred()
+    assert not ops._DEFER["targets"]

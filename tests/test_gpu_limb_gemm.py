@@ -744,9 +744,106 @@ def test_producer_consumer_product_is_bit_identical(gpu_device, M, K, N):
                         DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, bias, _lib.ACT_TANH),
                         DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, dact=_lib.ACT_RELU, dy=y),
                         DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, dact=_lib.ACT_TANH, dy=y))
-    torch.cuda.synchronize()
-    s = ctypes.c_int32(-1)
-    _lib.check(_lib.load_library().relgnn_rgcn_fused_status(ctypes.byref(s), 1), "relgnn_rgcn_fused_status")
-    assert s.value == 0
+    from tf_gnn_samples_amd import ops
+    assert ops.handover_status() == 0
     for p, q in zip(outs["0"], outs["1"]):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("K,N,act", [(768, 256, "relu"), (768, 256, "linear"), (256, 256, "tanh"), (128, 256, "tanh"), (512, 256, "tanh"),
+                                     (256, 768, "relu"), (128, 1024, "linear"), (256, 512, "tanh"), (384, 256, "relu"),
+                                     (1024, 256, "linear")])
+def test_every_wave_role_variant_against_float64_at_the_baseline_height(gpu_device, K, N, act):
+    """relgnn_limb_gemm_xf32_pc — the DEFAULT forward product since round 5 — against float64 directly (not through the older HIP
+    kernel), on the C2 batch's height (32 203 rows: 1007 units, an odd count, the last one ragged) for every instantiated variant:
+    ReLU / linear at K = 768 (the layer's product), tanh at K in {128, 256, 512} (the Dense layers), several column chunks at
+    K <= 256, and the activation-gradient epilogues.  Bar: 1e-5 absolute (north_star) with outputs up to ~|2|."""
+    from tf_gnn_samples_amd import _lib, config, dense as DN, ops
+    dev, M = gpu_device, 32203
+    a = _rand((M, K), dev, 11 + K)
+    w = [_rand((N, 128), dev, 300 + i, 0.08) for i in range(K // 128)]
+    bias = _rand((N,), dev, 7, 0.1)
+    act_id = {"relu": _lib.ACT_RELU, "linear": _lib.ACT_LINEAR, "tanh": _lib.ACT_TANH}[act]
+    assert _lib.load_library().relgnn_limb_gemm_xf32_pc_supported(act_id, M, N, K) == 1
+    with config.override(limb_pc="1"):
+        assert DN._limb_pc_ok(a, N, K, bias, act_id, None, torch.empty((M, N), device=dev), DN.WEIGHT_NT)
+        got = DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, bias, act_id)
+    W = torch.cat([x.double() for x in w], dim=1)                       # [N, K]
+    z = a.double() @ W.t() + bias.double()
+    want = {"relu": torch.relu, "linear": lambda t: t, "tanh": torch.tanh}[act](z)
+    err = float((got.double() - want).abs().max())
+    assert err <= 1e-5, (K, N, act, err, float(want.abs().max()))
+    if act == "linear":                                                  # the input-gradient form: times act'(y) in the epilogue
+        y = _rand((M, N), dev, 9)
+        for dact, factor in ((_lib.ACT_RELU, (y > 0).double()), (_lib.ACT_TANH, 1.0 - y.double() ** 2)):
+            with config.override(limb_pc="1"):
+                g = DN.limb_gemm_weight(a, w, DN.WEIGHT_NT, None, _lib.ACT_LINEAR, dact=dact, dy=y)
+            e = float((g.double() - (a.double() @ W.t()) * factor).abs().max())
+            assert e <= 1e-5, (K, N, dact, e)
+    assert ops.handover_status() == 0
+
+
+def test_a_product_that_gives_up_on_a_hand_over_fails_the_next_metrics_fetch(gpu_device):
+    """The wave-role kernel bounds every poll of its LDS counters; a wave whose poll runs out finishes with wrong numbers and ORs a
+    bit into the CALLER's status block (include/relgnn.h: relgnn_limb_gemm_xf32_pc, `status`).  The model owns that block and reads
+    it with every step's metrics copy (MetricsReadback): with the poll bound set to 1 — word 1 of the block, the debug knob — a
+    C2-size forward product gives up and the step's metrics fetch raises instead of training on."""
+    from tf_gnn_samples_amd import ops
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.models.sparse_graph_model import MetricsReadback
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(4, 1, seed=3)
+    p = RGCN_Model.default_params()
+    p.update(hidden_size=256, graph_num_layers=3, graph_layer_input_dropout_keep_prob=1.0)
+    model = RGCN_Model(p, task, device=str(gpu_device))
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
+    assert mb.num_nodes >= 4096                                          # tall enough for the limb kernels
+    batch = DeviceBatch(mb, gpu_device)
+    word = ops.handover_word(gpu_device)
+    assert word is model.handover_word and word.dtype == torch.int32 and word.numel() == 2
+    assert ops.handover_status() == 0
+    good = MetricsReadback(model.train_step(batch)).get()               # the default bound: clean
+    assert np.isfinite(good['loss'])
+    word[1] = 1
+    try:
+        with torch.no_grad():                                            # (forward only: the garbage must not reach the weights)
+            rb = MetricsReadback(model.forward_batch(batch, training=False))
+        with pytest.raises(ops.HandoverError, match="gave up on an LDS hand-over"):
+            rb.get()
+        assert int(word[0].item()) == 0                                  # reported once, then cleared
+        # the epoch loop of the model goes through the same fetch
+        with pytest.raises(ops.HandoverError):
+            model.test(task._loaded_data[DataFold.TRAIN], quiet=True)
+    finally:
+        word[1] = 0
+        word[0] = 0
+    again = MetricsReadback(model.train_step(batch)).get()
+    assert np.isfinite(again['loss']) and ops.handover_status() == 0
+
+
+def test_the_status_block_survives_a_captured_step(gpu_device):
+    """A hipGraph replays the pointers it was captured with: the status block exists before the capture (the model allocates it
+    when it is built), so a captured step reports like an eager one."""
+    from tf_gnn_samples_amd import ops
+    from tf_gnn_samples_amd.models import RGCN_Model
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(4, 1, seed=4)
+    p = RGCN_Model.default_params()
+    p.update(hidden_size=256, graph_num_layers=2, graph_layer_input_dropout_keep_prob=1.0)
+    model = RGCN_Model(p, task, device=str(gpu_device))
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
+    batch = DeviceBatch(mb, gpu_device)
+    cap = model.capture_train_step(batch)
+    cap.replay()
+    assert cap.handover_status() == 0
+    word = ops.handover_word(gpu_device)
+    word[1] = 1
+    try:
+        cap.replay()
+        torch.cuda.synchronize()
+        assert cap.handover_status() & 12                               # bits 2 / 3: the product kernel's waves
+    finally:
+        word[1] = 0
+        word[0] = 0

@@ -105,6 +105,19 @@ def test_hip_backward_reproduces_the_gradients_of_the_reference_s_own_code(gpu_d
             assert fro <= 1e-4 and err <= 1e-4 * scale, (case["function"], name, err, scale, fro)
 
 
+ADAM_OUTLIERS = []
+
+
+def teardown_module(module):
+    import json
+    import os
+    if ADAM_OUTLIERS:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "adam_outliers.json"), "w") as f:
+            json.dump(ADAM_OUTLIERS, f, indent=1)
+
+
 @pytest.mark.parametrize("i", range(len(AUTOGRAD["train"])), ids=["%s-%s" % (t["model"], t["steps"][0]["optimizer"]) for t in AUTOGRAD["train"]])
 def test_two_training_steps_land_where_the_reference_s_train_step_lands(gpu_device, tmp_path, i):
     """Sparse_Graph_Model.train_step twice on the reference-built minibatch, from the reference's initial variables, against the
@@ -139,9 +152,20 @@ def test_two_training_steps_land_where_the_reference_s_train_step_lands(gpu_devi
             diff = np.abs(got - want)
             if adam:
                 # Adam moves every element by ~lr in the direction of its gradient's sign: an element whose gradient sits at the float32
-                # noise floor may go the other way; all but a handful agree closely, none is off by more than the two directions
+                # noise floor may go the other way.  Round 6: such elements must be FEW (<= 2e-3 of a variable; round 5 allowed 2 %,
+                # which a sign error on a small variable would have passed) and each must be one whose reference gradient really is
+                # noise — below 1e-6 of the variable's largest gradient entry in the step that moved it (either step for step 2);
+                # none is off by more than the two directions
                 assert float(diff.max()) <= 2.2 * lr * (step + 1), (step, n, float(diff.max()))
-                assert float((diff > 0.05 * lr).mean()) <= 0.02, (step, n, float((diff > 0.05 * lr).mean()))
+                outlier = diff > 0.05 * lr
+                frac = float(outlier.mean())
+                grads = [np.abs(z["%s/step%d/applied_gradient/%s" % (k, j, n)]) for j in range(step + 1)]
+                rel = np.minimum.reduce([g / max(float(g.max()), 1e-300) for g in grads])
+                worst = float(rel[outlier].max()) if outlier.any() else 0.0
+                ADAM_OUTLIERS.append({"case": t["model"], "step": step, "variable": n, "outlier_fraction": frac,
+                                      "largest_relative_gradient_of_an_outlier": worst, "elements": int(diff.size)})
+                assert frac <= 2e-3, (step, n, frac)
+                assert worst <= 1e-6, (step, n, worst)
             else:
                 assert float(diff.max()) <= 2e-5 * max(1.0, float(np.abs(want).max())) * (step + 1), (step, n, float(diff.max()))
 

@@ -42,11 +42,8 @@ def _two_kernels(H, graph, w, kernels, relu):
 
 
 def _status():
-    import ctypes
-    from tf_gnn_samples_amd import _lib
-    s = ctypes.c_int32(-1)
-    _lib.check(_lib.load_library().relgnn_rgcn_fused_status(ctypes.byref(s), 1), "relgnn_rgcn_fused_status")
-    return s.value
+    from tf_gnn_samples_amd import ops
+    return ops.handover_status()
 
 
 CASES = [
@@ -150,8 +147,8 @@ def test_unsupported_shapes_are_refused_not_computed(gpu_device):
     out = torch.zeros((40, 128), device=dev)
     buf = torch.zeros(1 << 16, dtype=torch.bfloat16, device=dev)
     rc = lib.relgnn_rgcn_fused_fwd(H.data_ptr(), 40, 128, graph.rowptr_t.data_ptr(), 40, 1, graph.src_t.data_ptr(), None,
-                                   buf.data_ptr(), None, 0, None, 0, out.data_ptr(), 128, 128, 128, None)
+                                   buf.data_ptr(), None, 0, None, 0, out.data_ptr(), 128, 128, 128, None, None)
     assert rc == _lib.EUNSUPPORTED
     rc = lib.relgnn_rgcn_fused_fwd(None, 40, 256, graph.rowptr_t.data_ptr(), 40, 1, graph.src_t.data_ptr(), None,
-                                   buf.data_ptr(), None, 0, None, 0, out.data_ptr(), 256, 256, 256, None)
+                                   buf.data_ptr(), None, 0, None, 0, out.data_ptr(), 256, 256, 256, None, None)
     assert rc == _lib.EINVAL

@@ -96,10 +96,10 @@ _SIGNATURES = {
     "relgnn_limb16_gemm_xf32_dact": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr,
                                                     _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_rgcn_fused_fwd": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _ptr, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr,
-                                             _c_i64, _c_i32, _c_i32, _ptr]),
-    "relgnn_rgcn_fused_status": (ctypes.c_int, [_ptr, _c_i32]),
+                                             _c_i64, _c_i32, _c_i32, _ptr, _ptr]),
     "relgnn_limb_gemm_xf32_pc": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _c_i32, _c_i32,
-                                                _ptr]),
+                                                _ptr, _ptr]),
+    "relgnn_limb_gemm_xf32_pc_supported": (ctypes.c_int, [_c_i32, _c_i32, _c_i32, _c_i32]),
     "relgnn_limb_gemm_tn_chunks": (_c_i64, [_c_i32, _c_i32, _c_i32]),
     "relgnn_limb_gemm_tn_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i32, _c_i32, _c_i32, _ptr]),
     "relgnn_limb_gemm_tn_tiles_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i32, _c_i32, _c_i32, _c_i32, _ptr]),

@@ -89,12 +89,13 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
   const int nseq = nfull * 2 * S2 + (nu & 1) * S2;
   const int rend = min((u0 + nu) * 32, a.M);
   bool dead = false;
+  const int spin_limit = handover_limit(a.status);
   auto poll = [&](int* p, int target) {
     if (dead) return;
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(handover_counter(p)) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > HANDOVER_SPIN_LIMIT) { dead = true; if (lane == 0 && a.status) atomicOr(a.status, 4 + (wave < 8 ? 0 : 4)); break; }
+      if (++spins > spin_limit) { dead = true; if (lane == 0 && a.status) atomicOr(a.status, 4 + (wave < 8 ? 0 : 4)); break; }
     }
     handover_fence();
   };
@@ -289,13 +290,22 @@ __global__ __launch_bounds__(1024) void limb_gemm_pc_kernel(const PcArgs a) {
 
 extern "C" {
 
+// the shapes the kernel is instantiated for: K / 128 in {1, 2, 3, 4, 6, 8} (tanh epilogue: {1, 2, 4}), whole 256-column chunks,
+// several chunks only while a pass's W fragments stay short (K <= 256)
+int relgnn_limb_gemm_xf32_pc_supported(int32_t act, int32_t M, int32_t N, int32_t K) {
+  if (M < 0 || N <= 0 || K <= 0) return 0;
+  if (K % 128 != 0 || K > 1024 || K == 640 || K == 896 || N % 256 != 0 || (N != 256 && K > 256)) return 0;
+  if (act == RELGNN_ACT_TANH) return K == 128 || K == 256 || K == 512;
+  return act == RELGNN_ACT_LINEAR || act == RELGNN_ACT_RELU;
+}
+
 int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uint16_t* B, const float* bias, int32_t dact,
-                             const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+                             const float* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t* status,
+                             void* stream) {
   if (M < 0 || N < 0 || K < 0 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
   if (M == 0 || N == 0) return RELGNN_OK;
   if (!A || !B || !C) return RELGNN_EINVAL;
-  if (K == 0 || K % 128 != 0 || K > 1024 || K == 640 || K == 896 || N % 256 != 0 || (N != 256 && K > 256) || (act != RELGNN_ACT_LINEAR && act != RELGNN_ACT_RELU && act != RELGNN_ACT_TANH))
-    return RELGNN_EUNSUPPORTED;
+  if (!relgnn_limb_gemm_xf32_pc_supported(act, M, N, K)) return RELGNN_EUNSUPPORTED;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias)) || ldc % 4 || ldc < N || lda % 4 || lda < K)
     return RELGNN_EUNSUPPORTED;
   if (Y) {
@@ -305,7 +315,7 @@ int relgnn_limb_gemm_xf32_pc(int32_t act, const float* A, int64_t lda, const uin
   PcArgs a{};
   a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.dy = Y; a.ldy = ldy; a.dact = dact; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.act = act;
-  a.status = handover_status_word(as_stream(stream));
+  a.status = status;
   // the fewest workgroups that keep the longest range: 1128 units over 256 CUs are ranges of 4 and 5 units — 226 ranges of 5 finish
   // at the same time and leave 30 CUs to whatever runs next to this kernel (the weight gradient on the side stream)
   const int units = (M + 31) / 32;

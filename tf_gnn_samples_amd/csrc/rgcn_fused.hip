@@ -115,6 +115,7 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
   const int rend = min((u0 + nu) * 32, a.V);                 // first row that is not mine
   const int ntiles = L * 16;
   bool dead = false;                                          // a poll gave up: stop waiting for anything
+  const int spin_limit = handover_limit(a.status);
 #ifdef RELGNN_FUSED_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TSTAMP(t_begin);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(lds_counter(p)) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > HANDOVER_SPIN_LIMIT) { dead = true; if (lane == 0 && a.status) atomicOr(a.status, 1 + (wave < 8 ? 0 : 1)); break; }
+      if (++spins > spin_limit) { dead = true; if (lane == 0 && a.status) atomicOr(a.status, 1 + (wave < 8 ? 0 : 1)); break; }
     }
     compiler_fence();
 #ifdef RELGNN_FUSED_TIMING
@@ -453,33 +454,14 @@ __global__ __launch_bounds__(1024) void rgcn_fused_kernel(const FusedArgs a) {
 #endif
 }
 
-int32_t* g_status = nullptr;
-int g_status_device = -1;
-
 }  // namespace
-
-namespace relgnn {
-int32_t* handover_status_word(hipStream_t stream) {
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (g_status && dev != g_status_device) return nullptr;      // (one process per GPU: a second device in the process reports nothing)
-  if (!g_status) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-    if (hipMalloc(reinterpret_cast<void**>(&g_status), sizeof(int32_t)) != hipSuccess) { g_status = nullptr; return nullptr; }
-    if (hipMemset(g_status, 0, sizeof(int32_t)) != hipSuccess) return nullptr;
-    g_status_device = dev;
-  }
-  return g_status;
-}
-}  // namespace relgnn
 
 extern "C" {
 
 int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const int32_t* rowptr, int32_t num_nodes,
                           int32_t num_edge_types, const int32_t* col, const float* w, const uint16_t* w_limbs, const float* bias,
                           int32_t act, float* bucket_sums, int64_t lds, float* out, int64_t ldo, int32_t d_in, int32_t d_out,
-                          void* stream) {
+                          int32_t* status, void* stream) {
   if (num_nodes < 0 || num_edge_types <= 0 || d_in < 0 || d_out < 0 || num_rows_h < 0 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU)
     return RELGNN_EINVAL;
   if (num_nodes == 0 || d_out == 0) return RELGNN_OK;
@@ -492,7 +474,7 @@ int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const
     return RELGNN_EUNSUPPORTED;
   FusedArgs a{};
   a.H = H; a.ldh = ldh; a.rowptr = rowptr; a.col = col; a.w = w; a.B = w_limbs; a.bias = bias; a.S = bucket_sums; a.lds_ = lds;
-  a.C = out; a.ldc = ldo; a.V = num_nodes; a.L = num_edge_types; a.act = act; a.status = handover_status_word(as_stream(stream));
+  a.C = out; a.ldc = ldo; a.V = num_nodes; a.L = num_edge_types; a.act = act; a.status = status;
 #ifdef RELGNN_FUSED_TIMING
   a.timing = g_fused_timing;
 #endif
@@ -510,15 +492,5 @@ int relgnn_rgcn_fused_fwd(const float* H, int64_t num_rows_h, int64_t ldh, const
 #ifdef RELGNN_FUSED_TIMING
 void relgnn_rgcn_fused_timing_buffer(unsigned long long* p) { g_fused_timing = p; }
 #endif
-
-int relgnn_rgcn_fused_status(int32_t* status, int32_t reset) {
-  if (!status) return RELGNN_EINVAL;
-  *status = 0;
-  if (!g_status) return RELGNN_OK;
-  if (hipDeviceSynchronize() != hipSuccess) return RELGNN_EHIP;
-  if (hipMemcpy(status, g_status, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return RELGNN_EHIP;
-  if (reset && hipMemset(g_status, 0, sizeof(int32_t)) != hipSuccess) return RELGNN_EHIP;
-  return RELGNN_OK;
-}
 
 }  // extern "C"

@@ -34,6 +34,13 @@ import torch
 # `triple` keeps the exact split everywhere.
 from .config import settings as _cfg
 
+
+
+def _ops():
+    from . import ops            # (ops imports this module lazily too)
+    return ops
+
+
 _LIMB_MIN_ROWS, _LIMB_MAX_K = 4096, 1024
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 _WARNED_UNSUPPORTED = False
@@ -641,7 +648,8 @@ def limb_gemm_weight(a: torch.Tensor, w, kind: str, bias: torch.Tensor = None, a
         # wave roles instead of k-loop phases (csrc/limb_gemm_pc.hip): the same bits, the matrix waves at their MFMA-only time
         _lib.check(lib.relgnn_limb_gemm_xf32_pc(act, a.data_ptr(), a.stride(0), buf.data_ptr(), _lib.ptr(bias), int(dact),
                                                 dy.data_ptr() if dy is not None else None, dy.stride(0) if dy is not None else 0,
-                                                out.data_ptr(), out.stride(0), a.shape[0], n, k, _lib.current_stream()),
+                                                out.data_ptr(), out.stride(0), a.shape[0], n, k,
+                                                _ops().handover_word(a.device).data_ptr(), _lib.current_stream()),
                    "relgnn_limb_gemm_xf32_pc")
         return out
     if dy is not None:
@@ -664,9 +672,9 @@ def _limb_pc_ok(a, n: int, k: int, bias, act: int, dy, out, kind: str) -> bool:
     mode = _cfg.limb_pc
     if mode == "0" or (mode == "fwd" and kind != WEIGHT_NN):     # (the small input-gradient products, K <= 256 and N = 256, on it too: no
         return False                                              #  difference, 1.8115 vs 1.8101 ms over three alternations)
-    if (act not in (0, 1, 2) or (act == 1 and k not in (128, 256, 512)) or k % 128 or k > 1024 or k in (640, 896) or n % 256
-            or (n != 256 and k > 256) or a.shape[0] < _LIMB_MIN_ROWS):
-        return False
+    from . import _lib
+    if a.shape[0] < _LIMB_MIN_ROWS or not _lib.load_library().relgnn_limb_gemm_xf32_pc_supported(int(act), a.shape[0], n, k):
+        return False                                              # (the shape list lives in the library: csrc/limb_gemm_pc.hip)
     return (a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
             and (bias is None or bias.data_ptr() % 16 == 0) and (dy is None or (dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0)))
 

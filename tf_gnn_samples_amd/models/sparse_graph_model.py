@@ -235,31 +235,54 @@ class MetricsReadback:
         dev = [(k, v.detach()) for k, v in metrics.items() if torch.is_tensor(v) and v.is_cuda]
         self._names = [k for k, _ in dev]
         self._event = self._slot = None
+        self._status_at = None
         if dev:
             device = dev[0][1].device
             # one small kernel when the metrics share a dtype (the usual case: fp32 scalars), converted only if they differ
             dtype = dev[0][1].dtype if all(v.dtype == dev[0][1].dtype for _, v in dev) else torch.float64
-            packed = torch.stack([v.reshape(()) if v.dtype == dtype else v.reshape(()).to(dtype) for _, v in dev])
-            ring = MetricsReadback._ring.setdefault((device, len(dev), dtype), [])
+            parts = [v.reshape(()) if v.dtype == dtype else v.reshape(()).to(dtype) for _, v in dev]
+            # The hand-over status word of the device (ops.handover_word: a wave-role product kernel that gave up on an LDS
+            # hand-over has written wrong numbers and says so there) rides in the same copy: its int32 bits as one more fp32
+            # entry of the packed vector (a view, no launch of its own); get() raises when it is not zero.
+            from .. import ops as _ops
+            word = _ops._HANDOVER_WORDS.get(device.index)
+            if word is not None:
+                if dtype == torch.float32:
+                    parts.append(word[0].view(torch.float32))
+                else:
+                    parts.append(word[0].to(dtype))
+                self._status_at = len(dev)
+            packed = torch.stack(parts)
+            ring = MetricsReadback._ring.setdefault((device, len(parts), dtype), [])
             # a pinned slot is taken until its reader has consumed it (get()) or dropped it
             slot = next((b for b in ring if not b[1]), None)
             if slot is None:
-                slot = [torch.empty(len(dev), dtype=dtype).pin_memory(), False]
+                slot = [torch.empty(len(parts), dtype=dtype).pin_memory(), False]
                 ring.append(slot)
             slot[1] = True
             slot[0].copy_(packed, non_blocking=True)
             self._event = torch.cuda.Event()
             self._event.record(torch.cuda.current_stream(device))
             self._slot = slot
+            self._device = device
 
     def get(self) -> Dict[str, float]:
         out = {k: (float(v) if torch.is_tensor(v) else v) for k, v in self._host_values.items()}
         if self._event is not None:
             self._event.synchronize()
-            out.update(zip(self._names, self._slot[0].tolist()))
+            host = self._slot[0]
+            status = 0
+            if self._status_at is not None:
+                status = (int(host[self._status_at:self._status_at + 1].view(torch.int32)[0]) if host.dtype == torch.float32
+                          else int(host[self._status_at]))
+            out.update(zip(self._names, host.tolist()))
             self._event = None
             self._slot[1] = False
             self._values = {k: out[k] for k in self._names}
+            if status:
+                from .. import ops as _ops
+                _ops._HANDOVER_WORDS[self._device.index][0].zero_()      # reported once; later steps start clean
+                _ops.raise_on_handover(status)
         elif self._names:
             out.update(self._values)
         return out
@@ -296,6 +319,12 @@ class CapturedTrainStep:
         opt.t += 1
         self._expected_t = opt.t
         return self.metrics
+
+    def handover_status(self) -> int:
+        """The device's hand-over status word (ops.handover_status: synchronises).  A replay loop that reads the metric tensors
+        itself instead of going through MetricsReadback checks this where it syncs anyway."""
+        from .. import ops as _ops
+        return _ops.handover_status(device=self.model.device)
 
 
 class Sparse_Graph_Model(ABC):
@@ -340,6 +369,11 @@ class Sparse_Graph_Model(ABC):
         self.training = False
         torch.manual_seed(params['random_seed'])
         np.random.seed(params['random_seed'])
+        if self.device.type == "cuda":
+            # the hand-over status block of this device (ops.handover_word): exists before any step can be captured into a hipGraph;
+            # read back with every step's metrics (MetricsReadback) and by handover_status()
+            from .. import ops as _ops
+            self.handover_word = _ops.handover_word(self.device)
         self.variables = VariableStore(seed=params['random_seed'])
         self.__make_model()
         self.variables.to(self.device)

@@ -854,8 +854,20 @@ class deferred_weight_gradient_join:
         _DEFER["on"] = True
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc, tb):
         _DEFER["on"] = self._old
+        if exc_type is not None:
+            # the backward raised (out of memory, a check inside a Function): nobody will call join_deferred() for this pass.  Wait
+            # for the side streams and forget the pass — stale `handed` entries would hold the parameters alive and make the NEXT
+            # step's join verify gradients that belong to this one
+            pending, _DEFER["pending"] = _DEFER["pending"], []
+            _DEFER["handed"] = []
+            _DEFER["targets"].clear()
+            for device, side in pending:
+                try:
+                    torch.cuda.current_stream(device).wait_stream(side)
+                except Exception:
+                    pass
         return False
 
 
@@ -976,15 +988,50 @@ def _pair_products(X, rowptr, stride, V, k, n, kernels, kind) -> bool:
             and DN.weight_image_ok(list(kernels), DN.WEIGHT_NN if kind == "nn" else DN.WEIGHT_NT))
 
 
-def handover_status(reset: bool = True) -> int:
-    """The give-up word of the kernels whose wave roles hand data over through LDS counters (relgnn_limb_gemm_xf32_pc: the default
-    forward products; relgnn_rgcn_fused_fwd): 0 = every poll of every launch so far completed.  A poll is bounded (2^22 rounds)
-    so that a protocol bug cannot hang the device; a kernel that gave up has written wrong results and says so here.  Synchronises
-    the device: call it where the host waits anyway (bench.py and smoke() do, behind their timed regions)."""
-    import ctypes
-    s = ctypes.c_int32(-1)
-    _lib.check(_lib.load_library().relgnn_rgcn_fused_status(ctypes.byref(s), 1 if reset else 0), "relgnn_rgcn_fused_status")
-    return int(s.value)
+_HANDOVER_WORDS = {}
+
+
+def handover_word(device=None) -> torch.Tensor:
+    """The hand-over status block of `device` (int32[2] in HBM, include/relgnn.h RELGNN_HANDOVER_*): the kernels whose wave roles hand
+    data over through LDS counters (relgnn_limb_gemm_xf32_pc: the default forward products; relgnn_rgcn_fused_fwd) OR a bit into
+    word 0 when one of their bounded polls runs out — such a launch has written wrong numbers.  The library neither allocates nor
+    remembers anything: the block is the caller's, like `err_flag`.  One per device, allocated by the first caller — a model does it
+    when it is built, so that a step captured into a hipGraph carries a live pointer (an allocation cannot be captured)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    w = _HANDOVER_WORDS.get(dev.index)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the hand-over status block of %s does not exist yet and cannot be allocated inside a stream "
+                               "capture: call ops.handover_word(device) (or build the model) before capturing" % dev)
+        w = torch.zeros(2, dtype=torch.int32, device=dev)
+        _HANDOVER_WORDS[dev.index] = w
+    return w
+
+
+def handover_status(reset: bool = True, device=None) -> int:
+    """Word 0 of handover_word(device): 0 = every poll of every launch so far completed.  Synchronises: a training / evaluation
+    loop does not call this — it reads the word with every step's metrics copy (models.sparse_graph_model.MetricsReadback) and
+    raises there; this is for code that launches the kernels directly (tests, scripts, smoke())."""
+    w = handover_word(device)
+    v = int(w[0].item())
+    if reset and v:
+        w[0].zero_()
+    return v
+
+
+class HandoverError(RuntimeError):
+    pass
+
+
+def raise_on_handover(value: int):
+    if value:
+        raise HandoverError(
+            "a wave-role kernel gave up on an LDS hand-over (status 0x%x:%s%s%s%s): the results of that launch are wrong — every "
+            "step since the last clean check is suspect" % (
+                value, " fused-layer matrix wave" if value & 1 else "", " fused-layer gather wave" if value & 2 else "",
+                " product matrix wave" if value & 4 else "", " product producer wave" if value & 8 else ""))
 
 
 def _fused_layer_ok(H, graph, w, kernels) -> bool:
@@ -1010,7 +1057,7 @@ def _rgcn_fused(H, graph, w, kernels, relu: bool, want_sums: bool):
     _lib.check(lib.relgnn_rgcn_fused_fwd(_lib.ptr(H, rows_strided=True), H.shape[0], H.stride(0), _lib.ptr(graph.rowptr_t), V, L,
                                          _lib.ptr(graph.src_t), _lib.ptr(w), buf.data_ptr(), None,
                                          _lib.ACT_RELU if relu else _lib.ACT_LINEAR, _lib.ptr(agg), L * 256, _lib.ptr(out), 256,
-                                         256, 256, _lib.current_stream()), "relgnn_rgcn_fused_fwd")
+                                         256, 256, handover_word(H.device).data_ptr(), _lib.current_stream()), "relgnn_rgcn_fused_fwd")
     return agg, out
 
 
