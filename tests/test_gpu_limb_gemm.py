@@ -847,3 +847,47 @@ def test_the_status_block_survives_a_captured_step(gpu_device):
     finally:
         word[1] = 0
         word[0] = 0
+
+
+@pytest.mark.parametrize("model_name", ["RGCN", "GGNN", "RGAT", "RGIN", "GNN-FiLM", "GNN-Edge-MLP0"])
+@pytest.mark.parametrize("res_every,dense_every", [(1, 1), (2, 1), (2, 2), (10000, 1), (10000, 2)])
+def test_folding_changes_no_bit_of_any_model_s_step(gpu_device, monkeypatch, model_name, res_every, dense_every):
+    """The folding of activation gradients rides on tags and on two 'I am the only reader' words (dense.py) — nothing at run time
+    cross-checks them.  This does, for every model class x residual cadence x Dense cadence with tanh Dense layers (the
+    non-idempotent case): one training step's loss and EVERY gradient with the folding allowed against the same step with every
+    producer running its own pass, bit for bit.  A layer that reads its input twice and says sole_reader, or a driver loop that
+    vouches for a tensor it keeps, shows up here as a differing gradient."""
+    from tf_gnn_samples_amd import dense as DN
+    from tf_gnn_samples_amd.graph import clear_graph_cache
+    from tf_gnn_samples_amd.models import name_to_model_class
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    task = PPI_Task(PPI_Task.default_params())
+    task.load_synthetic(2, 1, seed=5, mean_nodes=2400, std_nodes=100, min_nodes=2200, max_nodes=2600, fwd_edges_per_node=6.0)
+    mb = next(task.make_minibatch_iterator(task._loaded_data[DataFold.TRAIN], DataFold.VALIDATION, 10 ** 9))
+    assert mb.num_nodes >= 4096                                         # tall enough for the limb kernels' epilogues
+    cls, extra = name_to_model_class(model_name)
+
+    def step(fold: bool):
+        clear_graph_cache()
+        with monkeypatch.context() as mp:
+            if not fold:
+                mp.setattr(DN, "fusable_activation_of", lambda x, sole_reader=False: 0)
+            p = cls.default_params()
+            p.update(extra)
+            p.update(hidden_size=256, graph_num_layers=4, graph_layer_input_dropout_keep_prob=1.0, random_seed=0,
+                     graph_residual_connection_every_num_layers=res_every, graph_dense_between_every_num_gnn_layers=dense_every,
+                     graph_model_activation_function="tanh")
+            model = cls(p, task, device=str(gpu_device))
+            batch = DeviceBatch(mb, gpu_device)
+            model.optimizer.zero_grad()
+            m = model.forward_batch(batch, training=True)
+            m['loss'].backward()
+            torch.cuda.synchronize()
+            return (float(m['loss'].detach()),
+                    {n: model.variables[n].grad.detach().clone() for n in model.variables.names() if model.variables[n].grad is not None})
+
+    loss_f, grads_f = step(True)
+    loss_u, grads_u = step(False)
+    assert loss_f == loss_u and sorted(grads_f) == sorted(grads_u)
+    for n in grads_u:
+        assert torch.equal(grads_f[n], grads_u[n]), n

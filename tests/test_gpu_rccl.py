@@ -39,3 +39,49 @@ def test_rccl_process_group_on_one_gpu(gpu_device):
     env = dict(os.environ, REPO=repo)
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "RCCL_OK nccl" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def _bench(args, env=None, timeout=1500):
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, capture_output=True, text=True, cwd=repo,
+                       timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 6144
+    return json.loads(lines[0])
+
+
+def test_two_real_rccl_ranks_on_two_devices_run_the_bench_loop():
+    """bench.py --gpus 2 exactly as the driver's scaling run starts it (self-spawned torch.distributed.run, one rank per device,
+    RCCL over xGMI): skipped on a one-GPU box.  The line names both ranks, the flat all-reduce moved the RGCN gradient (2.8 MB) and
+    the aggregate rate is above one rank's."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two MI355X devices")
+    common = ["--steps", "4", "--warmup", "2", "--no-roofline", "--no-cpu-baseline", "--no-extras", "--no-detail"]
+    one = _bench(["--gpus", "1"] + common)
+    two = _bench(["--gpus", "2"] + common)
+    assert two["n_gpus"] == two["nranks"] == 2 and "nccl" in two["backend"] and len(two["per_rank_edges"]) == 2
+    assert two["gradient_allreduce_bytes"] >= 4 * 699257 and two["allreduce_ms"] > 0
+    assert two["value"] > 1.2 * one["value"], (one["value"], two["value"])
+
+
+def test_one_rank_launched_like_the_scaling_run_reproduces_the_plain_line():
+    """N = 1 of the driver's scaling command (torch.distributed.run --nproc-per-node 1) against `python bench.py`: the same loop, the
+    same number to within the box's run-to-run spread (asserted at 6 %: two 12-step runs on a shared box; typical 1-2 %)."""
+    import socket
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--steps", "12", "--warmup", "6", "--no-roofline", "--no-cpu-baseline", "--no-extras", "--no-detail"]
+    plain = _bench(common)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import json
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py")] + common,
+                       capture_output=True, text=True, cwd=repo, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    launched = json.loads(lines[0])
+    assert launched["n_gpus"] == 1 and launched["steps"] == 12
+    assert abs(launched["ms_per_step"] / plain["ms_per_step"] - 1.0) <= 0.06, (plain["ms_per_step"], launched["ms_per_step"])

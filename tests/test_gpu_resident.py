@@ -112,17 +112,6 @@ def test_resident_batches_and_plans_are_bit_identical(gpu_device, L):
     got = [x.num_graphs for x in resident.iterate(np.arange(30), 200)]
     want = [x.num_graphs for x in host.iterate(np.arange(30), 200)]
     assert got == want and sum(got) == 30
-    # RELGNN_ASSEMBLE_STREAM=side: every batch assembled on a side stream under the previous step — the same batches
-    from tf_gnn_samples_amd import config
-    with config.override(assemble_stream="side"):
-        side_batches = list(resident.iterate(np.arange(30), 200))
-    for x in side_batches:
-        x.wait_ready()
-    main_batches = list(resident.iterate(np.arange(30), 200))
-    assert len(side_batches) == len(main_batches)
-    for a, b in zip(side_batches, main_batches):
-        assert torch.equal(a.initial_node_features, b.initial_node_features) and torch.equal(a.graph.src_t, b.graph.src_t)
-        assert torch.equal(a.graph.rowptr_t, b.graph.rowptr_t) and torch.equal(a.graph.rowptr_s, b.graph.rowptr_s)
 
 
 def test_resident_qm9_with_per_graph_targets_and_training(gpu_device):
@@ -184,44 +173,3 @@ def test_lean_batches_stay_lean_through_an_rgcn_step_and_train_identically(gpu_d
         assert torch.equal(x, y)
     for name in ("perm_t", "col_t", "inv_perm_t", "perm_s", "frow_s", "pos_t_of_s"):
         assert torch.equal(getattr(lean_batch.graph, name), getattr(full_batch.graph, name)), name
-
-
-def test_padded_feature_rows_feed_the_input_projection(gpu_device):
-    """A resident fold keeps the [N, 50] node features in rows of 64 floats (zeros behind the features); a batch's feature tensor is
-    a [V, 50] view of such rows and says so (dense.mark_zero_padded); the input projection (models/sparse_graph_model.py:165-170:
-    Dense + activation) then runs as a K = 64 limb product with the activation in its epilogue.  Values: against float64 and
-    against the unpadded route (library product + activation pass); the kernel's gradient alike."""
-    from tf_gnn_samples_amd import _lib, config, dense as DN
-    from tf_gnn_samples_amd.tasks import DataFold, PPI_Task
-    from tf_gnn_samples_amd.tasks.resident import ResidentDataset
-    if not config.settings.limb_gemm:
-        pytest.skip("padded feature rows exist for the limb route (RELGNN_GEMM=limb)")
-    task = PPI_Task(PPI_Task.default_params())
-    task.load_synthetic(3, 1, seed=5)
-    store = task.make_graph_store(task._loaded_data[DataFold.TRAIN])
-    ids = np.array([0, 1, 2])
-    g = torch.Generator(device="cpu").manual_seed(3)
-    kernel = ((torch.rand((50, 256), generator=g) * 2 - 1) * 0.2).to(gpu_device)
-    gout = torch.randn((1, 256), generator=g).to(gpu_device)
-    res = {}
-    for pad in ("1", "0"):
-        with config.override(feature_pad=pad):
-            batch = ResidentDataset(store, gpu_device, constants={}).assemble(ids)
-            x = batch.initial_node_features
-            assert x.shape[1] == 50 and x.shape[0] >= 4096
-            padded = DN.zero_padded_operand(x)
-            if pad == "1":
-                assert padded is not None and padded.shape == (x.shape[0], 64) and float(padded[:, 50:].abs().max()) == 0.0
-            else:
-                assert padded is None and x.is_contiguous()
-            k = kernel.clone().requires_grad_(True)
-            y = DN.dense_act(x, k, None, _lib.ACT_TANH)
-            (y * gout).sum().backward()
-            res[pad] = (x.clone(), y.detach().clone(), k.grad.clone())
-    assert torch.equal(res["1"][0], res["0"][0])                         # the same features either way
-    x64 = res["1"][0].double()
-    truth = torch.tanh(x64 @ kernel.double())
-    gk = x64.t() @ ((1 - truth ** 2) * gout.double())
-    for pad in ("1", "0"):
-        assert float((res[pad][1].double() - truth).abs().max()) <= 2e-6, pad
-        assert float((res[pad][2].double() - gk).abs().max()) <= 4e-6 * float(gk.abs().max()), pad

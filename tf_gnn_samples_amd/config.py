@@ -38,12 +38,6 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                  "PPI head backward: the loss gradient written into rows zero-padded to a multiple of 16 columns, so that the head's "
                  "input-gradient product (K = 121) runs on the limb route with the last layer's ReLU' in its epilogue | the library "
                  "product + a ReLU' pass"),
-    "feature_pad": ("RELGNN_FEATURE_PAD", "0", ("0", "1"),
-                    "unpadded feature rows: the input projection is a K = 50 library product + an activation pass | resident folds keep "
-                    "the node features in rows zero-padded to a multiple of 16 columns (PPI: 50 -> 64) and the input projection runs on "
-                    "the limb route with its activation in the epilogue (measured: 1.996 vs 1.937 ms per C2 step, three alternations — "
-                    "a four-k-tile product is all prologue and epilogue on the limb kernel, and tanhf in the epilogue costs what the "
-                    "pass did: opt-in)"),
     "weight_limb_cache": ("RELGNN_WEIGHT_LIMB_CACHE", "1", ("0", "1"),
                           "limb images of the weights kept across the products of a step (re-split once after the optimizer's update)"),
     "act_fusion": ("RELGNN_ACT_FUSION", "1", ("0", "1"),
@@ -77,8 +71,6 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                     "compact tables over the non-empty (node, type) buckets (auto: L >= 8 and < 60 % of the buckets non-empty)"),
     "rgat_fused_sums": ("RELGNN_RGAT_FUSED_SUMS", "1", ("0", "1"),
                         "RGAT backward: the two score-table gradients carried along by the dz pass and the by-source gather"),
-    "assemble_stream": ("RELGNN_ASSEMBLE_STREAM", "main", ("main", "side"),
-                        "resident folds: the next batch's assembly on the caller's stream | on a side stream under the step"),
     "allreduce": ("RELGNN_ALLREDUCE", "flat", ("flat", "overlap"),
                   "data-parallel gradient all-reduce: one flat collective after the backward | buckets launched during the backward"),
 }
@@ -125,6 +117,10 @@ class _Settings:
 # switches that existed in earlier rounds and are gone (the environment variable is ignored: say so once, at import)
 _REMOVED = {
     "RELGNN_PAIR_CHUNK": "compact pair tables always use 512-row tiles (graph.PAIR_CHUNK)",
+    "RELGNN_FEATURE_PAD": "zero-padded feature rows for the input projection measured slower (1.996 vs 1.937 ms per C2 step, round 5) "
+                          "and were removed in round 6",
+    "RELGNN_ASSEMBLE_STREAM": "resident folds assemble the next batch on the caller's stream (the side-stream form stretched the GEMM "
+                              "it met from 113 to 229 us: 2.44 vs 2.38 ms, round 2; removed in round 6)",
 }
 
 

@@ -202,13 +202,6 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
     if act is None:
         act = 2 if relu else 0                                     # _lib.ACT_RELU / ACT_LINEAR
     relu = act == 2
-    if layout == GEMM_NN and weight and out is None and not accumulate and a.is_cuda and _cfg.limb_gemm and premask is None:
-        # node features whose rows their producer zero-padded to a multiple of 16 columns (a resident fold's [V, 50] features live
-        # in rows of 64: tasks/resident.py): the input projection on the limb route over the padded reduction length, its
-        # activation in the epilogue, instead of a K = 50 library product + an activation pass
-        ap = zero_padded_operand(a)
-        if ap is not None and _limb_padded_ok(ap, a.shape[1], b, bias, WEIGHT_NN):
-            return limb_gemm_weight(ap, b, WEIGHT_NN, bias, act)
     if layout == GEMM_NT and weight and out is None and not accumulate and a.is_cuda and _cfg.limb_gemm:
         # a gradient whose rows are zero-padded to a multiple of 16 columns by its producer (mark_zero_padded): the limb route over
         # the padded reduction length, with the activation gradient of the layer below in its epilogue — for the 121-label PPI
@@ -294,6 +287,11 @@ def _gemm_with_epilogues(layout: int, a, b, bias, act: int, weight: bool, premas
             and weight_image_ok(_weight_matrices(b), WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT)):
         return limb_gemm_weight(a, b, WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT, bias, act,
                                 dact=premask[0] if premask is not None else 0, dy=premask[1] if premask is not None else None)
+    if (premask is None and _cfg.limb_gemm and layout != GEMM_TN and act in _TORCH_ACT_
+            and _limb_route_ok(layout, a, b, bias, columns=128)):
+        # the D = 128 models' Dense layers (C3, C5: tanh between GNN layers): the 128-column panel kernels take any activation
+        # of the path in their epilogue (act_rt) — round 6: no tanh pass behind the product
+        return limb_dense_sel(layout, a, b, bias, act)
     res = lib_gemm(layout, a, b, bias, relu=(act == _lib.ACT_RELU), weight=weight)
     if act not in (_lib.ACT_LINEAR, _lib.ACT_RELU):
         fn = _TORCH_ACT_.get(act)

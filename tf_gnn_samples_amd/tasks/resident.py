@@ -51,15 +51,6 @@ class ResidentDataset:
             raise ValueError("data fold too large for one int32-indexed union; use the host batcher")
         # flat arrays -> HBM
         self.payload_d = [torch.as_tensor(a, device=dev) for a in store.payload]
-        # the node features in rows padded with zeros to a multiple of 16 columns (PPI: 50 -> 64): a batch's feature rows are then
-        # copied padded, and the input projection runs on the limb route over the padded reduction length (dense.mark_zero_padded)
-        self._feature_cols = None
-        if _cfg.settings.limb_gemm and _cfg.settings.feature_pad == "1" and features in store.payload_names:
-            i = store.payload_names.index(features)
-            t = self.payload_d[i]
-            if t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] % 16 and t.shape[0] > 0:
-                self._feature_cols = int(t.shape[1])
-                self.payload_d[i] = torch.nn.functional.pad(t, (0, (-t.shape[1]) % 16)).contiguous()
         self.graph_payload_d = {k: torch.as_tensor(v, device=dev) for k, v in store.graph_payload.items()}
         self.deg_d = torch.stack([torch.as_tensor(a, device=dev) for a in store.deg]) if L else torch.zeros((0, N), device=dev)
         self.adj_d = [torch.as_tensor(a, device=dev) for a in store.adj]         # [E_l, 2] int32, graph-local ids
@@ -102,7 +93,6 @@ class ResidentDataset:
         self._stage = [None] * 4
         self._stage_done = [None] * 4
         self._stage_at = 0
-        self._side = None
 
     def _staging(self, n: int) -> torch.Tensor:
         k = self._stage_at
@@ -161,9 +151,6 @@ class ResidentDataset:
             src = self.payload_d[i]
             out_fast.append(torch.empty((V,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev))
             payload[names[i]] = out_fast[-1]
-            if names[i] == self.features and self._feature_cols is not None:
-                from ..dense import mark_zero_padded
-                payload[names[i]] = mark_zero_padded(out_fast[-1][:, :self._feature_cols], int(src.shape[1]))
         deg = torch.empty((L, V), dtype=torch.float32, device=dev)
         n2g = torch.empty(V, dtype=torch.int32, device=dev)
         nf = len(self._fast)
@@ -250,25 +237,8 @@ class ResidentDataset:
         return batch
 
     def iterate(self, graph_ids: Sequence[int], max_nodes_per_batch: int) -> Iterator[DeviceBatch]:
-        """Batches of one epoch (the training loop asks for batch i+1 right after it has enqueued step i).  With
-        RELGNN_ASSEMBLE_STREAM=side each batch is assembled on a side stream under step i's kernels and the consumer's
-        stream waits for the batch's event (DeviceBatch.wait_ready / RelGraph.wait_ready) before its first kernel touches
-        the tensors."""
-        from ..config import settings
-        # Default: assemble on the CALLER's stream.  The lean assembly is ~85 us of streaming kernels; run on a side stream
-        # under the previous step they stretched whichever GEMM they met from 113 to 229 us (kernel timeline,
-        # scripts/gpu_step_timeline.sh) — 2.38 vs 2.44 ms per step in one A/B.  RELGNN_ASSEMBLE_STREAM=side keeps the overlap.
-        if settings.assemble_stream != "side":
-            for ids in self.store.split_batches(graph_ids, max_nodes_per_batch):
-                yield self.assemble(ids)
-            return
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+        """Batches of one epoch (the training loop asks for batch i+1 right after it has enqueued step i), assembled on the CALLER's
+        stream: the lean assembly is ~85 us of streaming kernels; on a side stream under the previous step they stretched whichever
+        GEMM they met from 113 to 229 us (2.38 vs 2.44 ms per step, round 2) — that form was a switch until round 6."""
         for ids in self.store.split_batches(graph_ids, max_nodes_per_batch):
-            with torch.cuda.stream(self._side):
-                batch = self.assemble(ids)
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-            batch.ready_event = ev
-            batch.graph.ready_event = ev
-            yield batch
+            yield self.assemble(ids)
