@@ -897,6 +897,14 @@ int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64
                               int64_t ldb, int32_t num_b, int64_t b_batch_stride, const int32_t* b_select, int32_t rows_per_select,
                               const float* bias, const void* zeros, uint16_t* limb_ws, int64_t limb_ws_elements, float* C,
                               int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* relgnn_limb_dense_sel_f32 with the weights ALREADY split (the same MatMul call sites: gnns/gnn_film.py:92-106, gnns/ggnn.py:76-81,
+ * the D = 128 Dense layers of models/sparse_graph_model.py:194-200): B_limbs holds num_b limb images of [N, K] operands one behind
+ * the other, relgnn_limb_elements(N, K) elements each, as relgnn_limb_split_multi_f32 / relgnn_limb_split_batch_f32 write them (an
+ * NN weight [K, N] is split transposed).  N % 128 == 0, K % 16 == 0, ldc % 4 == 0; a_rows / b_select / rows_per_select / bias / act
+ * as above.  The package splits the images of a step's weights once per optimizer step and calls this entry for every product. */
+int relgnn_limb_gemm_sel_xf32(int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const uint16_t* B_limbs, int32_t num_b,
+                              const int32_t* b_select, int32_t rows_per_select, const float* bias, const void* zeros, float* C,
+                              int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 /* Weight gradients dW = A^T @ G (A [V, J] = the saved layer input, G [V, C] = the output gradient; tf.gradients of the Dense
  * products above) on the same limb arithmetic: both operands fp32 row-major, split AND transposed in flight (the reduction index is
  * the row of both).  The kernel takes the first V - V % 32 rows, cut into relgnn_limb_gemm_tn_chunks(V, J, C) chunks; chunk z writes

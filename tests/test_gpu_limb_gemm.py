@@ -788,6 +788,9 @@ def test_a_product_that_gives_up_on_a_hand_over_fails_the_next_metrics_fetch(gpu
     bit into the CALLER's status block (include/relgnn.h: relgnn_limb_gemm_xf32_pc, `status`).  The model owns that block and reads
     it with every step's metrics copy (MetricsReadback): with the poll bound set to 1 — word 1 of the block, the debug knob — a
     C2-size forward product gives up and the step's metrics fetch raises instead of training on."""
+    from tf_gnn_samples_amd import config as _config
+    if not (_config.settings.limb_gemm and _config.settings.limb == "triple" and _config.settings.limb_pc != "0"):
+        pytest.skip("the wave-role product kernel runs on the exact-split limb route only")
     from tf_gnn_samples_amd import ops
     from tf_gnn_samples_amd.models import RGCN_Model
     from tf_gnn_samples_amd.models.sparse_graph_model import MetricsReadback
@@ -825,6 +828,9 @@ def test_a_product_that_gives_up_on_a_hand_over_fails_the_next_metrics_fetch(gpu
 def test_the_status_block_survives_a_captured_step(gpu_device):
     """A hipGraph replays the pointers it was captured with: the status block exists before the capture (the model allocates it
     when it is built), so a captured step reports like an eager one."""
+    from tf_gnn_samples_amd import config as _config
+    if not (_config.settings.limb_gemm and _config.settings.limb == "triple" and _config.settings.limb_pc != "0"):
+        pytest.skip("the wave-role product kernel runs on the exact-split limb route only")
     from tf_gnn_samples_amd import ops
     from tf_gnn_samples_amd.models import RGCN_Model
     from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
@@ -891,3 +897,75 @@ def test_folding_changes_no_bit_of_any_model_s_step(gpu_device, monkeypatch, mod
     assert loss_f == loss_u and sorted(grads_f) == sorted(grads_u)
     for n in grads_u:
         assert torch.equal(grads_f[n], grads_u[n]), n
+
+
+def test_panel_products_take_cached_weight_images_and_give_the_same_bits(gpu_device):
+    """relgnn_limb_gemm_sel_xf32 (round 6: the 128-column panel products read their weights' limb images from the step's cache,
+    dense.weight_image(separate=True)) against relgnn_limb_dense_sel_f32 (which splits a stacked copy of the weights in front of
+    every product): typed forward with gathered rows + per-tile kernels, typed input gradient, a plain Dense with a tanh epilogue —
+    the same bits; and the cache follows the weights (in-place write + weights_changed(): the next product uses the new values)."""
+    from tf_gnn_samples_amd import _lib, dense as DN
+    dev = gpu_device
+    L, tiles, V = 7, 40, 9000
+    P = tiles * 512
+    g = torch.Generator(device="cpu").manual_seed(0)
+    tile_type = torch.sort(torch.randint(0, L, (tiles,), generator=g)).values.to(torch.int32).to(dev)
+    node = torch.randint(-1, V, (P,), generator=g).to(torch.int32).to(dev)              # (-1: a padding row -> zeros)
+    H = _rand((V, 128), dev, 1)
+    for Dout in (128, 256):
+        Ws = [_rand((128, Dout), dev, 10 + l, 0.1) for l in range(L)]
+        assert DN.sel_weights_cacheable(Ws, DN.GEMM_NN) and DN.sel_weights_cacheable(Ws, DN.GEMM_NT)
+        stacked = torch.stack(Ws)
+        want = DN.limb_dense_sel(DN.GEMM_NN, H, stacked, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512)
+        got = DN.limb_dense_sel(DN.GEMM_NN, H, Ws, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512, cached=True)
+        assert torch.equal(got, want)
+        gY = _rand((P, Dout), dev, 3)
+        want = DN.limb_dense_sel(DN.GEMM_NT, gY, stacked, b_select=tile_type, rows_per_select=512)
+        got = DN.limb_dense_sel(DN.GEMM_NT, gY, Ws, b_select=tile_type, rows_per_select=512, cached=True)
+        assert torch.equal(got, want)
+        # the cache follows the weights
+        with torch.no_grad():
+            Ws[2].mul_(-0.5)                                                          # moves the tensor's version
+        stacked = torch.stack(Ws)
+        assert torch.equal(DN.limb_dense_sel(DN.GEMM_NT, gY, Ws, b_select=tile_type, rows_per_select=512, cached=True),
+                           DN.limb_dense_sel(DN.GEMM_NT, gY, stacked, b_select=tile_type, rows_per_select=512))
+        Ws[3].data.copy_(Ws[3].data * 2.0)                                            # behind torch's back: the caller says so
+        DN.weights_changed()
+        stacked = torch.stack(Ws)
+        assert torch.equal(DN.limb_dense_sel(DN.GEMM_NN, H, Ws, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512,
+                                             cached=True),
+                           DN.limb_dense_sel(DN.GEMM_NN, H, stacked, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512))
+    # a plain D = 128 Dense with tanh in the epilogue: cached image vs split-per-call, and vs float64
+    x, k, b = _rand((9000, 128), dev, 5), _rand((128, 128), dev, 6, 0.1), _rand((128,), dev, 7, 0.1)
+    a1 = DN.limb_dense_sel(DN.GEMM_NN, x, k, b, _lib.ACT_TANH, cached=True)
+    a0 = DN.limb_dense_sel(DN.GEMM_NN, x, k, b, _lib.ACT_TANH)
+    assert torch.equal(a1, a0)
+    assert float((a1.double() - torch.tanh(x.double() @ k.double() + b.double())).abs().max()) <= 2e-6
+    assert torch.equal(DN.lib_gemm(DN.GEMM_NN, x, k, b, weight=True, act=_lib.ACT_TANH), a0)      # the route the Dense layers take
+
+
+def test_dense_multi_is_the_product_with_the_concatenated_kernels(gpu_device):
+    """dense.dense_multi(x, [k_0 .. k_4]) = x @ [k_0 | .. | k_4] (gnns/ggnn.py:60-64,81 for every node) without the concatenated
+    operand: forward and input gradient bit for bit against dense(x, torch.cat(...)), the five weight gradients against float64,
+    each a dense tensor of its own."""
+    from tf_gnn_samples_amd import dense as DN
+    dev = gpu_device
+    V, K, N, L = 20000, 128, 128, 5
+    x = _rand((V, K), dev, 1).requires_grad_(True)
+    ks = [_rand((K, N), dev, 20 + l, 0.1).requires_grad_(True) for l in range(L)]
+    gy = _rand((V, L * N), dev, 2, 0.01)
+    y = DN.dense_multi(x, ks)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("_DenseMultiFn")
+    y.backward(gy)
+    got = (y.detach().clone(), x.grad.clone(), [k.grad.clone() for k in ks])
+    assert all(k.grad.is_contiguous() for k in ks)
+    x.grad = None
+    for k in ks:
+        k.grad = None
+    y2 = DN.dense(x, torch.cat(ks, dim=1))
+    y2.backward(gy)
+    assert torch.equal(got[0], y2.detach()) and torch.equal(got[1], x.grad)
+    for l in range(L):
+        want = x.detach().double().t() @ gy[:, l * N:(l + 1) * N].double()
+        assert float((got[2][l].double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), l
+        assert float((ks[l].grad.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), l

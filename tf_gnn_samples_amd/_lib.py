@@ -115,6 +115,8 @@ _SIGNATURES = {
     "relgnn_limb_split_batch_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr]),
     "relgnn_limb_dense_sel_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i64, _ptr, _c_i32, _ptr, _ptr,
                                                  _ptr, _c_i64, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _ptr]),
+    "relgnn_limb_gemm_sel_xf32": (ctypes.c_int, [_c_i32, _ptr, _c_i64, _ptr, _ptr, _c_i32, _ptr, _c_i32, _ptr, _ptr, _ptr, _c_i64, _c_i32,
+                                                 _c_i32, _c_i32, _ptr]),
     "relgnn_limb_dense_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _c_i32,
                                              _c_i32, _c_i32, _ptr]),
     "relgnn_blaslt_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32,

@@ -1875,6 +1875,32 @@ int relgnn_limb_gemm_tn_tiles_f32(const float* A, int64_t lda, const int32_t* a_
   return launch_status();
 }
 
+// launch of the 128-column panel kernels over limb images that exist (relgnn_limb_dense_sel_f32 splits first; relgnn_limb_gemm_sel_xf32
+// takes them from the caller)
+static int limb_sel_launch(int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const uint16_t* limbs, int64_t per,
+                           const int32_t* b_select, int32_t rows_per_select, const float* bias, const void* zeros, float* C,
+                           int64_t ldc, int32_t M, int32_t N, int32_t n_valid, int32_t K, bool cut, void* stream) {
+  LimbSelArgs a{};
+  a.n_valid = n_valid;
+  a.Ax = A; a.lda = lda; a.rows = a_rows; a.B = limbs; a.b_select = b_select; a.rows_per_select = rows_per_select; a.b_stride = per;
+  a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
+  a.chunks = N / 128;
+  // K = 128, tall: persistent workgroups with the weights resident in LDS (limb_gemm_tile_kernel), one per CU
+  static const bool tile_form = []() { const char* e = getenv("RELGNN_LIMB_TILE"); return !(e && e[0] == '0'); }();
+  // (typed products — large by construction; a plain product needs ~4 panels per workgroup before this form pays: measured)
+  if (tile_form && !cut && K == 128 && M >= 128 * 256 && (b_select || (int64_t)M * a.chunks >= (int64_t)128 * 256 * 4)) {
+    if (!b_select) a.rows_per_select = 128;
+    a.panels = 256 / a.chunks > 0 ? 256 / a.chunks : 1;          // workgroups per column chunk
+    const int64_t logical = (int64_t)a.panels * a.chunks;
+    limb_gemm_tile_kernel<<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, as_stream(stream)>>>(a);
+    return launch_status();
+  }
+  a.panels = (M + 127) / 128;
+  const int64_t logical = (int64_t)a.panels * a.chunks;
+  limb_gemm_sel_kernel<<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, as_stream(stream)>>>(a);
+  return launch_status();
+}
+
 // 128 x 128 panels with gathered rows and per-panel weights (limb_gemm_sel_kernel): the weights are `num_b` fp32 matrices at
 // B + i * b_batch_stride (RELGNN_GEMM_NN: [K, N] each; RELGNN_GEMM_NT: [N, K] each), all split into limb_ws first (one launch).
 int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const float* B,
@@ -1900,25 +1926,26 @@ int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64
   const int sp = layout == RELGNN_GEMM_NN ? relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, K, n_valid, 1, num_b, limb_ws, stream)
                                           : relgnn_limb_split_batch_f32(B, ldb, b_batch_stride, n_valid, K, 0, num_b, limb_ws, stream);
   if (sp != RELGNN_OK) return sp;
-  LimbSelArgs a{};
-  a.n_valid = n_valid;
-  a.Ax = A; a.lda = lda; a.rows = a_rows; a.B = limb_ws; a.b_select = b_select; a.rows_per_select = rows_per_select; a.b_stride = per;
-  a.bias = bias; a.zeros = static_cast<const uint16_t*>(zeros); a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
-  a.chunks = N / 128;
-  // K = 128, tall: persistent workgroups with the weights resident in LDS (limb_gemm_tile_kernel), one per CU
-  static const bool tile_form = []() { const char* e = getenv("RELGNN_LIMB_TILE"); return !(e && e[0] == '0'); }();
-  // (typed products — large by construction; a plain product needs ~4 panels per workgroup before this form pays: measured)
-  if (tile_form && !cut && K == 128 && M >= 128 * 256 && (b_select || (int64_t)M * a.chunks >= (int64_t)128 * 256 * 4)) {
-    if (!b_select) a.rows_per_select = 128;
-    a.panels = 256 / a.chunks > 0 ? 256 / a.chunks : 1;          // workgroups per column chunk
-    const int64_t logical = (int64_t)a.panels * a.chunks;
-    limb_gemm_tile_kernel<<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, as_stream(stream)>>>(a);
-    return launch_status();
-  }
-  a.panels = (M + 127) / 128;
-  const int64_t logical = (int64_t)a.panels * a.chunks;
-  limb_gemm_sel_kernel<<<(unsigned)(8 * ((logical + 7) / 8)), 512, 0, as_stream(stream)>>>(a);
-  return launch_status();
+  return limb_sel_launch(act, A, lda, a_rows, limb_ws, per, b_select, rows_per_select, bias, zeros, C, ldc, M, N, n_valid, K, cut, stream);
+}
+
+// The same product with the weights ALREADY split: B_limbs holds num_b limb images of [N, K] operands one behind the other
+// (relgnn_limb_elements(N, K) elements each; relgnn_limb_split_multi_f32 / _batch_f32 write them) — the form the package uses since
+// round 6: the images of a step's weights are split once per optimizer step, not in front of every product.
+int relgnn_limb_gemm_sel_xf32(int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const uint16_t* B_limbs, int32_t num_b,
+                              const int32_t* b_select, int32_t rows_per_select, const float* bias, const void* zeros, float* C,
+                              int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || num_b < 1 || act < RELGNN_ACT_LINEAR || act > RELGNN_ACT_GELU) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!A || !B_limbs || !C || !zeros) return RELGNN_EINVAL;
+  if (K == 0 || K % BK != 0 || N % 128 != 0 || ldc % 4 != 0) return RELGNN_EUNSUPPORTED;
+  if (!aligned16(A) || !aligned16(B_limbs) || !aligned16(zeros) || !aligned16(C) || (bias && !aligned16(bias)) || ldc < N || lda % 4 ||
+      lda < K)
+    return RELGNN_EUNSUPPORTED;
+  if (b_select && (rows_per_select <= 0 || rows_per_select % 128 != 0)) return RELGNN_EINVAL;
+  if (!b_select && num_b != 1) return RELGNN_EINVAL;
+  return limb_sel_launch(act, A, lda, a_rows, B_limbs, relgnn_limb_elements(N, K), b_select, rows_per_select, bias, zeros, C, ldc, M, N,
+                         N, K, false, stream);
 }
 
 // The Dense product as the path calls it: fp32 activations x fp32 weights.  The weights (N x K elements, a few hundred KB) are

@@ -217,7 +217,8 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
         if _limb_route_ok(layout, a, b, bias):
             return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR, weight=weight)
         if _limb_route_ok(layout, a, b, bias, columns=128):        # the D = 128 models: 128 x 128 panels, two workgroups per CU
-            return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
+            return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR,
+                                  cached=weight and sel_weights_cacheable(b, layout))
         if layout == GEMM_NN and _limb_cut_route_ok(a, b, bias):   # N just short of a multiple of 128 (the 121 labels of the PPI head)
             return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
     if ((_cfg.gemm == "panel") and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
@@ -291,7 +292,7 @@ def _gemm_with_epilogues(layout: int, a, b, bias, act: int, weight: bool, premas
             and _limb_route_ok(layout, a, b, bias, columns=128)):
         # the D = 128 models' Dense layers (C3, C5: tanh between GNN layers): the 128-column panel kernels take any activation
         # of the path in their epilogue (act_rt) — round 6: no tanh pass behind the product
-        return limb_dense_sel(layout, a, b, bias, act)
+        return limb_dense_sel(layout, a, b, bias, act, cached=weight and sel_weights_cacheable(b, layout))
     res = lib_gemm(layout, a, b, bias, relu=(act == _lib.ACT_RELU), weight=weight)
     if act not in (_lib.ACT_LINEAR, _lib.ACT_RELU):
         fn = _TORCH_ACT_.get(act)
@@ -557,25 +558,40 @@ def weight_limbs(w, kind: str) -> torch.Tensor:
     return weight_image(w, kind).buf
 
 
-def weight_image(w, kind: str, pair: bool = False) -> "_WeightImage":
+def weight_image(w, kind: str, pair: bool = False, separate: bool = False) -> "_WeightImage":
     """The limb image of a weight operand as the right operand B [N, K] of relgnn_limb_gemm_xf32 (pair: of relgnn_limb16_gemm_xf32:
     two fp16 limbs, .wmax = the device float its scale comes from); .buf is the flat 16-bit buffer.  w: a matrix, a
     [L, ., .] stack or a sequence of matrices (laid side by side along k):
       WEIGHT_NN  w_l [K_l, N]:  [x_0 | x_1 | ..] @ [w_0; w_1; ..] = sum_l x_l @ w_l     (Dense forward; gnns/rgcn.py:96-98 summed over
                                                                                           the edge types in one product)
       WEIGHT_NT  w_l [N, K_l]:  [g_0 | g_1 | ..] @ [w_0 | w_1 | ..]^T = sum_l g_l @ w_l^T   (the input gradients of the same)
+    separate: one image PER matrix, one behind the other in the buffer (matrix l at element l * relgnn_limb_elements(N, K); every
+    matrix the same shape, N % 128 == 0) — the per-edge-type operands of relgnn_limb_gemm_sel_xf32 (round 6: the typed transforms
+    and the D = 128 Dense layers no longer re-split their weights in front of every product).
     Valid until the next weights_changed() / in-place write to a matrix; on the current stream."""
     from . import _lib
     lib = _lib.load_library()
     ws = _weight_matrices(w)
-    rows, cols = _weight_image_shape(ws, kind)
+    if separate:
+        rows, cols = _weight_image_shape(ws[:1], kind)
+        per = int(lib.relgnn_limb_elements(rows, cols))
+        elements = per * len(ws)
+    else:
+        rows, cols = _weight_image_shape(ws, kind)
+        elements = int(lib.relgnn_limb16_elements(rows, cols) if pair else lib.relgnn_limb_elements(rows, cols))
     dev = ws[0].device
-    elements = int(lib.relgnn_limb16_elements(rows, cols) if pair else lib.relgnn_limb_elements(rows, cols))
+
+    def make_items(buf):
+        if not separate:
+            return _weight_image_items(ws, kind, buf)
+        return [(m.data_ptr(), m.stride(0), m.shape[0], m.shape[1], 1 if kind == WEIGHT_NN else 0, buf.data_ptr() + 2 * per * l, 0,
+                 cols // 16) for l, m in enumerate(ws)]
+
     if torch.cuda.is_current_stream_capturing() or _cfg.weight_limb_cache != "1":
         im = _WeightImage()
         im.pair, im.wmax = pair, None
         im.buf = torch.empty(elements, dtype=torch.bfloat16, device=dev)
-        im.items = _weight_image_items(ws, kind, im.buf)
+        im.items = make_items(im.buf)
         _split_weight_images([im])
         return im
     import weakref
@@ -583,7 +599,7 @@ def weight_image(w, kind: str, pair: bool = False) -> "_WeightImage":
     table = _WEIGHT_LIMBS.lookup(skey)
     if table is None:
         table = _WEIGHT_LIMBS.store(skey, {})
-    key = (kind, pair) + tuple((m.data_ptr(), m.shape[0], m.shape[1], m.stride(0)) for m in ws)
+    key = (kind, pair, separate) + tuple((m.data_ptr(), m.shape[0], m.shape[1], m.stride(0)) for m in ws)
     gen = _WEIGHT_GEN[0]
     im = table.get(key)
     bases = [m._base if m._base is not None else m for m in ws]
@@ -597,7 +613,7 @@ def weight_image(w, kind: str, pair: bool = False) -> "_WeightImage":
         im.refs, im.gen, im.versions, im.used_gen = [weakref.ref(b) for b in bases], -1, None, gen
         im.pair, im.wmax = pair, None
         im.buf = torch.empty(elements, dtype=torch.bfloat16, device=dev)
-        im.items = _weight_image_items(ws, kind, im.buf)
+        im.items = make_items(im.buf)
     todo = [im]
     for k, other in list(table.items()):
         if other is im:
@@ -754,14 +770,41 @@ def _limb_ws(device, need: int) -> torch.Tensor:
     return ws
 
 
-def limb_dense_sel(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor = None, act: int = 0, *,
-                   a_rows: torch.Tensor = None, num_rows: int = None, b_select: torch.Tensor = None, rows_per_select: int = 0
-                   ) -> torch.Tensor:
+def sel_weights_cacheable(ws, layout: int) -> bool:
+    """May the 128-column panel product take its weights from the step's limb-image cache (weight_image(separate=True))?  ws: the
+    weight matrices as the caller holds them (parameters or views of parameters: something whose storage outlives the product and
+    whose version moves when it is written) — all the same shape, N % 128 == 0, K % 16 == 0."""
+    ws = _weight_matrices(ws)
+    kind = WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT
+    n, k = (ws[0].shape[1], ws[0].shape[0]) if layout == GEMM_NN else (ws[0].shape[0], ws[0].shape[1])
+    return (_cfg.weight_limb_cache == "1" and n % 128 == 0 and k % 16 == 0 and all(m.shape == ws[0].shape for m in ws)
+            and weight_image_ok(ws[:1], kind) and all(weight_image_ok([m], kind) for m in ws[1:]))
+
+
+def limb_dense_sel(layout: int, a: torch.Tensor, b, bias: torch.Tensor = None, act: int = 0, *,
+                   a_rows: torch.Tensor = None, num_rows: int = None, b_select: torch.Tensor = None, rows_per_select: int = 0,
+                   cached: bool = False, as_one: bool = False) -> torch.Tensor:
     """relgnn_limb_dense_sel_f32: the limb product in 128 x 128 panels.  b: [K, N] / [N, K] (NN / NT) or, with b_select,
-    [num_b, K, N] / [num_b, N, K]; a_rows: int32 row ids of `a` per output row (< 0: zeros), num_rows output rows."""
+    [num_b, K, N] / [num_b, N, K]; a_rows: int32 row ids of `a` per output row (< 0: zeros), num_rows output rows.
+    cached=True (sel_weights_cacheable(b, layout)): b is the weight matrix / the LIST of per-type weight matrices themselves; their
+    limbs come from the step's image cache (relgnn_limb_gemm_sel_xf32: no split launch, no stacked copy of the weights)."""
     from . import _lib
     lib = _lib.load_library()
     K = a.shape[1]
+    if cached:
+        ws = _weight_matrices(b)
+        kind = WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT
+        N = ws[0].shape[1] if layout == GEMM_NN else ws[0].shape[0]
+        M = int(num_rows) if a_rows is not None else a.shape[0]
+        im = weight_image(ws, kind, separate=True)
+        if as_one:           # the images one behind the other = the image of [w_0 | w_1 | ..] stacked along N: ONE product, L*N columns
+            return _sel_with_image(a, im, len(ws) * N, K, act, bias)
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _lib.check(lib.relgnn_limb_gemm_sel_xf32(act, a.data_ptr(), a.stride(0), _lib.ptr(a_rows), im.buf.data_ptr(), len(ws),
+                                                 _lib.ptr(b_select), int(rows_per_select), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
+                                                 out.data_ptr(), out.stride(0), M, N, K, _lib.current_stream()),
+                   "relgnn_limb_gemm_sel_xf32")
+        return out
     num_b = b.shape[0] if b.dim() == 3 else 1
     N = b.shape[-1] if layout == GEMM_NN else b.shape[-2]
     M = int(num_rows) if a_rows is not None else a.shape[0]
@@ -1052,6 +1095,63 @@ class _DenseFn(torch.autograd.Function):
                 gx = lib_gemm(GEMM_NT, g, kernel, weight=True)
         gk, gb = aside if aside is not None else weight_side()
         return gx, gk, gb, None, None
+
+
+class _DenseMultiFn(torch.autograd.Function):
+    """x @ [k_0 | k_1 | ..] for L kernels [K, N] (the per-edge-type Dense kernels of a GGNN / FiLM layer applied to every node:
+    gnns/ggnn.py:60-64,81) WITHOUT forming the column-concatenated [K, L*N] operand: the limb images of the kernels, one behind the
+    other, ARE the image of the concatenation (row blocks of 32 output columns are contiguous), and they come from the step's cache.
+    Round 6: per layer one torch.cat, its five slice copies in the backward and three split launches less."""
+
+    @staticmethod
+    def forward(ctx, x, *kernels):
+        y = limb_dense_sel(GEMM_NN, x, list(kernels), cached=True, as_one=True)
+        ctx.save_for_backward(x, *kernels)
+        ctx.leaf_params = tuple(kernels) if all(k.is_leaf for k in kernels) else None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *kernels = ctx.saved_tensors
+        L, (K, N) = len(kernels), kernels[0].shape
+        g = g.contiguous()
+        gx = gks = None
+
+        def weight_side():
+            # dk_l = x^T @ g[:, block l], one streaming product per kernel: each gradient is a dense [K, N] tensor of its own, which
+            # autograd's accumulator keeps as it is (a column block of one [K, L*N] product would be cloned — five copies, and on
+            # the main stream while the side stream still writes it)
+            return tuple(matmul_tn_splitk(x, g[:, l * N:(l + 1) * N]) if ctx.needs_input_grad[1 + l] else None for l in range(L))
+
+        aside = _on_side_stream(weight_side, (x, g), ctx.leaf_params, want=ctx.needs_input_grad[0] and any(ctx.needs_input_grad[1:]))
+        if ctx.needs_input_grad[0]:
+            # gx = sum_l g[:, block l] @ k_l^T: the kernels side by side along the reduction (WEIGHT_NT image), 128 output columns
+            im = weight_image(kernels, WEIGHT_NT)                        # B [K, L*N] = [k_0 | k_1 | ..] as stored
+            gx = _sel_with_image(g, im, K, L * N)
+        gks = aside if aside is not None else (weight_side() if any(ctx.needs_input_grad[1:]) else (None,) * L)
+        return (gx,) + tuple(gks)
+
+
+def _sel_with_image(a: torch.Tensor, im, n: int, k: int, act: int = 0, bias: torch.Tensor = None) -> torch.Tensor:
+    """act(bias + a @ B^T) on the 128-column panels, B [n, k] = the limb image im (relgnn_limb_gemm_sel_xf32, one matrix)."""
+    from . import _lib
+    lib = _lib.load_library()
+    out = torch.empty((a.shape[0], n), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_limb_gemm_sel_xf32(act, a.data_ptr(), a.stride(0), None, im.buf.data_ptr(), 1, None, 0, _lib.ptr(bias),
+                                             _lib.ptr(_zeros(a.device)), out.data_ptr(), out.stride(0), a.shape[0], n, k,
+                                             _lib.current_stream()), "relgnn_limb_gemm_sel_xf32")
+    return out
+
+
+def dense_multi(x: torch.Tensor, kernels) -> torch.Tensor:
+    """x @ [k_0 | k_1 | ..] ([V, L*N]; row v viewed as [L, N] is (x_v k_0, .., x_v k_{L-1})) for L same-shaped kernels [K, N]."""
+    kernels = list(kernels)
+    K, N = kernels[0].shape
+    if (_cfg.limb_gemm and _rows_ok(x) and x.shape[0] >= _LIMB_MIN_ROWS and x.shape[1] == K and N % 128 == 0 and K % 128 == 0
+            and len(kernels) * N <= _LIMB_MAX_K and sel_weights_cacheable(kernels, GEMM_NN)
+            and all(k.is_contiguous() and k.data_ptr() % 16 == 0 for k in kernels) and not torch.cuda.is_current_stream_capturing()):
+        return _DenseMultiFn.apply(x, *kernels)
+    return dense(x, torch.cat(kernels, dim=1))
 
 
 def dense(x: torch.Tensor, kernel: torch.Tensor, bias: torch.Tensor = None, sole_reader: bool = False) -> torch.Tensor:

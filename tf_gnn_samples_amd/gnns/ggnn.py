@@ -8,10 +8,10 @@ from typing import List, Mapping, Optional
 import torch
 
 from .. import ops
-from ..dense import dense
+from ..dense import dense_multi
 from ..graph import as_rel_graph
 from ..utils import gated_unit_variable_shapes, get_gated_unit
-from ._common import concat_edge_kernels, require_weights
+from ._common import require_weights
 
 
 def ggnn_layer_variables(num_edge_types: int, in_dim: int, state_dim: int, gated_unit_type: str = "gru"):
@@ -52,13 +52,13 @@ def sparse_ggnn_layer(node_embeddings: torch.Tensor,
         kernels = [weights["Edge_%i_Weight/kernel" % l] for l in range(L)]
     else:
         plan = graph.plan_transformed(None)
-        w_cat = concat_edge_kernels(weights, L, "Edge_%i_Weight/kernel")
+        kernels = [weights["Edge_%i_Weight/kernel" % l] for l in range(L)]
     cur_node_states = node_embeddings
     for _ in range(num_timesteps):
         if pairs is not None:
             transformed = ops.typed_linear(cur_node_states, pairs.src, kernels)
         else:
-            transformed = dense(cur_node_states, w_cat).view(num_nodes * L, state_dim)
+            transformed = dense_multi(cur_node_states, kernels).view(num_nodes * L, state_dim)   # row v*L + l = h_v W_l
         aggregated_messages = ops.seg_gather_reduce(transformed, plan, message_aggregation_function, None)
         cur_node_states = gated_cell(aggregated_messages, [cur_node_states])[0]
     return cur_node_states

@@ -517,23 +517,35 @@ class _TypedLinearPanel(torch.autograd.Function):
                                                    partials summed per type by the gather-reduce kernel (tile order)"""
 
     @staticmethod
-    def forward(ctx, H, side, W, leaves):
-        from .dense import GEMM_NN, limb_dense_sel, panel_gemm
-        ctx.leaf_params = leaves            # the per-type weights W was stacked from, when every one is a leaf parameter
-        L, Din, Dout = W.shape
+    def forward(ctx, H, side, leaves, *weights):
+        from .dense import GEMM_NN, limb_dense_sel, panel_gemm, sel_weights_cacheable
+        ctx.leaf_params = leaves            # the per-type weights themselves, when every one is a leaf parameter
+        L, (Din, Dout) = len(weights), weights[0].shape
         node32, tile_type = side.panel_indices()
-        if _typed_limb_ok(Din, Dout):
+        # round 6: the limb images of the per-type weights come from the step's cache (dense.weight_image(separate=True)): neither a
+        # stacked [L, Din, Dout] copy nor a split launch in front of the product
+        cached = _typed_limb_ok(Din, Dout) and _typed_limb_ok(Dout, Din) and sel_weights_cacheable(weights, GEMM_NN) \
+            and sel_weights_cacheable(weights, GEMM_NT)
+        W = None if cached else torch.stack(weights)
+        if cached:
+            Y = limb_dense_sel(GEMM_NN, H, list(weights), a_rows=node32, num_rows=side.P, b_select=tile_type,
+                               rows_per_select=side.chunk, cached=True)
+        elif _typed_limb_ok(Din, Dout):
             Y = limb_dense_sel(GEMM_NN, H, W, a_rows=node32, num_rows=side.P, b_select=tile_type, rows_per_select=side.chunk)
         else:
             Y = panel_gemm(GEMM_NN, H, W, a_rows=node32, num_rows=side.P, b_select=tile_type, rows_per_select=side.chunk)
-        ctx.side, ctx.shape = side, (L, Din, Dout)
-        ctx.save_for_backward(H, W)
+        ctx.side, ctx.shape, ctx.cached = side, (L, Din, Dout), cached
+        if cached:
+            ctx.save_for_backward(H, *weights)
+        else:
+            ctx.save_for_backward(H, W)
         return Y
 
     @staticmethod
     def backward(ctx, gY):
         from .dense import GEMM_NT, GEMM_TN, limb_dense_sel, panel_gemm
-        H, W = ctx.saved_tensors
+        H, *saved = ctx.saved_tensors
+        W = None if ctx.cached else saved[0]
         side = ctx.side
         L, Din, Dout = ctx.shape
         gY = gY.contiguous()
@@ -563,7 +575,8 @@ class _TypedLinearPanel(torch.autograd.Function):
         # kernels that follow on the main stream (the other typed product's row sums, the next layer's fused edge backward); the
         # join is deferred behind the whole backward inside train_step (deferred_weight_gradient_join above).
         side_stream = None
-        if (ctx.needs_input_grad[2] and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and gY.is_cuda
+        want_w = any(ctx.needs_input_grad[3:])
+        if (want_w and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and gY.is_cuda
                 and (not _DEFER["on"] or deferred_targets_ok(ctx.leaf_params, gY.device))):
             side_stream = _side_stream(gY.device)
             cur = torch.cuda.current_stream(gY.device)
@@ -573,7 +586,9 @@ class _TypedLinearPanel(torch.autograd.Function):
             for t in (H, gY):
                 t.record_stream(side_stream)
         if ctx.needs_input_grad[0]:
-            if _typed_limb_ok(Dout, Din):
+            if ctx.cached:
+                gX = limb_dense_sel(GEMM_NT, gY, list(saved), b_select=tile_type, rows_per_select=side.chunk, cached=True)
+            elif _typed_limb_ok(Dout, Din):
                 gX = limb_dense_sel(GEMM_NT, gY, W, b_select=tile_type, rows_per_select=side.chunk)
             else:
                 gX = panel_gemm(GEMM_NT, gY, W, b_select=tile_type, rows_per_select=side.chunk, dims=(side.P, Din, Dout))
@@ -584,10 +599,11 @@ class _TypedLinearPanel(torch.autograd.Function):
             else:
                 torch.cuda.current_stream(gY.device).wait_stream(side_stream)
             gW.record_stream(torch.cuda.current_stream(gY.device))
-        elif ctx.needs_input_grad[2]:
+        elif want_w:
             wait_if_in_flight(ctx.leaf_params, gY.device)     # (no-op unless an earlier use of these weights went aside)
             gW = weight_gradient()
-        return gH, None, gW, None
+        need = ctx.needs_input_grad[3:]
+        return (gH, None, None) + (tuple(g if n else None for g, n in zip(gW.unbind(0), need)) if gW is not None else (None,) * L)
 
 
 def _typed_limb_ok(k: int, n: int) -> bool:
@@ -610,7 +626,7 @@ def typed_linear(H, side, weights):
     if _typed_panel_ok(H, side, weights):
         weights = list(weights)
         leaves = tuple(weights) if all(w.is_leaf and w.requires_grad for w in weights) else None
-        return _TypedLinearPanel.apply(H, side, torch.stack(weights), leaves)
+        return _TypedLinearPanel.apply(H, side, leaves, *weights)
     return _TypedLinear.apply(H, side, *weights)
 
 

@@ -148,13 +148,17 @@ class _FusedGRU(torch.autograd.Function):
         from . import _lib
         lib = _lib.load_library()
         st = _lib.current_stream()
-        xk, rec, h, u_h = xk.contiguous(), rec.contiguous(), h.contiguous(), u_h.contiguous()
+        xk, rec, h = xk.contiguous(), rec.contiguous(), h.contiguous()
+        # (u_h = recurrent_kernel[:, 2u:] stays the strided view of the parameter it is: the product reads it with its leading
+        #  dimension and keeps its limb image with the step's other weights — round 6: no copy, no split launch per cell)
+        if not (u_h.dim() == 2 and u_h.stride(1) == 1 and u_h.stride(0) % 4 == 0 and u_h.data_ptr() % 16 == 0):
+            u_h = u_h.contiguous()
         V, u = h.shape
         z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
         _lib.check(lib.relgnn_gru_gates_fwd(_lib.ptr(xk), _lib.ptr(rec), _lib.ptr(h), V, u, _lib.ptr(z), _lib.ptr(r),
                                             _lib.ptr(rh), st), "relgnn_gru_gates_fwd")
         from .dense import GEMM_NN, lib_gemm
-        q = lib_gemm(GEMM_NN, rh, u_h)
+        q = lib_gemm(GEMM_NN, rh, u_h, weight=True)
         hh, out = torch.empty_like(h), torch.empty_like(h)
         _lib.check(lib.relgnn_gru_out_fwd(_lib.ptr(xk), _lib.ptr(q), _lib.ptr(z), _lib.ptr(h), V, u, act, _lib.ptr(hh),
                                           _lib.ptr(out), st), "relgnn_gru_out_fwd")
@@ -176,7 +180,7 @@ class _FusedGRU(torch.autograd.Function):
         _lib.check(lib.relgnn_gru_out_bwd(_lib.ptr(gout), _lib.ptr(z), _lib.ptr(h), _lib.ptr(hh), V, u, ctx.act,
                                           _lib.ptr(gxk), _lib.ptr(gq), _lib.ptr(gz), _lib.ptr(gh), st), "relgnn_gru_out_bwd")
         from .dense import GEMM_NT, lib_gemm
-        grh = lib_gemm(GEMM_NT, gq, u_h)
+        grh = lib_gemm(GEMM_NT, gq, u_h, weight=True)
         gu_h = matmul_tn_splitk(rh, gq) if ctx.needs_input_grad[3] else None
         _lib.check(lib.relgnn_gru_gates_bwd(_lib.ptr(grh), _lib.ptr(gz), _lib.ptr(z), _lib.ptr(r), _lib.ptr(h), V, u,
                                             _lib.ptr(gxk), _lib.ptr(gh), st), "relgnn_gru_gates_bwd")
