@@ -915,6 +915,7 @@ def test_panel_products_take_cached_weight_images_and_give_the_same_bits(gpu_dev
     for Dout in (128, 256):
         Ws = [_rand((128, Dout), dev, 10 + l, 0.1) for l in range(L)]
         assert DN.sel_weights_cacheable(Ws, DN.GEMM_NN) and DN.sel_weights_cacheable(Ws, DN.GEMM_NT)
+        assert DN.sel_image(Ws, DN.GEMM_NN) is DN.sel_image(Ws, DN.GEMM_NN)           # the second lookup: by identity
         stacked = torch.stack(Ws)
         want = DN.limb_dense_sel(DN.GEMM_NN, H, stacked, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512)
         got = DN.limb_dense_sel(DN.GEMM_NN, H, Ws, a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512, cached=True)

@@ -152,3 +152,28 @@ def test_unsupported_shapes_are_refused_not_computed(gpu_device):
     rc = lib.relgnn_rgcn_fused_fwd(None, 40, 256, graph.rowptr_t.data_ptr(), 40, 1, graph.src_t.data_ptr(), None,
                                    buf.data_ptr(), None, 0, None, 0, out.data_ptr(), 256, 256, 256, None, None)
     assert rc == _lib.EINVAL
+
+
+@pytest.mark.parametrize("V,edges", [(4800, [60000, 4800, 60000]), (8229, [200000, 8229, 200000])])
+def test_fused_layer_against_the_oracle_directly(gpu_device, V, edges):
+    """The fused kernel against the NumPy oracle's sparse_rgcn_layer (gnns/rgcn.py:60-117 in the reference's op order: per-type
+    Dense on gathered rows, 1/in-degree scale, concat, unsorted_segment_sum, ReLU) — not through the two-kernel HIP route: the
+    north star's 1e-5 absolute on bounded states."""
+    from oracle import bookkeeping, gnns as OG
+    from tf_gnn_samples_amd import ops
+    from tf_gnn_samples_amd.graph import RelGraph
+    dev = gpu_device
+    rng = np.random.default_rng(V)
+    adj = [np.stack([rng.integers(0, V, e), rng.integers(0, V, e)], axis=1).astype(np.int32) for e in edges]
+    deg = bookkeeping.in_degree_table(adj, V).astype(np.float32)
+    H = rng.uniform(-1, 1, size=(V, D)).astype(np.float32)
+    Ws = {"Edge_%i_Weight/kernel" % l: (rng.uniform(-1, 1, size=(D, D)) * (6.0 / (2 * D)) ** 0.5).astype(np.float32)
+          for l in range(len(edges))}
+    want = OG.sparse_rgcn_layer(H, adj, deg, D, 1, "ReLU", "sum", weights=Ws)
+    graph = RelGraph([torch.as_tensor(a, device=dev) for a in adj], V)
+    w = graph.degree_scale(torch.as_tensor(deg, device=dev))
+    kernels = [torch.as_tensor(Ws["Edge_%i_Weight/kernel" % l], device=dev) for l in range(len(edges))]
+    _, out = ops._rgcn_fused(torch.as_tensor(H, device=dev), graph, w, kernels, True, False)
+    assert _status() == 0
+    err = float(np.abs(out.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max())
+    assert err <= 1e-5, (err, float(np.abs(want).max()))

@@ -170,6 +170,8 @@ def clear_caches() -> None:
     _LIMB_WS.clear()
     _WORKSPACE.clear()
     _WEIGHT_LIMBS.clear()
+    _FAST_IMAGES.clear()
+    _SPLIT_ARGS.clear()
     _ZEROS.clear()
 
 
@@ -218,7 +220,7 @@ def lib_gemm(layout: int, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor =
             return limb_dense(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR, weight=weight)
         if _limb_route_ok(layout, a, b, bias, columns=128):        # the D = 128 models: 128 x 128 panels, two workgroups per CU
             return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR,
-                                  cached=weight and sel_weights_cacheable(b, layout))
+                                  image=sel_image(b, layout) if weight else None)
         if layout == GEMM_NN and _limb_cut_route_ok(a, b, bias):   # N just short of a multiple of 128 (the 121 labels of the PPI head)
             return limb_dense_sel(layout, a, b, bias, _lib.ACT_RELU if relu else _lib.ACT_LINEAR)
     if ((_cfg.gemm == "panel") and layout != GEMM_TN and out is None and not accumulate and panel_gemm_supported(layout, a, b)
@@ -292,7 +294,7 @@ def _gemm_with_epilogues(layout: int, a, b, bias, act: int, weight: bool, premas
             and _limb_route_ok(layout, a, b, bias, columns=128)):
         # the D = 128 models' Dense layers (C3, C5: tanh between GNN layers): the 128-column panel kernels take any activation
         # of the path in their epilogue (act_rt) — round 6: no tanh pass behind the product
-        return limb_dense_sel(layout, a, b, bias, act, cached=weight and sel_weights_cacheable(b, layout))
+        return limb_dense_sel(layout, a, b, bias, act, image=sel_image(b, layout) if weight else None)
     res = lib_gemm(layout, a, b, bias, relu=(act == _lib.ACT_RELU), weight=weight)
     if act not in (_lib.ACT_LINEAR, _lib.ACT_RELU):
         fn = _TORCH_ACT_.get(act)
@@ -469,6 +471,22 @@ _WEIGHT_GEN = [0]
 WEIGHT_NN, WEIGHT_NT = "nn", "nt"
 
 
+_CAPTURE_IMAGES = {"on": False, "images": {}}
+
+
+class capture_image_cache:
+    """Around the capture of ONE training step into a hipGraph: limb images split inside the capture are reused by later products of
+    the same capture (forward -> backward) until weights_changed() — which the captured optimizer update calls — drops them."""
+
+    def __enter__(self):
+        _CAPTURE_IMAGES["on"], _CAPTURE_IMAGES["images"] = True, {}
+        return self
+
+    def __exit__(self, *exc):
+        _CAPTURE_IMAGES["on"], _CAPTURE_IMAGES["images"] = False, {}
+        return False
+
+
 def weights_changed() -> None:
     """Tell the limb-image cache that parameters were rewritten in place by something torch's version counters do not see:
     a kernel that writes through raw pointers (models/sparse_graph_model.py: the fused clip + Adam launch; a hipGraph replay of
@@ -478,6 +496,7 @@ def weights_changed() -> None:
     behind torch's back calls tf_gnn_samples_amd.dense.weights_changed() (cheap: a counter) — or runs with
     RELGNN_WEIGHT_LIMB_CACHE=0, which re-splits on every product."""
     _WEIGHT_GEN[0] += 1
+    _CAPTURE_IMAGES["images"] = {}
 
 
 class _WeightImage:
@@ -524,6 +543,9 @@ def _weight_image_items(ws, kind: str, buf: torch.Tensor):
     return items
 
 
+_SPLIT_ARGS = {}
+
+
 def _split_weight_images(images) -> None:
     import ctypes
     from . import _lib
@@ -531,13 +553,22 @@ def _split_weight_images(images) -> None:
     triples = [im for im in images if not im.pair]
     pairs = [im for im in images if im.pair]
     if triples:
-        items = [it for im in triples for it in im.items]
-        n = len(items)
-        cols = list(zip(*items))
-        vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
-        _lib.check(lib.relgnn_limb_split_multi_f32(n, vp(*cols[0]), i64(*cols[1]), i32(*cols[2]), i32(*cols[3]), i32(*cols[4]),
-                                                   vp(*cols[5]), i32(*cols[6]), i32(*cols[7]), _lib.current_stream()),
-                   "relgnn_limb_split_multi_f32")
+        # the argument arrays of a set of images are the same every step (an image's items never change): built once per set — a
+        # 23-type, 10-layer model re-splits ~1400 matrices per step, and marshalling them anew cost milliseconds of host time
+        key = tuple(map(id, triples))
+        ent = _SPLIT_ARGS.get(key)
+        if ent is None or len(ent[0]) != len(triples) or any(a is not b for a, b in zip(ent[0], triples)):
+            items = [it for im in triples for it in im.items]
+            n = len(items)
+            cols = list(zip(*items))
+            vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+            ent = (list(triples), n, (vp(*cols[0]), i64(*cols[1]), i32(*cols[2]), i32(*cols[3]), i32(*cols[4]), vp(*cols[5]),
+                                      i32(*cols[6]), i32(*cols[7])))
+            if len(_SPLIT_ARGS) > 64:
+                _SPLIT_ARGS.clear()
+            if len(triples) > 4:                       # (small sets are cheap to marshal and vary more)
+                _SPLIT_ARGS[key] = ent
+        _lib.check(lib.relgnn_limb_split_multi_f32(ent[1], *ent[2], _lib.current_stream()), "relgnn_limb_split_multi_f32")
     if pairs:           # two fp16 limbs: one magnitude per image first (its power-of-two scale), then the limbs — three launches
         wm = torch.empty(len(pairs), dtype=torch.float32, device=pairs[0].buf.device)
         items, image = [], []
@@ -588,11 +619,24 @@ def weight_image(w, kind: str, pair: bool = False, separate: bool = False) -> "_
                  cols // 16) for l, m in enumerate(ws)]
 
     if torch.cuda.is_current_stream_capturing() or _cfg.weight_limb_cache != "1":
+        # Under stream capture nothing outlives the capture — but WITHIN one captured training step the weights change once, at
+        # its end (the optimizer's update calls weights_changed()): an image split for the forward serves the backward too
+        # (capture_image_cache(): Sparse_Graph_Model.capture_train_step opens it around the capture).
+        ckey = None
+        if _CAPTURE_IMAGES["on"] and _cfg.weight_limb_cache == "1":
+            ckey = (kind, pair, separate, torch.cuda.current_stream(dev).cuda_stream) + tuple(
+                (m.data_ptr(), m.shape[0], m.shape[1], m.stride(0)) for m in ws)
+            hit = _CAPTURE_IMAGES["images"].get(ckey)
+            if hit is not None:
+                return hit
         im = _WeightImage()
         im.pair, im.wmax = pair, None
         im.buf = torch.empty(elements, dtype=torch.bfloat16, device=dev)
         im.items = make_items(im.buf)
         _split_weight_images([im])
+        if ckey is not None:
+            im.refs = list(ws)                      # (keeps the addresses of the key alive for the duration of the capture)
+            _CAPTURE_IMAGES["images"][ckey] = im
         return im
     import weakref
     skey = (dev, torch.cuda.current_stream(dev).cuda_stream)
@@ -770,6 +814,9 @@ def _limb_ws(device, need: int) -> torch.Tensor:
     return ws
 
 
+_SEL_CACHE = True          # (scripts flip this for A/B runs of the cached panel-product images; not a route switch)
+
+
 def sel_weights_cacheable(ws, layout: int) -> bool:
     """May the 128-column panel product take its weights from the step's limb-image cache (weight_image(separate=True))?  ws: the
     weight matrices as the caller holds them (parameters or views of parameters: something whose storage outlives the product and
@@ -777,13 +824,54 @@ def sel_weights_cacheable(ws, layout: int) -> bool:
     ws = _weight_matrices(ws)
     kind = WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT
     n, k = (ws[0].shape[1], ws[0].shape[0]) if layout == GEMM_NN else (ws[0].shape[0], ws[0].shape[1])
-    return (_cfg.weight_limb_cache == "1" and n % 128 == 0 and k % 16 == 0 and all(m.shape == ws[0].shape for m in ws)
+    return (_SEL_CACHE and _cfg.weight_limb_cache == "1" and n % 128 == 0 and k % 16 == 0 and all(m.shape == ws[0].shape for m in ws)
             and weight_image_ok(ws[:1], kind) and all(weight_image_ok([m], kind) for m in ws[1:]))
+
+
+_FAST_IMAGES = {}
+
+
+def sel_image(ws, layout: int):
+    """The cached limb images of the weight matrices `ws` (one image per matrix, one behind the other) for the 128-column panel
+    products, or None when they cannot come from the cache (shapes, switches).  Looked up by the IDENTITY of the weight tensors
+    first — a training step asks for the same parameters' images five or six times per layer, and the general lookup
+    (weight_image: addresses, shapes, strides, bases of every matrix) costs more host time than the split launch it saves when a
+    layer has 23 of them (measured, round 6: C5 31.2 -> 32.7 ms with the general lookup alone, eager)."""
+    if not (_SEL_CACHE and _cfg.weight_limb_cache == "1"):
+        return None
+    from . import _lib
+    ws = _weight_matrices(ws)
+    if not ws[0].is_cuda:
+        return None
+    kind = WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = None
+    if not capturing:
+        key = (kind, _lib.current_stream()) + tuple(map(id, ws))
+        ent = _FAST_IMAGES.get(key)
+        if ent is not None:
+            im, refs = ent
+            if im.gen == _WEIGHT_GEN[0]:
+                for w, r, v in zip(ws, refs, im.versions):
+                    if r() is not w or w._version != v:
+                        break
+                else:
+                    im.used_gen = im.gen
+                    return im
+    if not sel_weights_cacheable(ws, layout):
+        return None
+    im = weight_image(ws, kind, separate=True)
+    if key is not None and all(w._base is None for w in ws):
+        import weakref
+        if len(_FAST_IMAGES) > 512:
+            _FAST_IMAGES.clear()
+        _FAST_IMAGES[key] = (im, [weakref.ref(w) for w in ws])
+    return im
 
 
 def limb_dense_sel(layout: int, a: torch.Tensor, b, bias: torch.Tensor = None, act: int = 0, *,
                    a_rows: torch.Tensor = None, num_rows: int = None, b_select: torch.Tensor = None, rows_per_select: int = 0,
-                   cached: bool = False, as_one: bool = False) -> torch.Tensor:
+                   cached: bool = False, as_one: bool = False, image=None) -> torch.Tensor:
     """relgnn_limb_dense_sel_f32: the limb product in 128 x 128 panels.  b: [K, N] / [N, K] (NN / NT) or, with b_select,
     [num_b, K, N] / [num_b, N, K]; a_rows: int32 row ids of `a` per output row (< 0: zeros), num_rows output rows.
     cached=True (sel_weights_cacheable(b, layout)): b is the weight matrix / the LIST of per-type weight matrices themselves; their
@@ -791,12 +879,12 @@ def limb_dense_sel(layout: int, a: torch.Tensor, b, bias: torch.Tensor = None, a
     from . import _lib
     lib = _lib.load_library()
     K = a.shape[1]
-    if cached:
+    if cached or image is not None:          # (image: sel_image(b, layout), looked up by the caller)
         ws = _weight_matrices(b)
         kind = WEIGHT_NN if layout == GEMM_NN else WEIGHT_NT
         N = ws[0].shape[1] if layout == GEMM_NN else ws[0].shape[0]
         M = int(num_rows) if a_rows is not None else a.shape[0]
-        im = weight_image(ws, kind, separate=True)
+        im = image if image is not None else weight_image(ws, kind, separate=True)
         if as_one:           # the images one behind the other = the image of [w_0 | w_1 | ..] stacked along N: ONE product, L*N columns
             return _sel_with_image(a, im, len(ws) * N, K, act, bias)
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
@@ -1105,7 +1193,7 @@ class _DenseMultiFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, *kernels):
-        y = limb_dense_sel(GEMM_NN, x, list(kernels), cached=True, as_one=True)
+        y = limb_dense_sel(GEMM_NN, x, list(kernels), image=sel_image(kernels, GEMM_NN), as_one=True)
         ctx.save_for_backward(x, *kernels)
         ctx.leaf_params = tuple(kernels) if all(k.is_leaf for k in kernels) else None
         return y
@@ -1148,8 +1236,8 @@ def dense_multi(x: torch.Tensor, kernels) -> torch.Tensor:
     kernels = list(kernels)
     K, N = kernels[0].shape
     if (_cfg.limb_gemm and _rows_ok(x) and x.shape[0] >= _LIMB_MIN_ROWS and x.shape[1] == K and N % 128 == 0 and K % 128 == 0
-            and len(kernels) * N <= _LIMB_MAX_K and sel_weights_cacheable(kernels, GEMM_NN)
-            and all(k.is_contiguous() and k.data_ptr() % 16 == 0 for k in kernels) and not torch.cuda.is_current_stream_capturing()):
+            and len(kernels) * N <= _LIMB_MAX_K and all(k.is_contiguous() and k.data_ptr() % 16 == 0 for k in kernels)
+            and sel_image(kernels, GEMM_NN) is not None):
         return _DenseMultiFn.apply(x, *kernels)
     return dense(x, torch.cat(kernels, dim=1))
 

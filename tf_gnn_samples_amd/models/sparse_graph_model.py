@@ -567,7 +567,8 @@ class Sparse_Graph_Model(ABC):
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         opt.zero_grad()
-        with torch.cuda.graph(graph):
+        from ..dense import capture_image_cache
+        with capture_image_cache(), torch.cuda.graph(graph):      # (limb images of the weights: split once per captured step)
             metrics = self.train_step(batch, device_step_count=True)
         return CapturedTrainStep(self, graph, {k: v for k, v in metrics.items() if torch.is_tensor(v)}, batch)
 

@@ -518,18 +518,18 @@ class _TypedLinearPanel(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, H, side, leaves, *weights):
-        from .dense import GEMM_NN, limb_dense_sel, panel_gemm, sel_weights_cacheable
+        from .dense import GEMM_NN, GEMM_NT, limb_dense_sel, panel_gemm, sel_image
         ctx.leaf_params = leaves            # the per-type weights themselves, when every one is a leaf parameter
         L, (Din, Dout) = len(weights), weights[0].shape
         node32, tile_type = side.panel_indices()
         # round 6: the limb images of the per-type weights come from the step's cache (dense.weight_image(separate=True)): neither a
         # stacked [L, Din, Dout] copy nor a split launch in front of the product
-        cached = _typed_limb_ok(Din, Dout) and _typed_limb_ok(Dout, Din) and sel_weights_cacheable(weights, GEMM_NN) \
-            and sel_weights_cacheable(weights, GEMM_NT)
+        im = sel_image(weights, GEMM_NN) if (_typed_limb_ok(Din, Dout) and _typed_limb_ok(Dout, Din)) else None
+        cached = im is not None
         W = None if cached else torch.stack(weights)
         if cached:
-            Y = limb_dense_sel(GEMM_NN, H, list(weights), a_rows=node32, num_rows=side.P, b_select=tile_type,
-                               rows_per_select=side.chunk, cached=True)
+            Y = limb_dense_sel(GEMM_NN, H, weights, a_rows=node32, num_rows=side.P, b_select=tile_type,
+                               rows_per_select=side.chunk, image=im)
         elif _typed_limb_ok(Din, Dout):
             Y = limb_dense_sel(GEMM_NN, H, W, a_rows=node32, num_rows=side.P, b_select=tile_type, rows_per_select=side.chunk)
         else:
@@ -586,8 +586,14 @@ class _TypedLinearPanel(torch.autograd.Function):
             for t in (H, gY):
                 t.record_stream(side_stream)
         if ctx.needs_input_grad[0]:
+            im = None
             if ctx.cached:
-                gX = limb_dense_sel(GEMM_NT, gY, list(saved), b_select=tile_type, rows_per_select=side.chunk, cached=True)
+                from .dense import sel_image
+                im = sel_image(saved, GEMM_NT)
+                if im is None:                       # (switched off between forward and backward)
+                    W = torch.stack(saved)
+            if im is not None:
+                gX = limb_dense_sel(GEMM_NT, gY, saved, b_select=tile_type, rows_per_select=side.chunk, image=im)
             elif _typed_limb_ok(Dout, Din):
                 gX = limb_dense_sel(GEMM_NT, gY, W, b_select=tile_type, rows_per_select=side.chunk)
             else:
