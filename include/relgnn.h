@@ -905,6 +905,17 @@ int relgnn_limb_dense_sel_f32(int32_t layout, int32_t act, const float* A, int64
 int relgnn_limb_gemm_sel_xf32(int32_t act, const float* A, int64_t lda, const int32_t* a_rows, const uint16_t* B_limbs, int32_t num_b,
                               const int32_t* b_select, int32_t rows_per_select, const float* bias, const void* zeros, float* C,
                               int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
+/* The same typed product (no bias, no activation: gnns/gnn_film.py:92-106 and its input gradients) on the wave-role form of
+ * relgnn_limb_gemm_xf32_pc (csrc/limb_gemm_pc_typed.hip): eight producer waves gather the rows a_rows[r] of A (< 0: zeros), split
+ * them and hand 32-row x 128-k limb sub-slabs through LDS to eight matrix waves that read their W fragments straight from L2 — an
+ * N = 256 product gathers every row once (the LDS-resident-weights kernel behind relgnn_limb_gemm_sel_xf32: once per 128-column
+ * chunk).  Bit-identical to relgnn_limb_gemm_sel_xf32.  M % 64 == 0, N and K in {128, 256}, rows_per_select % 64 == 0
+ * (relgnn_limb_gemm_sel_pc_supported; RELGNN_EUNSUPPORTED otherwise); zeros: >= 128 zero floats; status: the hand-over status block
+ * of relgnn_limb_gemm_xf32_pc (nullable). */
+int relgnn_limb_gemm_sel_pc_supported(int32_t M, int32_t N, int32_t K, int32_t rows_per_select);
+int relgnn_limb_gemm_sel_pc_xf32(const float* A, int64_t lda, const int32_t* a_rows, const uint16_t* B_limbs, int32_t num_b,
+                                 const int32_t* b_select, int32_t rows_per_select, const void* zeros, float* C, int64_t ldc,
+                                 int32_t M, int32_t N, int32_t K, int32_t* status, void* stream);
 /* Weight gradients dW = A^T @ G (A [V, J] = the saved layer input, G [V, C] = the output gradient; tf.gradients of the Dense
  * products above) on the same limb arithmetic: both operands fp32 row-major, split AND transposed in flight (the reduction index is
  * the row of both).  The kernel takes the first V - V % 32 rows, cut into relgnn_limb_gemm_tn_chunks(V, J, C) chunks; chunk z writes

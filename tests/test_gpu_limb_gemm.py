@@ -970,3 +970,44 @@ def test_dense_multi_is_the_product_with_the_concatenated_kernels(gpu_device):
         want = x.detach().double().t() @ gy[:, l * N:(l + 1) * N].double()
         assert float((got[2][l].double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), l
         assert float((ks[l].grad.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), l
+
+
+@pytest.mark.parametrize("Dout,kind", [(128, "nn"), (256, "nn"), (128, "nt"), (256, "nt")])
+@pytest.mark.parametrize("tiles", [1, 7, 40, 300])
+def test_typed_products_on_the_wave_role_kernel_give_the_same_bits(gpu_device, tiles, Dout, kind):
+    """relgnn_limb_gemm_sel_pc_xf32 (csrc/limb_gemm_pc_typed.hip: gathering producer waves + barrier-free matrix waves) against the
+    panel kernels behind relgnn_limb_gemm_sel_xf32 on the per-(node, type) products of a many-type graph: forward (gathered rows,
+    padding rows, per-tile kernels; N = 128 and 256) and input gradient (K = 128 and 256) — bit for bit, and the hand-over status
+    stays clean; 1 .. 300 tiles of 512 rows (fewer pairs than workgroups, ragged ranges, several pairs per workgroup)."""
+    from tf_gnn_samples_amd import config, dense as DN, ops
+    dev = gpu_device
+    L, V = 5, 3000
+    P = tiles * 512
+    g = torch.Generator(device="cpu").manual_seed(tiles + Dout)
+    tile_type = torch.sort(torch.randint(0, L, (tiles,), generator=g)).values.to(torch.int32).to(dev)
+    node = torch.randint(-1, V, (P,), generator=g).to(torch.int32).to(dev)
+    Ws = [_rand((128, Dout), dev, 10 + l, 0.1) for l in range(L)]
+    if kind == "nn":
+        H = _rand((V, 128), dev, 1)
+        H[5, 3] = -torch.finfo(torch.float32).max                                       # the saturating split
+        args = dict(a_rows=node, num_rows=P, b_select=tile_type, rows_per_select=512)
+        a, layout = H, DN.GEMM_NN
+    else:
+        a, layout = _rand((P, Dout), dev, 3), DN.GEMM_NT
+        args = dict(b_select=tile_type, rows_per_select=512)
+    outs = {}
+    for pc in ("0", "1"):
+        with config.override(typed_pc=pc):
+            outs[pc] = DN.limb_dense_sel(layout, a, Ws, image=DN.sel_image(Ws, layout), **args)
+    assert ops.handover_status() == 0
+    assert torch.equal(outs["1"], outs["0"])
+    if tiles == 7:                                                                      # and against float64
+        W = torch.stack(Ws).double()
+        t = tile_type.long().repeat_interleave(512)
+        if kind == "nn":
+            rows = torch.where(node.long().unsqueeze(1) >= 0, a.double()[node.long().clamp(min=0)], torch.zeros(1, dtype=torch.float64, device=dev))
+            want = torch.einsum("pk,pkn->pn", rows, W[t])
+        else:
+            want = torch.einsum("pn,pkn->pk", a.double(), W[t])
+        scale = float(want.abs().max())
+        assert float((outs["1"].double() - want).abs().max()) <= 4e-6 * max(scale, 1.0)

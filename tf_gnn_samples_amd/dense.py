@@ -888,6 +888,17 @@ def limb_dense_sel(layout: int, a: torch.Tensor, b, bias: torch.Tensor = None, a
         if as_one:           # the images one behind the other = the image of [w_0 | w_1 | ..] stacked along N: ONE product, L*N columns
             return _sel_with_image(a, im, len(ws) * N, K, act, bias)
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        if ((_cfg.typed_pc == "1" or (_cfg.typed_pc == "fwd" and a_rows is not None and N == 256)) and b_select is not None
+                and bias is None and act == 0
+                and lib.relgnn_limb_gemm_sel_pc_supported(M, N, K, int(rows_per_select))
+                and (a_rows is None or a_rows.data_ptr() % 16 == 0)):
+            # wave roles (csrc/limb_gemm_pc_typed.hip): the same bits, every gathered row read once
+            _lib.check(lib.relgnn_limb_gemm_sel_pc_xf32(a.data_ptr(), a.stride(0), _lib.ptr(a_rows), im.buf.data_ptr(), len(ws),
+                                                        _lib.ptr(b_select), int(rows_per_select), _lib.ptr(_zeros(a.device)),
+                                                        out.data_ptr(), out.stride(0), M, N, K,
+                                                        _ops().handover_word(a.device).data_ptr(), _lib.current_stream()),
+                       "relgnn_limb_gemm_sel_pc_xf32")
+            return out
         _lib.check(lib.relgnn_limb_gemm_sel_xf32(act, a.data_ptr(), a.stride(0), _lib.ptr(a_rows), im.buf.data_ptr(), len(ws),
                                                  _lib.ptr(b_select), int(rows_per_select), _lib.ptr(bias), _lib.ptr(_zeros(a.device)),
                                                  out.data_ptr(), out.stride(0), M, N, K, _lib.current_stream()),
