@@ -867,7 +867,9 @@ int relgnn_limb_gemm_xf32_pc_supported(int32_t act, int32_t M, int32_t N, int32_
  * with the gather and the matrix-pipe work of a row panel overlapped on one CU (csrc/rgcn_fused.hip: gather waves hand the
  * bucket sums, already split into limbs, to the MFMA waves through LDS).
  *
- * H [num_rows_h, ldh] fp32 (256 columns read); w_limbs: the limb tiles of the stacked W^T [256, L*256]
+ * H [num_rows_h, ldh] fp32 (256 columns read; `col` holds row ids of H as relgnn_plan_* / relgnn_relational_keys bucketed them —
+ * their range was checked there, through err_flag: like relgnn_seg_reduce_fwd this entry does not look at them again, num_rows_h
+ * documents the table's height and is checked for sign only); w_limbs: the limb tiles of the stacked W^T [256, L*256]
  * (relgnn_limb_split_multi_f32 with transpose: the operand relgnn_limb_gemm_xf32 takes as B); bias nullable;
  * bucket_sums (nullable, [V, lds >= L*256]): S as fp32, for the weight gradient of a training step (dW_l = S_l^T dOut);
  * out [V, ldo].  d_in = d_out = 256 only (RELGNN_EUNSUPPORTED otherwise); 16-byte aligned pointers, strides % 4 == 0.
