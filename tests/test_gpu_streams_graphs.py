@@ -326,3 +326,54 @@ def test_deferred_weight_gradients_stay_on_the_main_stream_whenever_autograd_wou
         assert pend == 0                    # (the plain op's gradient arrived first: nothing went aside)
     assert not ops._DEFER["pending"] and not ops._DEFER["targets"] and not ops._DEFER["handed"]
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("which", ["film_many_types", "ggnn_d128"])
+def test_captured_step_of_the_d128_models_reuses_its_limb_images_inside_the_capture(gpu_device, which):
+    """Round 6: the 128-column panel products (typed transforms of a 23-type GNN-FiLM model incl. the wave-role kernel for the
+    FiLM weights; the GGNN transform through dense_multi and its GRU) take their weights' limb images from a cache — inside a
+    captured step from the capture-local one (dense.capture_image_cache: split once in the forward, reused by the backward, dropped
+    by the captured optimizer update).  N replays must train like N eager steps, and eager code behind a replay sees the update."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from tf_gnn_samples_amd import config, ops
+    from tf_gnn_samples_amd.models import name_to_model_class
+    from tf_gnn_samples_amd.tasks import DataFold, DeviceBatch, PPI_Task
+    if not config.settings.limb_gemm:
+        pytest.skip("the limb route is what this test is about")
+    if which == "film_many_types":
+        import bench_other
+        task, graphs = bench_other.c5_task_and_graphs(4)
+        cls, extra = name_to_model_class("GNN-FiLM")
+        hp = dict(hidden_size=128, graph_num_layers=2, graph_dense_between_every_num_gnn_layers=1,
+                  graph_residual_connection_every_num_layers=2)
+    else:
+        task = PPI_Task(PPI_Task.default_params())
+        task.load_synthetic(3, 1, seed=4)
+        graphs = task._loaded_data[DataFold.TRAIN]
+        cls, extra = name_to_model_class("GGNN")
+        hp = dict(hidden_size=128, graph_num_layers=2, graph_rnn_cell="GRU", message_aggregation_function="sum")
+    mb = next(task.make_minibatch_iterator(list(graphs), DataFold.VALIDATION, 10 ** 9))
+    assert mb.num_nodes >= 4096
+
+    def fresh():
+        p = cls.default_params()
+        p.update(extra)
+        p.update(hp)
+        p.update(graph_layer_input_dropout_keep_prob=1.0, random_seed=3)
+        return cls(p, task, device=str(gpu_device)), DeviceBatch(mb, gpu_device)
+
+    eager, batch_e = fresh()
+    losses_e = [float(eager.train_step(batch_e)['loss'].detach()) for _ in range(6)]
+    with torch.no_grad():
+        eval_e = float(eager.forward_batch(batch_e, training=False)['loss'])
+    captured, batch_c = fresh()
+    step = captured.capture_train_step(batch_c, warmup_steps=3)
+    losses_c = [float(step.replay()['loss']) for _ in range(3)]
+    with torch.no_grad():
+        eval_c = float(captured.forward_batch(batch_c, training=False)['loss'])
+    torch.cuda.synchronize()
+    assert step.handover_status() == 0 and ops.handover_status() == 0
+    np.testing.assert_allclose(losses_c, losses_e[3:], rtol=5e-5)
+    np.testing.assert_allclose(eval_c, eval_e, rtol=5e-5)
