@@ -814,6 +814,14 @@ def main():
     nodes = sorted(len(g.node_features) for g in fold)
     params['max_nodes_in_batch'] = int(sum(nodes) / max(1, len(fold) // cfg["graphs_per_batch"])) + nodes[-1]
     model = model_cls(params, task, device=str(device))
+    # The fold is millions of long-lived Python objects (graphs, arrays, tensors): moved out of the cyclic collector's sight, so that a
+    # full collection inside the timed loop scans the step's own objects only and a step's cyclic garbage (autograd graphs hold device
+    # tensors) is not kept waiting by CPython's "a quarter of all tracked objects" rule.  Hygiene, not a cure: the distinct-batch C5
+    # loop shows rare 75-290 ms steps (0-4 per 60 steps, different per run and per box; none when every step is synchronised:
+    # scripts/exp_c5_outliers.py) with and without this — 6 clean runs and 3 with such steps with it, 0 clean of 3 without.
+    import gc
+    gc.collect()
+    gc.freeze()
     # The gradient all-reduce (N > 1): one flat collective behind the backward (`flat`, the default) or buckets that leave during the
     # backward (`overlap`, parallel.py).  The timed region runs the form config.settings.allreduce names; at N > 1 the OTHER form is
     # timed right behind it over the same batch sequence (same shuffling seed), so that one run on an N-GPU node compares the two.
@@ -935,7 +943,8 @@ def main():
                 "buckets": len(reducer.buckets) if overlap_reduce and reducer is not None else (1 if reducer is not None else 0)}
         if reducer is not None and hasattr(reducer, "close"):
             reducer.close()                     # (the bucketed form's post-accumulate hooks must not outlive it)
-        return {"elapsed": elapsed, "per_rank": per_rank, "edges_rs": edges_rs, "state": state, "reducer": info}
+        return {"elapsed": elapsed, "per_rank": per_rank, "edges_rs": edges_rs, "state": state, "reducer": info,
+                "step_ms": [round(float(x), 3) for x in step_ms]}
 
     run = timed_loop(primary_kind, args.steps, args.warmup)
     elapsed, per_rank, edges_rs, state, reducer_info = run["elapsed"], run["per_rank"], run["edges_rs"], run["state"], run["reducer"]
@@ -1014,6 +1023,8 @@ def main():
             "wall_ms_per_step": [round(float(x), 4) for x in per_rank[:, 8]],
         },
         "step_edge_imbalance_max_over_mean": {"mean": float(imbalance.mean()), "max": float(imbalance.max())},
+        # rank 0's GPU-side duration of every timed step (sidecar only): a mean far above the median is a few long steps
+        "gpu_step_ms_rank0": run["step_ms"],
         "gradient_allreduce_bytes": reducer_info["nbytes"],
         "gradient_allreduce": ("none" if world == 1 else
                                "%d buckets launched from the backward's post-accumulate hooks" % reducer_info["buckets"] if overlap_reduce

@@ -38,6 +38,9 @@ def _quiet(fn):
 
 def _time_steps(model, batch, prime, steps):
     from tf_gnn_samples_amd.graph import clear_graph_cache
+    import gc
+    gc.collect()
+    gc.freeze()                    # (the loaded graphs out of the collector's sight: bench.py says why)
 
     def step():
         clear_graph_cache()
@@ -196,8 +199,8 @@ def run_c5(dev):
     mb = next(task.make_minibatch_iterator(list(graphs), DataFold.VALIDATION, 10 ** 9))
     batch = DeviceBatch(mb, dev)
     model, _ = c5_model(task, dev)
-    # (6 + 8 steps: from a cold process the 4th .. 9th step of this model is once a ~60 ms one — first collection of the step's
-    #  cyclic garbage —, which a 3 + 5 window turned into "40 ms per step": scripts/exp_c5_steps.py)
+    # (6 + 8 steps: from a cold process one of the first ten steps of this model is a ~60 ms one, which a 3 + 5 window turned into
+    #  "40 ms per step": scripts/exp_c5_steps.py)
     train_ms, fwd_ms = _time_steps(model, batch, 6, 8)
     g = as_rel_graph(batch.adjacency_lists, mb.num_nodes)
     pairs = g.pair_tables()

@@ -12,6 +12,7 @@
 
 #include <hipblaslt/hipblaslt.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -119,6 +120,7 @@ int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t 
   const Key key{layout, N, layout == RELGNN_GEMM_TN ? (K >> (m_shift > 4 ? m_shift - 4 : 0)) : K, batch, M >> m_shift, bias ? 1 : 0,
                 accumulate ? 1 : 0, act};
   auto it = s.algos.find(key);
+  bool first_use = false;
   if (it == s.algos.end()) {
     if (!s.pref && hipblasLtMatmulPreferenceCreate(&s.pref) != HIPBLAS_STATUS_SUCCESS) return RELGNN_EHIP;
     const uint64_t ws = (uint64_t)workspace_bytes;
@@ -170,9 +172,18 @@ int relgnn_blaslt_gemm_f32(int32_t layout, int32_t act, const float* A, int64_t 
       }
     }
     it = s.algos.emplace(key, res[best].algo).first;
+    first_use = true;
   }
+  static const bool miss_log = getenv("RELGNN_GEMM_MISS_LOG") != nullptr;
+  if (miss_log && first_use) hipStreamSynchronize(st_);
+  const auto t_miss = std::chrono::steady_clock::now();
   hipblasStatus_t st = hipblasLtMatmul(s.handle, desc.d, &alpha, B, first.l, A, second.l, &beta, C, out.l, C, out.l, &it->second,
                                        workspace, (size_t)workspace_bytes, st_);
+  if (miss_log && first_use) {          // (diagnostic: what the FIRST launch of a newly picked solution costs — its code object may load now)
+    hipStreamSynchronize(st_);
+    fprintf(stderr, "relgnn_blaslt_gemm_f32: new class layout %d M %d N %d K %d batch %d: first launch %.1f ms\n", layout, M, N, K, batch,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_miss).count());
+  }
   if (st != HIPBLAS_STATUS_SUCCESS) {
     // a cached solution that does not take this V: ask again for exactly this shape (and keep that answer)
     s.algos.erase(it);
