@@ -32,13 +32,12 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                 "exact-split products with N = 256 or K <= 256: producer / matrix wave roles with LDS hand-over "
                 "(csrc/limb_gemm_pc.hip) for the forward products only (input-gradient products run next to the side stream's weight "
                 "gradient, which a kernel that holds every CU starves) | never | for every product that fits; the same bits"),
-    "typed_pc": ("RELGNN_TYPED_PC", "fwd", ("fwd", "0", "1"),
-                 "per-(node, type) products of many-type graphs (K, N in {128, 256}): the wave-role kernel (csrc/limb_gemm_pc_typed.hip: "
-                 "gathering producer waves + barrier-free matrix waves, every row gathered once) for the gathered N = 256 forward "
-                 "product (the FiLM weights: 343 vs 368 us in the C5 step, 340 vs 403 us alone on random row ids), the "
-                 "LDS-resident-weights panel kernels for everything else (N = 128 forward 198 vs 192 us in the step; input "
-                 "gradients 242 vs 239 and 376 vs 362 us alone) | the panel kernels everywhere | the wave-role kernel for every typed "
-                 "product it takes; the same bits"),
+    "typed_pc": ("RELGNN_TYPED_PC", "0", ("0", "fwd", "1"),
+                 "per-(node, type) products of many-type graphs (K, N in {128, 256}): the LDS-resident-weights panel kernels | the "
+                 "wave-role kernel (csrc/limb_gemm_pc_typed.hip: gathering producer waves + barrier-free matrix waves, every row "
+                 "gathered once) for the gathered N = 256 forward product | for every typed product it takes.  The same bits; alone "
+                 "330-340 vs 402-407 us (forward N = 256), 202 vs 222 (forward N = 128), 234 vs 230 and 350 vs 366 (input "
+                 "gradients); on the C5 step no difference outside the noise (33.0-34.0 ms on all three values), hence off"),
     "limb_cut": ("RELGNN_LIMB_CUT", "1", ("0", "1"),
                  "N % 128 >= 96 products (the 121 logits of the PPI head) on the 128-column limb panels with the last chunk cut at N"),
     "head_pad": ("RELGNN_HEAD_PAD", "1", ("0", "1"),
