@@ -83,3 +83,33 @@ def test_a_backward_that_raises_leaves_no_deferred_join_state_behind():
     assert ops._DEFER["targets"]
     ops.join_deferred()
     assert not ops._DEFER["targets"]
+
+
+def test_combined_node_csr_of_both_pair_tables_sums_what_the_two_reductions_sum():
+    """graph.PairTables.node_csr_both: one CSR node -> (its by-source table rows, then its by-target table rows + P_s) — the
+    single reduction of ops._TypedLinearPair — gives every node the sum of the two separate reductions, the by-source rows first."""
+    import types
+    from tf_gnn_samples_amd.graph import PairTables
+    g = torch.Generator().manual_seed(0)
+    V = 50
+
+    def side(P):
+        cnt = torch.randint(0, 4, (V,), dtype=torch.int32, generator=g)
+        rp = torch.zeros(V + 1, dtype=torch.int32)
+        rp[1:] = torch.cumsum(cnt, 0)
+        n = int(rp[-1])
+        return types.SimpleNamespace(V=V, node_rowptr=rp, node_col=torch.randperm(P, generator=g)[:n].to(torch.int32), num_pairs=n, P=P)
+
+    pt = PairTables.__new__(PairTables)
+    pt.src, pt.tgt = side(200), side(300)
+    rowptr, col = pt.node_csr_both()
+    assert pt.node_csr_both()[1] is col                                 # built once per graph
+    assert int(rowptr[-1]) == pt.src.num_pairs + pt.tgt.num_pairs and rowptr.dtype == col.dtype == torch.int32
+    Xa, Xb = torch.randn(200, 3, dtype=torch.float64, generator=g), torch.randn(300, 3, dtype=torch.float64, generator=g)
+    X = torch.cat([Xa, Xb])
+    for v in range(V):
+        rows_a = pt.src.node_col[pt.src.node_rowptr[v]:pt.src.node_rowptr[v + 1]].long()
+        rows_b = pt.tgt.node_col[pt.tgt.node_rowptr[v]:pt.tgt.node_rowptr[v + 1]].long()
+        mine = col[rowptr[v]:rowptr[v + 1]].long()
+        assert mine.tolist() == rows_a.tolist() + (rows_b + 200).tolist()
+        assert torch.allclose(X[mine].sum(0), Xa[rows_a].sum(0) + Xb[rows_b].sum(0))

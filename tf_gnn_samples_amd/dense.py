@@ -871,7 +871,7 @@ def sel_image(ws, layout: int):
 
 def limb_dense_sel(layout: int, a: torch.Tensor, b, bias: torch.Tensor = None, act: int = 0, *,
                    a_rows: torch.Tensor = None, num_rows: int = None, b_select: torch.Tensor = None, rows_per_select: int = 0,
-                   cached: bool = False, as_one: bool = False, image=None) -> torch.Tensor:
+                   cached: bool = False, as_one: bool = False, image=None, out: torch.Tensor = None) -> torch.Tensor:
     """relgnn_limb_dense_sel_f32: the limb product in 128 x 128 panels.  b: [K, N] / [N, K] (NN / NT) or, with b_select,
     [num_b, K, N] / [num_b, N, K]; a_rows: int32 row ids of `a` per output row (< 0: zeros), num_rows output rows.
     cached=True (sel_weights_cacheable(b, layout)): b is the weight matrix / the LIST of per-type weight matrices themselves; their
@@ -887,7 +887,10 @@ def limb_dense_sel(layout: int, a: torch.Tensor, b, bias: torch.Tensor = None, a
         im = image if image is not None else weight_image(ws, kind, separate=True)
         if as_one:           # the images one behind the other = the image of [w_0 | w_1 | ..] stacked along N: ONE product, L*N columns
             return _sel_with_image(a, im, len(ws) * N, K, act, bias)
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        elif out.shape != (M, N) or out.dtype != torch.float32 or out.stride(1) != 1:
+            raise ValueError("limb_dense_sel: out must be a float32 [%d, %d] matrix with dense rows" % (M, N))
         if ((_cfg.typed_pc == "1" or (_cfg.typed_pc == "fwd" and a_rows is not None and N == 256)) and b_select is not None
                 and bias is None and act == 0
                 and lib.relgnn_limb_gemm_sel_pc_supported(M, N, K, int(rows_per_select))

@@ -61,10 +61,9 @@ def sparse_gnn_film_layer(node_embeddings: torch.Tensor,
     cur_node_states = node_embeddings
     for t in range(num_timesteps):
         if pairs is not None:
-            transformed = ops.typed_linear(cur_node_states, pairs.src,
-                                           [weights["Edge_%i_Weight/kernel" % l] for l in range(L)])
-            film = ops.typed_linear(cur_node_states, pairs.tgt,
-                                    [weights["Edge_%i_FiLM_Computations/kernel" % l] for l in range(L)])
+            transformed, film = ops.typed_linear_pair(cur_node_states, pairs,
+                                                      [weights["Edge_%i_Weight/kernel" % l] for l in range(L)],
+                                                      [weights["Edge_%i_FiLM_Computations/kernel" % l] for l in range(L)])
             aggregated = ops.film_messages_reduce(transformed, film, graph, w, message_aggregation_function,
                                                   activation_function, pairs)
             cur_node_states = layer_norm(aggregated, weights[layer_norm_scope(t) + "/gamma"], weights[layer_norm_scope(t) + "/beta"])

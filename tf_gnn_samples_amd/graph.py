@@ -717,6 +717,31 @@ class PairTables:
         self._by_row = None
         self._plans = {}
 
+    def node_csr_both(self):
+        """(rowptr [V+1], col [num_pairs_src + num_pairs_tgt]) int32: node -> its rows in the by-source table FOLLOWED by its rows in
+        the by-target table, the latter numbered behind the former (row + P_s) — the CSR of ONE reduction that sums the per-row
+        input gradients of both typed transforms of a layer into the nodes (ops._TypedLinearPair)."""
+        both = getattr(self, "_both", None)
+        if both is None:
+            a, b = self.src, self.tgt
+            V, dev = a.V, a.node_rowptr.device
+            ca, cb = torch.diff(a.node_rowptr), torch.diff(b.node_rowptr)
+            rowptr = torch.zeros(V + 1, dtype=torch.int32, device=dev)
+            torch.cumsum(ca + cb, 0, dtype=torch.int32, out=rowptr[1:])
+            nodes = torch.arange(V, device=dev)
+            col = torch.empty(a.num_pairs + b.num_pairs, dtype=torch.int32, device=dev)
+            for side, cnt, lead, shift in ((a, ca, None, 0), (b, cb, ca, a.P)):
+                n = side.num_pairs
+                if n == 0:
+                    continue
+                node_of = torch.repeat_interleave(nodes, cnt.long(), output_size=n)
+                dest = rowptr[node_of].long() + (torch.arange(n, device=dev) - side.node_rowptr[node_of].long())
+                if lead is not None:
+                    dest = dest + lead[node_of].long()
+                col[dest] = side.node_col + shift
+            both = self._both = (rowptr, col)
+        return both
+
     def _messages_by_source_row(self):
         """Stable bucketing of the messages by the compact row of their (source, type) bucket: the transposed plan
         whose output rows ARE the compact rows (the table is type-major, the by-source order of RelGraph node-major)."""

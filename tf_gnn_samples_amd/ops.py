@@ -506,6 +506,122 @@ def blocked_linear(X, offsets, weights):
     return _BlockedLinear.apply(X, [int(o) for o in offsets], *weights)
 
 
+def _typed_weight_gradient(H, gY, side, L: int, Din: int, Dout: int):
+    """[L, Din, Dout]: per-tile partials gather(H)^T @ gY (one launch), summed per edge type in tile order."""
+    from .dense import GEMM_TN, limb_gemm_tn_tiles, limb_tn_tiles_supported, panel_gemm
+    node32, _ = side.panel_indices()
+    tiles = side.P // side.chunk
+    if ((_cfg.typed_tn == "limb" or (_cfg.typed_tn == "auto" and Dout % 256 == 0))
+            and limb_tn_tiles_supported(H, gY, node32, side.chunk)):
+        # (round 5, isolated at a C5-sized table of 1400 tiles: three-limb TN 405 us vs exact-fp32 panel TN 484 us for
+        #  [128, 256] partials, 325 vs 262 us for [128, 128] ones — the panel kernel runs near the fp32 matrix pipe's rate;
+        #  the 0.6 / 0.96 ms per launch of the round-4 traces were contention on the side stream, not the kernel)
+        part = limb_gemm_tn_tiles(H, gY, node32, side.chunk)                 # [tiles, Din, Dout]
+    else:
+        part = panel_gemm(GEMM_TN, H, gY, a_rows=node32, batch=tiles, strides=(0, side.chunk * Dout, Din * Dout),
+                          dims=(Din, Dout, side.chunk))                      # [tiles, Din, Dout]
+    n = Din * Dout
+    sub = 1024 if n % 1024 == 0 else n
+    K = n // sub
+    rowptr, col = side.weight_grad_plan(K)
+    return _seg_reduce_raw(_lib.AGG_SUM, part.view(-1, sub), rowptr, 1, col, None, L * K).view(L, Din, Dout)
+
+
+class _TypedLinearPair(torch.autograd.Function):
+    """The two per-(node, type) transforms of a GNN-FiLM layer (gnns/gnn_film.py:92-106: messages h_u W_l over the by-source pair
+    table, FiLM weights h_v F_l over the by-target one) as ONE autograd node: the forward is the two products of
+    _TypedLinearPanel; the backward sums BOTH tables' per-row input gradients into the nodes with one gather-reduce over a
+    combined node -> rows CSR (graph.PairTables.node_csr_both) instead of two reductions and an addition of their [V, D] results
+    (round 6: one launch and ~0.1 ms less per layer of the C5 step).  Cached limb images only (dense.sel_image)."""
+
+    @staticmethod
+    def forward(ctx, H, pairs, leaves, La: int, *weights):
+        from .dense import GEMM_NN, limb_dense_sel, sel_image
+        wa, wb = weights[:La], weights[La:]
+        ctx.leaf_params, ctx.pairs, ctx.La = leaves, pairs, La
+        outs = []
+        for side, ws in ((pairs.src, wa), (pairs.tgt, wb)):
+            node32, tile_type = side.panel_indices()
+            outs.append(limb_dense_sel(GEMM_NN, H, ws, a_rows=node32, num_rows=side.P, b_select=tile_type,
+                                       rows_per_select=side.chunk, image=sel_image(ws, GEMM_NN)))
+        ctx.save_for_backward(H, *weights)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, gYa, gYb):
+        from .dense import GEMM_NT, limb_dense_sel, sel_image
+        H, *weights = ctx.saved_tensors
+        pairs, La = ctx.pairs, ctx.La
+        wa, wb = weights[:La], weights[La:]
+        sides = ((pairs.src, wa, gYa.contiguous()), (pairs.tgt, wb, gYb.contiguous()))
+        Din = wa[0].shape[0]
+        gH, gWs = None, None
+        want_w = any(ctx.needs_input_grad[4:])
+
+        def weight_gradients():
+            return tuple(_typed_weight_gradient(H, g, side, len(ws), Din, ws[0].shape[1]) for side, ws, g in sides)
+
+        side_stream = None
+        if (want_w and ctx.needs_input_grad[0] and _cfg.bwd_overlap_on and H.is_cuda
+                and (not _DEFER["on"] or deferred_targets_ok(ctx.leaf_params, H.device))):
+            side_stream = _side_stream(H.device)
+            cur = torch.cuda.current_stream(H.device)
+            side_stream.wait_stream(cur)
+            with torch.cuda.stream(side_stream):
+                gWs = weight_gradients()
+            for t in (H, sides[0][2], sides[1][2]):
+                t.record_stream(side_stream)
+        if ctx.needs_input_grad[0]:
+            Pa, Pb = pairs.src.P, pairs.tgt.P
+            gX = torch.empty((Pa + Pb, Din), dtype=torch.float32, device=H.device)
+            at = 0
+            images = [sel_image(ws, GEMM_NT) for _, ws, _ in sides]
+            for (side, ws, g), im in zip(sides, images):
+                _, tile_type = side.panel_indices()
+                if im is not None:
+                    limb_dense_sel(GEMM_NT, g, ws, b_select=tile_type, rows_per_select=side.chunk, image=im, out=gX[at:at + side.P])
+                else:                                                   # (switched off between forward and backward)
+                    gX[at:at + side.P] = limb_dense_sel(GEMM_NT, g, torch.stack(ws), b_select=tile_type, rows_per_select=side.chunk)
+                at += side.P
+            rowptr, col = pairs.node_csr_both()
+            gH = _seg_reduce_raw(_lib.AGG_SUM, gX, rowptr, 1, col, None, H.shape[0])
+        if side_stream is not None:
+            flat = gWs[0].unbind(0) + gWs[1].unbind(0)
+            if _DEFER["on"]:
+                hand_over_deferred(H.device, side_stream, ctx.leaf_params, flat)
+            else:
+                torch.cuda.current_stream(H.device).wait_stream(side_stream)
+            for g in gWs:
+                g.record_stream(torch.cuda.current_stream(H.device))
+        elif want_w:
+            wait_if_in_flight(ctx.leaf_params, H.device)
+            gWs = weight_gradients()
+        need = ctx.needs_input_grad[4:]
+        grads = (gWs[0].unbind(0) + gWs[1].unbind(0)) if gWs is not None else (None,) * len(weights)
+        return (gH, None, None, None) + tuple(g if n else None for g, n in zip(grads, need))
+
+
+def typed_linear_pair(H, pairs, weights_src, weights_tgt):
+    """(typed_linear(H, pairs.src, weights_src), typed_linear(H, pairs.tgt, weights_tgt)) with ONE reduction of both input
+    gradients into the nodes (_TypedLinearPair) where the cached limb route applies; else the two separate calls."""
+    from .dense import GEMM_NN, GEMM_NT, sel_image
+    weights_src, weights_tgt = list(weights_src), list(weights_tgt)
+    _check_f32(H, "H")
+    H = H.contiguous()
+    ok = (_typed_panel_ok(H, pairs.src, weights_src) and _typed_panel_ok(H, pairs.tgt, weights_tgt)
+          and weights_src[0].shape[0] == weights_tgt[0].shape[0])
+    if ok:
+        for ws in (weights_src, weights_tgt):
+            Din, Dout = ws[0].shape
+            ok = ok and _typed_limb_ok(Din, Dout) and _typed_limb_ok(Dout, Din) and sel_image(ws, GEMM_NN) is not None \
+                and sel_image(ws, GEMM_NT) is not None
+    if not ok:
+        return typed_linear(H, pairs.src, weights_src), typed_linear(H, pairs.tgt, weights_tgt)
+    allw = weights_src + weights_tgt
+    leaves = tuple(allw) if all(w.is_leaf and w.requires_grad for w in allw) else None
+    return _TypedLinearPair.apply(H, pairs, leaves, len(weights_src), *allw)
+
+
 class _TypedLinearPanel(torch.autograd.Function):
     """_TypedLinear on the row-panel MFMA kernel (csrc/panel_gemm.hip): the gather H[node[r]] and the per-tile kernel
     selection happen in the kernel's load addresses.  Nothing [P, Din] (the gathered rows) and nothing [tiles, Din, Dout] (a
@@ -553,22 +669,7 @@ class _TypedLinearPanel(torch.autograd.Function):
         gH = gW = None
 
         def weight_gradient():
-            tiles = side.P // side.chunk
-            from .dense import limb_gemm_tn_tiles, limb_tn_tiles_supported
-            if ((_cfg.typed_tn == "limb" or (_cfg.typed_tn == "auto" and Dout % 256 == 0))
-                    and limb_tn_tiles_supported(H, gY, node32, side.chunk)):
-                # (round 5, isolated at a C5-sized table of 1400 tiles: three-limb TN 405 us vs exact-fp32 panel TN 484 us for
-                #  [128, 256] partials, 325 vs 262 us for [128, 128] ones — the panel kernel runs near the fp32 matrix pipe's rate;
-                #  the 0.6 / 0.96 ms per launch of the round-4 traces were contention on the side stream, not the kernel)
-                part = limb_gemm_tn_tiles(H, gY, node32, side.chunk)                 # [tiles, Din, Dout]
-            else:
-                part = panel_gemm(GEMM_TN, H, gY, a_rows=node32, batch=tiles, strides=(0, side.chunk * Dout, Din * Dout),
-                                  dims=(Din, Dout, side.chunk))                      # [tiles, Din, Dout]
-            n = Din * Dout
-            sub = 1024 if n % 1024 == 0 else n
-            K = n // sub
-            rowptr, col = side.weight_grad_plan(K)
-            return _seg_reduce_raw(_lib.AGG_SUM, part.view(-1, sub), rowptr, 1, col, None, L * K).view(L, Din, Dout)
+            return _typed_weight_gradient(H, gY, side, L, Din, Dout)
 
         # The weight gradient (exact-fp32 matrix pipe, ~0.25-0.5 ms per product on a 23-type batch) depends on nothing the input
         # gradient computes: it runs on the side stream of the aggregate-first layer's weight gradient, under the memory-bound
