@@ -467,6 +467,10 @@ int relgnn_pair_materialize(int32_t act, const float* P, int64_t ldp, const floa
  * 6. Dense-layer helper (task-head plumbing around the path)
  * ========================================================================== */
 
+/* X[rows[i], 0 .. cols) = value for the num_rows listed rows (int64 ids on the device; ld floats between rows): the few padding rows
+ * of a compact pair table that the edge kernels leave unwritten and the typed weight-gradient product reads (gnns/gnn_film.py:92-106
+ * over graph.PairTables) — what torch's index_fill_ did in 30 us per call. */
+int relgnn_fill_rows_f32(float* X, int64_t ld, int32_t cols, const int64_t* rows, int64_t num_rows, float value, void* stream);
 /*
  * out[c] = sum_r X[r, c]: the bias gradient of a Keras Dense over V node rows (tasks/ppi_task.py:176-179
  * backward), deterministic two-stage reduction.  workspace: relgnn_column_sum_workspace_bytes().

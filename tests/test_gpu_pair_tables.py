@@ -313,3 +313,21 @@ def test_typed_weight_gradient_routes_agree(gpu_device, Dout):
             assert np.abs(grads[route][t] - want).max() <= 5e-6 * scale, (route, t)
         same = "limb" if Dout % 256 == 0 else "panel"
         assert np.array_equal(grads["auto"][t], grads[same][t])
+
+
+def test_fill_rows_zeroes_the_listed_rows_only(gpu_device):
+    """relgnn_fill_rows_f32 (the padding rows of a compact table in front of the typed weight-gradient product): the listed rows, whole,
+    nothing else; a list padded with -1 is tolerated; strided rows."""
+    from tf_gnn_samples_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    wide = torch.randn((300, 260), generator=g).to(gpu_device)
+    X = wide[:, 4:260]                                                   # row stride 260, 256 columns
+    before = wide.clone()
+    rows = torch.tensor([0, 7, 299, 150, -1, -1], dtype=torch.int64, device=gpu_device)
+    ops._fill_rows(X, rows, 0.0)
+    torch.cuda.synchronize()
+    want = before.clone()
+    want[[0, 7, 299, 150], 4:260] = 0.0
+    assert torch.equal(wide, want)
+    ops._fill_rows(X, rows[:0], 1.0)                                     # empty list: nothing
+    assert torch.equal(wide, want)

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "relgnn_limb_gemm_sel_pc_supported": (ctypes.c_int, [_c_i32, _c_i32, _c_i32, _c_i32]),
     "relgnn_limb_gemm_sel_pc_xf32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _ptr, _c_i32, _ptr, _c_i32, _ptr, _ptr, _c_i64, _c_i32, _c_i32,
                                                     _c_i32, _ptr, _ptr]),
+    "relgnn_fill_rows_f32": (ctypes.c_int, [_ptr, _c_i64, _c_i32, _ptr, _c_i64, ctypes.c_float, _ptr]),
     "relgnn_limb_dense_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr, _c_i64, _ptr, _c_i64, _c_i32,
                                              _c_i32, _c_i32, _ptr]),
     "relgnn_blaslt_gemm_f32": (ctypes.c_int, [_c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32,

@@ -32,9 +32,28 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict
   if (rg == 0 && c < cols) partial[(int64_t)blockIdx.x * cols + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
+// X[rows[i], 0 .. cols) = value: one lane group of 64 per listed row
+__global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ X, int64_t ld, int32_t cols, const int64_t* __restrict__ rows,
+                                                        int64_t n, float value) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t r = rows[i];
+  if (r < 0) return;                                   // (a list padded with -1: nothing to fill)
+  float* row = X + r * ld;
+  for (int c = threadIdx.x & 63; c < cols; c += 64) row[c] = value;
+}
+
 }  // namespace
 
 extern "C" {
+
+int relgnn_fill_rows_f32(float* X, int64_t ld, int32_t cols, const int64_t* rows, int64_t num_rows, float value, void* stream) {
+  if (cols < 0 || num_rows < 0 || ld < cols) return RELGNN_EINVAL;
+  if (cols == 0 || num_rows == 0) return RELGNN_OK;
+  if (!X || !rows) return RELGNN_EINVAL;
+  fill_rows_kernel<<<(unsigned)((num_rows + 3) / 4), 256, 0, as_stream(stream)>>>(X, ld, cols, rows, num_rows, value);
+  return launch_status();
+}
 
 size_t relgnn_column_sum_workspace_bytes(int64_t rows, int32_t cols) {
   (void)rows;
