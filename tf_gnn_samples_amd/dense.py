@@ -1044,6 +1044,22 @@ def _split_count(V: int, M: int, N: int) -> int:
     return int(max(1, min(want, V // 512, 64)))
 
 
+def tn_stream_into(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
+    """out[:] = a^T @ b through the streaming weight-gradient kernel, `out` a [M, N] block of a wider row-major matrix (dense rows,
+    any row stride): the two column blocks of a GRU's recurrent-kernel gradient are written in place, no zeros + copies + add."""
+    from . import _lib
+    lib = _lib.load_library()
+    V, M = a.shape
+    N = b.shape[1]
+    if out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.float32:
+        raise ValueError("tn_stream_into: out must be a float32 [%d, %d] block with dense rows" % (M, N))
+    nbytes = lib.relgnn_gemm_tn_stream_workspace_bytes(M, N, V)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_gemm_tn_stream_f32(_lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True), b.stride(0),
+                                             out.data_ptr(), out.stride(0), M, N, V, 0, _lib.ptr(ws), nbytes, _lib.current_stream()),
+               "relgnn_gemm_tn_stream_f32")
+
+
 def tn_stream_gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """a^T @ b for a [V, M], b [V, N] through the streaming weight-gradient kernel (csrc/gemm_tn_stream.hip);
     with `out` (contiguous [M, N]): out += a^T @ b."""

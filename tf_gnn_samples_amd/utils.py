@@ -187,6 +187,84 @@ class _FusedGRU(torch.autograd.Function):
         return gxk, gxk[:, :2 * u], gh, gu_h, None
 
 
+class _GRUCellFn(torch.autograd.Function):
+    """The whole Keras GRUCell (utils/utils.py:15-16 through gnns/ggnn.py:92; reset_after=False, gate order z, r, h) as ONE autograd
+    node over the cell's three variables as they are stored — kernel [D, 3u], recurrent_kernel [u, 3u], bias [3u]:
+        xk = x @ K + b;  rec = h @ U[:, :2u];  z, r = hs(xk_zr + rec);  q = (r * h) @ U[:, 2u:];  out = z h + (1 - z) act(xk_h + q)
+    Same kernels and the same arithmetic as the composition of dense() / _FusedGRU it replaces (round 6); what goes away is what
+    autograd wrapped around the two column views of the recurrent kernel — per cell and step two zero-fills, two copies and an add
+    for the views' gradients, a copy of U[:, 2u:] — because the recurrent kernel's gradient is written block by block into ONE
+    [u, 3u] tensor (dense.tn_stream_into).  The weight gradients go to the side stream like a Dense layer's (dense._on_side_stream)."""
+
+    @staticmethod
+    def forward(ctx, x, h, K, U, b, act: int):
+        from . import _lib
+        from .dense import GEMM_NN, lib_gemm
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        x, h = x.contiguous(), h.contiguous()
+        V, u = h.shape
+        xk = lib_gemm(GEMM_NN, x, K, b, weight=True)                       # [V, 3u]
+        rec = lib_gemm(GEMM_NN, h, U[:, :2 * u], weight=True)              # [V, 2u] (the view read with its leading dimension)
+        z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        _lib.check(lib.relgnn_gru_gates_fwd(_lib.ptr(xk), _lib.ptr(rec), _lib.ptr(h), V, u, _lib.ptr(z), _lib.ptr(r),
+                                            _lib.ptr(rh), st), "relgnn_gru_gates_fwd")
+        q = lib_gemm(GEMM_NN, rh, U[:, 2 * u:], weight=True)
+        hh, out = torch.empty_like(h), torch.empty_like(h)
+        _lib.check(lib.relgnn_gru_out_fwd(_lib.ptr(xk), _lib.ptr(q), _lib.ptr(z), _lib.ptr(h), V, u, act, _lib.ptr(hh),
+                                          _lib.ptr(out), st), "relgnn_gru_out_fwd")
+        ctx.act = act
+        ctx.save_for_backward(x, h, K, U, z, r, rh, hh)
+        ctx.leaf_params = (K, U, b) if all(p.is_leaf and p.requires_grad for p in (K, U, b)) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import _lib
+        from .dense import GEMM_NT, _on_side_stream, column_sum, lib_gemm, matmul_tn_splitk, tn_stream_into
+        lib = _lib.load_library()
+        st = _lib.current_stream()
+        x, h, K, U, z, r, rh, hh = ctx.saved_tensors
+        V, u = h.shape
+        gout = gout.contiguous()
+        gxk = torch.empty((V, 3 * u), dtype=torch.float32, device=h.device)
+        gq, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        _lib.check(lib.relgnn_gru_out_bwd(_lib.ptr(gout), _lib.ptr(z), _lib.ptr(h), _lib.ptr(hh), V, u, ctx.act,
+                                          _lib.ptr(gxk), _lib.ptr(gq), _lib.ptr(gz), _lib.ptr(gh), st), "relgnn_gru_out_bwd")
+        grh = lib_gemm(GEMM_NT, gq, U[:, 2 * u:], weight=True)
+        _lib.check(lib.relgnn_gru_gates_bwd(_lib.ptr(grh), _lib.ptr(gz), _lib.ptr(z), _lib.ptr(r), _lib.ptr(h), V, u,
+                                            _lib.ptr(gxk), _lib.ptr(gh), st), "relgnn_gru_gates_bwd")
+        grec = gxk[:, :2 * u]                                              # d loss / d rec = the z, r columns of d loss / d xk
+
+        def weight_side():
+            gK = matmul_tn_splitk(x, gxk) if ctx.needs_input_grad[2] else None
+            gU = None
+            if ctx.needs_input_grad[3]:
+                gU = torch.empty((u, 3 * u), dtype=torch.float32, device=h.device)
+                tn_stream_into(h, grec, gU[:, :2 * u])
+                tn_stream_into(rh, gq, gU[:, 2 * u:])
+            gb = column_sum(gxk) if ctx.needs_input_grad[4] else None
+            return gK, gU, gb
+
+        aside = _on_side_stream(weight_side, (x, h, rh, gxk, gq), ctx.leaf_params,
+                                want=(ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and any(ctx.needs_input_grad[2:5]))
+        gx = lib_gemm(GEMM_NT, gxk, K, weight=True) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[1]:
+            gh = gh.add_(lib_gemm(GEMM_NT, grec, U[:, :2 * u], weight=True))
+        else:
+            gh = None
+        gK, gU, gb = aside if aside is not None else weight_side()
+        return gx, gh, gK, gU, gb, None
+
+
+def _gru_cell_fused_ok(x, h, K, U, b, u: int) -> bool:
+    return (h.is_cuda and x.is_cuda and x.dim() == 2 and h.dim() == 2 and h.shape[1] == u and u % 4 == 0 and U.shape == (u, 3 * u)
+            and K.shape[1] == 3 * u and b is not None and b.shape == (3 * u,) and U.stride(1) == 1 and U.is_contiguous()
+            and x.dtype == h.dtype == torch.float32
+            # (the recurrent kernel's gradient blocks are written by the streaming weight-gradient kernel: its size class)
+            and 2 * u * u <= 256 * 256 and 0 < h.shape[0] <= (1 << 18))
+
+
 _GRU_FUSABLE = {None: 0, "linear": 0, "tanh": 1, "relu": 2, "leaky_relu": 3, "elu": 4, "selu": 5}
 
 
@@ -207,6 +285,9 @@ class _GatedUnit:
             out = apply_activation(act, out)
             return out, [out]
         # GRU, reset_after=False, gate order z, r, h (Keras GRUCell, TF 1.13)
+        if self.activation_name in _GRU_FUSABLE and _gru_cell_fused_ok(inputs, h, K, U, b, u):
+            out = _GRUCellFn.apply(inputs, h, K, U, b, _GRU_FUSABLE[self.activation_name])
+            return out, [out]
         xk = dense(inputs, K, b)                             # [V, 3u]
         rec = dense(h, U[:, :2 * u])                         # [V, 2u]
         if h.is_cuda and self.activation_name in _GRU_FUSABLE:
