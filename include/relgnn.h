@@ -707,6 +707,16 @@ int64_t relgnn_gemm_tn_stream_workspace_bytes(int32_t M, int32_t N, int64_t K);
 int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
                               int64_t K, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /*
+ * The same product with the output as N / block_cols matrices of their own: column block j of A^T @ B goes to the [M, block_cols]
+ * matrix at C + j * block_stride (row stride ldc >= block_cols).  The gradients of the L per-edge-type kernels a layer applies to
+ * the SAME node states (gnns/ggnn.py:63-67,80-81: dW_l = H^T @ G[:, l * D : (l + 1) * D]) are ONE product whose operand A is read
+ * once, each gradient a dense tensor of its own (block_stride = M * block_cols: a contiguous [L, M, block_cols] array).  Same
+ * workspace size, chunking and summation order as relgnn_gemm_tn_stream_f32 for (M, N, K).  N % block_cols != 0: RELGNN_EINVAL.
+ */
+int relgnn_gemm_tn_stream_blocks_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                     int64_t block_stride, int32_t M, int32_t N, int32_t block_cols, int64_t K, int32_t accumulate,
+                                     void* workspace, int64_t workspace_bytes, void* stream);
+/*
  * The closing pass of a split-K weight gradient: C[M, N] = sum over `num_slabs` partial products slabs[z] (each [M, N],
  * contiguous, summed in slab order) + At[R, M]^T @ Bt[R, N] for the R rows (R < one chunk, typically < 64) that the equal
  * chunks left over.  One launch instead of a sum, a second product and an accumulate.

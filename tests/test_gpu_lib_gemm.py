@@ -97,6 +97,44 @@ def test_streaming_weight_gradient_kernel(gpu_device, V):
     _close(D.tn_stream_gemm(a, b, out=acc), want, V)    # accumulate into an existing product
 
 
+@pytest.mark.parametrize("V", [51037, 4099, 130, 3])
+@pytest.mark.parametrize("M,bc,L", [(128, 128, 5), (128, 128, 1), (64, 50, 3), (50, 121, 2), (256, 64, 4)])
+def test_streaming_weight_gradient_into_blocks(gpu_device, V, M, bc, L):
+    """relgnn_gemm_tn_stream_blocks_f32: the L column blocks of ONE a^T @ b as L dense matrices (the per-edge-type kernel gradients
+    of gnns/ggnn.py:63-67,80-81) — the same numbers, bit for bit, as the one-matrix entry gives for the whole product (same
+    chunking and summation order), each block contiguous, and against float64."""
+    from tf_gnn_samples_amd import dense as D
+    gen = torch.Generator(device=gpu_device).manual_seed(V + M + L)
+    a, b = _rand(gen, V, M), _rand(gen, V, L * bc)
+    assert D.tn_stream_blocks_ok(a, b)
+    got = D.tn_stream_blocks(a, b, L)
+    assert got.shape == (L, M, bc) and got.is_contiguous()
+    whole = D.tn_stream_gemm(a, b)
+    for l, blk in enumerate(got.unbind(0)):
+        assert blk.is_contiguous()
+        assert torch.equal(blk, whole[:, l * bc:(l + 1) * bc]), l
+        _close(blk, a.double().t() @ b[:, l * bc:(l + 1) * bc].double(), V)
+    assert torch.equal(got, D.tn_stream_blocks(a, b, L))
+
+
+def test_streaming_weight_gradient_into_blocks_refuses_ragged_blocks(gpu_device):
+    import ctypes
+    from tf_gnn_samples_amd import _lib
+    lib = _lib.load_library()
+    a = torch.zeros((64, 32), device=gpu_device)
+    b = torch.zeros((64, 100), device=gpu_device)
+    out = torch.ones(4096, device=gpu_device)
+    ws = torch.zeros(1 << 20, device=gpu_device)
+    rc = lib.relgnn_gemm_tn_stream_blocks_f32(a.data_ptr(), 32, b.data_ptr(), 100, out.data_ptr(), 33, 32 * 33, 32, 100, 33, 64, 0,
+                                              ws.data_ptr(), ws.numel() * 4, None)
+    assert rc == _lib.EINVAL                      # 100 columns are not a whole number of 33-column blocks
+    rc = lib.relgnn_gemm_tn_stream_blocks_f32(a.data_ptr(), 32, b.data_ptr(), 100, out.data_ptr(), 50, 32 * 50, 32, 100, 50, 0, 0,
+                                              ws.data_ptr(), ws.numel() * 4, None)
+    assert rc == _lib.OK                          # no rows: the two [32, 50] blocks are zeroed, nothing behind them
+    torch.cuda.synchronize()
+    assert float(out[:3200].abs().sum()) == 0.0 and float(out[3200:].sum()) == 896.0
+
+
 def test_streaming_kernel_random_shapes(gpu_device):
     """Seeded sweep over node counts, output shapes and row strides (aligned / odd, views into wider storage): the kernel's
     load ring is hand-scheduled assembly, so every combination of its four load variants, of lean and masked passes and of

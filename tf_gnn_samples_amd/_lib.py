@@ -127,6 +127,8 @@ _SIGNATURES = {
                                               _c_i64, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_gemm_tn_stream_workspace_bytes": (_c_i64, [_c_i32, _c_i32, _c_i64]),
     "relgnn_gemm_tn_stream_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _c_i32, _c_i64, _c_i32, _ptr, _c_i64, _ptr]),
+    "relgnn_gemm_tn_stream_blocks_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i64,
+                                                        _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_sum_slabs_tail_f32": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _ptr]),
     "relgnn_rgdcn_apply_fwd": (ctypes.c_int, [_c_i32, _c_i32, _c_i32, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_rgdcn_apply_bwd": (ctypes.c_int, [_c_i32, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr]),

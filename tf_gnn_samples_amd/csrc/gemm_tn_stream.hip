@@ -91,10 +91,13 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
                                                              int64_t ldb, int64_t K, int32_t M, int32_t N, int64_t chunk_rows,
                                                              float* __restrict__ partial, int32_t tiles_n, int32_t tiles) {
   const int lane = threadIdx.x & 63;
+  // (grid: chunk-major.  A chunk's tile groups as neighbouring blocks of ONE XCD, so that they share its L2, measured the same:
+  //  [50 k, 128]^T [50 k, 640] 93.6 against 94.3 us, scripts/exp_tn_xcd.py at commit "XCD-grouped TN stream grid")
+  const int chunk = blockIdx.x;
   const int tile = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (tile >= tiles) return;                                   // whole wave
   const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
-  const int64_t k_begin = (int64_t)blockIdx.x * chunk_rows, k_end = min(K, k_begin + chunk_rows);
+  const int64_t k_begin = (int64_t)chunk * chunk_rows, k_end = min(K, k_begin + chunk_rows);
   const Cols ca = make_cols(m0 + 2 * (lane & 31), M), cb = make_cols(n0 + 2 * (lane & 31), N);
   const int rows = (int)(k_end - k_begin);                     // <= chunk_rows < 2^31
   const int half = lane >> 5;                                  // this lane's row inside a k-pair
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
   // the matrix is.)
   // C layout of v_mfma_f32_32x32x2: column index c = lane & 31, row index i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   // tile (a, b) holds output rows m0 + 2 i + a and columns n0 + 2 c + b.
-  float* out = partial + (int64_t)blockIdx.x * M * N;
+  float* out = partial + (int64_t)chunk * M * N;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -184,9 +187,11 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
 
 // C[m, n] (+)= sum over chunks.  256 threads = 64 outputs x 4 chunk groups: group g sums chunks g, g + 4, ... (independent
 // loads in flight instead of one long dependent chain per output), the four group sums are added in group order through
-// LDS — a fixed order, so the result is deterministic.
+// LDS — a fixed order, so the result is deterministic.  The output may be a row of column BLOCKS, each a matrix of its own
+// (bcols columns wide, bstride floats apart, row stride ldc): the L per-type weight gradients of one [M, L * bcols] product.
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int64_t mn, int32_t chunks, int32_t N,
-                                                           float* __restrict__ C, int64_t ldc, int32_t accumulate) {
+                                                           float* __restrict__ C, int64_t ldc, int32_t accumulate, int32_t bcols,
+                                                           int64_t bstride) {
   __shared__ float part[4][64];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + o;
@@ -203,7 +208,8 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   __syncthreads();
   if (g == 0 && i < mn) {
     const float s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
-    float* dst = C + (i / N) * ldc + (i % N);
+    const int n = (int)(i % N);
+    float* dst = C + (n / bcols) * bstride + (i / N) * ldc + (n % bcols);
     *dst = accumulate ? *dst + s : s;
   }
 }
@@ -244,7 +250,10 @@ Plan make_plan(int32_t M, int32_t N, int64_t K) {
   // one wave per SIMD, one round of workgroups (256 CUs x 4): measured at [36 k, 256]^T @ [36 k, 256 | 121 | 50-row]:
   // 512 waves 94 / 65 / 39 us, 768: 70 / 50 / 33, 1024: 59 / 43 / 33, 1280: 84 / 59 / 41, 2048: 64 / 49 / 41, 4096: 73 / 64 / 49
   static const int64_t waves = [] { const char* e = getenv("RELGNN_TN_WAVES"); return e ? (int64_t)atoi(e) : (int64_t)1024; }();
-  int64_t chunks = (waves + p.tiles - 1) / p.tiles;
+  // whole workgroups (four tiles of a chunk), and never one more than the round holds: 20 tiles ([128, 640]) x 52 chunks are 260
+  // workgroups — four CUs run two of them and the launch takes twice as long (155 us against 94: scripts/exp_tn_xcd.py)
+  const int64_t tgroups = (p.tiles + 3) / 4;
+  int64_t chunks = std::max<int64_t>(1, (waves / 4) / tgroups);
   chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, (K + 63) / 64));
   int64_t rows = (K + chunks - 1) / chunks;
   rows = (rows + 2 * kDepth - 1) / (2 * kDepth) * (2 * kDepth);
@@ -263,14 +272,14 @@ int64_t relgnn_gemm_tn_stream_workspace_bytes(int32_t M, int32_t N, int64_t K) {
   return (int64_t)p.chunks * M * N * 4;
 }
 
-int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
-                              int64_t K, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
-  if (M < 0 || N < 0 || K < 0 || lda < M || ldb < N || ldc < N) return RELGNN_EINVAL;
-  if (M == 0 || N == 0) return RELGNN_OK;
-  if (!C) return RELGNN_EINVAL;
+static int tn_stream_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                            int64_t K, int32_t bcols, int64_t bstride, int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
   hipStream_t st = as_stream(stream);
   if (K == 0) {
-    if (!accumulate && hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, st) != hipSuccess) return RELGNN_EHIP;
+    if (accumulate) return RELGNN_OK;
+    for (int32_t b = 0; b < N / bcols; ++b)
+      if (hipMemset2DAsync(C + b * bstride, (size_t)ldc * 4, 0, (size_t)bcols * 4, (size_t)M, st) != hipSuccess) return RELGNN_EHIP;
     return RELGNN_OK;
   }
   if (!A || !B || !workspace) return RELGNN_EINVAL;
@@ -289,8 +298,26 @@ int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64
   else RELGNN_TN_LAUNCH(false, false);
 #undef RELGNN_TN_LAUNCH
   const int64_t mn = (int64_t)M * N;
-  sum_partials_kernel<<<(unsigned)((mn + 63) / 64), 256, 0, st>>>(partial, mn, p.chunks, N, C, ldc, accumulate);
+  sum_partials_kernel<<<(unsigned)((mn + 63) / 64), 256, 0, st>>>(partial, mn, p.chunks, N, C, ldc, accumulate, bcols, bstride);
   return launch_status();
+}
+
+int relgnn_gemm_tn_stream_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N,
+                              int64_t K, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || lda < M || ldb < N || ldc < N) return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!C) return RELGNN_EINVAL;
+  return tn_stream_launch(A, lda, B, ldb, C, ldc, M, N, K, N, 0, accumulate, workspace, workspace_bytes, stream);
+}
+
+int relgnn_gemm_tn_stream_blocks_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                     int64_t block_stride, int32_t M, int32_t N, int32_t block_cols, int64_t K, int32_t accumulate,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || block_cols <= 0 || N % block_cols || lda < M || ldb < N || ldc < block_cols || block_stride < 0)
+    return RELGNN_EINVAL;
+  if (M == 0 || N == 0) return RELGNN_OK;
+  if (!C) return RELGNN_EINVAL;
+  return tn_stream_launch(A, lda, B, ldb, C, ldc, M, N, K, block_cols, block_stride, accumulate, workspace, workspace_bytes, stream);
 }
 
 int relgnn_sum_slabs_tail_f32(const float* slabs, int32_t num_slabs, int32_t M, int32_t N, const float* At, int64_t lda,

@@ -1060,6 +1060,31 @@ def tn_stream_into(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> None:
                "relgnn_gemm_tn_stream_f32")
 
 
+_TN_BLOCKS_MAX_OUT = 128 * 1024      # outputs of the block form (measured up to [128, 640]; its partial sums are chunks * M * N floats)
+
+
+def tn_stream_blocks_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return (_cfg.tn == "stream" and a.is_cuda and a.shape[1] * b.shape[1] <= _TN_BLOCKS_MAX_OUT and 0 < a.shape[0] <= (1 << 18)
+            and _lib_rows_ok(a) and _lib_rows_ok(b))
+
+
+def tn_stream_blocks(a: torch.Tensor, b: torch.Tensor, L: int) -> torch.Tensor:
+    """[L, M, N / L]: block l = a^T @ b[:, l * N / L : (l + 1) * N / L] for a [V, M], b [V, N] — ONE pass of the streaming
+    weight-gradient kernel over a, every block a dense matrix of its own (relgnn_gemm_tn_stream_blocks_f32)."""
+    from . import _lib
+    lib = _lib.load_library()
+    V, M = a.shape
+    N = b.shape[1]
+    bc = N // L
+    out = torch.empty((L, M, bc), dtype=torch.float32, device=a.device)
+    nbytes = lib.relgnn_gemm_tn_stream_workspace_bytes(M, N, V)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=a.device)
+    _lib.check(lib.relgnn_gemm_tn_stream_blocks_f32(_lib.ptr(a, rows_strided=True), a.stride(0), _lib.ptr(b, rows_strided=True),
+                                                    b.stride(0), out.data_ptr(), bc, M * bc, M, N, bc, V, 0, _lib.ptr(ws), nbytes,
+                                                    _lib.current_stream()), "relgnn_gemm_tn_stream_blocks_f32")
+    return out
+
+
 def tn_stream_gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """a^T @ b for a [V, M], b [V, N] through the streaming weight-gradient kernel (csrc/gemm_tn_stream.hip);
     with `out` (contiguous [M, N]): out += a^T @ b."""
@@ -1236,9 +1261,12 @@ class _DenseMultiFn(torch.autograd.Function):
         gx = gks = None
 
         def weight_side():
-            # dk_l = x^T @ g[:, block l], one streaming product per kernel: each gradient is a dense [K, N] tensor of its own, which
-            # autograd's accumulator keeps as it is (a column block of one [K, L*N] product would be cloned — five copies, and on
-            # the main stream while the side stream still writes it)
+            # dk_l = x^T @ g[:, block l].  Each gradient has to be a dense [K, N] tensor of its own — autograd's accumulator keeps
+            # such a tensor as it is, a column block of a [K, L*N] product it would clone (five copies, and on the main stream
+            # while the side stream still writes it) — so the ONE product x^T @ g writes its column blocks as L matrices
+            # (tn_stream_blocks: x read once, two launches instead of 2 L; C3: 50 us instead of 5 x 50 per layer)
+            if all(ctx.needs_input_grad[1:]) and tn_stream_blocks_ok(x, g):
+                return tuple(tn_stream_blocks(x, g, L).unbind(0))
             return tuple(matmul_tn_splitk(x, g[:, l * N:(l + 1) * N]) if ctx.needs_input_grad[1 + l] else None for l in range(L))
 
         aside = _on_side_stream(weight_side, (x, g), ctx.leaf_params, want=ctx.needs_input_grad[0] and any(ctx.needs_input_grad[1:]))
