@@ -548,6 +548,25 @@ int relgnn_gru_out_bwd(const float* gout, const float* z, const float* h, const 
                        int32_t units, int32_t act, float* gxk, float* gq, float* gz, float* gh, void* stream);
 int relgnn_gru_gates_bwd(const float* grh, const float* gz, const float* z, const float* r, const float* h,
                          int64_t num_nodes, int32_t units, float* gxk, float* gh, void* stream);
+/*
+ * The whole cell forward as ONE kernel (csrc/gru_cell.hip), three-bf16-limb products on the matrix cores (exact-fp32 operands,
+ * fp32 accumulation: section 12's limb route):
+ *   [z | r] = hs([x | h] @ [[K_z K_r]; [U_z U_r]] + b[:2u]);  hh = act([x | r*h] @ [K_h; U_h] + b[2u:]);  out = z*h + (1-z)*hh
+ * — x @ kernel + h @ recurrent_kernel as ONE accumulation over k = [x | h] (the composition above rounds the two sums separately:
+ * results agree to the last few bits, not bit for bit).  A persistent workgroup per CU owns 64-row panels: producer waves split the
+ * rows of x and h into limbs in LDS, matrix waves compute z and r, r*h goes to the candidate's k-loop through LDS, and nothing but
+ * the results leaves the CU.
+ *   w_zr_limbs: limb image (relgnn_limb_split_multi_f32) of the [2u, in_dim + u] right operand [K[:, :2u]; U[:, :2u]]^T
+ *   w_h_limbs : limb image of the [u, in_dim + u] right operand [K[:, 2u:]; U[:, 2u:]]^T;   bias [3u]
+ *   z, r, rh, hh: [num_nodes, u] dense outputs for the backward — all four or all NULL (an inference pass); out [num_nodes, u]
+ *   status: the caller's hand-over block (RELGNN_HANDOVER_PC_*: section 12), may be NULL.
+ * units == in_dim == 128, act in {LINEAR, TANH, RELU, LEAKY_RELU} (relgnn_gru_cell_fwd_supported), 16-byte aligned rows:
+ * RELGNN_EUNSUPPORTED otherwise (the caller composes the cell from the entries above).
+ */
+int relgnn_gru_cell_fwd_supported(int32_t act, int32_t units, int32_t in_dim);
+int relgnn_gru_cell_fwd_xf32(const float* x, int64_t ldx, const float* h, int64_t ldh, const uint16_t* w_zr_limbs,
+                             const uint16_t* w_h_limbs, const float* bias, int32_t act, float* z, float* r, float* rh, float* hh,
+                             float* out, int64_t num_nodes, int32_t units, int32_t in_dim, int32_t* status, void* stream);
 
 /* ---- layer normalisation of node states ------------------------------------------------------------------
  * Replaces: tf.contrib.layers.layer_norm at gnns/gnn_film.py:120, gnns/rgin.py:139, gnns/gnn_edge_mlp.py:120 and

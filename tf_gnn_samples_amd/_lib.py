@@ -74,6 +74,9 @@ _SIGNATURES = {
     "relgnn_sigmoid_ce_bwd": (ctypes.c_int, [_ptr, _ptr, _c_i64, _ptr, _c_f32, _ptr, _ptr, _ptr]),
     "relgnn_sigmoid_ce_bwd_padded": (ctypes.c_int, [_ptr, _ptr, _c_i64, _c_i32, _ptr, _c_f32, _ptr, _ptr, _c_i32, _ptr]),
     "relgnn_gru_gates_fwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr, _ptr]),
+    "relgnn_gru_cell_fwd_supported": (ctypes.c_int, [_c_i32, _c_i32, _c_i32]),
+    "relgnn_gru_cell_fwd_xf32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                                _c_i64, _c_i32, _c_i32, _ptr, _ptr]),
     "relgnn_gru_out_fwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_gru_out_bwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_gru_gates_bwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr]),

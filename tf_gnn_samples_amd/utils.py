@@ -204,6 +204,25 @@ class _GRUCellFn(torch.autograd.Function):
         st = _lib.current_stream()
         x, h = x.contiguous(), h.contiguous()
         V, u = h.shape
+        if _gru_cell_kernel_ok(x, h, K, U, b, act):
+            # one launch (csrc/gru_cell.hip): both products, the gates, the candidate and the blend; z, r, r * h and the candidate
+            # are written only when a backward will read them
+            from . import ops
+            from .dense import WEIGHT_NN, weight_image
+            train = any(ctx.needs_input_grad[:5])
+            im_zr = weight_image([K[:, :2 * u], U[:, :2 * u]], WEIGHT_NN)  # B [2u, D + u]: k = [x | h]
+            im_h = weight_image([K[:, 2 * u:], U[:, 2 * u:]], WEIGHT_NN)   # B [u, D + u]:  k = [x | r * h]
+            z, r, rh, hh = (torch.empty_like(h) for _ in range(4)) if train else (None,) * 4
+            out = torch.empty_like(h)
+            _lib.check(lib.relgnn_gru_cell_fwd_xf32(_lib.ptr(x), x.stride(0), _lib.ptr(h), h.stride(0), im_zr.buf.data_ptr(),
+                                                    im_h.buf.data_ptr(), _lib.ptr(b), act, _lib.ptr(z), _lib.ptr(r), _lib.ptr(rh),
+                                                    _lib.ptr(hh), _lib.ptr(out), V, u, x.shape[1],
+                                                    ops.handover_word(h.device).data_ptr(), st), "relgnn_gru_cell_fwd_xf32")
+            ctx.act = act
+            if train:
+                ctx.save_for_backward(x, h, K, U, z, r, rh, hh)
+            ctx.leaf_params = (K, U, b) if all(p.is_leaf and p.requires_grad for p in (K, U, b)) else None
+            return out
         xk = lib_gemm(GEMM_NN, x, K, b, weight=True)                       # [V, 3u]
         rec = lib_gemm(GEMM_NN, h, U[:, :2 * u], weight=True)              # [V, 2u] (the view read with its leading dimension)
         z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
@@ -255,6 +274,21 @@ class _GRUCellFn(torch.autograd.Function):
             gh = None
         gK, gU, gb = aside if aside is not None else weight_side()
         return gx, gh, gK, gU, gb, None
+
+
+def _gru_cell_kernel_ok(x, h, K, U, b, act: int) -> bool:
+    """The one-kernel forward (relgnn_gru_cell_fwd_xf32): the limb route, 128 units over 128-wide inputs, rows it can read in place."""
+    from . import _lib
+    from .config import settings as cfg
+    from .dense import WEIGHT_NN, weight_image_ok
+    u = h.shape[1]
+    if not (cfg.limb_gemm and cfg.gru_cell == "1" and h.is_cuda and 0 < h.shape[0] <= (1 << 22) and h.shape[0] * h.stride(0) < (1 << 30) and K.shape[0] == x.shape[1]
+            and b.is_contiguous() and b.data_ptr() % 16 == 0
+            and all(t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (x, h))):
+        return False
+    if not _lib.load_library().relgnn_gru_cell_fwd_supported(act, u, x.shape[1]):
+        return False
+    return weight_image_ok([K[:, :2 * u], U[:, :2 * u]], WEIGHT_NN) and weight_image_ok([K[:, 2 * u:], U[:, 2 * u:]], WEIGHT_NN)
 
 
 def _gru_cell_fused_ok(x, h, K, U, b, u: int) -> bool:
