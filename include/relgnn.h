@@ -736,6 +736,18 @@ int relgnn_gemm_tn_stream_blocks_f32(const float* A, int64_t lda, const float* B
                                      int64_t block_stride, int32_t M, int32_t N, int32_t block_cols, int64_t K, int32_t accumulate,
                                      void* workspace, int64_t workspace_bytes, void* stream);
 /*
+ * Up to four such products over the SAME K rows in one launch pair (one list of 64 x 64 tiles cut into the same row chunks, one
+ * reduction launch): C[i][M[i], N[i]] = A[i][K, M[i]]^T @ B[i][K, N[i]] — the three weight gradients of a GRU cell (gnns/ggnn.py:92
+ * through utils/utils.py:15-16: x^T gxk, h^T gxk[:, :2u], (r*h)^T gxk[:, 2u:]).  colsum0 (nullable, [N[0]]): the column sums of
+ * B[0] — the bias gradient of the layer whose kernel gradient product 0 is — from the registers the matrix instructions read.
+ * The pointer and size arrays are HOST arrays of `num` entries.  8-byte aligned operands with even row strides and M, N multiples
+ * of 64 (RELGNN_EUNSUPPORTED otherwise: launch such products one by one); workspace: relgnn_gemm_tn_stream_group_workspace_bytes.
+ */
+int64_t relgnn_gemm_tn_stream_group_workspace_bytes(int32_t num, const int32_t* M, const int32_t* N, int64_t K, int32_t with_colsum);
+int relgnn_gemm_tn_stream_group_f32(int32_t num, const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                    float* const* C, const int64_t* ldc, const int32_t* M, const int32_t* N, int64_t K,
+                                    float* colsum0, void* workspace, int64_t workspace_bytes, void* stream);
+/*
  * The closing pass of a split-K weight gradient: C[M, N] = sum over `num_slabs` partial products slabs[z] (each [M, N],
  * contiguous, summed in slab order) + At[R, M]^T @ Bt[R, N] for the R rows (R < one chunk, typically < 64) that the equal
  * chunks left over.  One launch instead of a sum, a second product and an accumulate.

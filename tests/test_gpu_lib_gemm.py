@@ -117,6 +117,65 @@ def test_streaming_weight_gradient_into_blocks(gpu_device, V, M, bc, L):
     assert torch.equal(got, D.tn_stream_blocks(a, b, L))
 
 
+@pytest.mark.parametrize("V", [49986, 4099, 130, 3])
+def test_streaming_weight_gradients_as_one_group(gpu_device, V):
+    """relgnn_gemm_tn_stream_group_f32 on a GRU cell's three weight gradients (gnns/ggnn.py:92: x^T gxk, h^T gxk[:, :2u],
+    (r*h)^T gxk[:, 2u:], the last two written as column blocks of ONE [u, 3u] gradient) and its bias gradient (the column sums of
+    gxk): against float64, reproducible, and nothing written outside the blocks."""
+    from tf_gnn_samples_amd import dense as D
+    u = 128
+    gen = torch.Generator(device=gpu_device).manual_seed(V)
+    x, h, rh, gxk = _rand(gen, V, u), _rand(gen, V, u), _rand(gen, V, u), _rand(gen, V, 3 * u)
+    gq = gxk[:, 2 * u:].contiguous()
+    gK = torch.full((u, 3 * u), 9.0, device=gpu_device)
+    gU = torch.full((u, 3 * u), 9.0, device=gpu_device)
+    gb = torch.full((3 * u,), 9.0, device=gpu_device)
+    products = [(x, gxk, gK), (h, gxk[:, :2 * u], gU[:, :2 * u]), (rh, gq, gU[:, 2 * u:])]
+    assert D.tn_stream_group_ok(products)
+    D.tn_stream_group(products, colsum=gb)
+    _close(gK, x.double().t() @ gxk.double(), V)
+    _close(gU[:, :2 * u], h.double().t() @ gxk[:, :2 * u].double(), V)
+    _close(gU[:, 2 * u:], rh.double().t() @ gq.double(), V)
+    _close(gb, gxk.double().sum(0), V)
+    first = (gK.clone(), gU.clone(), gb.clone())
+    D.tn_stream_group(products, colsum=gb)
+    assert all(torch.equal(a, b) for a, b in zip(first, (gK, gU, gb)))
+    # a group of one without the column sums, a group of four
+    one = torch.empty((u, 3 * u), device=gpu_device)
+    D.tn_stream_group([(x, gxk, one)])
+    _close(one, x.double().t() @ gxk.double(), V)
+    outs = [torch.empty((u, 64), device=gpu_device) for _ in range(4)]
+    D.tn_stream_group([(x, gxk[:, 64 * i:64 * (i + 1)], outs[i]) for i in range(4)], colsum=gb[:64].clone())
+    for i in range(4):
+        _close(outs[i], x.double().t() @ gxk[:, 64 * i:64 * (i + 1)].double(), V)
+
+
+def test_streaming_group_refuses_what_it_cannot_take(gpu_device):
+    import ctypes
+    from tf_gnn_samples_amd import _lib, dense as D
+    lib = _lib.load_library()
+    a = torch.zeros((64, 50), device=gpu_device)
+    b = torch.zeros((64, 128), device=gpu_device)
+    out = torch.zeros((50, 128), device=gpu_device)
+    assert not D.tn_stream_group_ok([(a, b, out)])                # 50 columns: not whole tiles
+    vp, i64, i32 = ctypes.c_void_p * 1, ctypes.c_int64 * 1, ctypes.c_int32 * 1
+    ws = torch.zeros(1 << 20, device=gpu_device)
+    rc = lib.relgnn_gemm_tn_stream_group_f32(1, vp(a.data_ptr()), i64(50), vp(b.data_ptr()), i64(128), vp(out.data_ptr()), i64(128),
+                                             i32(50), i32(128), 64, None, ws.data_ptr(), ws.numel() * 4, None)
+    assert rc == _lib.EUNSUPPORTED
+    rc = lib.relgnn_gemm_tn_stream_group_f32(5, vp(a.data_ptr()), i64(50), vp(b.data_ptr()), i64(128), vp(out.data_ptr()), i64(128),
+                                             i32(50), i32(128), 64, None, ws.data_ptr(), ws.numel() * 4, None)
+    assert rc == _lib.EINVAL                                      # more than four products
+    a64 = torch.zeros((64, 64), device=gpu_device)
+    o64 = torch.ones((64, 128), device=gpu_device)
+    cs = torch.ones(128, device=gpu_device)
+    rc = lib.relgnn_gemm_tn_stream_group_f32(1, vp(a64.data_ptr()), i64(64), vp(b.data_ptr()), i64(128), vp(o64.data_ptr()), i64(128),
+                                             i32(64), i32(128), 0, cs.data_ptr(), None, 0, None)
+    assert rc == _lib.OK                                          # no rows: zeros
+    torch.cuda.synchronize()
+    assert float(o64.abs().sum()) == 0.0 and float(cs.abs().sum()) == 0.0
+
+
 def test_streaming_weight_gradient_into_blocks_refuses_ragged_blocks(gpu_device):
     import ctypes
     from tf_gnn_samples_amd import _lib

@@ -130,6 +130,9 @@ _SIGNATURES = {
                                               _c_i64, _c_i64, _c_i64, _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_gemm_tn_stream_workspace_bytes": (_c_i64, [_c_i32, _c_i32, _c_i64]),
     "relgnn_gemm_tn_stream_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _c_i32, _c_i64, _c_i32, _ptr, _c_i64, _ptr]),
+    "relgnn_gemm_tn_stream_group_workspace_bytes": (_c_i64, [_c_i32, _ptr, _ptr, _c_i64, _c_i32]),
+    "relgnn_gemm_tn_stream_group_f32": (ctypes.c_int, [_c_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i64,
+                                                       _ptr]),
     "relgnn_gemm_tn_stream_blocks_f32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _c_i64, _c_i64, _c_i32, _c_i32, _c_i32, _c_i64,
                                                         _c_i32, _ptr, _c_i64, _ptr]),
     "relgnn_sum_slabs_tail_f32": (ctypes.c_int, [_ptr, _c_i32, _c_i32, _c_i32, _ptr, _c_i64, _ptr, _c_i64, _c_i32, _ptr, _ptr]),

@@ -86,17 +86,14 @@ __device__ __forceinline__ void take(const Slot<false>& s, float& x, float& y) {
   asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(x), "=&v"(y) : "v"(s.x), "v"(s.y));
 }
 
+// One wave's 64 x 64 tile of one chunk.  colsum (nullable, [2, N] of this chunk): the sums of the chunk's rows of B by row parity —
+// the bias gradient of the Dense layer whose kernel gradient this product is (column sums of the same operand), taken from the
+// registers the MFMAs read; written by the waves of the first tile row only.
 template <bool VEC_A, bool VEC_B>
-__global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                                             int64_t ldb, int64_t K, int32_t M, int32_t N, int64_t chunk_rows,
-                                                             float* __restrict__ partial, int32_t tiles_n, int32_t tiles) {
+__device__ __forceinline__ void tn_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int64_t K,
+                                        int32_t M, int32_t N, int64_t chunk_rows, float* __restrict__ out, int chunk, int m0, int n0,
+                                        float* __restrict__ colsum) {
   const int lane = threadIdx.x & 63;
-  // (grid: chunk-major.  A chunk's tile groups as neighbouring blocks of ONE XCD, so that they share its L2, measured the same:
-  //  [50 k, 128]^T [50 k, 640] 93.6 against 94.3 us, scripts/exp_tn_xcd.py at commit "XCD-grouped TN stream grid")
-  const int chunk = blockIdx.x;
-  const int tile = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (tile >= tiles) return;                                   // whole wave
-  const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
   const int64_t k_begin = (int64_t)chunk * chunk_rows, k_end = min(K, k_begin + chunk_rows);
   const Cols ca = make_cols(m0 + 2 * (lane & 31), M), cb = make_cols(n0 + 2 * (lane & 31), N);
   const int rows = (int)(k_end - k_begin);                     // <= chunk_rows < 2^31
@@ -121,6 +118,7 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
     pb = pb + step_b < pb_last ? pb + step_b : pb_last;
   };
 
+  float cs0 = 0.f, cs1 = 0.f;                                   // this lane's two columns of B, summed over its rows (half = parity)
   constexpr int kLoadsPerPair = (VEC_A ? 1 : 2) + (VEC_B ? 1 : 2);
   Slot<VEC_A> ra[kDepth] = {};
   Slot<VEC_B> rb[kDepth] = {};
@@ -146,6 +144,9 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
         const float live = r0 + 2 * u + half < rows ? 1.f : 0.f;
         a0 *= live * ca.on0; a1 *= live * ca.on1;
         b0 *= cb.on0; b1 *= cb.on1;
+        cs0 += live * b0; cs1 += live * b1;
+      } else {
+        cs0 += b0; cs1 += b1;
       }
       issue(ra[u], pa, ca);
       issue(rb[u], pb, cb);
@@ -171,7 +172,11 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
   // the matrix is.)
   // C layout of v_mfma_f32_32x32x2: column index c = lane & 31, row index i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   // tile (a, b) holds output rows m0 + 2 i + a and columns n0 + 2 c + b.
-  float* out = partial + (int64_t)chunk * M * N;
+  if (colsum && m0 == 0) {
+    const int n = n0 + 2 * (lane & 31);
+    if (n < N) colsum[(int64_t)half * N + n] = cs0;
+    if (n + 1 < N) colsum[(int64_t)half * N + n + 1] = cs1;
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -183,6 +188,78 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __rest
         if (n + 1 < N) out[(int64_t)m * N + n + 1] = acc[a][1][r];
       }
     }
+}
+
+template <bool VEC_A, bool VEC_B>
+__global__ __launch_bounds__(256) void gemm_tn_stream_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                             int64_t ldb, int64_t K, int32_t M, int32_t N, int64_t chunk_rows,
+                                                             float* __restrict__ partial, int32_t tiles_n, int32_t tiles) {
+  // (grid: chunk-major.  A chunk's tile groups as neighbouring blocks of ONE XCD, so that they share its L2, measured the same:
+  //  [50 k, 128]^T [50 k, 640] 93.6 against 94.3 us, scripts/exp_tn_xcd.py at commit "XCD-grouped TN stream grid")
+  const int chunk = blockIdx.x;
+  const int tile = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (tile >= tiles) return;                                   // whole wave
+  tn_tile<VEC_A, VEC_B>(A, lda, B, ldb, K, M, N, chunk_rows, partial + (int64_t)chunk * M * N, chunk, (tile / tiles_n) * 64,
+                        (tile % tiles_n) * 64, nullptr);
+}
+
+// Up to four products over the SAME rows in one launch (the three weight gradients of a GRU cell, gnns/ggnn.py:92: x^T gxk,
+// h^T gxk[:, :2u], (r * h)^T gxk[:, 2u:]): the tiles of all of them are one list, cut into the same row chunks.
+constexpr int kGroupMax = 4;
+struct TnGroupArgs {
+  const float* A[kGroupMax]; const float* B[kGroupMax];
+  int64_t lda[kGroupMax], ldb[kGroupMax];
+  float* partial[kGroupMax];              // [chunks, M, N] each
+  int32_t M[kGroupMax], N[kGroupMax], tiles_n[kGroupMax], tile_end[kGroupMax];      // tile_end: running total of 64 x 64 tiles
+  int32_t num, tiles;
+  int64_t K, chunk_rows;
+  float* colsum;                          // nullable: [chunks, 2, N[0]] partial column sums of B[0]
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_stream_group_kernel(const TnGroupArgs g) {
+  const int chunk = blockIdx.x;
+  int tile = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (tile >= g.tiles) return;                                 // whole wave
+  int p = 0;
+  while (p + 1 < g.num && tile >= g.tile_end[p]) ++p;          // (wave-uniform; num <= 4)
+  p = __builtin_amdgcn_readfirstlane(p);
+  if (p > 0) tile -= g.tile_end[p - 1];
+  const int32_t M = g.M[p], N = g.N[p];
+  tn_tile<true, true>(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.K, M, N, g.chunk_rows, g.partial[p] + (int64_t)chunk * M * N, chunk,
+                      (tile / g.tiles_n[p]) * 64, (tile % g.tiles_n[p]) * 64,
+                      p == 0 && g.colsum ? g.colsum + (int64_t)chunk * 2 * N : nullptr);
+}
+
+// the reductions of such a group in one launch: segment j sums chunks[j] slabs of mn[j] floats into C[j] (row stride ldc[j]); the
+// column sums are a segment of their own (one row, 2 * chunks slabs).  Blocks of 64 outputs never straddle segments.
+struct SumGroupArgs {
+  const float* partial[kGroupMax + 1]; float* C[kGroupMax + 1];
+  int64_t ldc[kGroupMax + 1];
+  int32_t mn[kGroupMax + 1], N[kGroupMax + 1], chunks[kGroupMax + 1], block_end[kGroupMax + 1];
+  int32_t num;
+};
+
+__global__ __launch_bounds__(256) void sum_partials_group_kernel(const SumGroupArgs g) {
+  __shared__ float part[4][64];
+  int j = 0;
+  while (j + 1 < g.num && (int)blockIdx.x >= g.block_end[j]) ++j;
+  const int block = (int)blockIdx.x - (j ? g.block_end[j - 1] : 0);
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = block * 64 + o;
+  const int mn = g.mn[j], chunks = g.chunks[j];
+  const float* partial = g.partial[j];
+  float s0 = 0.f, s1 = 0.f;
+  if (i < mn) {
+    int c = grp;
+    for (; c + 4 < chunks; c += 8) {
+      s0 += partial[(int64_t)c * mn + i];
+      s1 += partial[(int64_t)(c + 4) * mn + i];
+    }
+    if (c < chunks) s0 += partial[(int64_t)c * mn + i];
+  }
+  part[grp][o] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && i < mn) g.C[j][(int64_t)(i / g.N[j]) * g.ldc[j] + (i % g.N[j])] = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
 }
 
 // C[m, n] (+)= sum over chunks.  256 threads = 64 outputs x 4 chunk groups: group g sums chunks g, g + 4, ... (independent
@@ -318,6 +395,84 @@ int relgnn_gemm_tn_stream_blocks_f32(const float* A, int64_t lda, const float* B
   if (M == 0 || N == 0) return RELGNN_OK;
   if (!C) return RELGNN_EINVAL;
   return tn_stream_launch(A, lda, B, ldb, C, ldc, M, N, K, block_cols, block_stride, accumulate, workspace, workspace_bytes, stream);
+}
+
+static Plan make_group_plan(int32_t num, const int32_t* M, const int32_t* N, int64_t K, int32_t* tile_end) {
+  Plan p{};
+  for (int i = 0; i < num; ++i) {
+    p.tiles += ((M[i] + 63) / 64) * ((N[i] + 63) / 64);
+    if (tile_end) tile_end[i] = p.tiles;
+  }
+  const int64_t tgroups = (p.tiles + 3) / 4;
+  int64_t chunks = std::max<int64_t>(1, 256 / tgroups);
+  chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, (K + 63) / 64));
+  int64_t rows = (K + chunks - 1) / chunks;
+  rows = (rows + 2 * kDepth - 1) / (2 * kDepth) * (2 * kDepth);
+  p.chunk_rows = rows;
+  p.chunks = (int32_t)((K + rows - 1) / rows);
+  return p;
+}
+
+static bool group_shapes_ok(int32_t num, const int32_t* M, const int32_t* N, int64_t K) {
+  if (num < 1 || num > kGroupMax || !M || !N || K < 0) return false;
+  for (int i = 0; i < num; ++i)
+    if (M[i] <= 0 || N[i] <= 0) return false;
+  return true;
+}
+
+int64_t relgnn_gemm_tn_stream_group_workspace_bytes(int32_t num, const int32_t* M, const int32_t* N, int64_t K, int32_t with_colsum) {
+  if (!group_shapes_ok(num, M, N, K) || K == 0) return 0;
+  const Plan p = make_group_plan(num, M, N, K, nullptr);
+  int64_t floats = with_colsum ? (int64_t)p.chunks * 2 * N[0] : 0;
+  for (int i = 0; i < num; ++i) floats += (int64_t)p.chunks * M[i] * N[i];
+  return floats * 4;
+}
+
+int relgnn_gemm_tn_stream_group_f32(int32_t num, const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                    float* const* C, const int64_t* ldc, const int32_t* M, const int32_t* N, int64_t K,
+                                    float* colsum0, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!group_shapes_ok(num, M, N, K) || !A || !lda || !B || !ldb || !C || !ldc) return RELGNN_EINVAL;
+  for (int i = 0; i < num; ++i)
+    if (!C[i] || lda[i] < M[i] || ldb[i] < N[i] || ldc[i] < N[i]) return RELGNN_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (K == 0) {
+    for (int i = 0; i < num; ++i)
+      if (hipMemset2DAsync(C[i], (size_t)ldc[i] * 4, 0, (size_t)N[i] * 4, (size_t)M[i], st) != hipSuccess) return RELGNN_EHIP;
+    if (colsum0 && hipMemsetAsync(colsum0, 0, (size_t)N[0] * 4, st) != hipSuccess) return RELGNN_EHIP;
+    return RELGNN_OK;
+  }
+  if (!workspace || K >= ((int64_t)1 << 40)) return workspace ? RELGNN_EUNSUPPORTED : RELGNN_EINVAL;
+  for (int i = 0; i < num; ++i) {
+    if (!A[i] || !B[i]) return RELGNN_EINVAL;
+    if (reinterpret_cast<uintptr_t>(A[i]) % 8 || reinterpret_cast<uintptr_t>(B[i]) % 8 || lda[i] % 2 || ldb[i] % 2 || M[i] % 64 || N[i] % 64)
+      return RELGNN_EUNSUPPORTED;                               // (8-byte loads and whole tiles only: the caller launches such products one by one)
+  }
+  if (workspace_bytes < relgnn_gemm_tn_stream_group_workspace_bytes(num, M, N, K, colsum0 != nullptr)) return RELGNN_EINVAL;
+  TnGroupArgs g{};
+  SumGroupArgs sg{};
+  const Plan p = make_group_plan(num, M, N, K, g.tile_end);
+  float* ws = static_cast<float*>(workspace);
+  int blocks = 0;
+  for (int i = 0; i < num; ++i) {
+    g.A[i] = A[i]; g.B[i] = B[i]; g.lda[i] = lda[i]; g.ldb[i] = ldb[i]; g.M[i] = M[i]; g.N[i] = N[i]; g.tiles_n[i] = (N[i] + 63) / 64;
+    g.partial[i] = ws;
+    sg.partial[i] = ws; sg.C[i] = C[i]; sg.ldc[i] = ldc[i]; sg.mn[i] = M[i] * N[i]; sg.N[i] = N[i]; sg.chunks[i] = p.chunks;
+    blocks += (M[i] * N[i] + 63) / 64;
+    sg.block_end[i] = blocks;
+    ws += (int64_t)p.chunks * M[i] * N[i];
+  }
+  g.num = num; g.tiles = p.tiles; g.K = K; g.chunk_rows = p.chunk_rows;
+  sg.num = num;
+  if (colsum0) {
+    g.colsum = ws;
+    sg.partial[num] = ws; sg.C[num] = colsum0; sg.ldc[num] = N[0]; sg.mn[num] = N[0]; sg.N[num] = N[0]; sg.chunks[num] = 2 * p.chunks;
+    blocks += (N[0] + 63) / 64;
+    sg.block_end[num] = blocks;
+    sg.num = num + 1;
+  }
+  gemm_tn_stream_group_kernel<<<dim3((unsigned)p.chunks, (unsigned)((p.tiles + 3) / 4)), 256, 0, st>>>(g);
+  sum_partials_group_kernel<<<(unsigned)blocks, 256, 0, st>>>(sg);
+  return launch_status();
 }
 
 int relgnn_sum_slabs_tail_f32(const float* slabs, int32_t num_slabs, int32_t M, int32_t N, const float* At, int64_t lda,

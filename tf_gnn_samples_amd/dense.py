@@ -1085,6 +1085,42 @@ def tn_stream_blocks(a: torch.Tensor, b: torch.Tensor, L: int) -> torch.Tensor:
     return out
 
 
+def tn_stream_group_ok(products) -> bool:
+    """May these (a [V, M], b [V, N], out [M, N] block) triples go through relgnn_gemm_tn_stream_group_f32?  At most four, the same
+    V, whole 64 x 64 tiles, 8-byte aligned operands with even row strides."""
+    if not (_cfg.tn == "stream" and 1 <= len(products) <= 4):
+        return False
+    V = products[0][0].shape[0]
+    for a, b, out in products:
+        if not (a.is_cuda and a.dtype == b.dtype == out.dtype == torch.float32 and a.shape[0] == b.shape[0] == V and 0 < V <= (1 << 18)
+                and a.shape[1] % 64 == 0 and b.shape[1] % 64 == 0 and out.shape == (a.shape[1], b.shape[1])
+                and all(t.stride(1) == 1 and t.stride(0) % 2 == 0 and t.data_ptr() % 8 == 0 for t in (a, b))
+                and out.stride(1) == 1 and out.stride(0) >= out.shape[1]):
+            return False
+    return sum(a.shape[1] * b.shape[1] for a, b, _ in products) <= 4 * _TN_BLOCKS_MAX_OUT
+
+
+def tn_stream_group(products, colsum: torch.Tensor = None) -> None:
+    """out_i[:] = a_i^T @ b_i for every (a_i, b_i, out_i) — ONE pass of the streaming weight-gradient kernel and one reduction launch
+    for all of them (relgnn_gemm_tn_stream_group_f32); colsum (contiguous [N_0]): also the column sums of b_0, the bias gradient of
+    the layer whose kernel gradient product 0 is."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load_library()
+    n = len(products)
+    V = products[0][0].shape[0]
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+    M = i32(*[a.shape[1] for a, _, _ in products])
+    N = i32(*[b.shape[1] for _, b, _ in products])
+    nbytes = lib.relgnn_gemm_tn_stream_group_workspace_bytes(n, M, N, V, 1 if colsum is not None else 0)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=products[0][0].device)
+    _lib.check(lib.relgnn_gemm_tn_stream_group_f32(
+        n, vp(*[a.data_ptr() for a, _, _ in products]), i64(*[a.stride(0) for a, _, _ in products]),
+        vp(*[b.data_ptr() for _, b, _ in products]), i64(*[b.stride(0) for _, b, _ in products]),
+        vp(*[o.data_ptr() for _, _, o in products]), i64(*[o.stride(0) for _, _, o in products]), M, N, V, _lib.ptr(colsum),
+        _lib.ptr(ws), nbytes, _lib.current_stream()), "relgnn_gemm_tn_stream_group_f32")
+
+
 def tn_stream_gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """a^T @ b for a [V, M], b [V, N] through the streaming weight-gradient kernel (csrc/gemm_tn_stream.hip);
     with `out` (contiguous [M, N]): out += a^T @ b."""

@@ -256,6 +256,17 @@ class _GRUCellFn(torch.autograd.Function):
         grec = gxk[:, :2 * u]                                              # d loss / d rec = the z, r columns of d loss / d xk
 
         def weight_side():
+            if all(ctx.needs_input_grad[2:5]):
+                # the three products over the same rows and the bias gradient (the column sums of gxk, which the first product
+                # reads anyway): one launch pair instead of four products, four reductions and two column-sum launches
+                from .dense import tn_stream_group, tn_stream_group_ok
+                gK = torch.empty((x.shape[1], 3 * u), dtype=torch.float32, device=h.device)
+                gU = torch.empty((u, 3 * u), dtype=torch.float32, device=h.device)
+                products = [(x, gxk, gK), (h, grec, gU[:, :2 * u]), (rh, gq, gU[:, 2 * u:])]
+                if tn_stream_group_ok(products):
+                    gb = torch.empty(3 * u, dtype=torch.float32, device=h.device)
+                    tn_stream_group(products, colsum=gb)
+                    return gK, gU, gb
             gK = matmul_tn_splitk(x, gxk) if ctx.needs_input_grad[2] else None
             gU = None
             if ctx.needs_input_grad[3]:
