@@ -563,10 +563,25 @@ int relgnn_gru_gates_bwd(const float* grh, const float* gz, const float* z, cons
  * units == in_dim == 128, act in {LINEAR, TANH, RELU, LEAKY_RELU} (relgnn_gru_cell_fwd_supported), 16-byte aligned rows:
  * RELGNN_EUNSUPPORTED otherwise (the caller composes the cell from the entries above).
  */
+/*
+ * relgnn_gru_cell_bwd_xf32: the data path of the cell's backward as ONE kernel (what gru_out_bwd / gru_gates_bwd above and three
+ * limb products did in seven launches), from the tensors the forward kept:
+ *   gpre = g (1-z) act'(hh);  gzp = g (h-hh) hs'(z);  [gx_h | grh] = gpre @ [K_h; U_h]^T;  grp = grh h hs'(r);
+ *   [gx | gh] = [gx_h | g z + grh r] + [gzp | grp] @ [[K_z K_r]; [U_z U_r]]^T;   gxk = [gzp | grp | gpre]
+ * gxk [num_nodes, 3u] is the right operand of the cell's weight gradients (x^T gxk, h^T gxk[:, :2u], (r*h)^T gxk[:, 2u:], bias =
+ * its column sums: relgnn_gemm_tn_stream_group_f32).  Producer waves do every elementwise step and hand limbs to the matrix waves
+ * through LDS; grh and g z + grh r cross between the two roles in LDS as well.
+ *   w_h_nt_limbs : limb image of [K[:, 2u:]; U[:, 2u:]] as the [in_dim + u, u] right operand (rows = x | h columns)
+ *   w_zr_nt_limbs: limb image of [K[:, :2u]; U[:, :2u]] as the [in_dim + u, 2u] right operand
+ *   z, r, hh, gxk, gx, gh dense; gout, h with row strides.  Same shapes, activations and status block as the forward entry.
+ */
 int relgnn_gru_cell_fwd_supported(int32_t act, int32_t units, int32_t in_dim);
 int relgnn_gru_cell_fwd_xf32(const float* x, int64_t ldx, const float* h, int64_t ldh, const uint16_t* w_zr_limbs,
                              const uint16_t* w_h_limbs, const float* bias, int32_t act, float* z, float* r, float* rh, float* hh,
                              float* out, int64_t num_nodes, int32_t units, int32_t in_dim, int32_t* status, void* stream);
+int relgnn_gru_cell_bwd_xf32(const float* gout, int64_t ldg, const float* z, const float* r, const float* h, int64_t ldh,
+                             const float* hh, const uint16_t* w_h_nt_limbs, const uint16_t* w_zr_nt_limbs, int32_t act, float* gxk,
+                             float* gx, float* gh, int64_t num_nodes, int32_t units, int32_t in_dim, int32_t* status, void* stream);
 
 /* ---- layer normalisation of node states ------------------------------------------------------------------
  * Replaces: tf.contrib.layers.layer_norm at gnns/gnn_film.py:120, gnns/rgin.py:139, gnns/gnn_edge_mlp.py:120 and

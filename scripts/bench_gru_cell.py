@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""The GRU cell forward of a GGNN layer at C3's size (49 986 nodes, 128 units): the one-kernel form (relgnn_gru_cell_fwd_xf32)
-against the composition it replaces (three limb products + gru.hip's gate and output kernels), training form (z, r, r * h and the
-candidate kept) and inference form; HIP events, median of 7 x 20 launches."""
+"""The GRU cell of a GGNN layer at C3's size (49 986 nodes, 128 units): the one-kernel forward and backward (relgnn_gru_cell_fwd_xf32,
+relgnn_gru_cell_bwd_xf32) against the composition they replace (three limb products + gru.hip's gate and output kernels, and the
+same in reverse); forward in the training form (z, r, r * h and the candidate kept) and the inference form; the backward with its
+weight gradients on the same stream.  HIP events, median of 7 x 20 launches."""
 import json, statistics, sys
 from pathlib import Path
 import torch
@@ -30,13 +31,21 @@ def timed(fn, reps=7, iters=20):
 
 
 for V in (49986, 16416, 200000):
-    x = (torch.rand((V, U), generator=g) * 2 - 1).to(dev)
-    h = (torch.rand((V, U), generator=g) * 2 - 1).to(dev)
+    x = (torch.rand((V, U), generator=g) * 2 - 1).to(dev).requires_grad_(True)
+    h = (torch.rand((V, U), generator=g) * 2 - 1).to(dev).requires_grad_(True)
+    gout = torch.randn((V, U), generator=g).to(dev)
     row = {"nodes": V}
     for sw in ("0", "1"):
         with config.override(gru_cell=sw):
-            row["train_form_us_gru_cell_" + sw] = timed(lambda: utils._GRUCellFn.apply(x, h, K, R, b, 1))
+            fwd = timed(lambda: utils._GRUCellFn.apply(x, h, K, R, b, 1))
+            row["train_form_us_gru_cell_" + sw] = fwd
             with torch.no_grad():
                 row["inference_form_us_gru_cell_" + sw] = timed(lambda: utils._GRUCellFn.apply(x, h, K, R, b, 1))
+
+            def both():
+                for t in (x, h, K, R, b):
+                    t.grad = None
+                utils._GRUCellFn.apply(x, h, K, R, b, 1).backward(gout)
+            row["forward_backward_us_gru_cell_" + sw] = timed(both)
     row["handover_status"] = ops.handover_status()
     print(json.dumps(row), flush=True)

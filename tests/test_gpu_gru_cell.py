@@ -29,7 +29,7 @@ def _states(dev, V, seed):
 
 
 def _cell64(x, h, K, R, b, act):
-    x, h, K, R, b = (t.double() for t in (x, h, K, R, b))
+    x, h, K, R, b = (t if t.dtype == torch.float64 else t.double() for t in (x, h, K, R, b))
     hs = lambda t: torch.clamp(0.2 * t + 0.5, 0.0, 1.0)
     xk = x @ K + b
     z = hs(xk[:, :U] + h @ R[:, :U])
@@ -125,6 +125,69 @@ def test_rows_with_non_finite_values_spoil_their_own_rows_only(gpu_device):
     # arithmetic makes of it — gates clipped to {0, 1}, a finite candidate
     ref40 = _cell64(x[40:41], h[40:41], K, R, b, "tanh")[-1]
     assert torch.equal(torch.isfinite(got[40]), torch.isfinite(ref40[0]))
+
+
+def _cell_backward64(x, h, K, R, z, r, hh, g, act):
+    """The cell's gradients in float64 from the float32 forward's own z, r and candidate — the derivative of hard_sigmoid / ReLU
+    is a step, and a gate that float32 put ON the step (z == 1.0f where float64 has 1 - 1e-9) would make an autograd reference
+    differ by a whole term."""
+    x, h, K, R, z, r, hh, g = (t.double() for t in (x, h, K, R, z, r, hh, g))
+    dact = {"tanh": lambda y: 1 - y * y, "relu": lambda y: (y > 0).double(), "linear": lambda y: torch.ones_like(y),
+            "leaky_relu": lambda y: torch.where(y > 0, 1.0, 0.2)}[act]
+    hsg = lambda y: ((y > 0) & (y < 1)).double() * 0.2
+    gpre = g * (1 - z) * dact(hh)
+    gzp = g * (h - hh) * hsg(z)
+    grh = gpre @ R[:, 2 * U:].t()
+    grp = grh * h * hsg(r)
+    gxk = torch.cat([gzp, grp, gpre], 1)
+    gx = gxk @ K.t()
+    gh = g * z + grh * r + gxk[:, :2 * U] @ R[:, :2 * U].t()
+    gR = torch.cat([h.t() @ gxk[:, :2 * U], (r * h).t() @ gpre], 1)
+    return gx, gh, x.t() @ gxk, gR, gxk.sum(0)
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu", "linear", "leaky_relu"])
+@pytest.mark.parametrize("V", [1, 33, 64, 97, 2250, 16416, 49986])
+def test_cell_backward_kernel_against_float64(gpu_device, V, act):
+    """relgnn_gru_cell_bwd_xf32 through utils._GRUCellFn: the gradients of the inputs, the states and the three variables against
+    the float64 formulas (gnns/ggnn.py:92's cell differentiated by hand, on the forward's own gate values); the hand-over status
+    stays clean."""
+    from tf_gnn_samples_amd import _lib, ops, utils
+    dev = gpu_device
+    K, R, b = _weights(dev, 31)
+    x, h = _states(dev, V, V + 5)
+    g = torch.Generator(device="cpu").manual_seed(V)
+    gout = torch.randn((V, U), generator=g).to(dev)
+    z, r, rh, hh, _ = _launch(x, h, K, R, b, act)
+    leaves = [t.clone().requires_grad_(True) for t in (x, h, K, R, b)]
+    act_id = {"linear": _lib.ACT_LINEAR, "tanh": _lib.ACT_TANH, "relu": _lib.ACT_RELU, "leaky_relu": _lib.ACT_LEAKY_RELU}[act]
+    out = utils._GRUCellFn.apply(*leaves, act_id)
+    out.backward(gout)
+    torch.cuda.synchronize()
+    assert ops.handover_status() == 0
+    want = _cell_backward64(x, h, K, R, z, r, hh, gout, act)
+    for name, got, w in zip(("x", "h", "kernel", "recurrent_kernel", "bias"), leaves, want):
+        scale = max(1.0, float(w.abs().max()))
+        err = float((got.grad.double() - w).abs().max())
+        assert err <= 4e-6 * scale * max(1.0, float(np.sqrt(V)) / 30), (name, V, act, err, scale)
+
+
+def test_cell_backward_kernel_is_reproducible_and_reads_strided_gradients(gpu_device):
+    from tf_gnn_samples_amd import _lib, utils
+    dev = gpu_device
+    V = 4097
+    K, R, b = _weights(dev, 41)
+    x, h = _states(dev, V, 42)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    wide = torch.randn((V, 260), generator=g).to(dev)
+    results = []
+    for gout in (wide[:, 4:132], wide[:, 4:132].contiguous(), wide[:, 4:132]):
+        leaves = [t.clone().requires_grad_(True) for t in (x, h, K, R, b)]
+        utils._GRUCellFn.apply(*leaves, _lib.ACT_TANH).backward(gout)
+        torch.cuda.synchronize()
+        results.append([t.grad.clone() for t in leaves])
+    for other in results[1:]:
+        assert all(torch.equal(a, c) for a, c in zip(results[0], other))
 
 
 @pytest.mark.parametrize("aggregation", ["sum", "max"])

@@ -77,6 +77,8 @@ _SIGNATURES = {
     "relgnn_gru_cell_fwd_supported": (ctypes.c_int, [_c_i32, _c_i32, _c_i32]),
     "relgnn_gru_cell_fwd_xf32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _c_i64, _ptr, _ptr, _ptr, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr,
                                                 _c_i64, _c_i32, _c_i32, _ptr, _ptr]),
+    "relgnn_gru_cell_bwd_xf32": (ctypes.c_int, [_ptr, _c_i64, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr, _c_i32, _ptr, _ptr, _ptr, _c_i64,
+                                                _c_i32, _c_i32, _ptr, _ptr]),
     "relgnn_gru_out_fwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr]),
     "relgnn_gru_out_bwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _c_i32, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "relgnn_gru_gates_bwd": (ctypes.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i32, _ptr, _ptr, _ptr]),

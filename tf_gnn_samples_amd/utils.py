@@ -218,11 +218,12 @@ class _GRUCellFn(torch.autograd.Function):
                                                     im_h.buf.data_ptr(), _lib.ptr(b), act, _lib.ptr(z), _lib.ptr(r), _lib.ptr(rh),
                                                     _lib.ptr(hh), _lib.ptr(out), V, u, x.shape[1],
                                                     ops.handover_word(h.device).data_ptr(), st), "relgnn_gru_cell_fwd_xf32")
-            ctx.act = act
+            ctx.act, ctx.cell_kernel = act, True
             if train:
                 ctx.save_for_backward(x, h, K, U, z, r, rh, hh)
             ctx.leaf_params = (K, U, b) if all(p.is_leaf and p.requires_grad for p in (K, U, b)) else None
             return out
+        ctx.cell_kernel = False
         xk = lib_gemm(GEMM_NN, x, K, b, weight=True)                       # [V, 3u]
         rec = lib_gemm(GEMM_NN, h, U[:, :2 * u], weight=True)              # [V, 2u] (the view read with its leading dimension)
         z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
@@ -247,12 +248,27 @@ class _GRUCellFn(torch.autograd.Function):
         V, u = h.shape
         gout = gout.contiguous()
         gxk = torch.empty((V, 3 * u), dtype=torch.float32, device=h.device)
-        gq, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
-        _lib.check(lib.relgnn_gru_out_bwd(_lib.ptr(gout), _lib.ptr(z), _lib.ptr(h), _lib.ptr(hh), V, u, ctx.act,
-                                          _lib.ptr(gxk), _lib.ptr(gq), _lib.ptr(gz), _lib.ptr(gh), st), "relgnn_gru_out_bwd")
-        grh = lib_gemm(GEMM_NT, gq, U[:, 2 * u:], weight=True)
-        _lib.check(lib.relgnn_gru_gates_bwd(_lib.ptr(grh), _lib.ptr(gz), _lib.ptr(z), _lib.ptr(r), _lib.ptr(h), V, u,
-                                            _lib.ptr(gxk), _lib.ptr(gh), st), "relgnn_gru_gates_bwd")
+        fused = ctx.cell_kernel and _gru_cell_kernel_ok(x, h, K, U, None, ctx.act)
+        if fused:
+            # one launch (csrc/gru_cell.hip): the gate / candidate gradients and the three input-gradient products; gxk for the
+            # weight gradients below
+            from . import ops
+            from .dense import WEIGHT_NT, weight_image
+            im_h = weight_image([K[:, 2 * u:], U[:, 2 * u:]], WEIGHT_NT, separate=True)
+            im_zr = weight_image([K[:, :2 * u], U[:, :2 * u]], WEIGHT_NT, separate=True)
+            gx, gh = torch.empty_like(x), torch.empty_like(h)
+            _lib.check(lib.relgnn_gru_cell_bwd_xf32(_lib.ptr(gout), gout.stride(0), _lib.ptr(z), _lib.ptr(r), _lib.ptr(h), h.stride(0),
+                                                    _lib.ptr(hh), im_h.buf.data_ptr(), im_zr.buf.data_ptr(), ctx.act, _lib.ptr(gxk),
+                                                    _lib.ptr(gx), _lib.ptr(gh), V, u, x.shape[1],
+                                                    ops.handover_word(h.device).data_ptr(), st), "relgnn_gru_cell_bwd_xf32")
+            gq = gxk[:, 2 * u:]
+        else:
+            gq, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+            _lib.check(lib.relgnn_gru_out_bwd(_lib.ptr(gout), _lib.ptr(z), _lib.ptr(h), _lib.ptr(hh), V, u, ctx.act,
+                                              _lib.ptr(gxk), _lib.ptr(gq), _lib.ptr(gz), _lib.ptr(gh), st), "relgnn_gru_out_bwd")
+            grh = lib_gemm(GEMM_NT, gq, U[:, 2 * u:], weight=True)
+            _lib.check(lib.relgnn_gru_gates_bwd(_lib.ptr(grh), _lib.ptr(gz), _lib.ptr(z), _lib.ptr(r), _lib.ptr(h), V, u,
+                                                _lib.ptr(gxk), _lib.ptr(gh), st), "relgnn_gru_gates_bwd")
         grec = gxk[:, :2 * u]                                              # d loss / d rec = the z, r columns of d loss / d xk
 
         def weight_side():
@@ -278,11 +294,12 @@ class _GRUCellFn(torch.autograd.Function):
 
         aside = _on_side_stream(weight_side, (x, h, rh, gxk, gq), ctx.leaf_params,
                                 want=(ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and any(ctx.needs_input_grad[2:5]))
-        gx = lib_gemm(GEMM_NT, gxk, K, weight=True) if ctx.needs_input_grad[0] else None
-        if ctx.needs_input_grad[1]:
-            gh = gh.add_(lib_gemm(GEMM_NT, grec, U[:, :2 * u], weight=True))
-        else:
-            gh = None
+        if not fused:
+            gx = lib_gemm(GEMM_NT, gxk, K, weight=True) if ctx.needs_input_grad[0] else None
+            if ctx.needs_input_grad[1]:
+                gh = gh.add_(lib_gemm(GEMM_NT, grec, U[:, :2 * u], weight=True))
+            else:
+                gh = None
         gK, gU, gb = aside if aside is not None else weight_side()
         return gx, gh, gK, gU, gb, None
 
@@ -293,8 +310,8 @@ def _gru_cell_kernel_ok(x, h, K, U, b, act: int) -> bool:
     from .config import settings as cfg
     from .dense import WEIGHT_NN, weight_image_ok
     u = h.shape[1]
-    if not (cfg.limb_gemm and cfg.gru_cell == "1" and h.is_cuda and 0 < h.shape[0] <= (1 << 22) and h.shape[0] * h.stride(0) < (1 << 30) and K.shape[0] == x.shape[1]
-            and b.is_contiguous() and b.data_ptr() % 16 == 0
+    if not (cfg.limb_gemm and cfg.gru_cell == "1" and h.is_cuda and 0 < h.shape[0] <= (1 << 21) and h.shape[0] * h.stride(0) < (1 << 30) and K.shape[0] == x.shape[1]
+            and (b is None or (b.is_contiguous() and b.data_ptr() % 16 == 0))
             and all(t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (x, h))):
         return False
     if not _lib.load_library().relgnn_gru_cell_fwd_supported(act, u, x.shape[1]):
