@@ -239,3 +239,36 @@ def test_unsupported_cells_are_refused(gpu_device):
     rc = lib.relgnn_gru_cell_fwd_xf32(t.data_ptr(), 128, t.data_ptr(), 128, w.data_ptr(), w.data_ptr(), b.data_ptr(), _lib.ACT_TANH,
                                       t.data_ptr(), None, None, None, t.data_ptr(), 64, 128, 128, None, None)
     assert rc == _lib.EINVAL                                   # the backward's tensors: all four or none
+
+
+def test_cell_kernels_that_give_up_on_a_hand_over_say_so_and_end(gpu_device):
+    """Every poll of the cell kernels' LDS counters is bounded (csrc/handover.h): with the poll bound at 1 (word 1 of the caller's
+    status block, the debug knob) both kernels run to their end — with wrong numbers — and OR the give-up bits into word 0, which
+    the model reads with every step's metrics (tests/test_gpu_limb_gemm.py covers that fetch)."""
+    from tf_gnn_samples_amd import _lib, config, ops, utils
+    if not config.settings.limb_gemm:
+        pytest.skip("the cell kernels belong to the limb route (RELGNN_GEMM is set to another route in this run)")
+    dev = gpu_device
+    V = 20000
+    K, R, b = _weights(dev, 51)
+    x, h = _states(dev, V, 52)
+    gout = torch.ones((V, U), device=dev)
+    word = ops.handover_word(dev)
+    assert ops.handover_status() == 0
+    leaves = [t.clone().requires_grad_(True) for t in (x, h, K, R, b)]
+    word[1] = 1
+    try:
+        out = utils._GRUCellFn.apply(*leaves, _lib.ACT_TANH)
+        torch.cuda.synchronize()
+        assert int(word[0].item()) & (4 | 8)                  # RELGNN_HANDOVER_PC_MATRIX | RELGNN_HANDOVER_PC_PRODUCER (include/relgnn.h)
+        word[0] = 0
+        out.backward(gout)
+        torch.cuda.synchronize()
+        assert int(word[0].item()) & (4 | 8)
+    finally:
+        word[1] = 0
+        word[0] = 0
+    clean = [t.clone().requires_grad_(True) for t in (x, h, K, R, b)]
+    utils._GRUCellFn.apply(*clean, _lib.ACT_TANH).backward(gout)
+    torch.cuda.synchronize()
+    assert ops.handover_status() == 0 and all(bool(torch.isfinite(t.grad).all()) for t in clean)
