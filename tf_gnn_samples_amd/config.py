@@ -40,8 +40,8 @@ _SPEC: Dict[str, Tuple[str, str, Tuple[str, ...], str]] = {
                  "gradients); on the C5 step no difference outside the noise (33.0-34.0 ms on all three values), hence off"),
     "gru_cell": ("RELGNN_GRU_CELL", "1", ("0", "1"),
                  "the GRU cell forward of a GGNN layer (128 units over 128-wide messages): three limb products + the gate kernel + "
-                 "the output kernel | ONE wave-role kernel (csrc/gru_cell.hip): both products, gates, candidate and blend, r * h "
-                 "handed from the gates' epilogue to the candidate's k-loop through LDS; x @ kernel + h @ recurrent_kernel is one "
+                 "the output kernel | ONE wave-role kernel per pass (csrc/gru_cell.hip): both products, gates, candidate and blend, r * h "
+                 "handed to the candidate's k-loop through LDS, and the data path of the backward; x @ kernel + h @ recurrent_kernel is one "
                  "accumulation there: the last bits differ from the composition"),
     "limb_cut": ("RELGNN_LIMB_CUT", "1", ("0", "1"),
                  "N % 128 >= 96 products (the 121 logits of the PPI head) on the 128-column limb panels with the last chunk cut at N"),
