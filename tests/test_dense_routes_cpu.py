@@ -113,3 +113,26 @@ def test_combined_node_csr_of_both_pair_tables_sums_what_the_two_reductions_sum(
         mine = col[rowptr[v]:rowptr[v + 1]].long()
         assert mine.tolist() == rows_a.tolist() + (rows_b + 200).tolist()
         assert torch.allclose(X[mine].sum(0), Xa[rows_a].sum(0) + Xb[rows_b].sum(0))
+
+
+def test_the_grouped_weight_gradient_and_the_cell_kernels_are_gpu_routes_only():
+    """Host tensors never reach relgnn_gemm_tn_stream_group_f32 / _blocks_f32 or the GRU cell kernels: the route predicates say no
+    and the cell falls back to the composition, whose numbers are the oracle's (oracle/tf_ops.py: gru_cell)."""
+    import numpy as np
+    import torch
+    from oracle import tf_ops
+    from tf_gnn_samples_amd import dense as DN, utils
+    u = 128
+    g = torch.Generator().manual_seed(0)
+    x, h = torch.randn((40, u), generator=g), torch.rand((40, u), generator=g) * 2 - 1
+    K, R = (torch.rand((u, 3 * u), generator=g) - 0.5) * 0.2, (torch.rand((u, 3 * u), generator=g) - 0.5) * 0.2
+    b = torch.rand((3 * u,), generator=g) - 0.5
+    gxk = torch.randn((40, 3 * u), generator=g)
+    assert not DN.tn_stream_blocks_ok(x, gxk)
+    assert not DN.tn_stream_group_ok([(x, gxk, torch.empty((u, 3 * u)))])
+    assert not DN.tn_stream_group_ok([])
+    assert not utils._gru_cell_kernel_ok(x, h, K, R, b, 1)
+    cell = utils.get_gated_unit(u, "gru", "tanh", {"kernel": K, "recurrent_kernel": R, "bias": b})
+    out = cell(x, [h])[0]
+    want = tf_ops.gru_cell(x.numpy(), h.numpy(), K.numpy(), R.numpy(), b.numpy(), np.tanh)
+    assert float(np.abs(out.numpy() - want).max()) <= 2e-6
